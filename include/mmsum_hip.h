@@ -1,0 +1,187 @@
+/* libmmsum_hip -- C ABI of the MI355X (gfx950) kernels behind the MultimodalSum training hot path.
+ *
+ * The reference (nc-ai/MultimodalSum) has no FFI/plugin interface: every device op on its hot
+ * path is an implicit PyTorch/ATen/cuDNN/apex launch.  Each entry point below replaces the
+ * launches of one reference call site (cited as /root/reference/<file>:<line>); the Python host
+ * (multimodalsum_amd/) binds them with ctypes and keeps the reference's nn.Module signatures.
+ *
+ * Conventions: plain pointers to DEVICE memory owned by the caller (PyTorch), explicit sizes and
+ * leading dimensions in ELEMENTS, `dtype` = MMSUM_F32 | MMSUM_BF16 for activations/weights
+ * (statistics, gradients of parameters and optimiser state are always f32), `stream` = a
+ * hipStream_t.  Every function only enqueues work: it never allocates, synchronises or throws,
+ * keeps no mutable global state, and returns MMSUM_OK or a negative error code.
+ */
+#ifndef MMSUM_HIP_H
+#define MMSUM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMSUM_ABI_VERSION 1
+
+enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
+enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
+       MMSUM_ERR_WORKSPACE = -4, MMSUM_ERR_HIP = -5 };
+
+/* mmsum_gemm flags */
+#define MMSUM_GEMM_A_T     0x001  /* A(m,k) = A[k*lda+m] (else A[m*lda+k]) */
+#define MMSUM_GEMM_B_T     0x002  /* B(n,k) = B[k*ldb+n] (else B[n*ldb+k]) */
+#define MMSUM_GEMM_BIAS    0x004  /* + bias[n] (f32) */
+#define MMSUM_EPI_NONE     0
+#define MMSUM_EPI_GELU     1      /* aux <- pre-activation, C <- gelu(erf form) */
+#define MMSUM_EPI_GELU_BWD 2      /* C <- v * gelu'(aux) */
+#define MMSUM_EPI_RELU     3
+#define MMSUM_EPI_RELU_BWD 4      /* C <- v * (aux > 0), aux = forward output */
+#define MMSUM_GEMM_EPI(e)  ((e) << 3)
+#define MMSUM_GEMM_ACCUM   0x040  /* C += */
+#define MMSUM_GEMM_OUT_F32 0x080  /* C is f32 regardless of dtype */
+
+int mmsum_abi_version(void);
+
+/* C[m][n] = epi(alpha * sum_k A(m,k) B(n,k) + bias[n]) (+C).  Replaces every nn.Linear / F.linear
+ * on the path and their autograd (modeling_multimodalsum.py:302,304,783-792,885,738-739,2281;
+ * table_encoder.py:62,65,71-73; img_encoder.py:40; 1x1 and im2col'ed convolutions of ResNet101).
+ * A2/ksplit: for k >= ksplit the A operand continues in A2 (K split over two tensors: the
+ * torch.cat([text, table]) of :738-739 without the concat).  splitk > 1 needs OUT_F32|ACCUM
+ * (f32 atomics). */
+int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
+               void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
+               int flags, int splitk, void* stream);
+
+/* out[c] (+)= sum_r X[r][c]  (bias gradients; BatchNorm reductions).  partial: f32 workspace of
+ * mmsum_colsum_workspace(C) bytes. */
+long mmsum_colsum_workspace(int C);
+int mmsum_colsum(int dtype, const void* X, long ld, int R, int C, float* out, int accumulate, void* workspace,
+                 void* stream);
+
+/* K1/K7: y = dropout(LN(E[ids] + P[t+pos_offset] + rating_diff[seq]*rvec))
+ * (modeling_multimodalsum.py:368-372, 581-597).  ids [nseq*T] int64; rating_diff/rvec may be NULL. */
+int mmsum_embed_ln_fwd(int dtype, const int64_t* ids, const void* E, const void* P, const float* rating_diff,
+                       const void* rvec, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                       int nseq, int T, int D, int pos_offset, float eps, float p_drop, uint64_t seed, void* stream);
+/* backward of the above: scatter-adds into dE (skipping pad_id rows), dP, drvec, dgamma, dbeta (all f32). */
+int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids, const void* E, const void* P,
+                       const float* rating_diff, const void* rvec, const void* gamma, const float* mean,
+                       const float* rstd, float* dE, float* dP, float* drvec, float* dgamma, float* dbeta, int nseq,
+                       int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, void* stream);
+
+/* K4/K6/K21: y = LN(res + dropout(x))  (modeling_multimodalsum.py:294-297,305-308,458-461,474-477,486-489;
+ * apex FusedLayerNorm :972-980). */
+int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,
+                     float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, void* stream);
+/* dres <- dz (or += if accumulate_dres), dx <- dz * dropmask/(1-p); dgamma/dbeta += (f32). */
+int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, const void* gamma, const float* mean,
+                     const float* rstd, void* dx, void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R,
+                     int D, float p_drop, uint64_t seed, void* stream);
+
+/* Entity attention (K3, K8, K11; modeling_multimodalsum.py:752-875).  One description covers
+ * encoder self-attention, causal decoder self-attention and the per-entity cross-attention with
+ * entity mean:
+ *   query block qb (T rows, row = qb*T + t, T <= 128) belongs to business b = qb / qpb; it attends,
+ *   entity by entity, to entities n = 0..N-1 of b (rows mem_row0 + ((b*N+n)*S + s), S <= 224),
+ *   skipping n == qb % qpb when `exclude_self` (leave-one-out) and entities with null[b*N+n] != 0;
+ *   out = mean over the attended entities of softmax_s(scale * q.k + mask) v   (0 if none).
+ *   pad [B*N*S] uint8 (1 = masked key) or NULL; causal: key s > query t masked (self-attention).
+ * head_dim is 64; q/k/v/out are head-merged [rows, H*64] with leading dimensions ldq/ldk/ldv/ldo. */
+typedef struct {
+    const void* q; const void* k; const void* v; void* out;
+    long ldq, ldk, ldv, ldo;
+    const uint8_t* pad; const uint8_t* null_entity;
+    int n_qblocks, T, qpb, N, S, H;
+    int exclude_self, causal;
+    float scale;
+} mmsum_attn_desc;
+int mmsum_entity_null(const uint8_t* pad, uint8_t* null_entity, int n_entities, int S, void* stream);
+int mmsum_attn_fwd(int dtype, const mmsum_attn_desc* d, void* stream);
+/* Backward: dq [n_qblocks*T, H*64] (accumulated if accumulate_dq), dk/dv [entity rows, H*64]
+ * overwritten for every entity row of the modality.  stats: f32 workspace of
+ * mmsum_attn_bwd_workspace() bytes (per-entity log-sum-exp and delta handed from the dQ kernel
+ * to the dK/dV kernel). */
+long mmsum_attn_bwd_workspace(const mmsum_attn_desc* d);
+int mmsum_attn_bwd(int dtype, const mmsum_attn_desc* d, const void* dout, long lddo, void* dq, long lddq,
+                   int accumulate_dq, void* dk, long lddk, void* dv, long lddv, void* stats, void* stream);
+
+/* K13 elementwise part (modeling_multimodalsum.py:732-744): given pre-activations pa, pb,
+ * out = yt + relu(tanh(pa))*[!no_table[b]]*ytab + relu(tanh(pb))*[!no_img[b]]*yimg; row r -> b = r / rows_per_b. */
+int mmsum_gate_fwd(int dtype, const void* pa, const void* pb, const void* yt, const void* ytab, const void* yimg,
+                   const uint8_t* no_table, const uint8_t* no_img, void* out, int R, int D, int rows_per_b,
+                   void* stream);
+int mmsum_gate_bwd(int dtype, const void* dout, const void* pa, const void* pb, const void* ytab, const void* yimg,
+                   const uint8_t* no_table, const uint8_t* no_img, void* dpa, void* dpb, void* dyt, void* dytab,
+                   void* dyimg, int R, int D, int rows_per_b, void* stream);
+
+/* K16: label-smoothing loss (/root/reference/src/utils.py:32-38), fused forward + backward:
+ * row_loss[r] = -sum_v true_dist*log_softmax(logits[r,:V]); logits[r,:] <- gscale*(softmax - true_dist)
+ * in place (columns V..ld-1 are zeroed).  smoothing == 0 gives nn.CrossEntropyLoss rows. */
+int mmsum_ls_loss(int dtype, void* logits, long ld, const int64_t* target, float* row_loss, int R, int V,
+                  float smoothing, float gscale, int write_grad, void* stream);
+/* out[s] = scale * sum(x[s*seg : (s+1)*seg]) -- deterministic (per-pass losses, mean loss). */
+int mmsum_segment_sum(const float* x, float* out, int nseg, int seg, float scale, void* stream);
+
+/* K22: out[0] = sum g^2 over n f32 elements (clip_grad_norm_, multimodal_train.py:361-362).
+ * workspace: mmsum_l2_workspace() bytes. */
+long mmsum_l2_workspace(void);
+int mmsum_l2norm_sq(const float* g, long n, float* out, int accumulate, void* workspace, void* stream);
+/* K23: HF AdamW (transformer/optimization.py:240-265) over a flat f32 arena slice.
+ * hyper (device, f32[4]) = {step_size = lr*sqrt(bc2)/bc1, lr*weight_decay, max_grad_norm (<=0: no clip), unused};
+ * norm_sq (device) = total squared grad norm; grads are scaled by min(1, max_norm/(sqrt(norm_sq)+1e-6))
+ * on the fly (the stored gradient is left unscaled).  shadow (bf16, may be NULL) <- bf16(p). */
+int mmsum_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* hyper,
+                const float* norm_sq, float beta1, float beta2, float eps, void* stream);
+/* dst <- cast(src) over n elements; dtype_dst/dtype_src in {F32,BF16}. */
+int mmsum_cast(int dtype_dst, void* dst, int dtype_src, const void* src, long n, void* stream);
+/* dst[i] = scale * src[i] (f32), used to apply the clip coefficient to stored gradients when the
+ * caller (torch.nn.utils.clip_grad_norm_ drop-in) needs them scaled in place. */
+int mmsum_scale_by_clip(float* g, long n, const float* norm_sq, float max_norm, void* stream);
+
+/* ---- ResNet101 stages (img_encoder.py:21-24,31-41; torchvision 0.6.1 resnet101) -------------
+ * Activations are NHWC.  A KxK convolution is im2col (this kernel) + mmsum_gemm; 1x1 stride-1
+ * convolutions are plain GEMMs on the NHWC matrix.  Column order of the im2col matrix is
+ * (kh, kw, c), c fastest; Kpad >= kh*kw*C columns (zero-filled tail). */
+int mmsum_im2col(int dtype, const void* x, void* col, int N, int H, int W, int C, int KH, int KW, int stride,
+                 int pad, int Ho, int Wo, int Kpad, void* stream);
+/* dx[n,h,w,c] = sum of dcol entries that im2col copied from x[n,h,w,c] (gather form, no atomics). */
+int mmsum_col2im(int dtype, const void* dcol, void* dx, int N, int H, int W, int C, int KH, int KW, int stride,
+                 int pad, int Ho, int Wo, int Kpad, void* stream);
+/* f32 [Cout, Cin, KH, KW] <-> dtype [Cout, Kpad] with (kh,kw,c) column order.
+ * to_matrix=1: weight -> matrix (cast, zero tail); to_matrix=0: f32 matrix gradient -> weight-layout
+ * gradient (+= if accumulate). */
+int mmsum_conv_weight_permute(int dtype, void* matrix, float* weight, int Cout, int Cin, int KH, int KW, int Kpad,
+                              int to_matrix, int accumulate, void* stream);
+/* BatchNorm2d (train mode, batch statistics over R = N*H*W rows of an [R, C] NHWC matrix).
+ * stats: sums[2*C] f32 = {sum x, sum x^2} produced by mmsum_bn_reduce; bn_apply normalises with
+ * them (y = relu?(gamma*(x-mean)*rstd + beta (+ residual))) and updates running stats (momentum,
+ * unbiased variance) when running_mean != NULL. */
+long mmsum_bn_workspace(int C);
+int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, void* stream);
+int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gamma, const float* beta,
+                   const void* residual, void* y, float* running_mean, float* running_var, int R, int C, float eps,
+                   float momentum, int relu, int training, void* stream);
+/* BN backward, two launches: bn_reduce over (dy', dy'*xhat) via mmsum_bn_bwd_reduce, then bn_bwd_apply.
+ * dy' = dy * (y > 0) when relu (y = forward output).  dsums[2*C] = {sum dy', sum dy'*xhat}. */
+int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* sums, int R, int C,
+                        float eps, int relu, float* dsums, void* workspace, void* stream);
+int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
+                       const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C,
+                       float eps, int relu, void* stream);
+int mmsum_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* NCHW f32 image -> NHWC dtype. */
+int mmsum_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, void* stream);
+
+/* ---- Table encoder (table_encoder.py:14-83) ---------------------------------------------------
+ * Builds all_embeddings [B,47,2D] = [field-name masked sum | field value] and the mask [B,47];
+ * embedding reads are gradient-free in the reference (torch.no_grad). */
+int mmsum_table_gather(int dtype, const void* E, const int64_t* field, const int64_t* name, const int64_t* category,
+                       const int64_t* str_cat, const int64_t* str_bool, const int64_t* rating, const int64_t* hours,
+                       const void* w_rating, const void* w_hours, void* out, uint8_t* mask, int B, int D, int pad_id,
+                       void* stream);
+/* d w_rating [D,4] += sum_b rating[b,k] * dvalue[b,39,d]; d w_hours [D,4] += sum_{b,j} hours[b,j,k]*dvalue[b,40+j,d]
+ * where dvalue = dall[:, :, D:2D] (f32 accumulation). */
+int mmsum_table_gather_bwd(int dtype, const void* dall, const int64_t* rating, const int64_t* hours, float* dw_rating,
+                           float* dw_hours, int B, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

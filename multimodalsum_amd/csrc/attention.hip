@@ -1,0 +1,505 @@
+// Entity attention for gfx950: encoder self-attention, causal decoder self-attention and the
+// reference's per-entity cross-attention with entity mean (modeling_multimodalsum.py:752-875),
+// forward and backward, bf16 or f32 operands with f32 softmax/accumulation.  head_dim = 64.
+//
+// Forward / dQ kernels: one workgroup = (query block of <=128 rows, head); 4 waves x 32 query rows.
+//   Scores are computed TRANSPOSED (S^T = K Q^T: keys on accumulator rows, the query on the lane),
+//   so the row softmax is register-local plus one cross-half shuffle, and the probabilities go to
+//   LDS through the cheap transposed accumulator store to become the A operand of P.V.
+//   One LDS tile region is reused per entity: K (natural) -> V^T (forward) or V -> K^T (dQ).
+//   The [N,B,H,T,hd] per-entity outputs of the reference are never materialised: 1/(count*l) is
+//   folded into P and every entity accumulates into the same O registers.
+// dK/dV kernel: one workgroup = (entity, head); waves own 32-key blocks and sweep the query
+//   blocks that attend to the entity (8 of the 9 leave-one-out passes for a review), so dK/dV need
+//   no atomics.  Softmax statistics (log-sum-exp, delta) come from the dQ kernel via `stats`.
+#include "mmsum_device.h"
+#include "mmsum_kernels.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int ATT_THREADS = 256;
+
+template <typename T> struct AttnTraits {
+    static constexpr int kSlabsHD = HD * sizeof(T) / SLAB_BYTES;      // slabs covering head_dim (2 bf16 / 4 f32)
+    static constexpr int kSlabsPer32 = 32 * sizeof(T) / SLAB_BYTES;   // slabs covering 32 reduction elements (1 / 2)
+};
+
+__device__ __forceinline__ int count_valid(const mmsum_attn_desc& d, int b, int excl) {
+    int cnt = 0;
+    for (int n = 0; n < d.N; ++n) {
+        if (n == excl) continue;
+        if (d.null_entity && d.null_entity[b * d.N + n]) continue;
+        ++cnt;
+    }
+    return cnt;
+}
+
+// Stage the key mask of one entity into LDS: 1 = masked (padded key, or key index >= S).
+__device__ __forceinline__ void stage_mask(uint8_t* m, const uint8_t* pad, long ent, int S, int spad, int tid) {
+    for (int s = tid; s < spad; s += ATT_THREADS) m[s] = (s >= S) ? 1 : (pad ? pad[ent * S + s] : 0);
+}
+
+// Scores of one entity for this wave's 32 queries, transposed: sacc[kb][reg] = q . k[key], key =
+// kb*32 + acc_row(reg).  Then scale + mask + softmax statistics.  On return sacc holds
+// exp(s - m) (0 for masked keys); *m_out, *l_out are the row max and sum for the lane's query.
+template <typename T, int NKB>
+__device__ __forceinline__ void scores_softmax(f32x16_t (&sacc)[NKB], const char* ktile, int spad, const Frag* qf,
+                                               const uint8_t* maskb, int S, float scale, bool causal, int qpos, int lane,
+                                               float& m_out, float& l_out) {
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        sacc[kb] = zero_acc();
+        if (kb * 32 < S) {
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const Frag a = lds_frag<T>(ktile + sl * (spad * SLAB_BYTES), kb * 32, lane);
+                mma_slab<T>(sacc[kb], a, qf[sl]);
+            }
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + acc_row(r, lane);
+            const bool masked = (kb * 32 >= S) || maskb[key] || (causal && key > qpos);
+            const float s = masked ? -INFINITY : sacc[kb][r] * scale;
+            sacc[kb][r] = s;
+            m = fmaxf(m, s);
+        }
+    }
+    m = wave_half_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (m == -INFINITY) ? 0.f : __expf(sacc[kb][r] - m);
+            sacc[kb][r] = p;
+            l += p;
+        }
+    }
+    l = wave_half_sum(l);
+    m_out = m;
+    l_out = l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NKB>
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(mmsum_attn_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+    constexpr int TILE = SPAD * HD * sizeof(T);
+    char* tile = smem;
+    char* img = smem + TILE + (threadIdx.x >> 6) * ImageTraits<T>::kBytes;
+    uint8_t* maskb = reinterpret_cast<uint8_t*>(smem + TILE + 4 * ImageTraits<T>::kBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, qb = blockIdx.y;
+    const int b = qb / d.qpb;
+    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
+    const int cnt = count_valid(d, b, excl);
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+    T* O = static_cast<T*>(d.out);
+
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+    Frag qf[NS];
+    {
+        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) qf[sl] = global_frag<T>(qrow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
+    }
+    f32x16_t oacc[2] = {zero_acc(), zero_acc()};
+
+    for (int n = 0; n < d.N; ++n) {
+        if (n == excl) continue;
+        const long ent = (long)b * d.N + n;
+        if (d.null_entity && d.null_entity[ent]) continue;
+        const long row0 = ent * d.S;
+        __syncthreads();
+        stage_natural<T, SPAD, NS, ATT_THREADS>(tile, K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
+        stage_mask(maskb, d.pad, ent, d.S, SPAD, tid);
+        __syncthreads();
+        f32x16_t sacc[NKB];
+        float m, l;
+        scores_softmax<T, NKB>(sacc, tile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
+        __syncthreads();
+        // V^T: tile row = d (64 rows), reduction = key
+        stage_transposed<T, HD, NKB * AttnTraits<T>::kSlabsPer32, ATT_THREADS>(tile, V + row0 * d.ldv + h * HD, d.ldv, 0, HD, 0, d.S, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * 32 < d.S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] *= norm;
+                acc_to_image<T>(img, sacc[kb], lane);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    mma_image<T>(oacc[db], img, tile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + acc_row(r, lane);
+            if (qq < d.T) O[((long)qb * d.T + qq) * d.ldo + col] = from_f32<T>(oacc[db][r]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, kernel A: dQ (+ per-entity log-sum-exp and delta for kernel B)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NKB>
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
+                                                                  T* __restrict__ dQ, long lddq, int accumulate_dq,
+                                                                  float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+    constexpr int TILE = SPAD * HD * sizeof(T);
+    char* tile = smem;
+    char* img = smem + TILE + (threadIdx.x >> 6) * ImageTraits<T>::kBytes;
+    uint8_t* maskb = reinterpret_cast<uint8_t*>(smem + TILE + 4 * ImageTraits<T>::kBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, qb = blockIdx.y;
+    const int b = qb / d.qpb;
+    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
+    const int cnt = count_valid(d, b, excl);
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+    Frag qf[NS], dof[NS];
+    {
+        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
+        const T* drow = dO + ((long)qb * d.T + qpos) * lddo + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            qf[sl] = global_frag<T>(qrow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
+            dof[sl] = global_frag<T>(drow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
+        }
+    }
+    f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
+
+    for (int n = 0; n < d.N; ++n) {
+        if (n == excl) continue;
+        const long ent = (long)b * d.N + n;
+        if (d.null_entity && d.null_entity[ent]) continue;
+        const long row0 = ent * d.S;
+        __syncthreads();
+        stage_natural<T, SPAD, NS, ATT_THREADS>(tile, K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
+        stage_mask(maskb, d.pad, ent, d.S, SPAD, tid);
+        __syncthreads();
+        f32x16_t p[NKB];
+        float m, l;
+        scores_softmax<T, NKB>(p, tile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        const float invl = (l > 0.f) ? 1.f / l : 0.f;
+        __syncthreads();
+        stage_natural<T, SPAD, NS, ATT_THREADS>(tile, V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
+        __syncthreads();
+        // dP^T[key][q] = v[key] . dO[q]
+        f32x16_t dp[NKB];
+        float delta = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            dp[kb] = zero_acc();
+            if (kb * 32 < d.S) {
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const Frag a = lds_frag<T>(tile + sl * (SPAD * SLAB_BYTES), kb * 32, lane);
+                    mma_slab<T>(dp[kb], a, dof[sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[kb][r] *= invl;                 // normalised probability
+                    dp[kb][r] *= inv_cnt;             // dO_e = dO / count
+                    delta += p[kb][r] * dp[kb][r];
+                }
+            }
+        }
+        delta = wave_half_sum(delta);
+        if (lane < 32 && qvalid) {
+            float* st = stats + ((((long)qb * d.N + n) * d.H + h) * d.T + qpos) * 2;
+            st[0] = m + __logf(l);
+            st[1] = delta;
+        }
+        __syncthreads();
+        // K^T: tile row = d, reduction = key
+        stage_transposed<T, HD, NKB * AttnTraits<T>::kSlabsPer32, ATT_THREADS>(tile, K + row0 * d.ldk + h * HD, d.ldk, 0, HD, 0, d.S, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * 32 < d.S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[kb][r] = p[kb][r] * (dp[kb][r] - delta) * d.scale;   // dS^T
+                acc_to_image<T>(img, p[kb], lane);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    mma_image<T>(dqacc[db], img, tile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + acc_row(r, lane);
+            if (qq < d.T) {
+                T* o = dQ + ((long)qb * d.T + qq) * lddq + col;
+                const float v = dqacc[db][r] + (accumulate_dq ? to_f32(*o) : 0.f);
+                *o = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward, kernel B: dK, dV
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NKB>
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
+                                                                   T* __restrict__ dK, long lddk, T* __restrict__ dV, long lddv,
+                                                                   const float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+    constexpr int TQ = 64;                                   // query rows staged per step
+    constexpr int NOWN = (NKB + 3) / 4;                      // key blocks owned by a wave
+    constexpr int QT_TILE = TQ * HD * sizeof(T);             // one staged tile
+    constexpr int NSQ = TQ * sizeof(T) / SLAB_BYTES;         // slabs covering TQ queries (2 / 4)
+    char* qn = smem;                  // Q natural  [TQ rows][64]
+    char* don = smem + QT_TILE;       // dO natural
+    char* qt = smem + 2 * QT_TILE;    // Q^T  [64 rows (d)][TQ]
+    char* dot = smem + 3 * QT_TILE;   // dO^T
+    char* imgP = smem + 4 * QT_TILE + (threadIdx.x >> 6) * 2 * ImageTraits<T>::kBytes;
+    char* imgS = imgP + ImageTraits<T>::kBytes;
+    float* st = reinterpret_cast<float*>(smem + 4 * QT_TILE + 8 * ImageTraits<T>::kBytes);   // [TQ][2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x;
+    const long ent = blockIdx.y;
+    const int b = (int)(ent / d.N), n = (int)(ent % d.N);
+    const long row0 = ent * d.S;
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+    const bool is_null = d.null_entity && d.null_entity[ent];
+
+    Frag kf[NOWN][NS], vf[NOWN][NS];
+    bool keymask[NOWN];
+    f32x16_t dkacc[NOWN][2], dvacc[NOWN][2];
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int key = (wave + 4 * o) * 32 + (lane & 31);
+        const bool kvalid = key < d.S;
+        keymask[o] = !kvalid || (d.pad && d.pad[ent * d.S + (kvalid ? key : 0)]);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            kf[o][sl] = global_frag<T>(K + (row0 + key) * d.ldk + h * HD + sl * ElemTraits<T>::kPerSlab, lane, kvalid);
+            vf[o][sl] = global_frag<T>(V + (row0 + key) * d.ldv + h * HD + sl * ElemTraits<T>::kPerSlab, lane, kvalid);
+        }
+        dkacc[o][0] = dkacc[o][1] = dvacc[o][0] = dvacc[o][1] = zero_acc();
+    }
+
+    if (!is_null) {
+        for (int i = 0; i < d.qpb; ++i) {
+            if (d.exclude_self && i == n) continue;
+            const int qb = b * d.qpb + i;
+            const int cnt = count_valid(d, b, d.exclude_self ? i : -1);
+            const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+            const T* qbase = Q + (long)qb * d.T * d.ldq + h * HD;
+            const T* dobase = dO + (long)qb * d.T * lddo + h * HD;
+            const float* sbase = stats + (((long)qb * d.N + n) * d.H + h) * d.T * 2;
+            for (int qc = 0; qc < d.T; qc += TQ) {
+                __syncthreads();
+                stage_natural<T, TQ, NS, ATT_THREADS>(qn, qbase, d.ldq, qc, d.T, 0, HD, tid);
+                stage_natural<T, TQ, NS, ATT_THREADS>(don, dobase, lddo, qc, d.T, 0, HD, tid);
+                // transposed: tile row = d (64), reduction index = query (element (d, q) at base[q*ld + d])
+                stage_transposed<T, HD, NSQ, ATT_THREADS>(qt, qbase, d.ldq, 0, HD, qc, d.T, tid);
+                stage_transposed<T, HD, NSQ, ATT_THREADS>(dot, dobase, lddo, 0, HD, qc, d.T, tid);
+                for (int j = tid; j < TQ * 2; j += ATT_THREADS) st[j] = (qc + (j >> 1) < d.T) ? sbase[(long)qc * 2 + j] : 0.f;
+                __syncthreads();
+#pragma unroll
+                for (int o = 0; o < NOWN; ++o) {
+                    const int kb = wave + 4 * o;
+                    if (kb >= NKB || kb * 32 >= d.S) continue;
+                    const int key = kb * 32 + (lane & 31);
+#pragma unroll
+                    for (int qq = 0; qq < TQ / 32; ++qq) {
+                        if (qc + qq * 32 >= d.T) continue;
+                        f32x16_t s = zero_acc(), dp = zero_acc();
+#pragma unroll
+                        for (int sl = 0; sl < NS; ++sl) {
+                            const Frag aq = lds_frag<T>(qn + sl * (TQ * SLAB_BYTES), qq * 32, lane);
+                            mma_slab<T>(s, aq, kf[o][sl]);
+                            const Frag ad = lds_frag<T>(don + sl * (TQ * SLAB_BYTES), qq * 32, lane);
+                            mma_slab<T>(dp, ad, vf[o][sl]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ql = qq * 32 + acc_row(r, lane);      // query within the staged chunk
+                            const int qg = qc + ql;                         // query position in the block
+                            const bool masked = keymask[o] || qg >= d.T || (d.causal && key > qg);
+                            const float pr = masked ? 0.f : __expf(s[r] * d.scale - st[ql * 2]);
+                            dp[r] = pr * (dp[r] * inv_cnt - st[ql * 2 + 1]) * d.scale;   // dS
+                            s[r] = pr * inv_cnt;                                        // P / count
+                        }
+                        acc_to_image<T>(imgP, s, lane);
+                        acc_to_image<T>(imgS, dp, lane);
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            mma_image<T>(dvacc[o][db], imgP, dot + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                            mma_image<T>(dkacc[o][db], imgS, qt + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int kb = wave + 4 * o;
+        if (kb >= NKB) continue;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, lane);
+                if (key < d.S) {
+                    dK[(row0 + key) * lddk + col] = from_f32<T>(dkacc[o][db][r]);
+                    dV[(row0 + key) * lddv + col] = from_f32<T>(dvacc[o][db][r]);
+                }
+            }
+        }
+    }
+}
+
+__global__ void entity_null_kernel(const uint8_t* __restrict__ pad, uint8_t* __restrict__ null_entity, int S) {
+    __shared__ int any_live;
+    if (threadIdx.x == 0) any_live = 0;
+    __syncthreads();
+    int live = 0;
+    for (int s = threadIdx.x; s < S; s += blockDim.x) live |= (pad[(long)blockIdx.x * S + s] == 0);
+    if (live) any_live = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) null_entity[blockIdx.x] = any_live ? 0 : 1;
+}
+
+template <typename T> size_t fwd_lds(int nkb) { return (size_t)nkb * 32 * HD * sizeof(T) + 4 * ImageTraits<T>::kBytes + nkb * 32 + 16; }
+template <typename T> size_t dkv_lds() { return 4 * (size_t)64 * HD * sizeof(T) + 8 * ImageTraits<T>::kBytes + 64 * 2 * sizeof(float); }
+
+// Dynamic LDS above 64 KiB must be opted into per kernel (once; read-only afterwards).
+template <typename KernelT>
+inline void allow_lds(KernelT kernel, size_t bytes) {
+    if (bytes > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+#define LAUNCH_LDS(kern, grid, block, lds, s, ...)            \
+    do {                                                      \
+        static bool once = false;                             \
+        if (!once) { allow_lds(kern, lds); once = true; }     \
+        kern<<<grid, block, lds, s>>>(__VA_ARGS__);           \
+    } while (0)
+
+inline int nkb_for(int S) { return S <= 64 ? 2 : (S <= 128 ? 4 : 7); }
+
+template <typename T>
+int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
+    const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
+    const int nkb = nkb_for(d.S);
+    const size_t lds = fwd_lds<T>(nkb);
+    if (nkb == 2) LAUNCH_LDS((attn_fwd_kernel<T, 2>), grid, block, lds, s, d);
+    else if (nkb == 4) LAUNCH_LDS((attn_fwd_kernel<T, 4>), grid, block, lds, s, d);
+    else LAUNCH_LDS((attn_fwd_kernel<T, 7>), grid, block, lds, s, d);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+template <typename T>
+int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, long lddq, int accumulate_dq, void* dk, long lddk,
+               void* dv, long lddv, void* stats, hipStream_t s) {
+    const int nkb = nkb_for(d.S);
+    {
+        const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
+        const size_t lds = fwd_lds<T>(nkb);
+        if (nkb == 2) LAUNCH_LDS((attn_bwd_dq_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        else if (nkb == 4) LAUNCH_LDS((attn_bwd_dq_kernel<T, 4>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        else LAUNCH_LDS((attn_bwd_dq_kernel<T, 7>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+    }
+    {
+        const int n_ent = (d.n_qblocks / d.qpb) * d.N;
+        const dim3 grid(d.H, n_ent), block(ATT_THREADS);
+        const size_t lds = dkv_lds<T>();
+        if (nkb == 2) LAUNCH_LDS((attn_bwd_dkv_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        else if (nkb == 4) LAUNCH_LDS((attn_bwd_dkv_kernel<T, 4>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        else LAUNCH_LDS((attn_bwd_dkv_kernel<T, 7>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+    }
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+int check_desc(const mmsum_attn_desc* d, int dtype) {
+    if (!d || d->T <= 0 || d->T > 128 || d->S <= 0 || d->S > 224 || d->N <= 0 || d->H <= 0 || d->qpb <= 0 || d->n_qblocks <= 0 ||
+        d->n_qblocks % d->qpb)
+        return MMSUM_ERR_BAD_SHAPE;
+    if (dtype != MMSUM_F32 && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
+    const long es = dtype == MMSUM_BF16 ? 2 : 4;
+    if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) return MMSUM_ERR_BAD_ALIGN;
+    if (((d->ldq | d->ldk | d->ldv) * es) & 15) return MMSUM_ERR_BAD_ALIGN;
+    return MMSUM_OK;
+}
+
+}  // namespace
+
+extern "C" int mmsum_entity_null(const uint8_t* pad, uint8_t* null_entity, int n_entities, int S, void* stream) {
+    if (n_entities <= 0 || S <= 0) return MMSUM_ERR_BAD_SHAPE;
+    entity_null_kernel<<<dim3(n_entities), dim3(64), 0, (hipStream_t)stream>>>(pad, null_entity, S);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+extern "C" int mmsum_attn_fwd(int dtype, const mmsum_attn_desc* d, void* stream) {
+    const int rc = check_desc(d, dtype);
+    if (rc != MMSUM_OK) return rc;
+    return dtype == MMSUM_BF16 ? attn_fwd_t<bf16_t>(*d, (hipStream_t)stream) : attn_fwd_t<float>(*d, (hipStream_t)stream);
+}
+
+extern "C" long mmsum_attn_bwd_workspace(const mmsum_attn_desc* d) {
+    if (!d) return 0;
+    return (long)d->n_qblocks * d->N * d->H * d->T * 2 * (long)sizeof(float);
+}
+
+extern "C" int mmsum_attn_bwd(int dtype, const mmsum_attn_desc* d, const void* dout, long lddo, void* dq, long lddq,
+                              int accumulate_dq, void* dk, long lddk, void* dv, long lddv, void* stats, void* stream) {
+    const int rc = check_desc(d, dtype);
+    if (rc != MMSUM_OK) return rc;
+    const long es = dtype == MMSUM_BF16 ? 2 : 4;
+    if (((uintptr_t)dout & 15) || ((lddo * es) & 15)) return MMSUM_ERR_BAD_ALIGN;
+    if (!stats) return MMSUM_ERR_WORKSPACE;
+    return dtype == MMSUM_BF16 ? attn_bwd_t<bf16_t>(*d, dout, lddo, dq, lddq, accumulate_dq, dk, lddk, dv, lddv, stats, (hipStream_t)stream)
+                               : attn_bwd_t<float>(*d, dout, lddo, dq, lddq, accumulate_dq, dk, lddk, dv, lddv, stats, (hipStream_t)stream);
+}

@@ -1,0 +1,222 @@
+// MFMA GEMM for gfx950:  C[m][n] = epi(alpha * sum_k A(m,k) * B(n,k) + bias[n])  (+ C)
+//
+// One kernel covers the three products of a linear layer by choosing how each operand is staged
+// into the common k-slab LDS format (mmsum_device.h):
+//   forward  y = x W^T        : A natural  (x  [M,K]),   B natural    (W [N,K])
+//   dgrad    dx = dy W        : A natural  (dy [M,N']),  B transposed (W [N',K'] read as B(n=k',k=n'))
+//   wgrad    dW = dy^T x      : A transposed (dy [M',N]), B transposed (x [M',K'])
+// Block tile 128x128, 4 waves in a 2x2 grid, each wave 64x64 = 2x2 MFMA 32x32 tiles; K step =
+// two 64-byte slabs (64 bf16 / 32 f32); register-staged double buffering (global loads for tile
+// t+1 are issued before the MFMAs of tile t, the LDS writes after them); one barrier per K step.
+// Workgroup ids are remapped so that consecutive tiles (which share an A panel) land on one XCD.
+#include "mmsum_device.h"
+#include "mmsum_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, NSLAB = 2, THREADS = 256;
+constexpr int TILE_BYTES = BM * NSLAB * SLAB_BYTES;  // 16 KiB per operand per stage
+
+struct GemmArgs {
+    const void* A; const void* A2; const void* B; void* C; const float* bias; void* aux;
+    int M, N, K; long lda, lda2, ldb, ldc, ldaux; int ksplit; float alpha; int flags; int splitk;
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+template <typename T> struct NatRegs { u32x4_t v[4]; };
+
+template <typename T>
+__device__ __forceinline__ void nat_load(NatRegs<T>& r, const T* __restrict__ g, long ld, int row_lo, int R, int k0, int K, int tid) {
+    constexpr int CPR = NSLAB * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int id = tid + it * THREADS;
+        const int row = id / CPR, cc = id % CPR;
+        const int grow = row_lo + row, gk = k0 + cc * ElemTraits<T>::kPerChunk;
+        r.v[it] = u32x4_t{0, 0, 0, 0};
+        if (grow < R && gk < K) r.v[it] = *reinterpret_cast<const u32x4_t*>(g + (long)grow * ld + gk);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void nat_store(char* lds, const NatRegs<T>& r, int tid) {
+    constexpr int CPR = NSLAB * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int id = tid + it * THREADS;
+        const int row = id / CPR, cc = id % CPR;
+        *reinterpret_cast<u32x4_t*>(lds + (cc >> 2) * (BM * SLAB_BYTES) + slab_off(row, cc & 3)) = r.v[it];
+    }
+}
+
+template <typename T, bool AT, bool BT>
+__global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KC = ElemTraits<T>::kPerChunk;
+    constexpr int BK = NSLAB * ElemTraits<T>::kPerSlab;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- tile assignment (bijective XCD remap: blocks b and b+8 share an XCD) -------------
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int tiles = tiles_m * tiles_n;
+    const int ks = wg / tiles;                 // split-K slice
+    const int t = wg % tiles;
+    const int tm = t / tiles_n, tn = t % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- K range of this slice ---------------------------------------------------------------
+    const int ktiles = (p.K + BK - 1) / BK;
+    const int per = (ktiles + p.splitk - 1) / p.splitk;
+    const int kt_beg = ks * per, kt_end = min(ktiles, kt_beg + per);
+
+    const T* A = static_cast<const T*>(p.A);
+    const T* A2 = static_cast<const T*>(p.A2);
+    const T* B = static_cast<const T*>(p.B);
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero_acc();
+
+    NatRegs<T> an, bn;
+    TBlock<T> at, bt;
+    const int t_rg = tid & 31, t_kg = tid >> 5;   // transposed staging: 32 row groups x 8 k groups
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+        if constexpr (AT) {
+            load_tblock<T>(at, A, p.lda, m0 + t_rg * 4, p.M, k0 + t_kg * KC, p.K);
+        } else {
+            if (A2 != nullptr && k0 >= p.ksplit) nat_load<T>(an, A2, p.lda2, m0, p.M, k0 - p.ksplit, p.K - p.ksplit, tid);
+            else nat_load<T>(an, A, p.lda, m0, p.M, k0, (A2 != nullptr) ? p.ksplit : p.K, tid);
+        }
+        if constexpr (BT) load_tblock<T>(bt, B, p.ldb, n0 + t_rg * 4, p.N, k0 + t_kg * KC, p.K);
+        else nat_load<T>(bn, B, p.ldb, n0, p.N, k0, p.K, tid);
+    };
+    auto store_tile = [&](int buf) {
+        char* As = smem + buf * 2 * TILE_BYTES;
+        char* Bs = As + TILE_BYTES;
+        if constexpr (AT) store_tblock<T>(As, BM, at, t_rg * 4, t_kg, m0 + t_rg * 4, p.M);
+        else nat_store<T>(As, an, tid);
+        if constexpr (BT) store_tblock<T>(Bs, BN, bt, t_rg * 4, t_kg, n0 + t_rg * 4, p.N);
+        else nat_store<T>(Bs, bn, tid);
+    };
+
+    if (kt_beg < kt_end) {
+        load_tile(kt_beg);
+        store_tile(0);
+        __syncthreads();
+        int cur = 0;
+        for (int kt = kt_beg; kt < kt_end; ++kt) {
+            const bool more = (kt + 1 < kt_end);
+            if (more) load_tile(kt + 1);
+            const char* As = smem + cur * 2 * TILE_BYTES;
+            const char* Bs = As + TILE_BYTES;
+#pragma unroll
+            for (int s = 0; s < NSLAB; ++s) {
+                Frag a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) a[i] = lds_frag<T>(As + s * (BM * SLAB_BYTES), wm * 64 + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b[j] = lds_frag<T>(Bs + s * (BN * SLAB_BYTES), wn * 64 + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma_slab<T>(acc[i][j], a[i], b[j]);
+            }
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    const int epi = (p.flags >> 3) & 7;
+    const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
+    const bool accum = p.flags & MMSUM_GEMM_ACCUM;
+    const bool out_f32 = p.flags & MMSUM_GEMM_OUT_F32;
+    const bool atomic = p.splitk > 1;
+    float* Cf = static_cast<float*>(p.C);
+    T* Ct = static_cast<T*>(p.C);
+    T* aux = static_cast<T*>(p.aux);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (col >= p.N) continue;
+        const float bv = has_bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha + bv;
+                if (epi == MMSUM_EPI_GELU) {
+                    if (aux) aux[(long)row * p.ldaux + col] = from_f32<T>(v);
+                    v = gelu_f(v);
+                } else if (epi == MMSUM_EPI_GELU_BWD) {
+                    v *= gelu_grad_f(to_f32(aux[(long)row * p.ldaux + col]));
+                } else if (epi == MMSUM_EPI_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if (epi == MMSUM_EPI_RELU_BWD) {
+                    v = (to_f32(aux[(long)row * p.ldaux + col]) > 0.f) ? v : 0.f;
+                }
+                const long o = (long)row * p.ldc + col;
+                if (atomic) {
+                    atomicAdd(Cf + o, v);
+                } else if (out_f32) {
+                    Cf[o] = accum ? Cf[o] + v : v;
+                } else {
+                    Ct[o] = from_f32<T>(accum ? to_f32(Ct[o]) + v : v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const dim3 grid(tiles * a.splitk), block(THREADS);
+    const size_t lds = 4 * TILE_BYTES;
+    const bool at = a.flags & MMSUM_GEMM_A_T, bt = a.flags & MMSUM_GEMM_B_T;
+    if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, lds, stream, a);
+    else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, lds, stream, a);
+    else if (at && bt) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, lds, stream, a);
+    else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, lds, stream, a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+}  // namespace
+
+extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
+                          void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
+                          int flags, int splitk, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || splitk < 1) return MMSUM_ERR_BAD_SHAPE;
+    if (dtype != MMSUM_F32 && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
+    const int kc = (dtype == MMSUM_BF16) ? 8 : 4;
+    const int bk = (dtype == MMSUM_BF16) ? 64 : 32;
+    const bool at = flags & MMSUM_GEMM_A_T, bt = flags & MMSUM_GEMM_B_T;
+    if (!at && (K % kc)) return MMSUM_ERR_BAD_SHAPE;
+    if (!bt && (K % kc)) return MMSUM_ERR_BAD_SHAPE;
+    if (A2 && (at || ksplit % bk || ksplit <= 0 || ksplit >= K)) return MMSUM_ERR_BAD_SHAPE;
+    if (splitk > 1 && !((flags & MMSUM_GEMM_OUT_F32) && (flags & MMSUM_GEMM_ACCUM))) return MMSUM_ERR_BAD_SHAPE;
+    const size_t es = (dtype == MMSUM_BF16) ? 2 : 4;
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2) & 15) return MMSUM_ERR_BAD_ALIGN;
+    if (!at && ((lda * es) & 15)) return MMSUM_ERR_BAD_ALIGN;
+    if (!bt && ((ldb * es) & 15)) return MMSUM_ERR_BAD_ALIGN;
+    if (at && ((lda * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
+    if (bt && ((ldb * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
+    GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
+}

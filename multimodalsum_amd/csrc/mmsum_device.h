@@ -1,0 +1,262 @@
+// Device-side building blocks shared by every MFMA kernel of libmmsum_hip (gfx950 / CDNA4 only).
+//
+// One LDS operand format serves GEMM, attention forward and both attention backward kernels:
+//
+//   "k-slab tile": an operand tile of R rows x K reduction elements, K-contiguous, is stored as
+//   K*sizeof(T)/64 slabs; slab s holds bytes [64 s, 64 s + 64) of every row, i.e. R rows of 64 B
+//   (32 bf16 or 16 f32 reduction elements).  Inside a slab the four 16-B chunks of row r are
+//   XOR-swizzled with (r >> 2) & 3, which makes the ds_read_b128 fragment reads of a 32-row MFMA
+//   operand block conflict-free (bank = (addr/4) % 64, 16-lane groups; MI355X guide section LDS).
+//
+//   A wave computes a 32x32 f32 tile  acc[i][j] += sum_k A[i][k] * B[j][k]  from two such
+//   tiles (both "row x k", so B is addressed by OUTPUT COLUMN) with
+//     bf16: 2 x v_mfma_f32_32x32x16_bf16 per slab   (lane (r=l&31,h=l>>5) reads chunks h and 2+h)
+//     f32 : 8 x v_mfma_f32_32x32x2_f32  per slab   (lane reads chunks 2h and 2h+1; the k order is
+//           permuted identically for A and B, which a reduction does not see)
+//   Accumulator layout (both dtypes): col j = lane & 31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define MMSUM_WAVE 64
+#define SLAB_BYTES 64
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> { static constexpr int kPerChunk = 8; static constexpr int kPerSlab = 32; };
+template <> struct ElemTraits<float>  { static constexpr int kPerChunk = 4; static constexpr int kPerSlab = 16; };
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// Byte offset of chunk c (0..3) of row r inside one slab.
+__device__ __forceinline__ int slab_off(int r, int c) { return r * SLAB_BYTES + (((c ^ (r >> 2)) & 3) << 4); }
+
+// The two 16-B chunks a lane feeds to the MFMAs of one slab.
+struct Frag { u32x4_t c[2]; };
+
+template <typename T> __device__ __forceinline__ int lane_chunk(int h, int i);
+template <> __device__ __forceinline__ int lane_chunk<bf16_t>(int h, int i) { return 2 * i + h; }
+template <> __device__ __forceinline__ int lane_chunk<float>(int h, int i) { return 2 * h + i; }
+
+// Fragment of a 32-row operand block whose first row is `row0` (multiple of 4) of slab `slab`.
+template <typename T>
+__device__ __forceinline__ Frag lds_frag(const char* slab, int row0, int lane) {
+    const int r = row0 + (lane & 31), h = lane >> 5;
+    Frag f;
+    f.c[0] = *reinterpret_cast<const u32x4_t*>(slab + slab_off(r, lane_chunk<T>(h, 0)));
+    f.c[1] = *reinterpret_cast<const u32x4_t*>(slab + slab_off(r, lane_chunk<T>(h, 1)));
+    return f;
+}
+
+// Same fragment straight from global memory (row-major, K-contiguous): `rowptr` points at this
+// lane's row, element 0 of the slab.  Used for operands a wave reads once (Q / dO / K / V rows).
+template <typename T>
+__device__ __forceinline__ Frag global_frag(const T* rowptr, int lane, bool valid) {
+    const int h = lane >> 5;
+    Frag f;
+    if (valid) {
+        f.c[0] = *reinterpret_cast<const u32x4_t*>(rowptr + lane_chunk<T>(h, 0) * ElemTraits<T>::kPerChunk);
+        f.c[1] = *reinterpret_cast<const u32x4_t*>(rowptr + lane_chunk<T>(h, 1) * ElemTraits<T>::kPerChunk);
+    } else {
+        f.c[0] = u32x4_t{0, 0, 0, 0};
+        f.c[1] = u32x4_t{0, 0, 0, 0};
+    }
+    return f;
+}
+
+template <typename T> __device__ __forceinline__ void mma_slab(f32x16_t& acc, const Frag& a, const Frag& b);
+template <> __device__ __forceinline__ void mma_slab<bf16_t>(f32x16_t& acc, const Frag& a, const Frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.c[0]), __builtin_bit_cast(bf16x8_t, b.c[0]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a.c[1]), __builtin_bit_cast(bf16x8_t, b.c[1]), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma_slab<float>(f32x16_t& acc, const Frag& a, const Frag& b) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f32x4_t av = __builtin_bit_cast(f32x4_t, a.c[i]);
+        const f32x4_t bv = __builtin_bit_cast(f32x4_t, b.c[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc, 0, 0, 0);
+    }
+}
+
+// Row (A-operand index) of accumulator register `reg` for this lane.
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ f32x16_t zero_acc() {
+    f32x16_t z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// --------------------------------------------------------------------------------------------
+// Staging: global -> LDS k-slab tile
+// --------------------------------------------------------------------------------------------
+// (a) operand stored row-major with the reduction index contiguous ("natural"):
+//     rows [row_lo, row_lo+ROWS) x k [k0, k0 + NSLAB*kPerSlab), zero-filled outside [0,R) x [0,K).
+//     K must be a multiple of kPerChunk.  All THREADS threads of the block take part.
+template <typename T, int ROWS, int NSLAB, int THREADS>
+__device__ __forceinline__ void stage_natural(char* lds, const T* __restrict__ g, long ld, int row_lo, int R,
+                                              int k0, int K, int tid) {
+    constexpr int CPR = NSLAB * 4;                 // 16-B chunks per row
+    constexpr int TOTAL = ROWS * CPR;
+#pragma unroll
+    for (int it = 0; it < (TOTAL + THREADS - 1) / THREADS; ++it) {
+        const int id = tid + it * THREADS;
+        if (TOTAL % THREADS != 0 && id >= TOTAL) break;
+        const int r = id / CPR, cc = id % CPR;
+        const int grow = row_lo + r, gk = k0 + cc * ElemTraits<T>::kPerChunk;
+        u32x4_t v = u32x4_t{0, 0, 0, 0};
+        if (grow < R && gk < K) v = *reinterpret_cast<const u32x4_t*>(g + (long)grow * ld + gk);
+        *reinterpret_cast<u32x4_t*>(lds + (cc >> 2) * (ROWS * SLAB_BYTES) + slab_off(r, cc & 3)) = v;
+    }
+}
+
+// (b) operand stored with the OUTPUT index contiguous and the reduction index strided
+//     ("transposed": element (row, k) lives at g[k*ld + row]).  Each thread moves a
+//     kPerChunk(k) x 4(rows) block through registers and writes 4 full 16-B chunks.
+//     rows [row_lo, row_lo+ROWS) x k [k0, k0+NSLAB*kPerSlab); zero-filled outside [0,R) x [0,K).
+//     Row guard on LOADS has 4-element granularity: the allocation must be readable up to the
+//     next multiple of 4 rows (all call sites have R % 4 == 0 or a padded leading dimension);
+//     elements at rows >= R are zeroed before they reach LDS.
+template <typename T> struct TBlock { T e[ElemTraits<T>::kPerChunk][4]; };
+
+template <typename T>
+__device__ __forceinline__ void load_tblock(TBlock<T>& b, const T* __restrict__ g, long ld, int grow, int R, int gk0, int K) {
+    constexpr int KC = ElemTraits<T>::kPerChunk;
+#pragma unroll
+    for (int kk = 0; kk < KC; ++kk) {
+        const int gk = gk0 + kk;
+        if (grow < R && gk < K) {
+            if constexpr (sizeof(T) == 2) {
+                const u32x2_t v = *reinterpret_cast<const u32x2_t*>(g + (long)gk * ld + grow);
+                const bf16x4_t e = __builtin_bit_cast(bf16x4_t, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b.e[kk][r] = e[r];
+            } else {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(g + (long)gk * ld + grow);
+                const f32x4_t e = __builtin_bit_cast(f32x4_t, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b.e[kk][r] = e[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b.e[kk][r] = from_f32<T>(0.f);
+        }
+    }
+}
+
+// tile_rows = rows of the LDS tile (slab stride = tile_rows*64); r0 = first of the 4 tile rows,
+// kg = chunk index along k (slab kg>>2, chunk kg&3).
+template <typename T>
+__device__ __forceinline__ void store_tblock(char* lds, int tile_rows, const TBlock<T>& b, int r0, int kg, int grow, int R) {
+    constexpr int KC = ElemTraits<T>::kPerChunk;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        T outv[KC];
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) outv[kk] = (grow + r < R) ? b.e[kk][r] : from_f32<T>(0.f);
+        u32x4_t w;
+        __builtin_memcpy(&w, outv, 16);
+        *reinterpret_cast<u32x4_t*>(lds + (kg >> 2) * (tile_rows * SLAB_BYTES) + slab_off(r0 + r, kg & 3)) = w;
+    }
+}
+
+template <typename T, int ROWS, int NSLAB, int THREADS>
+__device__ __forceinline__ void stage_transposed(char* lds, const T* __restrict__ g, long ld, int row_lo, int R,
+                                                 int k0, int K, int tid) {
+    constexpr int KC = ElemTraits<T>::kPerChunk;
+    constexpr int RG = ROWS / 4;                   // row groups
+    constexpr int KG = NSLAB * 4;                  // k groups (one 16-B chunk each)
+    constexpr int TOTAL = RG * KG;
+#pragma unroll
+    for (int it = 0; it < (TOTAL + THREADS - 1) / THREADS; ++it) {
+        const int id = tid + it * THREADS;
+        if (TOTAL % THREADS != 0 && id >= TOTAL) break;
+        const int rg = id % RG, kg = id / RG;
+        const int grow = row_lo + rg * 4;
+        TBlock<T> b;
+        load_tblock<T>(b, g, ld, grow, R, k0 + kg * KC, K);
+        store_tblock<T>(lds, ROWS, b, rg * 4, kg, grow, R);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Accumulator -> LDS k-slab image, TRANSPOSED: image row = accumulator COLUMN (lane & 31),
+// image k = accumulator ROW.  This is the cheap direction (each lane owns 4 groups of 4
+// consecutive rows): 4 stores of 8 B (bf16) / 16 B (f32).  The image is a 32-row x 32-k tile:
+// bf16 -> one slab, f32 -> two slabs (slab stride = 32 rows * 64 B).
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void acc_to_image(char* img, const f32x16_t& acc, int lane) {
+    const int row = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        // k = 8 g + 4 h + (0..3)
+        if constexpr (sizeof(T) == 2) {
+            bf16x4_t v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (bf16_t)acc[4 * g + j];
+            // chunk g of the single slab, half h (8 bytes)
+            *reinterpret_cast<bf16x4_t*>(img + slab_off(row, g) + 8 * h) = v;
+        } else {
+            f32x4_t v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[4 * g + j];
+            // k = 8g+4h .. +3 -> byte 32 g + 16 h of the 128-B row: slab g>>1, chunk 2*(g&1)+h
+            *reinterpret_cast<f32x4_t*>(img + (g >> 1) * (32 * SLAB_BYTES) + slab_off(row, 2 * (g & 1) + h)) = v;
+        }
+    }
+}
+template <typename T> struct ImageTraits { static constexpr int kSlabs = (32 * sizeof(T)) / SLAB_BYTES; static constexpr int kBytes = 32 * 32 * sizeof(T); };
+
+// acc[i][j] += sum over the 32 k of an image A (32 rows) and an operand block B (32 rows) that
+// lives in a bigger tile: `b_slab0` is the first slab covering those 32 k, `b_slab_stride` the
+// byte distance between consecutive slabs of that tile.
+template <typename T>
+__device__ __forceinline__ void mma_image(f32x16_t& acc, const char* img, const char* b_slab0, int b_slab_stride,
+                                          int b_row0, int lane) {
+#pragma unroll
+    for (int s = 0; s < ImageTraits<T>::kSlabs; ++s) {
+        const Frag a = lds_frag<T>(img + s * (32 * SLAB_BYTES), 0, lane);
+        const Frag b = lds_frag<T>(b_slab0 + s * b_slab_stride, b_row0, lane);
+        mma_slab<T>(acc, a, b);
+    }
+}
+
+__device__ __forceinline__ float wave_half_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
+__device__ __forceinline__ float wave_half_sum(float v) { return v + __shfl_xor(v, 32); }
+
+__device__ __forceinline__ float warp_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float warp_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Counter-based dropout RNG: keep-decision is a pure function of (seed, element index), so the
+// backward pass regenerates the mask instead of storing it.
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t keep_threshold) {
+    const uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    const uint32_t r = hash_u32(lo ^ hash_u32(hi ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32));
+    return r < keep_threshold;  // keep_threshold = (1-p) * 2^32 (saturated)
+}

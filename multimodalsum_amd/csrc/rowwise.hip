@@ -1,0 +1,718 @@
+// HBM-bound row-wise kernels: LayerNorm (+residual, +dropout), embedding+LN, gated fusion,
+// label-smoothing loss, column sums, grad-norm, AdamW, casts.  All are one-pass-over-the-row
+// kernels with 8/16-byte vector accesses; a row of D <= 1024 lives in one wave's registers.
+#include "mmsum_device.h"
+#include "mmsum_kernels.h"
+#include <type_traits>
+
+namespace {
+
+template <typename T> __device__ __forceinline__ f32x4_t load4(const T* p);
+template <> __device__ __forceinline__ f32x4_t load4<float>(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+template <> __device__ __forceinline__ f32x4_t load4<bf16_t>(const bf16_t* p) {
+    const bf16x4_t v = *reinterpret_cast<const bf16x4_t*>(p);
+    return f32x4_t{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4_t v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4_t v) {
+    *reinterpret_cast<bf16x4_t*>(p) = bf16x4_t{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+}
+
+__device__ __forceinline__ uint32_t keep_threshold(float p_drop) {
+    if (p_drop <= 0.f) return 0xFFFFFFFFu;
+    const double t = (1.0 - (double)p_drop) * 4294967296.0;
+    return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+// --------------------------------------------------------------------------------------------
+// LayerNorm family.  One wave per row; lane owns columns  (i*64 + lane)*4 .. +3, i < VPL.
+// --------------------------------------------------------------------------------------------
+template <int VPL>
+__device__ __forceinline__ void ln_stats(const f32x4_t (&z)[VPL], int D, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) s += z[i][0] + z[i][1] + z[i][2] + z[i][3];
+    mean = warp_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = z[i][j] - mean; q += d * d; }
+    rstd = rsqrtf(warp_sum(q) / D + eps);
+}
+
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         T* __restrict__ y, float* __restrict__ mean_out,
+                                                         float* __restrict__ rstd_out, int R, int D, float eps,
+                                                         float p_drop, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const uint32_t thr = keep_threshold(p_drop);
+    const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < R; row += gridDim.x * wpb) {
+        f32x4_t z[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4_t xv = load4<T>(x + (long)row * D + c);
+            const f32x4_t rv = load4<T>(res + (long)row * D + c);
+            if (p_drop > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    xv[j] = dropout_keep(seed, (uint64_t)row * D + c + j, thr) ? xv[j] * dscale : 0.f;
+            }
+            z[i] = xv + rv;
+        }
+        float mean, rstd;
+        ln_stats<VPL>(z, D, eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const f32x4_t g = load4<float>(gamma + c), b = load4<float>(beta + c);
+            f32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (z[i][j] - mean) * rstd * g[j] + b[j];
+            store4<T>(y + (long)row * D + c, o);
+        }
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+
+// dz = rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); block accumulates dgamma/dbeta over its rows
+// in registers, reduces across its waves through LDS and issues one f32 atomic per column.
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                         const T* __restrict__ res, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                         T* __restrict__ dx, T* __restrict__ dres, int accumulate_dres,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int D,
+                                                         float p_drop, uint64_t seed) {
+    __shared__ float red[4][VPL * 256 * 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const uint32_t thr = keep_threshold(p_drop);
+    const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    f32x4_t ag[VPL], ab[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { ag[i] = f32x4_t{0, 0, 0, 0}; ab[i] = f32x4_t{0, 0, 0, 0}; }
+    for (int row = blockIdx.x * wpb + wave; row < R; row += gridDim.x * wpb) {
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        f32x4_t xh[VPL], gdy[VPL];
+        bool keep[VPL][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4_t xv = load4<T>(x + (long)row * D + c);
+            const f32x4_t rv = load4<T>(res + (long)row * D + c);
+            const f32x4_t dv = load4<T>(dy + (long)row * D + c);
+            const f32x4_t g = load4<float>(gamma + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                keep[i][j] = p_drop > 0.f ? dropout_keep(seed, (uint64_t)row * D + c + j, thr) : true;
+                const float zz = (keep[i][j] ? xv[j] * dscale : 0.f) + rv[j];
+                xh[i][j] = (zz - mean) * rstd;
+                gdy[i][j] = g[j] * dv[j];
+                s1 += gdy[i][j];
+                s2 += gdy[i][j] * xh[i][j];
+                ag[i][j] += dv[j] * xh[i][j];
+                ab[i][j] += dv[j];
+            }
+        }
+        s1 = warp_sum(s1) / D;
+        s2 = warp_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4_t dz, dxv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dz[j] = rstd * (gdy[i][j] - s1 - xh[i][j] * s2);
+                dxv[j] = keep[i][j] ? dz[j] * dscale : 0.f;
+            }
+            store4<T>(dx + (long)row * D + c, dxv);
+            if (accumulate_dres) dz = dz + load4<T>(dres + (long)row * D + c);
+            store4<T>(dres + (long)row * D + c, dz);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (i * 64 + lane) * 4 + j;
+            red[wave][c] = ag[i][j];
+            red[wave][VPL * 256 + c] = ab[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float g = 0.f, b = 0.f;
+        for (int w = 0; w < wpb; ++w) { g += red[w][c]; b += red[w][VPL * 256 + c]; }
+        atomicAdd(dgamma + c, g);
+        atomicAdd(dbeta + c, b);
+    }
+}
+
+// y = dropout(LN(E[id] + P[t + off] + rd[seq] * rvec))
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ E,
+                                                           const T* __restrict__ P, const float* __restrict__ rd,
+                                                           const T* __restrict__ rvec, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y,
+                                                           float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                           int R, int T_len, int D, int pos_offset, float eps, float p_drop,
+                                                           uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    const uint32_t thr = keep_threshold(p_drop);
+    const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < R; row += gridDim.x * wpb) {
+        const long id = ids[row];
+        const int t = row % T_len, seq = row / T_len;
+        const float r = rd ? rd[seq] : 0.f;
+        f32x4_t z[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            z[i] = load4<T>(E + id * D + c) + load4<T>(P + (long)(t + pos_offset) * D + c);
+            if (rd) z[i] = z[i] + load4<T>(rvec + c) * r;
+        }
+        float mean, rstd;
+        ln_stats<VPL>(z, D, eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const f32x4_t g = load4<float>(gamma + c), b = load4<float>(beta + c);
+            f32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = (z[i][j] - mean) * rstd * g[j] + b[j];
+                if (p_drop > 0.f) o[j] = dropout_keep(seed, (uint64_t)row * D + c + j, thr) ? o[j] * dscale : 0.f;
+            }
+            store4<T>(y + (long)row * D + c, o);
+        }
+        if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+    }
+}
+
+// Block = one position t (all sequences): dP[t+off] is written without atomics, dE rows get f32
+// atomics (pad rows skipped: nn.Embedding(padding_idx)), drvec/dgamma/dbeta one atomic per column.
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const T* __restrict__ dy, const int64_t* __restrict__ ids,
+                                                           const T* __restrict__ E, const T* __restrict__ P,
+                                                           const float* __restrict__ rd, const T* __restrict__ rvec,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean_in,
+                                                           const float* __restrict__ rstd_in, float* __restrict__ dE,
+                                                           float* __restrict__ dP, float* __restrict__ drvec,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int nseq,
+                                                           int T_len, int D, int pos_offset, int pad_id, float p_drop,
+                                                           uint64_t seed) {
+    __shared__ float red[4][VPL * 256 * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wpb = blockDim.x >> 6;
+    const int t = blockIdx.x;
+    const uint32_t thr = keep_threshold(p_drop);
+    const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+    f32x4_t ag[VPL], ab[VPL], ap[VPL], ar[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) { ag[i] = ab[i] = ap[i] = ar[i] = f32x4_t{0, 0, 0, 0}; }
+    for (int seq = wave; seq < nseq; seq += wpb) {
+        const int row = seq * T_len + t;
+        const long id = ids[row];
+        const float r = rd ? rd[seq] : 0.f;
+        const float mean = mean_in[row], rstd = rstd_in[row];
+        f32x4_t xh[VPL], gdy[VPL], dv[VPL];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            f32x4_t z = load4<T>(E + id * D + c) + load4<T>(P + (long)(t + pos_offset) * D + c);
+            if (rd) z = z + load4<T>(rvec + c) * r;
+            dv[i] = load4<T>(dy + (long)row * D + c);
+            const f32x4_t g = load4<float>(gamma + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (p_drop > 0.f) dv[i][j] = dropout_keep(seed, (uint64_t)row * D + c + j, thr) ? dv[i][j] * dscale : 0.f;
+                xh[i][j] = (z[j] - mean) * rstd;
+                gdy[i][j] = g[j] * dv[i][j];
+                s1 += gdy[i][j];
+                s2 += gdy[i][j] * xh[i][j];
+                ag[i][j] += dv[i][j] * xh[i][j];
+                ab[i][j] += dv[i][j];
+            }
+        }
+        s1 = warp_sum(s1) / D;
+        s2 = warp_sum(s2) / D;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float dz = rstd * (gdy[i][j] - s1 - xh[i][j] * s2);
+                ap[i][j] += dz;
+                ar[i][j] += dz * r;
+                if (id != pad_id) atomicAdd(dE + id * D + c + j, dz);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (i * 64 + lane) * 4 + j;
+            red[wave][c] = ag[i][j];
+            red[wave][VPL * 256 + c] = ab[i][j];
+            red[wave][2 * VPL * 256 + c] = ap[i][j];
+            red[wave][3 * VPL * 256 + c] = ar[i][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        float g = 0.f, b = 0.f, pp = 0.f, rr = 0.f;
+        for (int w = 0; w < wpb; ++w) {
+            g += red[w][c]; b += red[w][VPL * 256 + c]; pp += red[w][2 * VPL * 256 + c]; rr += red[w][3 * VPL * 256 + c];
+        }
+        atomicAdd(dgamma + c, g);
+        atomicAdd(dbeta + c, b);
+        atomicAdd(dP + (long)(t + pos_offset) * D + c, pp);
+        if (rd) atomicAdd(drvec + c, rr);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Gated fusion (elementwise)
+// --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ pa, const T* __restrict__ pb, const T* __restrict__ yt,
+                                                       const T* __restrict__ ytab, const T* __restrict__ yimg,
+                                                       const uint8_t* __restrict__ no_table, const uint8_t* __restrict__ no_img,
+                                                       T* __restrict__ out, long n4, int D, int rows_per_b) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const int b = (int)((e / D) / rows_per_b);
+        const float ma = no_table[b] ? 0.f : 1.f, mb = no_img[b] ? 0.f : 1.f;
+        const f32x4_t a = load4<T>(pa + e), bb = load4<T>(pb + e), t = load4<T>(yt + e), tb = load4<T>(ytab + e), im = load4<T>(yimg + e);
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = t[j] + ma * fmaxf(tanhf(a[j]), 0.f) * tb[j] + mb * fmaxf(tanhf(bb[j]), 0.f) * im[j];
+        store4<T>(out + e, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ pa, const T* __restrict__ pb,
+                                                       const T* __restrict__ ytab, const T* __restrict__ yimg,
+                                                       const uint8_t* __restrict__ no_table, const uint8_t* __restrict__ no_img,
+                                                       T* __restrict__ dpa, T* __restrict__ dpb, T* __restrict__ dyt,
+                                                       T* __restrict__ dytab, T* __restrict__ dyimg, long n4, int D, int rows_per_b) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long e = i * 4;
+        const int b = (int)((e / D) / rows_per_b);
+        const float ma = no_table[b] ? 0.f : 1.f, mb = no_img[b] ? 0.f : 1.f;
+        const f32x4_t g = load4<T>(dout + e), a = load4<T>(pa + e), bb = load4<T>(pb + e), tb = load4<T>(ytab + e), im = load4<T>(yimg + e);
+        f32x4_t oa, ob, otb, oim;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ta = tanhf(a[j]), tbv = tanhf(bb[j]);
+            const float al = ma * fmaxf(ta, 0.f), be = mb * fmaxf(tbv, 0.f);
+            otb[j] = g[j] * al;
+            oim[j] = g[j] * be;
+            oa[j] = (ta > 0.f) ? ma * g[j] * tb[j] * (1.f - ta * ta) : 0.f;
+            ob[j] = (tbv > 0.f) ? mb * g[j] * im[j] * (1.f - tbv * tbv) : 0.f;
+        }
+        store4<T>(dpa + e, oa);
+        store4<T>(dpb + e, ob);
+        store4<T>(dyt + e, g);
+        store4<T>(dytab + e, otb);
+        store4<T>(dyimg + e, oim);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Label-smoothing loss: one block per row, online max/sum in one sweep, second sweep writes the
+// gradient in place.
+// --------------------------------------------------------------------------------------------
+__device__ __forceinline__ void online_merge(float& m, float& s, float m2, float s2) {
+    const float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { s = 0.f; m = mn; return; }
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ls_loss_kernel(T* __restrict__ logits, long ld, const int64_t* __restrict__ target,
+                                                      float* __restrict__ row_loss, int V, float smoothing, float gscale,
+                                                      int write_grad) {
+    __shared__ float sm[4], ss[4], sx[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T* x = logits + (long)row * ld;
+    float m = -INFINITY, s = 0.f, sumx = 0.f;
+    for (int c = tid; c < V; c += 256) {
+        const float v = to_f32(x[c]);
+        sumx += v;
+        if (v > m) { s = s * __expf(m - v) + 1.f; m = v; } else { s += __expf(v - m); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(m, o), s2 = __shfl_xor(s, o);
+        online_merge(m, s, m2, s2);
+        sumx += __shfl_xor(sumx, o);
+    }
+    if (lane == 0) { sm[wave] = m; ss[wave] = s; sx[wave] = sumx; }
+    __syncthreads();
+    m = sm[0]; s = ss[0]; sumx = sx[0];
+    for (int w = 1; w < 4; ++w) { online_merge(m, s, sm[w], ss[w]); sumx += sx[w]; }
+    const float lse = m + logf(s);
+    const long y = target[row];
+    const float eps_p = (V > 1) ? smoothing / (float)(V - 1) : 0.f;
+    const float conf = 1.f - smoothing;
+    if (tid == 0) {
+        const float logp_y = to_f32(x[y]) - lse;
+        const float sum_logp = sumx - (float)V * lse;
+        row_loss[row] = -(conf * logp_y + eps_p * (sum_logp - logp_y));
+    }
+    if (write_grad) {
+        __syncthreads();
+        for (int c = tid; c < (int)ld; c += 256) {
+            float g = 0.f;
+            if (c < V) {
+                const float pr = __expf(to_f32(x[c]) - lse);
+                g = gscale * (pr - (c == y ? conf : eps_p));
+            }
+            x[c] = from_f32<T>(g);
+        }
+    }
+}
+
+__global__ void segment_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int seg, float scale) {
+    __shared__ double red[256];
+    const float* p = x + (long)blockIdx.x * seg;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < seg; i += 256) s += (double)p[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)(red[0] * (double)scale);
+}
+
+// --------------------------------------------------------------------------------------------
+// Column sums: grid (C/64 column groups, row splits); partials in workspace, then a finish pass.
+// --------------------------------------------------------------------------------------------
+constexpr int CS_SPLITS = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ part) {
+    // block: 64 columns x 4 row-lanes; each thread strides over rows
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float s = 0.f;
+    if (col < C)
+        for (int r = r0 + rl; r < r1; r += 4) s += to_f32(X[(long)r * ld + col]);
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && col < C) part[(long)blockIdx.y * C + col] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int splits, int C, float* __restrict__ out, int accumulate) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(long)k * C + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+// --------------------------------------------------------------------------------------------
+// Optimiser kernels over the flat f32 arena
+// --------------------------------------------------------------------------------------------
+constexpr int L2_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ g, long n, double* __restrict__ part) {
+    __shared__ double red[256];
+    double s = 0.0;
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(g + i * 4);
+        s += (double)(v[0] * v[0] + v[1] * v[1]) + (double)(v[2] * v[2] + v[3] * v[3]);
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += (double)g[i] * g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void l2_finish_kernel(const double* __restrict__ part, int nparts, float* __restrict__ out, int accumulate) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = accumulate ? out[0] + (float)red[0] : (float)red[0];
+}
+
+__device__ __forceinline__ float clip_coef(const float* norm_sq, float max_norm) {
+    if (norm_sq == nullptr || max_norm <= 0.f) return 1.f;
+    const float c = max_norm / (sqrtf(norm_sq[0]) + 1e-6f);
+    return c < 1.f ? c : 1.f;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ shadow, long n,
+                                                    const float* __restrict__ hyper, const float* __restrict__ norm_sq,
+                                                    float beta1, float beta2, float eps) {
+    const float step_size = hyper[0], lr_wd = hyper[1];
+    const float cc = clip_coef(norm_sq, hyper[2]);
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4_t pv = *reinterpret_cast<f32x4_t*>(p + i * 4);
+        const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g + i * 4) * cc;
+        f32x4_t mv = *reinterpret_cast<f32x4_t*>(m + i * 4), vv = *reinterpret_cast<f32x4_t*>(v + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            mv[j] = mv[j] * beta1 + gv[j] * (1.f - beta1);
+            vv[j] = vv[j] * beta2 + gv[j] * gv[j] * (1.f - beta2);
+            pv[j] = pv[j] - step_size * (mv[j] / (sqrtf(vv[j]) + eps));
+            pv[j] = pv[j] - lr_wd * pv[j];
+        }
+        *reinterpret_cast<f32x4_t*>(p + i * 4) = pv;
+        *reinterpret_cast<f32x4_t*>(m + i * 4) = mv;
+        *reinterpret_cast<f32x4_t*>(v + i * 4) = vv;
+        if (shadow) *reinterpret_cast<bf16x4_t*>(shadow + i * 4) = bf16x4_t{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            const float gg = g[i] * cc;
+            const float mm = m[i] * beta1 + gg * (1.f - beta1);
+            const float vv = v[i] * beta2 + gg * gg * (1.f - beta2);
+            float pp = p[i] - step_size * (mm / (sqrtf(vv) + eps));
+            pp -= lr_wd * pp;
+            p[i] = pp; m[i] = mm; v[i] = vv;
+            if (shadow) shadow[i] = (bf16_t)pp;
+        }
+}
+
+__global__ __launch_bounds__(256) void scale_by_clip_kernel(float* __restrict__ g, long n, const float* __restrict__ norm_sq, float max_norm) {
+    const float cc = clip_coef(norm_sq, max_norm);
+    if (cc >= 1.f) return;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) g[i] *= cc;
+}
+
+template <typename TD, typename TS>
+__global__ __launch_bounds__(256) void cast_kernel(TD* __restrict__ dst, const TS* __restrict__ src, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+inline int grid_for(long work_items, int per_block, int cap = 2048) {
+    long b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b > cap ? cap : b);
+}
+inline int ok() { return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP; }
+
+template <typename F>
+int dispatch_vpl(int D, F&& f) {
+    switch (D) {
+        case 256: f(std::integral_constant<int, 1>{}); break;
+        case 512: f(std::integral_constant<int, 2>{}); break;
+        case 768: f(std::integral_constant<int, 3>{}); break;
+        case 1024: f(std::integral_constant<int, 4>{}); break;
+        default: return MMSUM_ERR_BAD_SHAPE;
+    }
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+template <typename T>
+int add_ln_fwd_t(const void* x, const void* res, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int R,
+                 int D, float eps, float p_drop, uint64_t seed, hipStream_t s) {
+    const int grid = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
+    return dispatch_vpl(D, [&](auto vpl) {
+        constexpr int VPL = decltype(vpl)::value;
+        add_ln_fwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)x, (const T*)res, (const float*)gamma, (const float*)beta,
+                                                                  (T*)y, mean, rstd, R, D, eps, p_drop, seed);
+    });
+}
+template <typename T>
+int add_ln_bwd_t(const void* dy, const void* x, const void* res, const void* gamma, const float* mean, const float* rstd, void* dx,
+                 void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R, int D, float p_drop, uint64_t seed,
+                 hipStream_t s) {
+    int grid = (R + 15) / 16;
+    grid = grid > 1024 ? 1024 : grid;
+    return dispatch_vpl(D, [&](auto vpl) {
+        constexpr int VPL = decltype(vpl)::value;
+        add_ln_bwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)dy, (const T*)x, (const T*)res, (const float*)gamma, mean,
+                                                                  rstd, (T*)dx, (T*)dres, accumulate_dres, dgamma, dbeta, R, D, p_drop,
+                                                                  seed);
+    });
+}
+template <typename T>
+int embed_ln_fwd_t(const int64_t* ids, const void* E, const void* P, const float* rd, const void* rvec, const void* gamma,
+                   const void* beta, void* y, float* mean, float* rstd, int R, int T_len, int D, int pos_offset, float eps,
+                   float p_drop, uint64_t seed, hipStream_t s) {
+    const int grid = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
+    return dispatch_vpl(D, [&](auto vpl) {
+        constexpr int VPL = decltype(vpl)::value;
+        embed_ln_fwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>(ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
+                                                                    (const float*)gamma, (const float*)beta, (T*)y, mean, rstd, R,
+                                                                    T_len, D, pos_offset, eps, p_drop, seed);
+    });
+}
+template <typename T>
+int embed_ln_bwd_t(const void* dy, const int64_t* ids, const void* E, const void* P, const float* rd, const void* rvec,
+                   const void* gamma, const float* mean, const float* rstd, float* dE, float* dP, float* drvec, float* dgamma,
+                   float* dbeta, int nseq, int T_len, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, hipStream_t s) {
+    return dispatch_vpl(D, [&](auto vpl) {
+        constexpr int VPL = decltype(vpl)::value;
+        embed_ln_bwd_kernel<T, VPL><<<dim3(T_len), dim3(256), 0, s>>>((const T*)dy, ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
+                                                                     (const float*)gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta,
+                                                                     nseq, T_len, D, pos_offset, pad_id, p_drop, seed);
+    });
+}
+
+}  // namespace
+
+extern "C" int mmsum_abi_version(void) { return MMSUM_ABI_VERSION; }
+
+extern "C" int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,
+                                float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, void* stream) {
+    if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MMSUM_BF16) return add_ln_fwd_t<bf16_t>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, s);
+    if (dtype == MMSUM_F32) return add_ln_fwd_t<float>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, s);
+    return MMSUM_ERR_BAD_DTYPE;
+}
+
+extern "C" int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, const void* gamma, const float* mean,
+                                const float* rstd, void* dx, void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R,
+                                int D, float p_drop, uint64_t seed, void* stream) {
+    if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MMSUM_BF16) return add_ln_bwd_t<bf16_t>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, s);
+    if (dtype == MMSUM_F32) return add_ln_bwd_t<float>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, s);
+    return MMSUM_ERR_BAD_DTYPE;
+}
+
+extern "C" int mmsum_embed_ln_fwd(int dtype, const int64_t* ids, const void* E, const void* P, const float* rating_diff,
+                                  const void* rvec, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
+                                  int nseq, int T, int D, int pos_offset, float eps, float p_drop, uint64_t seed, void* stream) {
+    const int R = nseq * T;
+    if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MMSUM_BF16) return embed_ln_fwd_t<bf16_t>(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, R, T, D, pos_offset, eps, p_drop, seed, s);
+    if (dtype == MMSUM_F32) return embed_ln_fwd_t<float>(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, R, T, D, pos_offset, eps, p_drop, seed, s);
+    return MMSUM_ERR_BAD_DTYPE;
+}
+
+extern "C" int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids, const void* E, const void* P,
+                                  const float* rating_diff, const void* rvec, const void* gamma, const float* mean,
+                                  const float* rstd, float* dE, float* dP, float* drvec, float* dgamma, float* dbeta, int nseq,
+                                  int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, void* stream) {
+    if (nseq <= 0 || T <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MMSUM_BF16) return embed_ln_bwd_t<bf16_t>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, s);
+    if (dtype == MMSUM_F32) return embed_ln_bwd_t<float>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, s);
+    return MMSUM_ERR_BAD_DTYPE;
+}
+
+extern "C" int mmsum_gate_fwd(int dtype, const void* pa, const void* pb, const void* yt, const void* ytab, const void* yimg,
+                              const uint8_t* no_table, const uint8_t* no_img, void* out, int R, int D, int rows_per_b, void* stream) {
+    if (R <= 0 || D % 4) return MMSUM_ERR_BAD_SHAPE;
+    const long n4 = (long)R * D / 4;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n4, 256);
+    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((gate_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)pa, (const bf16_t*)pb, (const bf16_t*)yt, (const bf16_t*)ytab, (const bf16_t*)yimg, no_table, no_img, (bf16_t*)out, n4, D, rows_per_b);
+    else if (dtype == MMSUM_F32) hipLaunchKernelGGL((gate_fwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)pa, (const float*)pb, (const float*)yt, (const float*)ytab, (const float*)yimg, no_table, no_img, (float*)out, n4, D, rows_per_b);
+    else return MMSUM_ERR_BAD_DTYPE;
+    return ok();
+}
+
+extern "C" int mmsum_gate_bwd(int dtype, const void* dout, const void* pa, const void* pb, const void* ytab, const void* yimg,
+                              const uint8_t* no_table, const uint8_t* no_img, void* dpa, void* dpb, void* dyt, void* dytab,
+                              void* dyimg, int R, int D, int rows_per_b, void* stream) {
+    if (R <= 0 || D % 4) return MMSUM_ERR_BAD_SHAPE;
+    const long n4 = (long)R * D / 4;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n4, 256);
+    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)pa, (const bf16_t*)pb, (const bf16_t*)ytab, (const bf16_t*)yimg, no_table, no_img, (bf16_t*)dpa, (bf16_t*)dpb, (bf16_t*)dyt, (bf16_t*)dytab, (bf16_t*)dyimg, n4, D, rows_per_b);
+    else if (dtype == MMSUM_F32) hipLaunchKernelGGL((gate_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dout, (const float*)pa, (const float*)pb, (const float*)ytab, (const float*)yimg, no_table, no_img, (float*)dpa, (float*)dpb, (float*)dyt, (float*)dytab, (float*)dyimg, n4, D, rows_per_b);
+    else return MMSUM_ERR_BAD_DTYPE;
+    return ok();
+}
+
+extern "C" int mmsum_ls_loss(int dtype, void* logits, long ld, const int64_t* target, float* row_loss, int R, int V,
+                             float smoothing, float gscale, int write_grad, void* stream) {
+    if (R <= 0 || V <= 0 || ld < V) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((ls_loss_kernel<bf16_t>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+    else if (dtype == MMSUM_F32) hipLaunchKernelGGL((ls_loss_kernel<float>), dim3(R), dim3(256), 0, s, (float*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+    else return MMSUM_ERR_BAD_DTYPE;
+    return ok();
+}
+
+extern "C" int mmsum_segment_sum(const float* x, float* out, int nseg, int seg, float scale, void* stream) {
+    if (nseg <= 0 || seg <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, x, out, seg, scale);
+    return ok();
+}
+
+extern "C" long mmsum_colsum_workspace(int C) { return (long)CS_SPLITS * C * sizeof(float); }
+extern "C" int mmsum_colsum(int dtype, const void* X, long ld, int R, int C, float* out, int accumulate, void* workspace, void* stream) {
+    if (R <= 0 || C <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int splits = R < CS_SPLITS * 8 ? max(1, R / 8) : CS_SPLITS;
+    const dim3 grid((C + 63) / 64, splits);
+    float* part = (float*)workspace;
+    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ld, R, C, part);
+    else if (dtype == MMSUM_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ld, R, C, part);
+    else return MMSUM_ERR_BAD_DTYPE;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, s, part, splits, C, out, accumulate);
+    return ok();
+}
+
+extern "C" long mmsum_l2_workspace(void) { return (long)L2_BLOCKS * sizeof(double); }
+extern "C" int mmsum_l2norm_sq(const float* g, long n, float* out, int accumulate, void* workspace, void* stream) {
+    if (n <= 0) return MMSUM_ERR_BAD_SHAPE;
+    if ((uintptr_t)g & 15) return MMSUM_ERR_BAD_ALIGN;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = grid_for(n / 4 + 1, 256, L2_BLOCKS);
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(blocks), dim3(256), 0, s, g, n, (double*)workspace);
+    hipLaunchKernelGGL(l2_finish_kernel, dim3(1), dim3(256), 0, s, (const double*)workspace, blocks, out, accumulate);
+    return ok();
+}
+
+extern "C" int mmsum_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, const float* hyper,
+                           const float* norm_sq, float beta1, float beta2, float eps, void* stream) {
+    if (n <= 0) return MMSUM_ERR_BAD_SHAPE;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return MMSUM_ERR_BAD_ALIGN;
+    if ((uintptr_t)shadow_bf16 & 7) return MMSUM_ERR_BAD_ALIGN;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)shadow_bf16, n, hyper, norm_sq, beta1, beta2, eps);
+    return ok();
+}
+
+extern "C" int mmsum_scale_by_clip(float* g, long n, const float* norm_sq, float max_norm, void* stream) {
+    if (n <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipLaunchKernelGGL(scale_by_clip_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, g, n, norm_sq, max_norm);
+    return ok();
+}
+
+extern "C" int mmsum_cast(int dtype_dst, void* dst, int dtype_src, const void* src, long n, void* stream) {
+    if (n <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = grid_for(n, 256);
+    if (dtype_dst == MMSUM_BF16 && dtype_src == MMSUM_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (bf16_t*)dst, (const float*)src, n);
+    else if (dtype_dst == MMSUM_F32 && dtype_src == MMSUM_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (float*)dst, (const bf16_t*)src, n);
+    else if (dtype_dst == MMSUM_F32 && dtype_src == MMSUM_F32) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (float*)dst, (const float*)src, n);
+    else if (dtype_dst == MMSUM_BF16 && dtype_src == MMSUM_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (bf16_t*)dst, (const bf16_t*)src, n);
+    else return MMSUM_ERR_BAD_DTYPE;
+    return ok();
+}

@@ -1,0 +1,246 @@
+"""Tensor-level wrappers over the C ABI: raw device pointers + the current HIP stream.
+
+PyTorch is plumbing here (device memory, streams); every function below enqueues hand-written HIP
+kernels from libmmsum_hip.so and nothing else.  There is no fallback path: CPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, AttnDesc, F32, BF16
+
+EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError("unsupported dtype %s" % t.dtype)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmmsum_hip kernels need device tensors (no CPU fallback exists)")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "2-D tensor with unit inner stride expected"
+    return t.stride(0)
+
+
+def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None,
+         splitk=1):
+    """out[M,N] = epi(alpha * A.B^T + bias) (+ out).  a: [M,K] (or [K,M] when a_t); b: [N,K] (or [K,N] when b_t);
+    a2: optional second half of the K range ([M,K2], natural layout).  out may be f32 while a/b are bf16."""
+    dt = _dt(a)
+    assert _dt(b) == dt
+    M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
+    N, Kb = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
+    ksplit = 0
+    if a2 is not None:
+        ksplit = K
+        K = K + a2.shape[1]
+    assert K == Kb, (K, Kb)
+    assert out.shape[0] == M and out.shape[1] == N, (out.shape, M, N)
+    flags = (_lib.GEMM_A_T if a_t else 0) | (_lib.GEMM_B_T if b_t else 0) | (_lib.GEMM_BIAS if bias is not None else 0)
+    flags |= _lib.gemm_epi(epi) | (_lib.GEMM_ACCUM if accumulate else 0)
+    if out.dtype == torch.float32 and dt == BF16:
+        flags |= _lib.GEMM_OUT_F32
+    elif out.dtype == torch.float32:
+        flags |= _lib.GEMM_OUT_F32
+    else:
+        assert _dt(out) == dt
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    check(lib.mmsum_gemm(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(out), _ld(out),
+                         _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, float(alpha), flags, splitk, _stream()),
+          "mmsum_gemm")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device, key):
+    k = (key, str(device))
+    w = _ws_cache.get(k)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _ws_cache[k] = w
+    return w
+
+
+def colsum(x, out, accumulate=False):
+    R, C = x.shape
+    ws = _workspace(lib.mmsum_colsum_workspace(C), x.device, "colsum")
+    check(lib.mmsum_colsum(_dt(x), _p(x), _ld(x), R, C, _p(out), int(accumulate), _p(ws), _stream()), "mmsum_colsum")
+    return out
+
+
+def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq, T, pos_offset, eps, p_drop, seed):
+    D = E.shape[1]
+    check(lib.mmsum_embed_ln_fwd(_dt(E), _p(ids), _p(E), _p(P), _p(rating_diff), _p(rvec), _p(gamma), _p(beta), _p(y),
+                                 _p(mean), _p(rstd), nseq, T, D, pos_offset, eps, p_drop, seed, _stream()), "mmsum_embed_ln_fwd")
+
+
+def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, pos_offset,
+                 pad_id, p_drop, seed):
+    D = E.shape[1]
+    check(lib.mmsum_embed_ln_bwd(_dt(E), _p(dy), _p(ids), _p(E), _p(P), _p(rating_diff), _p(rvec), _p(gamma), _p(mean),
+                                 _p(rstd), _p(dE), _p(dP), _p(drvec), _p(dgamma), _p(dbeta), nseq, T, D, pos_offset, pad_id,
+                                 p_drop, seed, _stream()), "mmsum_embed_ln_bwd")
+
+
+def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed):
+    R, D = x.shape
+    check(lib.mmsum_add_ln_fwd(_dt(x), _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), R, D, eps, p_drop, seed,
+                               _stream()), "mmsum_add_ln_fwd")
+
+
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed):
+    R, D = x.shape
+    check(lib.mmsum_add_ln_bwd(_dt(x), _p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres),
+                               int(accumulate_dres), _p(dgamma), _p(dbeta), R, D, p_drop, seed, _stream()), "mmsum_add_ln_bwd")
+
+
+def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale):
+    d = AttnDesc()
+    d.q, d.k, d.v, d.out = _p(q), _p(k), _p(v), _p(out)
+    d.ldq, d.ldk, d.ldv = q.stride(0), k.stride(0), v.stride(0)
+    d.ldo = out.stride(0) if out is not None else 0
+    d.pad, d.null_entity = _p(pad), _p(null_entity)
+    d.n_qblocks, d.T, d.qpb, d.N, d.S, d.H = n_qblocks, T, qpb, N, S, H
+    d.exclude_self, d.causal, d.scale = int(exclude_self), int(causal), float(scale)
+    return d
+
+
+def entity_null(pad, null_entity, n_entities, S):
+    check(lib.mmsum_entity_null(_p(pad), _p(null_entity), n_entities, S, _stream()), "mmsum_entity_null")
+
+
+def attn_fwd(desc, dtype_tensor):
+    check(lib.mmsum_attn_fwd(_dt(dtype_tensor), ctypes.byref(desc), _stream()), "mmsum_attn_fwd")
+
+
+def attn_bwd_workspace(desc):
+    return lib.mmsum_attn_bwd_workspace(ctypes.byref(desc))
+
+
+def attn_bwd(desc, dout, dq, accumulate_dq, dk, dv, stats):
+    check(lib.mmsum_attn_bwd(_dt(dout), ctypes.byref(desc), _p(dout), dout.stride(0), _p(dq), dq.stride(0), int(accumulate_dq),
+                             _p(dk), dk.stride(0), _p(dv), dv.stride(0), _p(stats), _stream()), "mmsum_attn_bwd")
+
+
+def gate_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, out, rows_per_b):
+    R, D = yt.shape
+    check(lib.mmsum_gate_fwd(_dt(yt), _p(pa), _p(pb), _p(yt), _p(ytab), _p(yimg), _p(no_table), _p(no_img), _p(out), R, D,
+                             rows_per_b, _stream()), "mmsum_gate_fwd")
+
+
+def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, rows_per_b):
+    R, D = dout.shape
+    check(lib.mmsum_gate_bwd(_dt(dout), _p(dout), _p(pa), _p(pb), _p(ytab), _p(yimg), _p(no_table), _p(no_img), _p(dpa), _p(dpb),
+                             _p(dyt), _p(dytab), _p(dyimg), R, D, rows_per_b, _stream()), "mmsum_gate_bwd")
+
+
+def ls_loss(logits, target, row_loss, V, smoothing, gscale, write_grad=True):
+    R = logits.shape[0]
+    check(lib.mmsum_ls_loss(_dt(logits), _p(logits), logits.stride(0), _p(target), _p(row_loss), R, V, smoothing, gscale,
+                            int(write_grad), _stream()), "mmsum_ls_loss")
+
+
+def segment_sum(x, out, nseg, seg, scale):
+    check(lib.mmsum_segment_sum(_p(x), _p(out), nseg, seg, scale, _stream()), "mmsum_segment_sum")
+
+
+def l2norm_sq(g, out, accumulate=False):
+    ws = _workspace(lib.mmsum_l2_workspace(), g.device, "l2")
+    check(lib.mmsum_l2norm_sq(_p(g), g.numel(), _p(out), int(accumulate), _p(ws), _stream()), "mmsum_l2norm_sq")
+
+
+def adamw(p, g, m, v, shadow, hyper, norm_sq, beta1, beta2, eps):
+    check(lib.mmsum_adamw(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), _p(hyper), _p(norm_sq), beta1, beta2, eps, _stream()),
+          "mmsum_adamw")
+
+
+def cast(dst, src):
+    assert dst.numel() == src.numel() and dst.is_contiguous() and src.is_contiguous()
+    check(lib.mmsum_cast(_dt(dst), _p(dst), _dt(src), _p(src), src.numel(), _stream()), "mmsum_cast")
+    return dst
+
+
+def scale_by_clip(g, norm_sq, max_norm):
+    check(lib.mmsum_scale_by_clip(_p(g), g.numel(), _p(norm_sq), max_norm, _stream()), "mmsum_scale_by_clip")
+
+
+def im2col(x, col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
+    check(lib.mmsum_im2col(_dt(x), _p(x), _p(col), N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, _stream()), "mmsum_im2col")
+
+
+def col2im(dcol, dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
+    check(lib.mmsum_col2im(_dt(dcol), _p(dcol), _p(dx), N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, _stream()), "mmsum_col2im")
+
+
+def conv_weight_to_matrix(matrix, weight, Cout, Cin, KH, KW, Kpad):
+    check(lib.mmsum_conv_weight_permute(_dt(matrix), _p(matrix), _p(weight), Cout, Cin, KH, KW, Kpad, 1, 0, _stream()),
+          "mmsum_conv_weight_permute")
+
+
+def conv_matrix_grad_to_weight(matrix_f32, dweight, Cout, Cin, KH, KW, Kpad, accumulate):
+    check(lib.mmsum_conv_weight_permute(F32, _p(matrix_f32), _p(dweight), Cout, Cin, KH, KW, Kpad, 0, int(accumulate), _stream()),
+          "mmsum_conv_weight_permute")
+
+
+def bn_reduce(x, sums):
+    R, C = x.shape
+    ws = _workspace(lib.mmsum_bn_workspace(C), x.device, "bn")
+    check(lib.mmsum_bn_reduce(_dt(x), _p(x), R, C, _p(sums), _p(ws), _stream()), "mmsum_bn_reduce")
+
+
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training):
+    R, C = x.shape
+    check(lib.mmsum_bn_apply(_dt(x), _p(x), _p(sums), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean), _p(running_var),
+                             R, C, eps, momentum, int(relu), int(training), _stream()), "mmsum_bn_apply")
+
+
+def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu):
+    R, C = x.shape
+    ws = _workspace(lib.mmsum_bn_workspace(C), x.device, "bn")
+    check(lib.mmsum_bn_bwd_reduce(_dt(x), _p(dy), _p(y), _p(x), _p(sums), R, C, eps, int(relu), _p(dsums), _p(ws), _stream()),
+          "mmsum_bn_bwd_reduce")
+
+
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu):
+    R, C = x.shape
+    check(lib.mmsum_bn_bwd_apply(_dt(x), _p(dy), _p(y), _p(x), _p(sums), _p(dsums), _p(gamma), _p(dx), _p(dresidual), _p(dgamma),
+                                 _p(dbeta), R, C, eps, int(relu), _stream()), "mmsum_bn_bwd_apply")
+
+
+def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):
+    check(lib.mmsum_maxpool3x3s2(_dt(x), _p(x), _p(y), N, H, W, C, Ho, Wo, _stream()), "mmsum_maxpool3x3s2")
+
+
+def nchw_to_nhwc(x, y, N, C, H, W):
+    check(lib.mmsum_nchw_to_nhwc(_dt(y), _p(x), _p(y), N, C, H, W, _stream()), "mmsum_nchw_to_nhwc")
+
+
+def table_gather(E, field, fv, w_rating, w_hours, out, mask, B, pad_id):
+    name, category, str_cat, str_bool, rating, hours = fv
+    D = E.shape[1]
+    check(lib.mmsum_table_gather(_dt(E), _p(E), _p(field), _p(name), _p(category), _p(str_cat), _p(str_bool), _p(rating), _p(hours),
+                                 _p(w_rating), _p(w_hours), _p(out), _p(mask), B, D, pad_id, _stream()), "mmsum_table_gather")
+
+
+def table_gather_bwd(dall, rating, hours, dw_rating, dw_hours, B, D):
+    check(lib.mmsum_table_gather_bwd(_dt(dall), _p(dall), _p(rating), _p(hours), _p(dw_rating), _p(dw_hours), B, D, _stream()),
+          "mmsum_table_gather_bwd")

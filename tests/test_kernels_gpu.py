@@ -1,0 +1,451 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 statement of the same op (and the oracle /
+golden vectors where one exists).  f32 instantiations are held to ~1e-4, bf16 ones to bf16 rounding."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from multimodalsum_amd import kernels as kn
+    from multimodalsum_amd import _lib
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return (2e-4, 2e-4) if dtype == torch.float32 else (3e-2, 3e-2)
+
+
+def close(a, b, dtype, scale=1.0, what=""):
+    rt, at = tol(dtype)
+    a, b = a.double().cpu(), b.double().cpu()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert math.isfinite(err), "%s: non-finite" % what
+    assert err <= scale * (at + rt * ref), "%s: max err %.3e (ref max %.3e)" % (what, err, ref)
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(DEV).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("a_t,b_t", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K", [(200, 136, 96), (128, 128, 64), (47, 1024, 2048), (300, 72, 160)])
+def test_gemm_layouts(dtype, a_t, b_t, M, N, K):
+    a = rnd(M, K, dtype=dtype, seed=1)
+    b = rnd(N, K, dtype=dtype, seed=2)
+    ref = a.float() @ b.float().t()
+    A = a.t().contiguous() if a_t else a
+    B = b.t().contiguous() if b_t else b
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=dtype)
+    kn.gemm(A, B, out, a_t=a_t, b_t=b_t)
+    close(out, ref, dtype, scale=math.sqrt(K / 64), what="gemm")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(dtype):
+    M, N, Kd = 160, 200, 128
+    a, b = rnd(M, Kd, dtype=dtype, seed=3, std=0.3), rnd(N, Kd, dtype=dtype, seed=4, std=0.3)
+    bias = rnd(N, seed=5)
+    pre = a.float() @ b.float().t() * 0.5 + bias
+    # bias + alpha + GELU with aux
+    out = torch.empty(M, N, device=DEV, dtype=dtype)
+    aux = torch.empty(M, N, device=DEV, dtype=dtype)
+    kn.gemm(a, b, out, bias=bias, alpha=0.5, epi=kn.EPI_GELU, aux=aux)
+    close(aux, pre, dtype, what="gelu aux")
+    close(out, F.gelu(pre), dtype, what="gelu out")
+    # GELU backward: v * gelu'(aux)
+    u = rnd(M, N, dtype=dtype, seed=6)
+    uf = u.float().requires_grad_(True)
+    F.gelu(uf).backward(a.float() @ b.float().t())
+    out2 = torch.empty(M, N, device=DEV, dtype=dtype)
+    kn.gemm(a, b, out2, epi=kn.EPI_GELU_BWD, aux=u)
+    close(out2, uf.grad, dtype, what="gelu bwd")
+    # ReLU fwd / bwd
+    kn.gemm(a, b, out, bias=bias, epi=kn.EPI_RELU)
+    close(out, F.relu(a.float() @ b.float().t() + bias), dtype, what="relu")
+    kn.gemm(a, b, out2, epi=kn.EPI_RELU_BWD, aux=out)
+    close(out2, (a.float() @ b.float().t()) * (out.float() > 0), dtype, what="relu bwd")
+    # accumulate into f32 output (+ split-K atomics)
+    acc = rnd(M, N, seed=7)
+    ref = acc + a.float() @ b.float().t()
+    o1 = acc.clone()
+    kn.gemm(a, b, o1, accumulate=True)
+    close(o1, ref, dtype, what="accum f32")
+    o2 = acc.clone()
+    kn.gemm(a, b, o2, accumulate=True, splitk=2)
+    close(o2, ref, dtype, what="splitk")
+    # K split over two A operands
+    a2 = rnd(M, 64, dtype=dtype, seed=8, std=0.3)
+    b2 = rnd(N, Kd + 64, dtype=dtype, seed=9, std=0.3)
+    o3 = torch.empty(M, N, device=DEV, dtype=dtype)
+    kn.gemm(a, b2, o3, a2=a2)
+    close(o3, torch.cat([a.float(), a2.float()], 1) @ b2.float().t(), dtype, what="a2 split")
+    # strided views (sub-matrix of a wider buffer)
+    wide = rnd(M, 3 * Kd, dtype=dtype, seed=10, std=0.3)
+    o4 = torch.empty(M, N, device=DEV, dtype=dtype)
+    kn.gemm(wide[:, Kd:2 * Kd], b, o4)
+    close(o4, wide[:, Kd:2 * Kd].float() @ b.float().t(), dtype, what="strided A")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum(dtype):
+    x = rnd(1000, 200, dtype=dtype, seed=1)
+    out = torch.ones(200, device=DEV)
+    kn.colsum(x, out, accumulate=True)
+    close(out, 1 + x.float().sum(0), dtype, scale=4, what="colsum")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [256, 1024])
+def test_add_ln(dtype, D):
+    R = 77
+    x, res, dy = rnd(R, D, dtype=dtype, seed=1), rnd(R, D, dtype=dtype, seed=2), rnd(R, D, dtype=dtype, seed=3)
+    gamma, beta = (1 + 0.1 * rnd(D, seed=4)), 0.1 * rnd(D, seed=5)
+    xf, rf = x.float().requires_grad_(True), res.float().requires_grad_(True)
+    gf, bf = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xf + rf, (D,), gf, bf, 1e-5)
+    ref.backward(dy.float())
+    y = torch.empty_like(x)
+    mean, rstd = torch.empty(R, device=DEV), torch.empty(R, device=DEV)
+    kn.add_ln_fwd(x, res, gamma, beta, y, mean, rstd, 1e-5, 0.0, 0)
+    close(y, ref, dtype, what="ln fwd")
+    dx, dres = torch.empty_like(x), torch.empty_like(x)
+    dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    kn.add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, False, dg, db, 0.0, 0)
+    close(dx, xf.grad, dtype, what="ln dx")
+    close(dres, rf.grad, dtype, what="ln dres")
+    close(dg, gf.grad, dtype, scale=4, what="ln dgamma")
+    close(db, bf.grad, dtype, scale=4, what="ln dbeta")
+    # dropout: statistical + fwd/bwd mask consistency
+    kn.add_ln_fwd(x, torch.zeros_like(res), torch.ones_like(gamma), torch.zeros_like(beta), y, mean, rstd, 1e-5, 0.5, 1234)
+    kn.add_ln_bwd(dy, x, torch.zeros_like(res), torch.ones_like(gamma), mean, rstd, dx, dres, False, dg, db, 0.5, 1234)
+    frac_zero = (dx.float() == 0).float().mean().item()
+    assert 0.4 < frac_zero < 0.6, frac_zero
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_ln(dtype):
+    V, D, nseq, T = 50, 256, 6, 10
+    E, P = rnd(V, D, dtype=dtype, seed=1), rnd(T + 2, D, dtype=dtype, seed=2)
+    rvec = rnd(D, dtype=dtype, seed=3)
+    rd = rnd(nseq, seed=4)
+    gamma, beta = (1 + 0.1 * rnd(D, seed=5)), 0.1 * rnd(D, seed=6)
+    ids = torch.randint(0, V, (nseq, T), generator=torch.Generator().manual_seed(7)).to(DEV)
+    ids[0, 3] = 1
+    ids[2, 5:] = 1
+    dy = rnd(nseq * T, D, dtype=dtype, seed=8)
+    Ef, Pf, rf = E.float().requires_grad_(True), P.float().requires_grad_(True), rvec.float().requires_grad_(True)
+    gf, bf = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = F.embedding(ids, Ef, padding_idx=1) + Pf[torch.arange(T, device=DEV) + 2] + (rd[:, None] * rf)[:, None, :]
+    ref = F.layer_norm(z, (D,), gf, bf, 1e-5).view(-1, D)
+    ref.backward(dy.float())
+    y = torch.empty(nseq * T, D, device=DEV, dtype=dtype)
+    mean, rstd = torch.empty(nseq * T, device=DEV), torch.empty(nseq * T, device=DEV)
+    kn.embed_ln_fwd(ids, E, P, rd, rvec, gamma, beta, y, mean, rstd, nseq, T, 2, 1e-5, 0.0, 0)
+    close(y, ref, dtype, what="embed fwd")
+    dE, dP = torch.zeros(V, D, device=DEV), torch.zeros(T + 2, D, device=DEV)
+    dr, dg, db = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+    kn.embed_ln_bwd(dy, ids, E, P, rd, rvec, gamma, mean, rstd, dE, dP, dr, dg, db, nseq, T, 2, 1, 0.0, 0)
+    close(dE, Ef.grad, dtype, scale=4, what="dE")
+    close(dP, Pf.grad, dtype, scale=4, what="dP")
+    close(dr, rf.grad, dtype, scale=4, what="drvec")
+    close(dg, gf.grad, dtype, scale=4, what="dgamma")
+    close(db, bf.grad, dtype, scale=4, what="dbeta")
+    assert dE[1].abs().max().item() == 0.0  # padding_idx row gets no lookup gradient
+
+
+# ------------------------------------------------------------------------------------------------
+def attn_reference(q, k, v, pad, nq, T, qpb, N, S, H, exclude, causal, scale):
+    """q [nq*T, H*64]; k/v [B*N*S, H*64]; pad [B,N,S] bool.  Returns out [nq*T, H*64] (fp32 autograd)."""
+    B = nq // qpb
+    qh = q.view(nq, T, H, 64).permute(0, 2, 1, 3)                       # [nq,H,T,64]
+    kh = k.view(B, N, S, H, 64).permute(0, 1, 3, 2, 4)                   # [B,N,H,S,64]
+    vh = v.view(B, N, S, H, 64).permute(0, 1, 3, 2, 4)
+    outs = []
+    for qb in range(nq):
+        b, i = qb // qpb, qb % qpb
+        acc, cnt = 0, 0
+        for n in range(N):
+            if exclude and n == i:
+                continue
+            if pad is not None and bool(pad[b, n].all()):
+                continue
+            s = torch.einsum("htd,hsd->hts", qh[qb], kh[b, n]) * scale
+            if pad is not None:
+                s = s.masked_fill(pad[b, n][None, None, :], float("-inf"))
+            if causal:
+                s = s + torch.triu(torch.full((T, S), float("-inf"), device=s.device), 1)
+            acc = acc + torch.einsum("hts,hsd->htd", torch.softmax(s, -1), vh[b, n])
+            cnt += 1
+        if cnt == 0:
+            outs.append(torch.zeros(H, T, 64, device=q.device) + 0 * qh[qb])
+        else:
+            outs.append(acc / cnt)
+    return torch.stack(outs).permute(0, 2, 1, 3).reshape(nq * T, H * 64)
+
+
+ATTN_CASES = [
+    # name, B, qpb, N, S, T, H, exclude, causal, self
+    ("enc_self", 3, 1, 1, 40, 40, 2, False, False, True),
+    ("dec_self", 2, 1, 1, 128, 128, 2, False, True, True),
+    ("dec_self_short", 2, 1, 1, 10, 10, 1, False, True, True),
+    ("cross_text_loo", 2, 3, 3, 20, 12, 2, True, False, False),
+    ("cross_text_full", 1, 9, 9, 128, 128, 1, True, False, False),
+    ("cross_table", 2, 3, 1, 47, 12, 2, False, False, False),
+    ("cross_img", 2, 2, 3, 196, 33, 1, False, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ATTN_CASES, ids=[c[0] for c in ATTN_CASES])
+def test_attention(dtype, case):
+    name, B, qpb, N, S, T, H, exclude, causal, is_self = case
+    nq = B * qpb
+    D = H * 64
+    g = torch.Generator().manual_seed(11)
+    pad = torch.zeros(B, N, S, dtype=torch.bool)
+    for b in range(B):
+        for n in range(N):
+            L = int(torch.randint(max(1, S // 3), S + 1, (1,), generator=g))
+            pad[b, n, L:] = True
+    if not is_self and N > 1:
+        pad[0, N - 1, :] = True            # a null entity
+    if name == "cross_table":
+        pad[1, 0, :] = True                 # business without a table: output must be exactly 0
+    if causal:
+        pad[:, :, 0] = False
+    pad = pad.to(DEV)
+    if is_self:
+        qkv = rnd(nq * T, 3 * D, dtype=dtype, seed=1)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q = rnd(nq * T, D, dtype=dtype, seed=1)
+        kv = rnd(B * N * S, 2 * D, dtype=dtype, seed=2)
+        k, v = kv[:, :D], kv[:, D:]
+    dout = rnd(nq * T, D, dtype=dtype, seed=3)
+    scale = 0.125
+    qf, kf, vf = (t.float().contiguous().requires_grad_(True) for t in (q, k, v))
+    ref = attn_reference(qf, kf, vf, pad, nq, T, qpb, N, S, H, exclude, causal, scale)
+    ref.backward(dout.float())
+
+    pad_u8 = pad.to(torch.uint8).contiguous()
+    null = torch.empty(B * N, dtype=torch.uint8, device=DEV)
+    kn.entity_null(pad_u8, null, B * N, S)
+    assert torch.equal(null.bool().cpu(), pad.view(B * N, S).all(-1).cpu())
+    out = torch.full((nq * T, D), float("nan"), device=DEV, dtype=dtype)
+    desc = kn.make_attn_desc(q, k, v, out, pad_u8, null, nq, T, qpb, N, S, H, exclude, causal, scale)
+    kn.attn_fwd(desc, q)
+    close(out, ref, dtype, what=name + " fwd")
+
+    dq = torch.full((nq * T, D), float("nan"), device=DEV, dtype=dtype)
+    dk = torch.full((B * N * S, D), float("nan"), device=DEV, dtype=dtype)
+    dv = torch.full((B * N * S, D), float("nan"), device=DEV, dtype=dtype)
+    stats = torch.empty(kn.attn_bwd_workspace(desc) // 4, device=DEV)
+    kn.attn_bwd(desc, dout, dq, False, dk, dv, stats)
+    close(dq, qf.grad, dtype, what=name + " dq")
+    close(dk, kf.grad, dtype, what=name + " dk")
+    close(dv, vf.grad, dtype, what=name + " dv")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gate(dtype):
+    Bq, rows, D = 4, 6, 256
+    R = Bq * rows
+    ts = [rnd(R, D, dtype=dtype, seed=s) for s in range(1, 7)]
+    pa, pb, yt, ytab, yimg, dout = ts
+    no_table = torch.tensor([0, 1, 0, 0], dtype=torch.uint8, device=DEV)
+    no_img = torch.tensor([0, 0, 1, 0], dtype=torch.uint8, device=DEV)
+    fl = [t.float().requires_grad_(True) for t in (pa, pb, yt, ytab, yimg)]
+    ma = (1 - no_table.float()).repeat_interleave(rows)[:, None]
+    mb = (1 - no_img.float()).repeat_interleave(rows)[:, None]
+    ref = fl[2] + ma * F.relu(torch.tanh(fl[0])) * fl[3] + mb * F.relu(torch.tanh(fl[1])) * fl[4]
+    ref.backward(dout.float())
+    out = torch.empty_like(yt)
+    kn.gate_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, out, rows)
+    close(out, ref, dtype, what="gate fwd")
+    outs = [torch.empty_like(yt) for _ in range(5)]
+    kn.gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, *outs, rows)
+    for o, f, nm in zip(outs, fl, ["dpa", "dpb", "dyt", "dytab", "dyimg"]):
+        close(o, f.grad, dtype, what=nm)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ls_loss(dtype, golden_dir):
+    from oracle import bart_oracle as bo
+    from multimodalsum_amd.formula_init import formula_tensor
+    g = np.load(os.path.join(golden_dir, "f5_loss.npz"))
+    V, ld = 50265, 50304
+    target = torch.from_numpy(g["target"]).to(DEV)
+    logits_cpu = formula_tensor("f5.logits", (8, V), std=2.0)
+    buf = torch.zeros(8, ld, device=DEV, dtype=dtype)
+    buf[:, :V] = logits_cpu.to(DEV).to(dtype)
+    src = buf[:, :V].float().cpu().requires_grad_(True)
+    ref = bo.label_smoothing_loss(src, target.cpu(), V, 0.1)
+    ref.backward()
+    rows = torch.empty(8, device=DEV)
+    kn.ls_loss(buf, target, rows, V, 0.1, 1.0 / 8, True)
+    tot = torch.empty(1, device=DEV)
+    kn.segment_sum(rows, tot, 1, 8, 1.0 / 8)
+    assert abs(tot.item() - ref.item()) < 1e-4 * abs(ref.item()) + 1e-5
+    if dtype == torch.float32:
+        assert abs(tot.item() - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+        close(buf[:, :64], torch.from_numpy(g["grad_sample"]), dtype, scale=0.01, what="golden grad")
+    close(buf[:, :V], src.grad, dtype, scale=0.05, what="dlogits")
+    assert buf[:, V:].abs().max().item() == 0.0
+    # smoothing 0 == cross entropy
+    buf[:, :V] = logits_cpu.to(DEV).to(dtype)
+    kn.ls_loss(buf, target, rows, V, 0.0, 1.0, False)
+    ce = F.cross_entropy(buf[:, :V].float(), target, reduction="none")
+    close(rows, ce, torch.float32, scale=5, what="ce rows")
+
+
+def test_optimizer_kernels():
+    from oracle import step_oracle as so
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2, std=0.01)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    pc, gc, mc, vc = p.cpu().clone(), g.cpu().clone(), m.cpu().clone(), v.cpu().clone()
+    shadow = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    nsq = torch.empty(1, device=DEV)
+    kn.l2norm_sq(g, nsq)
+    ref_n = (gc.double() ** 2).sum().item()
+    assert abs(nsq.item() - ref_n) < 1e-5 * ref_n
+    for step in range(1, 4):
+        lr, wd = 1e-3, 0.01
+        step_size = lr * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        hyper = torch.tensor([step_size, lr * wd, 0.5, 0.0], device=DEV)
+        kn.adamw(p, g, m, v, shadow, hyper, nsq, 0.9, 0.999, 1e-6)
+        gcl = gc.clone()
+        so.clip_grad_norm([gcl], 0.5)
+        so.adamw_step(pc, gcl, mc, vc, step, lr, weight_decay=wd)
+    close(p, pc, torch.float32, scale=0.1, what="adamw p")
+    close(m, mc, torch.float32, scale=0.1, what="adamw m")
+    close(shadow, pc, torch.bfloat16, what="shadow")
+    g2 = g.clone()
+    kn.scale_by_clip(g2, nsq, 0.5)
+    close(g2, gcl, torch.float32, scale=0.1, what="clip scale")
+    x = rnd(1001, seed=5)
+    xb = torch.empty(1001, device=DEV, dtype=torch.bfloat16)
+    kn.cast(xb, x)
+    assert torch.equal(xb, x.to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 8, 16, 3, 1, 1), (2, 16, 16, 8, 16, 3, 2, 1), (2, 20, 20, 3, 8, 7, 2, 3)])
+def test_conv_im2col(dtype, cfg):
+    N, H, W, C, Cout, KS, stride, pad = cfg
+    Ho, Wo = (H + 2 * pad - KS) // stride + 1, (W + 2 * pad - KS) // stride + 1
+    Kd = KS * KS * C
+    Kpad = (Kd + 63) // 64 * 64
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(Cout, C, KS, KS, seed=2, std=0.2)
+    xn = torch.empty(N * H * W, C, device=DEV, dtype=dtype)
+    kn.nchw_to_nhwc(x, xn, N, C, H, W)
+    close(xn, x.permute(0, 2, 3, 1).reshape(-1, C), dtype, what="nhwc")
+    xr = xn.float().view(N, H, W, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    wm = torch.empty(Cout, Kpad, device=DEV, dtype=dtype)
+    kn.conv_weight_to_matrix(wm, w, Cout, C, KS, KS, Kpad)
+    wr = wm[:, :Kd].float().reshape(Cout, KS, KS, C).permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = F.conv2d(xr, wr, stride=stride, padding=pad)
+    col = torch.full((N * Ho * Wo, Kpad), float("nan"), device=DEV, dtype=dtype)
+    kn.im2col(xn, col, N, H, W, C, KS, KS, stride, pad, Ho, Wo, Kpad)
+    y = torch.empty(N * Ho * Wo, Cout, device=DEV, dtype=dtype)
+    kn.gemm(col, wm, y)
+    close(y, ref.permute(0, 2, 3, 1).reshape(-1, Cout), dtype, scale=2, what="conv fwd")
+    if C % 4 == 0:
+        dy = rnd(N * Ho * Wo, Cout, dtype=dtype, seed=3)
+        ref.backward(dy.float().view(N, Ho, Wo, Cout).permute(0, 3, 1, 2))
+        dcol = torch.empty(N * Ho * Wo, Kpad, device=DEV, dtype=dtype)
+        kn.gemm(dy, wm, dcol, b_t=True)
+        dx = torch.empty(N * H * W, C, device=DEV, dtype=dtype)
+        kn.col2im(dcol, dx, N, H, W, C, KS, KS, stride, pad, Ho, Wo, Kpad)
+        close(dx, xr.grad.permute(0, 2, 3, 1).reshape(-1, C), dtype, scale=4, what="conv dgrad")
+        dwm = torch.zeros(Cout, Kpad, device=DEV)
+        kn.gemm(dy, col, dwm, a_t=True, b_t=True, accumulate=True)
+        dw = torch.ones(Cout, C, KS, KS, device=DEV)
+        kn.conv_matrix_grad_to_weight(dwm, dw, Cout, C, KS, KS, Kpad, True)
+        close(dw, 1 + wr.grad, dtype, scale=4, what="conv wgrad")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm_pool(dtype):
+    R, C = 2 * 14 * 14, 64
+    x, res, dy = rnd(R, C, dtype=dtype, seed=1), rnd(R, C, dtype=dtype, seed=2), rnd(R, C, dtype=dtype, seed=3)
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    xf, rf = x.float().requires_grad_(True), res.float().requires_grad_(True)
+    gf, bf = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.relu(F.batch_norm(xf, rm_ref, rv_ref, gf, bf, True, 0.1, 1e-5) + rf)
+    ref.backward(dy.float())
+    sums = torch.empty(2 * C, device=DEV)
+    kn.bn_reduce(x, sums)
+    y = torch.empty_like(x)
+    kn.bn_apply(x, sums, gamma, beta, res, y, rm, rv, 1e-5, 0.1, True, True)
+    close(y, ref, dtype, what="bn fwd")
+    close(rm, rm_ref, torch.float32, scale=4, what="running mean")
+    close(rv, rv_ref, torch.float32, scale=4, what="running var")
+    dsums = torch.empty(2 * C, device=DEV)
+    kn.bn_bwd_reduce(dy, y, x, sums, dsums, 1e-5, True)
+    dx, dres = torch.empty_like(x), torch.empty_like(x)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    kn.bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dres, dg, db, 1e-5, True)
+    close(dx, xf.grad, dtype, scale=2, what="bn dx")
+    close(dres, rf.grad, dtype, what="bn dres")
+    close(dg, gf.grad, dtype, scale=8, what="bn dgamma")
+    close(db, bf.grad, dtype, scale=8, what="bn dbeta")
+    # eval mode
+    kn.bn_apply(x, sums, gamma, beta, None, y, rm, rv, 1e-5, 0.1, False, False)
+    close(y, F.batch_norm(x.float(), rm, rv, gamma, beta, False, 0.1, 1e-5), dtype, what="bn eval")
+    # max-pool 3x3/2 pad 1
+    N, H, W = 2, 14, 14
+    yp = torch.empty(N * 7 * 7, C, device=DEV, dtype=dtype)
+    kn.maxpool3x3s2(x, yp, N, H, W, C, 7, 7)
+    refp = F.max_pool2d(x.float().view(N, H, W, C).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, C)
+    close(yp, refp, dtype, what="maxpool")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_table_gather(dtype):
+    from multimodalsum_amd import synthetic as syn
+    B, V, D = 3, 200, 1024
+    field, fv = syn.table_batch(B, V, seed=21)
+    E = rnd(V, D, dtype=dtype, seed=1, std=0.05)
+    wr, wh = rnd(D, 4, dtype=dtype, seed=2), rnd(D, 4, dtype=dtype, seed=3)
+    Ef = E.float().cpu()
+    name, category, str_cat, str_bool, rating, hours = fv
+
+    def msum(ids, dim):
+        return (F.embedding(ids, Ef) * ids.ne(1).unsqueeze(-1).float()).sum(dim=dim)
+
+    names = msum(field, 1).unsqueeze(0).expand(B, -1, -1)
+    cat_valid = category.ne(1).any(-1).unsqueeze(-1).float()
+    vals = torch.cat([msum(name, 1).unsqueeze(1),
+                      (msum(category, 2) * cat_valid).sum(1, keepdim=True) / (cat_valid.sum(1, keepdim=True) + 1e-6),
+                      msum(str_cat, 2), F.embedding(str_bool.squeeze(-1), Ef) * str_bool.ne(1).float(),
+                      F.linear(rating.float(), wr.float().cpu()).unsqueeze(1), F.linear(hours.float(), wh.float().cpu())], 1)
+    ref = torch.cat([names, vals], -1)
+    ones = torch.ones(B, 1, dtype=torch.bool)
+    mref = torch.cat([ones, category[:, :1, 0].ne(1), str_cat[:, :, 0].ne(1), str_bool[:, :, 0].ne(1), ones, hours.sum(-1) != 0], 1)
+    out = torch.empty(B * 47, 2 * D, device=DEV, dtype=dtype)
+    mask = torch.empty(B, 47, dtype=torch.uint8, device=DEV)
+    kn.table_gather(E, field.to(DEV), [t.to(DEV).contiguous() for t in fv], wr, wh, out, mask, B, 1)
+    close(out, ref.view(B * 47, 2 * D), dtype, what="table gather")
+    assert torch.equal(mask.bool().cpu(), mref)
+    dall = rnd(B * 47, 2 * D, dtype=dtype, seed=4)
+    dwr, dwh = torch.zeros(D, 4, device=DEV), torch.zeros(D, 4, device=DEV)
+    kn.table_gather_bwd(dall, rating.to(DEV), hours.to(DEV), dwr, dwh, B, D)
+    dv = dall.float().cpu().view(B, 47, 2 * D)[:, :, D:]
+    close(dwr, torch.einsum("bk,bd->dk", rating.float(), dv[:, 39]), dtype, what="dw_rating")
+    close(dwh, torch.einsum("bjk,bjd->dk", hours.float(), dv[:, 40:47]), dtype, scale=2, what="dw_hours")
