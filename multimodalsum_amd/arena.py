@@ -1,0 +1,109 @@
+"""Flat HBM parameter arena.
+
+All parameters of the model live in ONE f32 buffer (`data`), their gradients in a second one
+(`grad`) and -- in bf16 compute mode -- a bf16 shadow of the weights in a third (`shadow`).
+`nn.Parameter`s are views into `data`, so the reference's `named_parameters()` / `state_dict()` /
+`torch.save` contract holds, while the hot path gets:
+
+  * q/k/v (and k/v of cross-attention) weights adjacent -> one [3D, D] GEMM operand;
+  * gradient clipping = one L2 kernel, AdamW = one kernel, per arena slice;
+  * DDP = a handful of large contiguous RCCL all-reduces over `grad`, no flatten/unflatten copies.
+
+Parameters are ordered [decay group | no-decay group]; the split follows the reference's substring
+filter (/root/reference/src/multimodal_train.py:462), so quirk Q1 ("the no-decay group is empty":
+/root/reference/src/train_utils.py:52-55) is simply "the optimiser only touches the first slice".
+"""
+import torch
+import torch.nn as nn
+
+NO_DECAY = ('bias', 'bn1.weight', 'bn2.weight', 'bn3.weight', 'layer_norm.weight', 'layernorm_embedding.weight')
+ALIGN = 64  # elements; keeps every parameter 256-B (f32) / 128-B (bf16) aligned
+
+
+def is_no_decay(name):
+    return any(nd in name for nd in NO_DECAY)
+
+
+class ParamArena:
+    def __init__(self, specs, device, compute_dtype):
+        """specs: ordered list of (name, shape).  Order inside each group is preserved (the engine
+        relies on q,k,v adjacency)."""
+        self.device = torch.device(device)
+        self.compute_dtype = compute_dtype
+        decay = [(n, s) for n, s in specs if not is_no_decay(n)]
+        nodecay = [(n, s) for n, s in specs if is_no_decay(n)]
+        self.offsets = {}
+        self.shapes = {}
+        off = 0
+        for group in (decay, nodecay):
+            for name, shape in group:
+                n = 1
+                for d in shape:
+                    n *= int(d)
+                self.offsets[name] = off
+                self.shapes[name] = tuple(int(d) for d in shape)
+                off += (n + ALIGN - 1) // ALIGN * ALIGN
+            if group is decay:
+                self.decay_end = off
+        self.total = off
+        self.data = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=self.device)
+        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device) if compute_dtype == torch.bfloat16 else None
+        self.params = {}
+        for name in self.offsets:
+            self.params[name] = nn.Parameter(self.view(self.data, name))
+        self.shadow_dirty = True
+
+    def numel(self, name):
+        n = 1
+        for d in self.shapes[name]:
+            n *= d
+        return n
+
+    def view(self, buf, name, shape=None):
+        o = self.offsets[name]
+        return buf[o:o + self.numel(name)].view(shape or self.shapes[name])
+
+    def span(self, buf, first, last, shape):
+        """A view covering parameters first..last, which must be adjacent and unpadded (q,k,v packs)."""
+        o0 = self.offsets[first]
+        o1 = self.offsets[last] + self.numel(last)
+        n = 1
+        for d in shape:
+            n *= d
+        assert o1 - o0 == n, "parameters %s..%s are not contiguous (%d vs %d)" % (first, last, o1 - o0, n)
+        return buf[o0:o1].view(shape)
+
+    # weights as the kernels read them (bf16 shadow or the f32 master)
+    def w(self, name, shape=None):
+        return self.view(self.shadow if self.shadow is not None else self.data, name, shape)
+
+    def wspan(self, first, last, shape):
+        return self.span(self.shadow if self.shadow is not None else self.data, first, last, shape)
+
+    def f32(self, name):
+        return self.view(self.data, name)
+
+    def g(self, name, shape=None):
+        return self.view(self.grad, name, shape)
+
+    def gspan(self, first, last, shape):
+        return self.span(self.grad, first, last, shape)
+
+    def prepare_grads(self):
+        """Gradient buffers accumulate (autograd semantics).  Parameters whose .grad is None
+        (fresh, or cleared by zero_grad(set_to_none=True)) start from zero; parameters that still
+        carry a .grad keep accumulating -- which is what happens to the reference's no-decay
+        parameters under quirk Q1 (optimizer.zero_grad() never reaches them)."""
+        none = [n for n, p in self.params.items() if p.grad is None]
+        if len(none) == len(self.params):
+            self.grad.zero_()
+        else:
+            for n in none:
+                self.g(n).zero_()
+
+    def attach_grads(self, names=None):
+        for n in (names if names is not None else self.params):
+            p = self.params[n]
+            if p.grad is None:
+                p.grad = self.g(n)

@@ -206,8 +206,11 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     const int kc = (dtype == MMSUM_BF16) ? 8 : 4;
     const int bk = (dtype == MMSUM_BF16) ? 64 : 32;
     const bool at = flags & MMSUM_GEMM_A_T, bt = flags & MMSUM_GEMM_B_T;
-    if (!at && (K % kc)) return MMSUM_ERR_BAD_SHAPE;
-    if (!bt && (K % kc)) return MMSUM_ERR_BAD_SHAPE;
+    // natural operands are read in 16-byte chunks along K: K must be a chunk multiple unless the row
+    // is padded (ld >= K rounded up) -- the caller then guarantees the padding holds zeros.
+    const long kround = ((long)K + kc - 1) / kc * kc;
+    if (!at && (K % kc) && lda < kround) return MMSUM_ERR_BAD_SHAPE;
+    if (!bt && (K % kc) && ldb < kround) return MMSUM_ERR_BAD_SHAPE;
     if (A2 && (at || ksplit % bk || ksplit <= 0 || ksplit >= K)) return MMSUM_ERR_BAD_SHAPE;
     if (splitk > 1 && !((flags & MMSUM_GEMM_OUT_F32) && (flags & MMSUM_GEMM_ACCUM))) return MMSUM_ERR_BAD_SHAPE;
     const size_t es = (dtype == MMSUM_BF16) ? 2 : 4;

@@ -1,0 +1,692 @@
+"""Hand-scheduled forward/backward programs of the hot path over the HIP kernels.
+
+There is no tracing compiler and no autograd graph inside the model: each sub-program below
+(encoder, table encoder, ResNet, multi-encoder decoder, LM head + loss) is an explicit kernel
+schedule with its own saved activations, and its backward is the explicit reverse schedule that
+writes parameter gradients straight into the flat gradient arena (arena.py).  torch.autograd only
+sees a few coarse nodes (modules.py), so whole steps can be captured into HIP graphs.
+
+Restructuring relative to the reference:
+  * the NR leave-one-out decoder passes (multimodal_train.py:150-163) run as ONE decoder call with
+    NR*B sequences; the cross-attention kernel skips entity i for pass i (exclude_self);
+  * cross-attention K/V of all reviews + table + images are projected once per layer per step
+    (one [Rmem, 2D] GEMM), q once per layer, the three out_proj calls as one [3*Rq, D] GEMM;
+  * torch.cat([text, table]) for alpha/beta is a K-split GEMM over two A operands.
+Numerics follow the reference op for op (same masks, same -inf/-2^16 semantics, entity mean with
+null entities, post-LN, erf-GELU); see the citations at each step.
+"""
+import math
+from types import SimpleNamespace as NS
+
+import torch
+
+from . import kernels as kn
+from .arena import ParamArena
+
+RESNET_LAYERS = (3, 4, 23, 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter inventory (names = the reference's state_dict keys)
+# ------------------------------------------------------------------------------------------------
+def bart_specs(cfg, multimodal, prefix):
+    D, V = cfg.d_model, cfg.vocab_size
+    P = cfg.max_position_embeddings + cfg.extra_pos_embeddings
+    s = [(prefix + "model.shared.weight", (V, D))]
+    for side, nl, Fd in (("encoder", cfg.encoder_layers, cfg.encoder_ffn_dim), ("decoder", cfg.decoder_layers, cfg.decoder_ffn_dim)):
+        b = prefix + "model.%s." % side
+        s.append((b + "embed_positions.weight", (P, D)))
+        s += [(b + "layernorm_embedding.weight", (D,)), (b + "layernorm_embedding.bias", (D,))]
+        if side == "decoder":
+            s.append((b + "rating_embeddings", (D,)))
+        for i in range(nl):
+            lb = b + "layers.%d." % i
+            for a in (["self_attn"] + (["encoder_attn"] if side == "decoder" else [])):
+                # q,k,v adjacent (weights in the decay group, biases in the no-decay group)
+                for p in ("q_proj", "k_proj", "v_proj"):
+                    s.append((lb + a + "." + p + ".weight", (D, D)))
+                for p in ("q_proj", "k_proj", "v_proj"):
+                    s.append((lb + a + "." + p + ".bias", (D,)))
+                s += [(lb + a + ".out_proj.weight", (D, D)), (lb + a + ".out_proj.bias", (D,))]
+                if a == "encoder_attn" and multimodal:
+                    for p in ("alpha_proj", "beta_proj"):
+                        s += [(lb + a + "." + p + ".weight", (D, 2 * D)), (lb + a + "." + p + ".bias", (D,))]
+                s += [(lb + a + "_layer_norm.weight", (D,)), (lb + a + "_layer_norm.bias", (D,))]
+            s += [(lb + "fc1.weight", (Fd, D)), (lb + "fc1.bias", (Fd,)), (lb + "fc2.weight", (D, Fd)), (lb + "fc2.bias", (D,))]
+            s += [(lb + "final_layer_norm.weight", (D,)), (lb + "final_layer_norm.bias", (D,))]
+    return s
+
+
+def table_specs(prefix="table_encoder."):
+    return [(prefix + "rating_embedding.weight", (1024, 4)), (prefix + "hours_embedding.weight", (1024, 4)),
+            (prefix + "fc.weight", (1024, 2048)), (prefix + "fc.bias", (1024,)), (prefix + "linear.weight", (1024, 1024))]
+
+
+def resnet_blocks():
+    """(layer index, block index, inplanes, planes, stride, has_downsample) of torchvision resnet101."""
+    out, inplanes = [], 64
+    for li, (planes, blocks) in enumerate(zip((64, 128, 256, 512), RESNET_LAYERS)):
+        for bi in range(blocks):
+            out.append((li + 1, bi, inplanes, planes, 2 if (bi == 0 and li > 0) else 1, bi == 0))
+            inplanes = planes * 4
+    return out
+
+
+def resnet_specs(embedding_dim, prefix="img_encoder."):
+    """Returns (param specs, buffer specs).  Live (layer3 + linear) parameters first, then the
+    gradient-free ones (stem/layer1/layer2: detached at img_encoder.py:33; layer4/fc: never called)."""
+    r = prefix + "resnet."
+    live, frozen, bufs = [], [], []
+
+    def bn(dst, name, c):
+        dst += [(name + ".weight", (c,)), (name + ".bias", (c,))]
+        bufs.extend([(name + ".running_mean", (c,)), (name + ".running_var", (c,)), (name + ".num_batches_tracked", ())])
+
+    frozen.append((r + "conv1.weight", (64, 3, 7, 7)))
+    bn(frozen, r + "bn1", 64)
+    for li, bi, inp, pl, stride, down in resnet_blocks():
+        dst = live if li == 3 else frozen
+        b = r + "layer%d.%d." % (li, bi)
+        dst.append((b + "conv1.weight", (pl, inp, 1, 1)))
+        bn(dst, b + "bn1", pl)
+        dst.append((b + "conv2.weight", (pl, pl, 3, 3)))
+        bn(dst, b + "bn2", pl)
+        dst.append((b + "conv3.weight", (pl * 4, pl, 1, 1)))
+        bn(dst, b + "bn3", pl * 4)
+        if down:
+            dst.append((b + "downsample.0.weight", (pl * 4, inp, 1, 1)))
+            bn(dst, b + "downsample.1", pl * 4)
+    frozen += [(r + "fc.weight", (1000, 2048)), (r + "fc.bias", (1000,))]
+    live.append((prefix + "linear.weight", (embedding_dim, 1024)))
+    return live, frozen, bufs
+
+
+class Engine:
+    def __init__(self, cfg, device="cuda", compute_dtype=torch.bfloat16, multimodal=True, with_table=False, with_img=False,
+                 bart_prefix="", deterministic=False):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.dtype = compute_dtype
+        self.multimodal = multimodal
+        self.with_table, self.with_img = with_table, with_img
+        self.bp = bart_prefix
+        self.deterministic = deterministic
+        self.training = True
+        self.seed_base = 0x5EED
+        self.step_count = 0
+        specs = bart_specs(cfg, multimodal, bart_prefix)
+        self.buffers = {bart_prefix + "final_logits_bias": torch.zeros(1, cfg.vocab_size, device=self.device)}
+        frozen = []
+        if with_table:
+            specs += table_specs()
+        if with_img:
+            live, frozen, bufs = resnet_specs(cfg.d_model)
+            specs += live
+            for name, shape in bufs:
+                if name.endswith("num_batches_tracked"):
+                    self.buffers[name] = torch.zeros((), dtype=torch.int64, device=self.device)
+                else:
+                    self.buffers[name] = (torch.ones if name.endswith("running_var") else torch.zeros)(shape, device=self.device)
+        self.frozen_names = [n for n, _ in frozen]
+        self.arena = ParamArena(specs + frozen, self.device, compute_dtype)
+        self.conv_mats = {}
+        self._conv_dirty = "all"
+        self.touched = set()
+        self.Vpad = (cfg.vocab_size + 127) // 128 * 128
+        self.post_backward_hooks = []      # run once when a whole backward pass has finished (DDP finalisation)
+        self.segment_hooks = []            # run when a parameter segment's gradients are final (DDP overlap)
+        for name, p in self.arena.params.items():   # lets optim.py / parallel.py find the arena from a parameter
+            p._mmsum_arena, p._mmsum_name, p._mmsum_engine = self.arena, name, self
+
+    def segment_ready(self, prefixes):
+        """Gradients of every parameter whose name starts with one of `prefixes` are final."""
+        for cb in self.segment_hooks:
+            cb(prefixes)
+
+    # ---- helpers --------------------------------------------------------------------------------
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=dtype or self.dtype, device=self.device)
+
+    def p_drop(self):
+        return float(self.cfg.dropout) if self.training else 0.0
+
+    def next_seed(self):
+        self.step_count += 1
+        return (self.seed_base * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
+
+    def sync_weights(self):
+        """Called at the start of every forward.  Parameters are ordinary f32 tensors that any
+        optimiser may update in place, so the bf16 shadow and the conv weight matrices are rebuilt
+        from the masters unless the fused optimiser (optim.FusedAdamW) has declared them current."""
+        a = self.arena
+        if a.shadow is not None and a.shadow_dirty:
+            kn.cast(a.shadow, a.data)
+        if self.with_img and self._conv_dirty:
+            self._build_conv_mats(all_layers=(self._conv_dirty == "all"))
+        a.shadow_dirty = True
+        self._conv_dirty = "all"
+
+    def mark_weights_changed(self):
+        self.arena.shadow_dirty = True
+        self._conv_dirty = "all"
+
+    def after_fused_optimizer_step(self):
+        """FusedAdamW wrote the bf16 shadow itself; only layer3's 3x3 matrices need a refresh."""
+        self.arena.shadow_dirty = False
+        self._conv_dirty = "layer3"
+
+    def splitk(self, M, N, Kred):
+        if self.deterministic:
+            return 1
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        ktiles = max(1, Kred // (64 if self.dtype == torch.bfloat16 else 32))
+        sk = max(1, min(16, 512 // max(tiles, 1), ktiles // 4))
+        return sk
+
+    def wgrad(self, dy, x, gname=None, gview=None):
+        """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena."""
+        out = gview if gview is not None else self.arena.g(gname)
+        kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=self.splitk(dy.shape[1], x.shape[1], dy.shape[0]))
+
+    def bgrad(self, dy, gname=None, gview=None):
+        kn.colsum(dy, gview if gview is not None else self.arena.g(gname), accumulate=True)
+
+    def touch(self, *names):
+        self.touched.update(names)
+
+    # =============================================================================================
+    # Encoder  (BartEncoder.forward, modeling_multimodalsum.py:346-404; EncoderLayer :276-309)
+    # =============================================================================================
+    def _attn_names(self, lb, a):
+        return [lb + a + "." + p for p in ("q_proj", "k_proj", "v_proj")]
+
+    def encoder_fwd(self, ids, attention_mask, out=None):
+        """ids [Bn,S] int64, attention_mask [Bn,S] (1 = keep).  -> hidden [Bn*S, D] (batch-major rows)."""
+        cfg, a = self.cfg, self.arena
+        D, H = cfg.d_model, cfg.heads
+        Bn, S = ids.shape
+        R = Bn * S
+        b = self.bp + "model.encoder."
+        c = NS(Bn=Bn, S=S, ids=ids.contiguous(), layers=[], p=self.p_drop())
+        c.pad = attention_mask.eq(0).to(torch.uint8).contiguous()
+        c.seed0 = self.next_seed()
+        x = self.empty(R, D)
+        c.mean0, c.rstd0 = self.empty(R, dtype=torch.float32), self.empty(R, dtype=torch.float32)
+        kn.embed_ln_fwd(c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), None, None,
+                        a.f32(b + "layernorm_embedding.weight"), a.f32(b + "layernorm_embedding.bias"), x, c.mean0, c.rstd0,
+                        Bn, S, cfg.extra_pos_embeddings, 1e-5, c.p, c.seed0)
+        c.x0 = x
+        for i in range(cfg.encoder_layers):
+            last = i == cfg.encoder_layers - 1
+            x, lc = self._self_block_fwd(b + "layers.%d." % i, x, c.pad, Bn, S, causal=False)
+            x, fc = self._ffn_block_fwd(b + "layers.%d." % i, x, out if last else None)
+            c.layers.append((lc, fc))
+        c.out = x
+        return x, c
+
+    def encoder_bwd(self, c, dout):
+        """dout [Bn*S, D] (consumed).  Accumulates every encoder parameter gradient."""
+        cfg, a = self.cfg, self.arena
+        b = self.bp + "model.encoder."
+        dx = dout
+        for i in reversed(range(cfg.encoder_layers)):
+            lc, fc = c.layers[i]
+            dx = self._ffn_block_bwd(b + "layers.%d." % i, fc, dx)
+            dx = self._self_block_bwd(b + "layers.%d." % i, lc, dx)
+        kn.embed_ln_bwd(dx, c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), None, None,
+                        a.f32(b + "layernorm_embedding.weight"), c.mean0, c.rstd0, a.g(self.bp + "model.shared.weight"),
+                        a.g(b + "embed_positions.weight"), None, a.g(b + "layernorm_embedding.weight"),
+                        a.g(b + "layernorm_embedding.bias"), c.Bn, c.S, cfg.extra_pos_embeddings, cfg.pad_token_id, c.p, c.seed0)
+        self.touch(self.bp + "model.shared.weight", b + "embed_positions.weight", b + "layernorm_embedding.weight",
+                   b + "layernorm_embedding.bias")
+
+    # ---- shared blocks ----------------------------------------------------------------------------
+    def _self_block_fwd(self, lb, x, pad, Bn, T, causal):
+        """x -> LN(x + drop(out_proj(self_attention(x))))   (:288-297 / :442-461)."""
+        cfg, a = self.cfg, self.arena
+        D, H = cfg.d_model, cfg.heads
+        R = x.shape[0]
+        q, k, v = self._attn_names(lb, "self_attn")
+        c = NS(x=x, pad=pad, Bn=Bn, T=T, causal=causal, p=self.p_drop(), seed=self.next_seed())
+        c.qkv = self.empty(R, 3 * D)
+        kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), c.qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)))
+        c.attn = self.empty(R, D)
+        c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], c.attn, pad, None, Bn, T, 1, 1, T, H,
+                                   False, causal, 64 ** -0.5)
+        kn.attn_fwd(c.desc, x)
+        c.o = self.empty(R, D)
+        kn.gemm(c.attn, a.w(lb + "self_attn.out_proj.weight"), c.o, bias=a.f32(lb + "self_attn.out_proj.bias"))
+        y = self.empty(R, D)
+        c.mean, c.rstd = self.empty(R, dtype=torch.float32), self.empty(R, dtype=torch.float32)
+        kn.add_ln_fwd(c.o, x, a.f32(lb + "self_attn_layer_norm.weight"), a.f32(lb + "self_attn_layer_norm.bias"), y, c.mean,
+                      c.rstd, 1e-5, c.p, c.seed)
+        return y, c
+
+    def _self_block_bwd(self, lb, c, dy):
+        cfg, a = self.cfg, self.arena
+        D = cfg.d_model
+        R = dy.shape[0]
+        q, k, v = self._attn_names(lb, "self_attn")
+        do, dx = self.empty(R, D), self.empty(R, D)
+        kn.add_ln_bwd(dy, c.o, c.x, a.f32(lb + "self_attn_layer_norm.weight"), c.mean, c.rstd, do, dx, False,
+                      a.g(lb + "self_attn_layer_norm.weight"), a.g(lb + "self_attn_layer_norm.bias"), c.p, c.seed)
+        self.bgrad(do, lb + "self_attn.out_proj.bias")
+        self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight")
+        dattn = self.empty(R, D)
+        kn.gemm(do, a.w(lb + "self_attn.out_proj.weight"), dattn, b_t=True)
+        dqkv = self.empty(R, 3 * D)
+        stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
+        kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
+        self.bgrad(dqkv, gview=a.gspan(q + ".bias", v + ".bias", (3 * D,)))
+        self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)))
+        kn.gemm(dqkv, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), dx, b_t=True, accumulate=True)
+        self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias",
+                   lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.bias", lb + "self_attn_layer_norm.weight",
+                   lb + "self_attn_layer_norm.bias")
+        return dx
+
+    def _ffn_block_fwd(self, lb, x, out=None):
+        """x -> LN(x + drop(fc2(gelu(fc1(x)))))   (:299-308 / :479-489)."""
+        cfg, a = self.cfg, self.arena
+        R, D = x.shape
+        Fd = a.shapes[lb + "fc1.weight"][0]
+        c = NS(x=x, p=self.p_drop(), seed=self.next_seed())
+        c.u, c.h = self.empty(R, Fd), self.empty(R, Fd)
+        kn.gemm(x, a.w(lb + "fc1.weight"), c.h, bias=a.f32(lb + "fc1.bias"), epi=kn.EPI_GELU, aux=c.u)
+        c.f = self.empty(R, D)
+        kn.gemm(c.h, a.w(lb + "fc2.weight"), c.f, bias=a.f32(lb + "fc2.bias"))
+        y = out if out is not None else self.empty(R, D)
+        c.mean, c.rstd = self.empty(R, dtype=torch.float32), self.empty(R, dtype=torch.float32)
+        kn.add_ln_fwd(c.f, x, a.f32(lb + "final_layer_norm.weight"), a.f32(lb + "final_layer_norm.bias"), y, c.mean, c.rstd,
+                      1e-5, c.p, c.seed)
+        return y, c
+
+    def _ffn_block_bwd(self, lb, c, dy):
+        a = self.arena
+        R, D = dy.shape
+        df, dx = self.empty(R, D), self.empty(R, D)
+        kn.add_ln_bwd(dy, c.f, c.x, a.f32(lb + "final_layer_norm.weight"), c.mean, c.rstd, df, dx, False,
+                      a.g(lb + "final_layer_norm.weight"), a.g(lb + "final_layer_norm.bias"), c.p, c.seed)
+        self.bgrad(df, lb + "fc2.bias")
+        self.wgrad(df, c.h, lb + "fc2.weight")
+        du = self.empty(R, c.u.shape[1])
+        kn.gemm(df, a.w(lb + "fc2.weight"), du, b_t=True, epi=kn.EPI_GELU_BWD, aux=c.u)
+        self.bgrad(du, lb + "fc1.bias")
+        self.wgrad(du, c.x, lb + "fc1.weight")
+        kn.gemm(du, a.w(lb + "fc1.weight"), dx, b_t=True, accumulate=True)
+        self.touch(lb + "fc1.weight", lb + "fc1.bias", lb + "fc2.weight", lb + "fc2.bias", lb + "final_layer_norm.weight",
+                   lb + "final_layer_norm.bias")
+        return dx
+
+    # =============================================================================================
+    # Decoder  (BartDecoder.forward :530-660, DecoderLayer :432-494, SelfAttention.forward :711-750)
+    # =============================================================================================
+    def make_memory(self, B, mods):
+        """mods: list of (N, S) per modality.  Returns the layout of the concatenated memory
+        matrix [Rmem, D]: rows of modality m start at off[m]; entity (b,n) at off[m] + (b*N+n)*S."""
+        offs, off = [], 0
+        for N, S in mods:
+            offs.append(off)
+            off += B * N * S
+        return NS(B=B, mods=list(mods), offs=offs, rows=off)
+
+    def decoder_fwd(self, dec_ids, dec_pad, rating_diff, mem, layout, pads, qpb, exclude_self):
+        """dec_ids [Bd,T]; dec_pad [Bd,T] uint8 or None; rating_diff [Bd] f32 or None; mem [Rmem,D];
+        pads: per-modality uint8 [B,N,S] (1 = padded key).  Bd = B*qpb."""
+        cfg, a = self.cfg, self.arena
+        D, H = cfg.d_model, cfg.heads
+        Bd, T = dec_ids.shape
+        Rq = Bd * T
+        b = self.bp + "model.decoder."
+        nm = len(layout.mods)
+        c = NS(Bd=Bd, T=T, ids=dec_ids.contiguous(), rd=rating_diff, mem=mem, layout=layout, pads=pads, qpb=qpb,
+               exclude_self=exclude_self, layers=[], p=self.p_drop(), seed0=self.next_seed(), dec_pad=dec_pad)
+        # null-entity flags per modality (:858) and the per-business no-table / no-image flags (:732-736)
+        c.nulls = []
+        for (N, S), pad in zip(layout.mods, pads):
+            nul = self.empty(layout.B * N, dtype=torch.uint8)
+            kn.entity_null(pad, nul, layout.B * N, S)
+            c.nulls.append(nul)
+        if self.multimodal:
+            c.no_table = c.nulls[1]
+            N2, S2 = layout.mods[2]
+            c.no_img = self.empty(layout.B, dtype=torch.uint8)
+            kn.entity_null(pads[2], c.no_img, layout.B, N2 * S2)
+        x = self.empty(Rq, D)
+        c.mean0, c.rstd0 = self.empty(Rq, dtype=torch.float32), self.empty(Rq, dtype=torch.float32)
+        kn.embed_ln_fwd(c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), rating_diff,
+                        a.w(b + "rating_embeddings") if rating_diff is not None else None, a.f32(b + "layernorm_embedding.weight"),
+                        a.f32(b + "layernorm_embedding.bias"), x, c.mean0, c.rstd0, Bd, T, cfg.extra_pos_embeddings, 1e-5, c.p,
+                        c.seed0)
+        for i in range(cfg.decoder_layers):
+            lb = b + "layers.%d." % i
+            x, sc = self._self_block_fwd(lb, x, dec_pad, Bd, T, causal=True)
+            x, cc = self._cross_block_fwd(lb, x, c)
+            x, fc = self._ffn_block_fwd(lb, x)
+            c.layers.append((sc, cc, fc))
+        c.out = x
+        return x, c
+
+    def decoder_bwd(self, c, dout):
+        """dout [Rq, D] (consumed) -> dmem [Rmem, D]; accumulates decoder parameter gradients."""
+        cfg, a = self.cfg, self.arena
+        b = self.bp + "model.decoder."
+        dmem = self.empty(c.layout.rows, cfg.d_model)
+        dx = dout
+        for i in reversed(range(cfg.decoder_layers)):
+            lb = b + "layers.%d." % i
+            sc, cc, fc = c.layers[i]
+            dx = self._ffn_block_bwd(lb, fc, dx)
+            dx = self._cross_block_bwd(lb, cc, c, dx, dmem, first=(i == cfg.decoder_layers - 1))
+            dx = self._self_block_bwd(lb, sc, dx)
+        has_r = c.rd is not None
+        kn.embed_ln_bwd(dx, c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), c.rd,
+                        a.w(b + "rating_embeddings") if has_r else None, a.f32(b + "layernorm_embedding.weight"), c.mean0, c.rstd0,
+                        a.g(self.bp + "model.shared.weight"), a.g(b + "embed_positions.weight"),
+                        a.g(b + "rating_embeddings") if has_r else None, a.g(b + "layernorm_embedding.weight"),
+                        a.g(b + "layernorm_embedding.bias"), c.Bd, c.T, cfg.extra_pos_embeddings, cfg.pad_token_id, c.p, c.seed0)
+        self.touch(self.bp + "model.shared.weight", b + "embed_positions.weight", b + "layernorm_embedding.weight",
+                   b + "layernorm_embedding.bias")
+        if has_r:
+            self.touch(b + "rating_embeddings")
+        return dmem
+
+    def _cross_block_fwd(self, lb, x, dc):
+        cfg, a = self.cfg, self.arena
+        D, H = cfg.d_model, cfg.heads
+        Rq = x.shape[0]
+        L = dc.layout
+        nm = len(L.mods)
+        q, k, v = self._attn_names(lb, "encoder_attn")
+        pre = lb + "encoder_attn."
+        c = NS(x=x, p=self.p_drop(), seed=self.next_seed())
+        c.q = self.empty(Rq, D)
+        kn.gemm(x, a.w(q + ".weight"), c.q, bias=a.f32(q + ".bias"))                                     # :783 (scale folded into the kernel)
+        c.kv = self.empty(L.rows, 2 * D)
+        kn.gemm(dc.mem, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), c.kv,
+                bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)))                                  # :788-789, hoisted
+        c.heads = self.empty(nm * Rq, D)
+        c.descs = []
+        for m, ((N, S), pad) in enumerate(zip(L.mods, dc.pads)):
+            rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
+            d = kn.make_attn_desc(c.q, c.kv[rows, :D], c.kv[rows, D:], c.heads[m * Rq:(m + 1) * Rq], pad, dc.nulls[m],
+                                  dc.Bd, dc.T, dc.qpb, N, S, H, dc.exclude_self and m == 0, False, 64 ** -0.5)
+            kn.attn_fwd(d, x)                                                                              # :819-869
+            c.descs.append(d)
+        c.y = self.empty(nm * Rq, D)
+        kn.gemm(c.heads, a.w(pre + "out_proj.weight"), c.y, bias=a.f32(pre + "out_proj.bias"))             # :728-730 / :885
+        if self.multimodal:
+            yt, ytab, yimg = c.y[:Rq], c.y[Rq:2 * Rq], c.y[2 * Rq:]
+            c.pa, c.pb = self.empty(Rq, D), self.empty(Rq, D)
+            kn.gemm(yt, a.w(pre + "alpha_proj.weight"), c.pa, a2=ytab, bias=a.f32(pre + "alpha_proj.bias"))  # :738
+            kn.gemm(yt, a.w(pre + "beta_proj.weight"), c.pb, a2=yimg, bias=a.f32(pre + "beta_proj.bias"))    # :739
+            c.c = self.empty(Rq, D)
+            kn.gate_fwd(c.pa, c.pb, yt, ytab, yimg, dc.no_table, dc.no_img, c.c, dc.qpb * dc.T)              # :740-744
+        else:
+            c.c = c.y
+        y = self.empty(Rq, D)
+        c.mean, c.rstd = self.empty(Rq, dtype=torch.float32), self.empty(Rq, dtype=torch.float32)
+        kn.add_ln_fwd(c.c, x, a.f32(lb + "encoder_attn_layer_norm.weight"), a.f32(lb + "encoder_attn_layer_norm.bias"), y, c.mean,
+                      c.rstd, 1e-5, c.p, c.seed)
+        return y, c
+
+    def _cross_block_bwd(self, lb, c, dc, dy, dmem, first):
+        cfg, a = self.cfg, self.arena
+        D = cfg.d_model
+        Rq = dy.shape[0]
+        L = dc.layout
+        nm = len(L.mods)
+        q, k, v = self._attn_names(lb, "encoder_attn")
+        pre = lb + "encoder_attn."
+        dcv, dx = self.empty(Rq, D), self.empty(Rq, D)
+        kn.add_ln_bwd(dy, c.c, c.x, a.f32(lb + "encoder_attn_layer_norm.weight"), c.mean, c.rstd, dcv, dx, False,
+                      a.g(lb + "encoder_attn_layer_norm.weight"), a.g(lb + "encoder_attn_layer_norm.bias"), c.p, c.seed)
+        if self.multimodal:
+            yt, ytab, yimg = c.y[:Rq], c.y[Rq:2 * Rq], c.y[2 * Rq:]
+            dyy = self.empty(3 * Rq, D)
+            dyt, dytab, dyimg = dyy[:Rq], dyy[Rq:2 * Rq], dyy[2 * Rq:]
+            dpa, dpb = self.empty(Rq, D), self.empty(Rq, D)
+            kn.gate_bwd(dcv, c.pa, c.pb, ytab, yimg, dc.no_table, dc.no_img, dpa, dpb, dyt, dytab, dyimg, dc.qpb * dc.T)
+            for name, dp, other, dother in ((pre + "alpha_proj", dpa, ytab, dytab), (pre + "beta_proj", dpb, yimg, dyimg)):
+                W, gW = a.w(name + ".weight"), a.g(name + ".weight")
+                self.bgrad(dp, name + ".bias")
+                self.wgrad(dp, yt, gview=gW[:, :D])
+                self.wgrad(dp, other, gview=gW[:, D:])
+                kn.gemm(dp, W[:, :D], dyt, b_t=True, accumulate=True)
+                kn.gemm(dp, W[:, D:], dother, b_t=True, accumulate=True)
+                self.touch(name + ".weight", name + ".bias")
+        else:
+            dyy = dcv
+        self.bgrad(dyy, pre + "out_proj.bias")
+        self.wgrad(dyy, c.heads, pre + "out_proj.weight")
+        dheads = self.empty(nm * Rq, D)
+        kn.gemm(dyy, a.w(pre + "out_proj.weight"), dheads, b_t=True)
+        dq = self.empty(Rq, D)
+        dkv = self.empty(L.rows, 2 * D)
+        for m, (N, S) in enumerate(L.mods):
+            rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
+            stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
+            kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
+        self.bgrad(dkv, gview=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
+        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)))
+        kn.gemm(dkv, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, b_t=True, accumulate=not first)
+        self.bgrad(dq, q + ".bias")
+        self.wgrad(dq, c.x, q + ".weight")
+        kn.gemm(dq, a.w(q + ".weight"), dx, b_t=True, accumulate=True)
+        self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias", pre + "out_proj.weight",
+                   pre + "out_proj.bias", lb + "encoder_attn_layer_norm.weight", lb + "encoder_attn_layer_norm.bias")
+        return dx
+
+    # =============================================================================================
+    # LM head (+ fused label-smoothing loss)   (:2281; utils.py:32-38)
+    # =============================================================================================
+    def lm_logits_fwd(self, h):
+        """-> logits buffer [Rq, Vpad] (columns >= V are scratch)."""
+        logits = self.empty(h.shape[0], self.Vpad)
+        kn.gemm(h, self.arena.w(self.bp + "model.shared.weight"), logits[:, :self.cfg.vocab_size])
+        return logits
+
+    def lm_head_bwd(self, h, dlogits):
+        """dlogits [Rq, Vpad] with zero padding columns.  -> dh; accumulates the tied-embedding gradient."""
+        V, name = self.cfg.vocab_size, self.bp + "model.shared.weight"
+        dh = self.empty(h.shape[0], h.shape[1])
+        kn.gemm(dlogits[:, :V], self.arena.w(name), dh, b_t=True)
+        self.wgrad(dlogits[:, :V], h, name)
+        self.touch(name)
+        return dh
+
+    def lm_loss_fwd(self, h, labels, smoothing, n_segments):
+        """Fused LM head + loss.  Returns (mean loss [1], per-segment losses [n_segments], dlogits)."""
+        Rq, V = h.shape[0], self.cfg.vocab_size
+        logits = self.lm_logits_fwd(h)
+        rows = self.empty(Rq, dtype=torch.float32)
+        kn.ls_loss(logits, labels.reshape(-1).contiguous(), rows, V, float(smoothing or 0.0), 1.0 / Rq, True)
+        seg = self.empty(n_segments, dtype=torch.float32)       # per decoder sequence (b, i): mean over its T rows
+        kn.segment_sum(rows, seg, n_segments, Rq // n_segments, float(n_segments) / Rq)
+        loss = self.empty(1, dtype=torch.float32)
+        kn.segment_sum(rows, loss, 1, Rq, 1.0 / Rq)
+        return loss, seg, logits
+
+    # =============================================================================================
+    # Table encoder  (table_encoder.py:14-83)
+    # =============================================================================================
+    def table_fwd(self, field, fv, out=None):
+        a = self.arena
+        B = fv[0].shape[0]
+        D = self.cfg.d_model
+        tp = "table_encoder."
+        c = NS(B=B, fv=[t.contiguous() for t in fv])
+        c.all = self.empty(B * 47, 2 * D)
+        c.mask = self.empty(B, 47, dtype=torch.uint8)
+        kn.table_gather(a.w(self.bp + "model.shared.weight"), field.contiguous(), c.fv, a.w(tp + "rating_embedding.weight"),
+                        a.w(tp + "hours_embedding.weight"), c.all, c.mask, B, self.cfg.pad_token_id)
+        c.t1 = self.empty(B * 47, D)
+        kn.gemm(c.all, a.w(tp + "fc.weight"), c.t1, bias=a.f32(tp + "fc.bias"), epi=kn.EPI_RELU)
+        y = out if out is not None else self.empty(B * 47, D)
+        kn.gemm(c.t1, a.w(tp + "linear.weight"), y)
+        return y, c
+
+    def table_bwd(self, c, dy):
+        a = self.arena
+        D = self.cfg.d_model
+        tp = "table_encoder."
+        self.wgrad(dy, c.t1, tp + "linear.weight")
+        dt1 = self.empty(c.B * 47, D)
+        kn.gemm(dy, a.w(tp + "linear.weight"), dt1, b_t=True, epi=kn.EPI_RELU_BWD, aux=c.t1)
+        self.bgrad(dt1, tp + "fc.bias")
+        self.wgrad(dt1, c.all, tp + "fc.weight")
+        dall = self.empty(c.B * 47, 2 * D)
+        kn.gemm(dt1, a.w(tp + "fc.weight"), dall, b_t=True)
+        kn.table_gather_bwd(dall, c.fv[4], c.fv[5], a.g(tp + "rating_embedding.weight"), a.g(tp + "hours_embedding.weight"), c.B, D)
+        self.touch(tp + "linear.weight", tp + "fc.bias", tp + "fc.weight", tp + "rating_embedding.weight", tp + "hours_embedding.weight")
+
+    # =============================================================================================
+    # ResNet101 stages 1-3 + projection  (img_encoder.py:31-41; torchvision 0.6.1 resnet101)
+    # =============================================================================================
+    def _build_conv_mats(self, all_layers):
+        """KxK conv weights as [Cout, Kpad] matrices with (kh,kw,c) column order, compute dtype."""
+        a = self.arena
+        r = "img_encoder.resnet."
+        todo = []
+        if all_layers:
+            todo.append((r + "conv1.weight", 64, 3, 7))
+        for li, bi, inp, pl, stride, down in resnet_blocks():
+            if li <= 3 and (all_layers or li == 3):
+                todo.append((r + "layer%d.%d.conv2.weight" % (li, bi), pl, pl, 3))
+        for name, co, ci, ks in todo:
+            Kpad = (ks * ks * ci + 63) // 64 * 64
+            m = self.conv_mats.get(name)
+            if m is None:
+                m = self.empty(co, Kpad)
+                self.conv_mats[name] = m
+            kn.conv_weight_to_matrix(m, a.f32(name), co, ci, ks, ks, Kpad)
+
+    def _bn_fwd(self, name, x, relu, residual=None):
+        a = self.arena
+        R, C = x.shape
+        c = NS(x=x, relu=relu, name=name)
+        c.y = self.empty(R, C)
+        c.sums = self.empty(2 * C, dtype=torch.float32)
+        training = self.training
+        if training:
+            kn.bn_reduce(x, c.sums)
+            self.buffers[name + ".num_batches_tracked"] += 1
+        kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, self.buffers[name + ".running_mean"],
+                    self.buffers[name + ".running_var"], 1e-5, 0.1, relu, training)
+        return c.y, c
+
+    def _bn_bwd(self, c, dy, dresidual=None):
+        a = self.arena
+        R, C = dy.shape
+        dsums = self.empty(2 * C, dtype=torch.float32)
+        kn.bn_bwd_reduce(dy, c.y, c.x, c.sums, dsums, 1e-5, c.relu)
+        dx = self.empty(R, C)
+        kn.bn_bwd_apply(dy, c.y, c.x, c.sums, dsums, a.f32(c.name + ".weight"), dx, dresidual, a.g(c.name + ".weight"),
+                        a.g(c.name + ".bias"), 1e-5, c.relu)
+        self.touch(c.name + ".weight", c.name + ".bias")
+        return dx
+
+    def _conv1x1(self, x, name):
+        w = self.arena.w(name)
+        y = self.empty(x.shape[0], w.shape[0])
+        kn.gemm(x, w.view(w.shape[0], w.shape[1]), y)
+        return y
+
+    def img_fwd(self, img, out=None):
+        """img [n,3,H,W] f32 NCHW -> [n*196, D] (rows (n, h, w)); saves what layer3's backward needs."""
+        a = self.arena
+        r = "img_encoder.resnet."
+        n, _, Hh, Ww = img.shape
+        c = NS(n=n, blocks=[])
+        x = self.empty(n * Hh * Ww, 3)
+        kn.nchw_to_nhwc(img.contiguous(), x, n, 3, Hh, Ww)
+        Ho, Wo = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
+        wm = self.conv_mats[r + "conv1.weight"]
+        col = self.empty(n * Ho * Wo, wm.shape[1])
+        kn.im2col(x, col, n, Hh, Ww, 3, 7, 7, 2, 3, Ho, Wo, wm.shape[1])
+        y = self.empty(n * Ho * Wo, 64)
+        kn.gemm(col, wm, y)
+        y, _ = self._bn_fwd(r + "bn1", y, True)
+        Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
+        x = self.empty(n * Hp * Wp, 64)
+        kn.maxpool3x3s2(y, x, n, Ho, Wo, 64, Hp, Wp)
+        Hc, Wc = Hp, Wp
+        for li, bi, inp, pl, stride, down in resnet_blocks():
+            if li > 3:
+                break
+            b = r + "layer%d.%d." % (li, bi)
+            bc = NS(x=x, H=Hc, W=Wc, inp=inp, pl=pl, stride=stride, down=down, name=b, li=li)
+            c1 = self._conv1x1(x, b + "conv1.weight")
+            o1, bc.bn1 = self._bn_fwd(b + "bn1", c1, True)
+            Ho2, Wo2 = (Hc + 2 - 3) // stride + 1, (Wc + 2 - 3) // stride + 1
+            wm = self.conv_mats[b + "conv2.weight"]
+            bc.col = self.empty(n * Ho2 * Wo2, wm.shape[1])
+            kn.im2col(o1, bc.col, n, Hc, Wc, pl, 3, 3, stride, 1, Ho2, Wo2, wm.shape[1])
+            c2 = self.empty(n * Ho2 * Wo2, pl)
+            kn.gemm(bc.col, wm, c2)
+            o2, bc.bn2 = self._bn_fwd(b + "bn2", c2, True)
+            bc.o1, bc.o2 = o1, o2
+            c3 = self._conv1x1(o2, b + "conv3.weight")
+            if down:
+                if stride == 1:
+                    xs = x
+                else:
+                    xs = self.empty(n * Ho2 * Wo2, inp)
+                    kn.im2col(x, xs, n, Hc, Wc, inp, 1, 1, stride, 0, Ho2, Wo2, inp)
+                bc.xs = xs
+                cd = self._conv1x1(xs, b + "downsample.0.weight")
+                idt, bc.bnd = self._bn_fwd(b + "downsample.1", cd, False)
+            else:
+                idt = x
+            x, bc.bn3 = self._bn_fwd(b + "bn3", c3, True, residual=idt)
+            Hc, Wc = Ho2, Wo2
+            if li == 3:
+                c.blocks.append(bc)
+        c.feat = x                                   # [n*14*14, 1024] for 224x224 inputs
+        y = out if out is not None else self.empty(x.shape[0], self.cfg.d_model)
+        kn.gemm(x, a.w("img_encoder.linear.weight"), y)
+        return y, c
+
+    def img_bwd(self, c, dy):
+        a = self.arena
+        n = c.n
+        self.wgrad(dy, c.feat, "img_encoder.linear.weight")
+        self.touch("img_encoder.linear.weight")
+        dx = self.empty(c.feat.shape[0], c.feat.shape[1])
+        kn.gemm(dy, a.w("img_encoder.linear.weight"), dx, b_t=True)
+        for bc in reversed(c.blocks):
+            b = bc.name
+            first_block = bc.down      # block 0: its input is the detached stage-2 output (:33) -> no input gradient
+            R2 = bc.o2.shape[0]
+            didt = self.empty(dx.shape[0], dx.shape[1])
+            dc3 = self._bn_bwd(bc.bn3, dx, dresidual=didt)
+            w3 = a.w(b + "conv3.weight")
+            self.wgrad(dc3, bc.o2, gview=a.g(b + "conv3.weight", (w3.shape[0], w3.shape[1])))
+            do2 = self.empty(R2, bc.pl)
+            kn.gemm(dc3, w3.view(w3.shape[0], w3.shape[1]), do2, b_t=True)
+            dc2 = self._bn_bwd(bc.bn2, do2)
+            wm = self.conv_mats[b + "conv2.weight"]
+            dwm = self.zeros(wm.shape[0], wm.shape[1], dtype=torch.float32)
+            kn.gemm(dc2, bc.col, dwm, a_t=True, b_t=True, accumulate=True, splitk=self.splitk(wm.shape[0], wm.shape[1], R2))
+            kn.conv_matrix_grad_to_weight(dwm, a.g(b + "conv2.weight"), bc.pl, bc.pl, 3, 3, wm.shape[1], True)
+            dcol = self.empty(R2, wm.shape[1])
+            kn.gemm(dc2, wm, dcol, b_t=True)
+            do1 = self.empty(bc.o1.shape[0], bc.pl)
+            Ho2, Wo2 = (bc.H + 2 - 3) // bc.stride + 1, (bc.W + 2 - 3) // bc.stride + 1
+            kn.col2im(dcol, do1, n, bc.H, bc.W, bc.pl, 3, 3, bc.stride, 1, Ho2, Wo2, wm.shape[1])
+            dc1 = self._bn_bwd(bc.bn1, do1)
+            w1 = a.w(b + "conv1.weight")
+            self.wgrad(dc1, bc.x, gview=a.g(b + "conv1.weight", (w1.shape[0], w1.shape[1])))
+            self.touch(b + "conv1.weight", b + "conv2.weight", b + "conv3.weight")
+            if first_block:
+                dcd = self._bn_bwd(bc.bnd, didt)
+                wd = a.w(b + "downsample.0.weight")
+                self.wgrad(dcd, bc.xs, gview=a.g(b + "downsample.0.weight", (wd.shape[0], wd.shape[1])))
+                self.touch(b + "downsample.0.weight")
+                dx = None
+            else:
+                kn.gemm(dc1, w1.view(w1.shape[0], w1.shape[1]), didt, b_t=True, accumulate=True)
+                dx = didt

@@ -1,0 +1,538 @@
+"""Drop-in nn.Modules: the reference's constructors, forward() signatures, attribute paths and
+state_dict keys over the HIP engine.
+
+  BartForMultiEncConditionalGeneration  <- modeling_multimodalsum.py:2181-2292
+  BartForEncConditionalGeneration       <- modeling_multimodalsum.py:1292-1396
+  YelpTableEncoder                      <- table_encoder.py:5-83
+  Resnet                                <- img_encoder.py:4-41
+  MultimodalSum / TextSupervised        <- multimodal_train.py:111-193 / text_pretrain.py:66-113
+
+Every forward runs HIP kernels only; torch.autograd sees one coarse node per sub-program whose
+backward is the engine's explicit reverse schedule (parameter gradients are written into the flat
+gradient arena and attached as `p.grad` views).
+"""
+import json
+import os
+
+import torch
+import torch.nn as nn
+
+from . import kernels as kn
+from .config import BartConfig
+from .engine import Engine, resnet_blocks
+from .formula_init import formula_state_dict
+
+
+class _Node(nn.Module):
+    pass
+
+
+def _attach(root, dotted, tensor, is_buffer=False):
+    parts = dotted.split(".")
+    node = root
+    for p in parts[:-1]:
+        if not hasattr(node, p):
+            node.add_module(p, _Node())
+        node = getattr(node, p)
+    if is_buffer:
+        node.register_buffer(parts[-1], tensor)
+    else:
+        node.register_parameter(parts[-1], tensor)
+
+
+def _get(root, dotted):
+    node = root
+    for p in dotted.split("."):
+        node = getattr(node, p)
+    return node
+
+
+def _anchor(engine):
+    if not hasattr(engine, "_anchor"):
+        engine._anchor = torch.zeros(1, device=engine.device, requires_grad=True)
+    return engine._anchor
+
+
+def _begin_backward(engine):
+    if not getattr(engine, "_grads_ready", False):
+        engine.arena.prepare_grads()
+        engine.touched = set()
+        engine._grads_ready = True
+        if engine.post_backward_hooks:
+            # fires once, after the LAST node of this backward pass (what torch DDP uses as well)
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: [cb() for cb in engine.post_backward_hooks])
+
+
+def _end_backward(engine):
+    engine.arena.attach_grads(engine.touched)
+
+
+def _new_forward(engine):
+    engine._grads_ready = False
+    engine.sync_weights()
+
+
+# ------------------------------------------------------------------------------------------------
+# coarse autograd nodes
+# ------------------------------------------------------------------------------------------------
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, engine, ids, mask):
+        h, c = engine.encoder_fwd(ids, mask)
+        ctx.engine, ctx.c = engine, c
+        return h.view(ids.shape[0], ids.shape[1], -1)
+
+    @staticmethod
+    def backward(ctx, dh):
+        e = ctx.engine
+        _begin_backward(e)
+        e.encoder_bwd(ctx.c, dh.reshape(-1, dh.shape[-1]).to(e.dtype).contiguous())
+        _end_backward(e)
+        return None, None, None, None
+
+
+class _TableFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, engine, field, *fv):
+        y, c = engine.table_fwd(field, list(fv))
+        ctx.engine, ctx.c = engine, c
+        ctx.mark_non_differentiable(c.mask)
+        return y.view(c.B, 47, -1), c.mask
+
+    @staticmethod
+    def backward(ctx, dy, _dmask):
+        e = ctx.engine
+        _begin_backward(e)
+        e.table_bwd(ctx.c, dy.reshape(-1, dy.shape[-1]).to(e.dtype).contiguous())
+        _end_backward(e)
+        return (None,) * (3 + 6)
+
+
+class _ImgFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, engine, img):
+        y, c = engine.img_fwd(img)
+        ctx.engine, ctx.c = engine, c
+        return y.view(img.shape[0], -1, y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        e = ctx.engine
+        _begin_backward(e)
+        e.img_bwd(ctx.c, dy.reshape(-1, dy.shape[-1]).to(e.dtype).contiguous())
+        _end_backward(e)
+        return None, None, None
+
+
+class _DecoderLogitsFn(torch.autograd.Function):
+    """decoder + LM head -> logits [Bd,T,V]; inputs: the per-modality encoder hiddens."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, dec_ids, dec_pad, rating_diff, pads, qpb, exclude_self, *hiddens):
+        e = engine
+        D = e.cfg.d_model
+        B = hiddens[0].shape[0]
+        layout = e.make_memory(B, [(h.shape[1], h.shape[2]) for h in hiddens])
+        mem = e.empty(layout.rows, D)
+        for m, h in enumerate(hiddens):
+            n = h.shape[0] * h.shape[1] * h.shape[2]
+            mem[layout.offs[m]:layout.offs[m] + n].copy_(h.reshape(n, D))
+        hL, c = e.decoder_fwd(dec_ids, dec_pad, rating_diff, mem, layout, pads, qpb, exclude_self)
+        logits = e.lm_logits_fwd(hL)
+        ctx.engine, ctx.c, ctx.hL, ctx.shapes = e, c, hL, [tuple(h.shape) for h in hiddens]
+        V = e.cfg.vocab_size
+        return logits[:, :V].float().view(dec_ids.shape[0], dec_ids.shape[1], V)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        e = ctx.engine
+        V, D = e.cfg.vocab_size, e.cfg.d_model
+        _begin_backward(e)
+        dl = e.zeros(ctx.hL.shape[0], e.Vpad)
+        dl[:, :V].copy_(dlogits.reshape(-1, V))
+        dh = e.lm_head_bwd(ctx.hL, dl)
+        dmem = e.decoder_bwd(ctx.c, dh)
+        _end_backward(e)
+        outs, L = [], ctx.c.layout
+        for m, shp in enumerate(ctx.shapes):
+            n = shp[0] * shp[1] * shp[2]
+            outs.append(dmem[L.offs[m]:L.offs[m] + n].view(shp))
+        return (None,) * 8 + tuple(outs)
+
+
+def shift_tokens_right_batched(labels, first_rows, pad, bos, eos):
+    """Quirk Q6 (modeling_multimodalsum.py:225-246): the last non-pad token becomes pad, tokens shift
+    right, and the first token is BOS unless `first_rows`' first token already is BOS (then EOS).
+    labels [..., T]; first_rows: the tensor whose [..., 0] decides per leading index (the reference
+    looks at row 0 of each pass batch)."""
+    n_real = labels.ne(pad).sum(dim=-1, keepdim=True)
+    pos = torch.arange(labels.shape[-1], device=labels.device)
+    body = torch.where(pos == (n_real - 1), torch.full_like(labels, pad), labels)
+    first = torch.where(first_rows[..., 0] != bos, torch.full_like(first_rows[..., 0], bos), torch.full_like(first_rows[..., 0], eos))
+    out = torch.empty_like(labels)
+    out[..., 0] = first.expand(labels.shape[:-1])
+    out[..., 1:] = body[..., :-1]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# module tree
+# ------------------------------------------------------------------------------------------------
+class BartEncoder(_Node):
+    def forward(self, input_ids, attention_mask=None, output_attentions=False, output_hidden_states=False, return_dict=False):
+        e = self._engine
+        _new_forward(e)
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        return (_EncoderFn.apply(_anchor(e), e, input_ids, attention_mask),)
+
+
+class _BartBase(nn.Module):
+    multimodal = True
+
+    def __init__(self, config, engine=None, prefix="", device="cuda", dtype=torch.bfloat16, deterministic=False):
+        super().__init__()
+        self.config = config
+        self._own_engine = engine is None
+        if engine is None:
+            engine = Engine(config, device=device, compute_dtype=dtype, multimodal=self.multimodal, bart_prefix="",
+                            deterministic=deterministic)
+        object.__setattr__(self, "_engine", engine)
+        self._prefix = prefix
+        self._build_tree()
+
+    def _build_tree(self):
+        e, pre = self._engine, self._prefix
+        model = _Node()
+        self.add_module("model", model)
+        _attach(self, "model.shared.weight", e.arena.params[pre + "model.shared.weight"])   # registered first, as in BartModel.__init__ (:1001)
+        enc = BartEncoder()
+        object.__setattr__(enc, "_engine", e)
+        model.add_module("encoder", enc)
+        for name, p in e.arena.params.items():
+            if name.startswith(pre + "model."):
+                _attach(self, name[len(pre):], p)
+        self.register_buffer("final_logits_bias", e.buffers[pre + "final_logits_bias"])
+        shared = model.shared.weight
+        for side in ("encoder", "decoder"):
+            tok = _Node()
+            tok.register_parameter("weight", shared)     # aliases of `shared` (state_dict keys encoder/decoder.embed_tokens.weight)
+            getattr(model, side).add_module("embed_tokens", tok)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, config=None, **kw):
+        """Construction contract of multimodal_train.py:116.  `config` is a BartConfig or a JSON path.
+        A directory holding pytorch_model.bin is loaded; anything else (e.g. 'facebook/bart-large':
+        no network) yields the reference's random init `_init_weights` equivalent via formula init."""
+        if isinstance(config, str):
+            config = BartConfig.from_json_file(config)
+        elif config is None:
+            cfgp = os.path.join(str(pretrained_model_name_or_path), "config.json")
+            config = BartConfig.from_json_file(cfgp)
+        m = cls(config, **kw)
+        ckpt = os.path.join(str(pretrained_model_name_or_path), "pytorch_model.bin")
+        if os.path.exists(ckpt):
+            sd = torch.load(ckpt, map_location="cpu")
+            m.load_state_dict(sd, strict=False)
+        else:
+            init_formula(m)
+        m.eval()
+        return m
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._engine.mark_weights_changed()
+        return r
+
+    def train(self, mode=True):
+        super().train(mode)
+        if self._own_engine:
+            self._engine.training = mode
+        return self
+
+    def _decode(self, hiddens, masks, rating_diff, labels, decoder_input_ids=None, decoder_attention_mask=None):
+        e = self._engine
+        _new_forward(e)
+        cfg = self.config
+        if labels is None:
+            raise NotImplementedError("generation (use_cache) path: SURVEY.md section 8f rank 1, not built yet")
+        if decoder_input_ids is None:
+            decoder_input_ids = shift_tokens_right_batched(labels, labels[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id)
+        if decoder_attention_mask is None:
+            dec_pad = decoder_input_ids.eq(cfg.pad_token_id).to(torch.uint8).contiguous()
+        else:
+            dec_pad = decoder_attention_mask.eq(0).to(torch.uint8).contiguous()
+        pads = [m.eq(0).to(torch.uint8).contiguous() for m in masks]
+        rd = rating_diff.reshape(-1).float().contiguous() if rating_diff is not None else None
+        hs = [h.to(e.dtype) for h in hiddens]
+        return _DecoderLogitsFn.apply(_anchor(e), e, decoder_input_ids, dec_pad, rd, pads, 1, False, *hs)
+
+
+class BartForMultiEncConditionalGeneration(_BartBase):
+    multimodal = True
+
+    def forward(self, text_hiddens, text_attention_mask, table_hiddens, table_attention_mask, img_hiddens, img_attention_mask,
+                rating_diff=None, decoder_input_ids=None, decoder_attention_mask=None, decoder_past_key_values=None, labels=None,
+                use_cache=None, output_attentions=False, output_hidden_states=False, return_dict=False, **unused):
+        logits = self._decode([text_hiddens, table_hiddens, img_hiddens],
+                              [text_attention_mask, table_attention_mask, img_attention_mask], rating_diff, labels,
+                              decoder_input_ids, decoder_attention_mask)
+        return (logits,)
+
+
+class BartForEncConditionalGeneration(_BartBase):
+    multimodal = False
+
+    def forward(self, encoder_hiddens, rating_diff=None, encoder_attention_mask=None, decoder_input_ids=None,
+                decoder_attention_mask=None, decoder_past_key_values=None, labels=None, use_cache=None, output_attentions=False,
+                output_hidden_states=False, return_dict=False, **unused):
+        if encoder_attention_mask is None:
+            encoder_attention_mask = torch.ones(encoder_hiddens.shape[:3], dtype=torch.bool, device=encoder_hiddens.device)
+        logits = self._decode([encoder_hiddens], [encoder_attention_mask], rating_diff, labels, decoder_input_ids,
+                              decoder_attention_mask)
+        return (logits,)
+
+
+class YelpTableEncoder(nn.Module):
+    """TableEncoder(bart_model.model.shared): must alias the embedding Parameter (multimodal_train.py:117)."""
+
+    def __init__(self, bart_embedding, engine=None):
+        super().__init__()
+        if engine is None:
+            raise RuntimeError("YelpTableEncoder needs the engine that owns the aliased embedding (build it through MultimodalSum)")
+        object.__setattr__(self, "_engine", engine)
+        emb = _Node()
+        emb.register_parameter("weight", bart_embedding.weight if hasattr(bart_embedding, "weight") else bart_embedding)
+        self.add_module("bart_embedding", emb)
+        for name, p in engine.arena.params.items():
+            if name.startswith("table_encoder."):
+                _attach(self, name[len("table_encoder."):], p)
+
+    def forward(self, field, field_value):
+        e = self._engine
+        _new_forward(e)
+        y, mask = _TableFn.apply(_anchor(e), e, field, *field_value)
+        return y, mask.bool()
+
+
+class Resnet(nn.Module):
+    def __init__(self, embedding_dim, model="resnet101", stage=3, engine=None):
+        super().__init__()
+        assert model == "resnet101" and stage == 3, "the hot path uses resnet101 stages 1-3 (img_encoder.py:5,21-26)"
+        if engine is None:
+            raise RuntimeError("Resnet needs an engine (build it through MultimodalSum)")
+        object.__setattr__(self, "_engine", engine)
+        pre = "img_encoder."
+        for name, p in engine.arena.params.items():
+            if name.startswith(pre):
+                _attach(self, name[len(pre):], p)
+        for name, b in engine.buffers.items():
+            if name.startswith(pre):
+                _attach(self, name[len(pre):], b, is_buffer=True)
+        r = self.resnet
+        r.add_module("relu", nn.ReLU(inplace=True))
+        r.add_module("maxpool", nn.MaxPool2d(3, 2, 1))
+        for li in (1, 2, 3, 4):
+            layer = getattr(r, "layer%d" % li)
+            seq = nn.Sequential(*[getattr(layer, str(i)) for i in range(len(layer._modules))])
+            r._modules["layer%d" % li] = seq
+        # aliased views of the same modules, as the reference registers them (img_encoder.py:21-24)
+        self.stage1 = nn.Sequential(r.conv1, r.bn1, r.relu, r.maxpool, r.layer1)
+        self.stage2 = nn.Sequential(r.layer2)
+        self.stage3 = nn.Sequential(r.layer3)
+
+    def forward(self, x):
+        e = self._engine
+        _new_forward(e)
+        return _ImgFn.apply(_anchor(e), e, x)
+
+
+# ------------------------------------------------------------------------------------------------
+# step wrappers
+# ------------------------------------------------------------------------------------------------
+class _StepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, batch):
+        ctx.model = model
+        ctx.saved = model._step_fwd(*batch)
+        return ctx.saved.loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        # the fused step assumes loss.backward() with unit upstream gradient (multimodal_train.py:360)
+        ctx.model._step_bwd(ctx.saved)
+        return None, None, None
+
+
+class MultimodalSum(nn.Module):
+    """MultimodalSum(bart_pretrained, table_pretrained, img_pretrained, TableEncoder)  (multimodal_train.py:111-122).
+
+    forward(reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask) -> (loss,)
+    runs the whole leave-one-out step as one fused schedule (see engine.py)."""
+
+    def __init__(self, bart_pretrained=None, table_pretrained=None, img_pretrained=None, TableEncoder=YelpTableEncoder,
+                 config="cfg/bart-large.json", label_smoothing=0.1, device="cuda", dtype=torch.bfloat16, deterministic=False):
+        super().__init__()
+        cfg = config if isinstance(config, BartConfig) else BartConfig.from_json_file(config)
+        e = Engine(cfg, device=device, compute_dtype=dtype, multimodal=True, with_table=True, with_img=True,
+                   bart_prefix="bart_model.", deterministic=deterministic)
+        object.__setattr__(self, "_engine", e)
+        self.label_smoothing = label_smoothing
+        self.bart_model = BartForMultiEncConditionalGeneration(cfg, engine=e, prefix="bart_model.")
+        self.table_encoder = TableEncoder(self.bart_model.model.shared, engine=e)
+        self.img_encoder = Resnet(cfg.d_model, engine=e)
+        init_formula(self)
+        for sub, path in ((self.bart_model, bart_pretrained), (self.table_encoder, table_pretrained), (self.img_encoder, img_pretrained)):
+            if path is not None and os.path.exists(os.path.join(str(path), "pytorch_model.bin")):
+                sub.load_state_dict(torch.load(os.path.join(str(path), "pytorch_model.bin"), map_location="cpu"), strict=False)
+        e.mark_weights_changed()
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._engine.training = mode
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._engine.mark_weights_changed()
+        return r
+
+    def forward(self, reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask, **unused):
+        e = self._engine
+        _new_forward(e)
+        loss = _StepFn.apply(_anchor(e), self, (reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask))
+        return (loss,)
+
+    def get_multimodal_outputs(self, reviews, reviews_mask, field, field_value, img, img_mask):
+        """Drop-in, un-fused variant (multimodal_train.py:165-193) built from the coarse modules."""
+        B, NR, S = reviews.shape
+        text_h = self.bart_model.model.encoder(input_ids=reviews.view(B * NR, S), attention_mask=reviews_mask.view(B * NR, S))[0]
+        text_h = text_h.view(B, NR, S, -1)
+        table_h, table_m = self.table_encoder(field, field_value)
+        I = img.size(1)
+        img_h = self.img_encoder(img.reshape(-1, 3, img.shape[-2], img.shape[-1])).reshape(B, I, -1, self.bart_model.config.d_model)
+        img_m = img_mask.unsqueeze(-1).repeat(1, 1, img_h.size(2))
+        return NR, text_h, reviews_mask, table_h.unsqueeze(1), table_m.unsqueeze(1), img_h, img_m
+
+    # ---- fused step -------------------------------------------------------------------------------
+    def _step_fwd(self, reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask):
+        e, cfg = self._engine, self._engine.cfg
+        B, NR, S = reviews.shape
+        I = img.shape[1]
+        D = cfg.d_model
+        imgs = img.reshape(-1, 3, img.shape[-2], img.shape[-1])
+        hw = ((imgs.shape[-2] + 6 - 7) // 2 + 1, (imgs.shape[-1] + 6 - 7) // 2 + 1)
+        for _ in range(3):   # maxpool, layer2, layer3 each halve the resolution
+            hw = ((hw[0] + 2 - 3) // 2 + 1, (hw[1] + 2 - 3) // 2 + 1)
+        P = hw[0] * hw[1]
+        s = type("Saved", (), {})()
+        s.layout = e.make_memory(B, [(NR, S), (1, 47), (I, P)])
+        s.mem = e.empty(s.layout.rows, D)
+        o1, o2 = s.layout.offs[1], s.layout.offs[2]
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1])
+        _, s.tab = e.table_fwd(field, field_value, out=s.mem[o1:o2])
+        _, s.img = e.img_fwd(imgs, out=s.mem[o2:])
+        pads = [reviews_mask.eq(0).to(torch.uint8).contiguous(), (1 - s.tab.mask).view(B, 1, 47).contiguous(),
+                img_mask.eq(0).to(torch.uint8).unsqueeze(-1).expand(B, I, P).contiguous()]
+        dec_in = shift_tokens_right_batched(reviews, reviews[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id)
+        dec_in = dec_in.reshape(B * NR, S)
+        dec_pad = dec_in.eq(cfg.pad_token_id).to(torch.uint8).contiguous()
+        r = reviews_rating.float()
+        rating_diff = (r - (r.sum(dim=1, keepdim=True) - r) / (NR - 1)).reshape(-1).contiguous()     # multimodal_train.py:153-156
+        hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True)
+        s.hL = hL
+        s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
+        return s
+
+    def _step_bwd(self, s):
+        e = self._engine
+        _begin_backward(e)
+        o1, o2 = s.layout.offs[1], s.layout.offs[2]
+        dh = e.lm_head_bwd(s.hL, s.dlogits)
+        s.dlogits = None
+        dmem = e.decoder_bwd(s.dec, dh)
+        _end_backward(e)
+        e.segment_ready([e.bp + "model.decoder."])
+        e.img_bwd(s.img, dmem[o2:])
+        e.table_bwd(s.tab, dmem[o1:o2])
+        _end_backward(e)
+        e.segment_ready(["img_encoder.", "table_encoder."])
+        e.encoder_bwd(s.enc, dmem[:o1])
+        _end_backward(e)
+        e.segment_ready([e.bp + "model.encoder.", e.bp + "model.shared."])
+
+
+class TextSupervised(nn.Module):
+    """TextSupervised (text_pretrain.py:66-113): text-only leave-one-out step, fused the same way."""
+
+    def __init__(self, bart_pretrained=None, config="cfg/bart-large.json", label_smoothing=None, device="cuda",
+                 dtype=torch.bfloat16, deterministic=False):
+        super().__init__()
+        cfg = config if isinstance(config, BartConfig) else BartConfig.from_json_file(config)
+        e = Engine(cfg, device=device, compute_dtype=dtype, multimodal=False, bart_prefix="bart_model.", deterministic=deterministic)
+        object.__setattr__(self, "_engine", e)
+        self.label_smoothing = label_smoothing
+        self.bart_model = BartForEncConditionalGeneration(cfg, engine=e, prefix="bart_model.")
+        init_formula(self)
+        if bart_pretrained is not None and os.path.exists(os.path.join(str(bart_pretrained), "pytorch_model.bin")):
+            self.bart_model.load_state_dict(torch.load(os.path.join(str(bart_pretrained), "pytorch_model.bin"), map_location="cpu"), strict=False)
+        e.mark_weights_changed()
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._engine.training = mode
+        return self
+
+    def forward(self, reviews, reviews_mask, reviews_rating, **unused):
+        e = self._engine
+        _new_forward(e)
+        return (_StepFn.apply(_anchor(e), self, (reviews, reviews_mask, reviews_rating)),)
+
+    def _step_fwd(self, reviews, reviews_mask, reviews_rating):
+        e, cfg = self._engine, self._engine.cfg
+        B, NR, S = reviews.shape
+        s = type("Saved", (), {})()
+        s.layout = e.make_memory(B, [(NR, S)])
+        s.mem = e.empty(s.layout.rows, cfg.d_model)
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem)
+        pads = [reviews_mask.eq(0).to(torch.uint8).contiguous()]
+        dec_in = shift_tokens_right_batched(reviews, reviews[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id).reshape(B * NR, S)
+        dec_pad = dec_in.eq(cfg.pad_token_id).to(torch.uint8).contiguous()
+        r = reviews_rating.float()
+        rating_diff = (r - (r.sum(dim=1, keepdim=True) - r) / (NR - 1)).reshape(-1).contiguous()
+        s.hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True)
+        s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(s.hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
+        return s
+
+    def _step_bwd(self, s):
+        e = self._engine
+        _begin_backward(e)
+        dh = e.lm_head_bwd(s.hL, s.dlogits)
+        s.dlogits = None
+        dmem = e.decoder_bwd(s.dec, dh)
+        _end_backward(e)
+        e.segment_ready([e.bp + "model.decoder."])
+        e.encoder_bwd(s.enc, dmem)
+        _end_backward(e)
+        e.segment_ready([e.bp + "model.encoder.", e.bp + "model.shared."])
+
+
+def init_formula(module, std=0.02, prefix=None):
+    """Fill every arena parameter / buffer with the RNG-free formula init (keyed by arena names)."""
+    e = module._engine
+    pre = prefix
+    names = {n: e.arena.shapes[n] for n in e.arena.params}
+    if pre is not None:
+        sd = formula_state_dict({pre + n[len(e.bp):] if n.startswith(e.bp) else n: s for n, s in names.items()}, std=std)
+        sd = {(e.bp + k[len(pre):]) if k.startswith(pre) else k: v for k, v in sd.items()}
+    else:
+        sd = formula_state_dict(names, std=std)
+    with torch.no_grad():
+        for n, v in sd.items():
+            e.arena.params[n].copy_(v.to(e.device))
+        for n, b in e.buffers.items():
+            if n.endswith("running_var"):
+                b.fill_(1.0)
+            elif n.endswith("running_mean") or n.endswith("final_logits_bias"):
+                b.zero_()
+    e.mark_weights_changed()

@@ -1,0 +1,181 @@
+"""Optimiser side of the training step over the flat arena.
+
+  FusedAdamW                     <- HF AdamW, /root/reference/src/transformer/optimization.py:208-267
+  clip_grad_norm_                <- torch.nn.utils.clip_grad_norm_ as called at multimodal_train.py:361-362
+  get_optimizer                  <- /root/reference/src/train_utils.py:49-57 (quirk Q1 reproduced by default)
+  get_linear_schedule_with_warmup<- /root/reference/src/transformer/optimization.py:70-96
+"""
+import math
+
+import torch
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import kernels as kn
+from .arena import NO_DECAY
+
+
+def _arena_of(params):
+    for p in params:
+        a = getattr(p, "_mmsum_arena", None)
+        if a is not None:
+            return a
+    return None
+
+
+def tag_arena(engine):
+    """Let optimiser utilities find the arena (and offsets) from any of its parameters."""
+    a = engine.arena
+    for name, p in a.params.items():
+        p._mmsum_arena = a
+        p._mmsum_name = name
+        p._mmsum_engine = engine
+
+
+def _ranges(arena, params):
+    """Merge the arena slices of `params` (those with a gradient) into maximal contiguous ranges."""
+    spans = []
+    for p in params:
+        if p.grad is None:
+            continue
+        o = arena.offsets[p._mmsum_name]
+        n = (arena.numel(p._mmsum_name) + 63) // 64 * 64
+        spans.append((o, o + n))
+    spans.sort()
+    out = []
+    for s, e in spans:
+        if out and s == out[-1][1]:
+            out[-1][1] = e
+        else:
+            out.append([s, e])
+    return out
+
+
+def clip_grad_norm_(parameters, max_norm, fused=False):
+    """Global L2 norm over every parameter that carries a gradient, then scale by
+    min(1, max_norm/(norm+1e-6)).  One L2 kernel per contiguous arena range instead of one torch
+    op per tensor.  fused=True leaves the scaling of the optimiser-owned gradients to
+    FusedAdamW.step() (applied on the fly) and only scales, in place, the ranges the optimiser
+    does not own -- under quirk Q1 those are the no-decay gradients that keep accumulating (Q1b),
+    so their stored values must carry the clip factor exactly like the reference's do.
+    Returns the total norm as a 0-d device tensor (no host sync)."""
+    params = [p for p in parameters if p.grad is not None]
+    arena = _arena_of(params)
+    if arena is None:
+        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+    eng = params[0]._mmsum_engine
+    rs = _ranges(arena, params)
+    if not hasattr(eng, "norm_sq"):
+        eng.norm_sq = torch.zeros(1, device=arena.device)
+    for i, (s, e) in enumerate(rs):
+        kn.l2norm_sq(arena.grad[s:e], eng.norm_sq, accumulate=i > 0)
+    eng.pending_clip = float(max_norm)
+    owned = getattr(eng, "optimizer_ranges", None) if fused else None
+    for s, e in rs:
+        if owned is None:
+            kn.scale_by_clip(arena.grad[s:e], eng.norm_sq, float(max_norm))
+        else:
+            for s2, e2 in _subtract((s, e), owned):
+                kn.scale_by_clip(arena.grad[s2:e2], eng.norm_sq, float(max_norm))
+    if owned is None:
+        eng.pending_clip = None
+    return eng.norm_sq.sqrt().reshape(())
+
+
+def _subtract(span, owned):
+    s, e = span
+    out = []
+    for os_, oe in sorted(owned):
+        if oe <= s or os_ >= e:
+            continue
+        if os_ > s:
+            out.append((s, os_))
+        s = max(s, oe)
+    if s < e:
+        out.append((s, e))
+    return out
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """HF AdamW semantics (eps outside the sqrt, bias correction folded into the step size, decoupled
+    decay applied after the Adam update with the updated weight) as one kernel per contiguous
+    arena range; also writes the bf16 weight shadow and applies a pending gradient clip on the fly."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
+        super().__init__(params, defaults)
+        self._state_bufs = None
+        self._steps = {}
+
+    def _arena(self):
+        for g in self.param_groups:
+            a = _arena_of(g["params"])
+            if a is not None:
+                return a
+        return None
+
+    def zero_grad(self, set_to_none=True):
+        super().zero_grad(set_to_none=set_to_none)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        arena = self._arena()
+        if arena is None:
+            raise RuntimeError("FusedAdamW only drives parameters that live in a multimodalsum_amd arena")
+        eng = next(p for g in self.param_groups for p in g["params"])._mmsum_engine
+        if self._state_bufs is None:
+            self._state_bufs = (torch.zeros_like(arena.data), torch.zeros_like(arena.data))
+            self._hyper = {}
+        m, v = self._state_bufs
+        pending = getattr(eng, "pending_clip", None)
+        all_ranges = []
+        for gi, group in enumerate(self.param_groups):
+            rs = _ranges(arena, group["params"])
+            if not rs:
+                continue
+            key = (gi,)
+            step = self._steps.get(key, 0) + 1
+            self._steps[key] = step
+            b1, b2 = group["betas"]
+            step_size = group["lr"]
+            if group["correct_bias"]:
+                step_size = step_size * math.sqrt(1.0 - b2 ** step) / (1.0 - b1 ** step)
+            hyper = self._hyper.get(gi)
+            if hyper is None:
+                hyper = torch.zeros(4, device=arena.device)
+                self._hyper[gi] = hyper
+            hyper.copy_(torch.tensor([step_size, group["lr"] * group["weight_decay"], pending if pending else 0.0, 0.0]))
+            for s, e in rs:
+                kn.adamw(arena.data[s:e], arena.grad[s:e], m[s:e], v[s:e], arena.shadow[s:e] if arena.shadow is not None else None,
+                         hyper, eng.norm_sq if pending else None, b1, b2, group["eps"])
+            all_ranges += rs
+        eng.optimizer_ranges = [tuple(r) for r in all_ranges]
+        eng.pending_clip = None
+        if arena.shadow is not None:
+            # parameters outside the updated ranges did not change, so their shadow is still current
+            eng.after_fused_optimizer_step()
+        return None
+
+
+def get_optimizer(lr, no_decay, named_parameters, special_condition=None, reproduce_q1=True, fused=True):
+    """train_utils.get_optimizer.  reproduce_q1=True keeps the reference's behaviour: the
+    `named_parameters` generator is exhausted by the first comprehension, so the no-decay group is
+    empty and biases / LayerNorm / BatchNorm weights are never updated."""
+    if special_condition is None:
+        special_condition = lambda n: True  # noqa: E731
+    it = named_parameters if reproduce_q1 else list(named_parameters)
+    groups = [
+        {'params': [p for n, p in it if special_condition(n) and (not any(nd in n for nd in no_decay))], 'weight_decay': 0.01},
+        {'params': [p for n, p in it if special_condition(n) and (any(nd in n for nd in no_decay))], 'weight_decay': 0.0},
+    ]
+    if fused:
+        return FusedAdamW(groups, lr=lr)
+    raise ValueError("only the fused optimiser ships with this package; pass the groups to any torch optimiser yourself")
+
+
+def get_linear_schedule_with_warmup(optimizer, num_warmup_steps, num_training_steps, last_epoch=-1):
+    def lr_lambda(current_step):
+        if current_step < num_warmup_steps:
+            return float(current_step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - current_step) / float(max(1, num_training_steps - num_warmup_steps)))
+
+    return LambdaLR(optimizer, lr_lambda, last_epoch)

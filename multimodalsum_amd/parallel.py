@@ -1,0 +1,86 @@
+"""Data-parallel gradient synchronisation over the flat gradient arena (one process per GPU,
+torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+Replaces apex.parallel.DistributedDataParallel(model, delay_allreduce=True)
+(/root/reference/src/multimodal_train.py:12,473-474) and reduce_tensor (/root/reference/src/utils.py:8-12).
+
+The reference flattens every gradient into one buffer AFTER backward and all-reduces it with no
+overlap.  Here the gradients already live in one arena, so there is nothing to flatten, and the
+fused step tells us when a whole parameter segment (decoder / image+table encoders / encoder +
+tied embedding) is final: its arena ranges are all-reduced on a side stream in large buckets while
+the rest of the backward keeps the compute stream busy.  Parameters that never receive a gradient
+(ResNet stem/layer1/layer2/layer4/fc) are simply absent from the ranges.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .optim import _ranges
+
+
+def reduce_tensor(tensor, world_size):
+    rt = tensor.clone()
+    dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    rt /= world_size
+    return rt
+
+
+class DistributedDataParallel(nn.Module):
+    def __init__(self, module, delay_allreduce=True, bucket_elems=64 * 1024 * 1024, overlap=True, process_group=None):
+        super().__init__()
+        self.module = module
+        self.group = process_group
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.bucket_elems = int(bucket_elems)
+        self.engine = module._engine
+        self.arena = self.engine.arena
+        self.overlap = overlap and self.arena.grad.is_cuda
+        self.comm_stream = torch.cuda.Stream() if self.overlap else None
+        self._done = set()
+        self._pending = []
+        if self.world_size > 1:
+            dist.broadcast(self.arena.data, 0, group=self.group)          # C2: parameters from rank 0
+            for b in self.engine.buffers.values():
+                if b.is_floating_point():
+                    dist.broadcast(b, 0, group=self.group)
+            self.engine.mark_weights_changed()
+            self.engine.segment_hooks.append(self._segment_ready)
+            self.engine.post_backward_hooks.append(self._finish)
+
+    def forward(self, *args, **kwargs):
+        self._done = set()
+        return self.module(*args, **kwargs)
+
+    # ---- gradient all-reduce ----------------------------------------------------------------------
+    def _reduce_ranges(self, ranges):
+        g = self.arena.grad
+        inv = 1.0 / self.world_size
+        for s, e in ranges:
+            for b0 in range(s, e, self.bucket_elems):
+                chunk = g[b0:min(e, b0 + self.bucket_elems)]
+                chunk.mul_(inv)                      # pre-divide: SUM of g/world == mean (apex divides after)
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _segment_ready(self, prefixes):
+        params = [p for n, p in self.arena.params.items() if p.grad is not None and n not in self._done
+                  and any(n.startswith(px) for px in prefixes)]
+        if not params:
+            return
+        self._done.update(p._mmsum_name for p in params)
+        ranges = _ranges(self.arena, params)
+        if self.overlap:
+            self.comm_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self._reduce_ranges(ranges)
+        else:
+            self._reduce_ranges(ranges)
+
+    def _finish(self):
+        """End of the whole backward pass: reduce whatever no segment notification covered (the
+        coarse, un-fused module path) and make the compute stream wait for the side stream."""
+        rest = [p for n, p in self.arena.params.items() if p.grad is not None and n not in self._done]
+        if rest:
+            self._done.update(p._mmsum_name for p in rest)
+            self._reduce_ranges(_ranges(self.arena, rest))
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)

@@ -1,0 +1,363 @@
+"""TEST INFRASTRUCTURE ONLY -- a torch-CPU stand-in for the C-ABI kernels.
+
+The development container has no GPU, and the host-side schedules in multimodalsum_amd/engine.py
+(which kernel runs when, on which arena view, what each backward accumulates into) are ~1000 lines
+of index arithmetic.  This module re-states the *contract* of every function of
+multimodalsum_amd.kernels with plain torch ops so that tests/test_host_logic_cpu.py can drive the
+real engine/modules/optimiser code on CPU tensors and compare it with the oracle.  It is never
+imported by the product package; the product raises on CPU tensors (tests/test_abi_cpu.py).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
+
+
+def _keep_mask(shape, p, seed):
+    if p <= 0:
+        return torch.ones(shape)
+    g = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF)
+    return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
+
+
+def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None, splitk=1):
+    A = a.float().t() if a_t else a.float()
+    if a2 is not None:
+        A = torch.cat([A, a2.float()], dim=1)
+    Bm = b.float().t() if b_t else b.float()
+    v = alpha * (A @ Bm.t())
+    if bias is not None:
+        v = v + bias
+    if epi == EPI_GELU:
+        if aux is not None:
+            aux.copy_(v)
+        v = F.gelu(v)
+    elif epi == EPI_GELU_BWD:
+        u = aux.float()
+        v = v * (0.5 * (1 + torch.erf(u / math.sqrt(2))) + u * torch.exp(-0.5 * u * u) / math.sqrt(2 * math.pi))
+    elif epi == EPI_RELU:
+        v = F.relu(v)
+    elif epi == EPI_RELU_BWD:
+        v = v * (aux.float() > 0)
+    if accumulate:
+        out.add_(v.to(out.dtype))
+    else:
+        out.copy_(v)
+    return out
+
+
+def colsum(x, out, accumulate=False):
+    s = x.float().sum(0)
+    out.copy_(out + s if accumulate else s)
+    return out
+
+
+def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq, T, pos_offset, eps, p_drop, seed):
+    D = E.shape[1]
+    z = E.float()[ids.reshape(nseq, T)] + P.float()[torch.arange(T) + pos_offset]
+    if rating_diff is not None:
+        z = z + rating_diff.view(nseq, 1, 1) * rvec.float()
+    z = z.view(nseq * T, D)
+    mu = z.mean(-1)
+    rs = (z.var(-1, unbiased=False) + eps).rsqrt()
+    mean.copy_(mu)
+    rstd.copy_(rs)
+    o = (z - mu[:, None]) * rs[:, None] * gamma + beta
+    y.copy_(o * _keep_mask(o.shape, p_drop, seed))
+
+
+def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, pos_offset, pad_id,
+                 p_drop, seed):
+    D = E.shape[1]
+    z = E.float()[ids.reshape(nseq, T)] + P.float()[torch.arange(T) + pos_offset]
+    if rating_diff is not None:
+        z = z + rating_diff.view(nseq, 1, 1) * rvec.float()
+    z = z.view(nseq * T, D)
+    g = dy.float() * _keep_mask(dy.shape, p_drop, seed)
+    xh = (z - mean[:, None]) * rstd[:, None]
+    gdy = g * gamma
+    dz = rstd[:, None] * (gdy - gdy.mean(-1, keepdim=True) - xh * (gdy * xh).mean(-1, keepdim=True))
+    dgamma.add_((g * xh).sum(0))
+    dbeta.add_(g.sum(0))
+    flat = ids.reshape(-1)
+    keep = flat != pad_id
+    dE.index_add_(0, flat[keep], dz[keep])
+    dP.index_add_(0, (torch.arange(T) + pos_offset).repeat(nseq), dz)
+    if rating_diff is not None:
+        drvec.add_((dz.view(nseq, T, D) * rating_diff.view(nseq, 1, 1)).sum((0, 1)))
+
+
+def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed):
+    z = x.float() * _keep_mask(x.shape, p_drop, seed) + res.float()
+    mu = z.mean(-1)
+    rs = (z.var(-1, unbiased=False) + eps).rsqrt()
+    mean.copy_(mu)
+    rstd.copy_(rs)
+    y.copy_((z - mu[:, None]) * rs[:, None] * gamma + beta)
+
+
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed):
+    km = _keep_mask(x.shape, p_drop, seed)
+    z = x.float() * km + res.float()
+    xh = (z - mean[:, None]) * rstd[:, None]
+    g = dy.float()
+    gdy = g * gamma
+    dz = rstd[:, None] * (gdy - gdy.mean(-1, keepdim=True) - xh * (gdy * xh).mean(-1, keepdim=True))
+    dgamma.add_((g * xh).sum(0))
+    dbeta.add_(g.sum(0))
+    dx.copy_(dz * km)
+    if accumulate_dres:
+        dres.add_(dz)
+    else:
+        dres.copy_(dz)
+
+
+class _Desc:
+    pass
+
+
+def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale):
+    d = _Desc()
+    d.__dict__.update(q=q, k=k, v=v, out=out, pad=pad, null=null_entity, nq=n_qblocks, T=T, qpb=qpb, N=N, S=S, H=H,
+                      excl=bool(exclude_self), causal=bool(causal), scale=scale)
+    return d
+
+
+def entity_null(pad, null_entity, n_entities, S):
+    null_entity.copy_(pad.reshape(n_entities, S).bool().all(-1).to(torch.uint8))
+
+
+def _attn_ref(d, q, k, v):
+    B = d.nq // d.qpb
+    qh = q.reshape(d.nq, d.T, d.H, 64).permute(0, 2, 1, 3)
+    kh = k.reshape(B, d.N, d.S, d.H, 64).permute(0, 1, 3, 2, 4)
+    vh = v.reshape(B, d.N, d.S, d.H, 64).permute(0, 1, 3, 2, 4)
+    pad = d.pad.reshape(B, d.N, d.S).bool() if d.pad is not None else None
+    null = d.null.reshape(B, d.N).bool() if d.null is not None else None
+    outs = []
+    for qb in range(d.nq):
+        b, i = qb // d.qpb, qb % d.qpb
+        acc, cnt = torch.zeros(d.H, d.T, 64), 0
+        for n in range(d.N):
+            if (d.excl and n == i) or (null is not None and bool(null[b, n])):
+                continue
+            s = torch.einsum("htd,hsd->hts", qh[qb], kh[b, n]) * d.scale
+            if pad is not None:
+                s = s.masked_fill(pad[b, n][None, None, :], float("-inf"))
+            if d.causal:
+                s = s + torch.triu(torch.full((d.T, d.S), float("-inf")), 1)
+            acc = acc + torch.einsum("hts,hsd->htd", torch.softmax(s, -1), vh[b, n])
+            cnt += 1
+        outs.append(acc / max(cnt, 1) + 0 * qh[qb])
+    return torch.stack(outs).permute(0, 2, 1, 3).reshape(d.nq * d.T, d.H * 64)
+
+
+def attn_fwd(d, dtype_tensor):
+    with torch.no_grad():
+        d.out.copy_(_attn_ref(d, d.q.float(), d.k.float(), d.v.float()))
+
+
+def attn_bwd_workspace(d):
+    return 16
+
+
+def attn_bwd(d, dout, dq, accumulate_dq, dk, dv, stats):
+    q, k, v = (t.float().clone().requires_grad_(True) for t in (d.q, d.k, d.v))
+    with torch.enable_grad():
+        o = _attn_ref(d, q, k, v)
+        gq, gk, gv = torch.autograd.grad(o, (q, k, v), dout.float(), allow_unused=True)
+    z = lambda g, t: torch.zeros_like(t) if g is None else g  # noqa: E731
+    if accumulate_dq:
+        dq.add_(z(gq, q))
+    else:
+        dq.copy_(z(gq, q))
+    dk.copy_(z(gk, k))
+    dv.copy_(z(gv, v))
+
+
+def gate_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, out, rows_per_b):
+    ma = (1 - no_table.float()).repeat_interleave(rows_per_b)[:, None]
+    mb = (1 - no_img.float()).repeat_interleave(rows_per_b)[:, None]
+    out.copy_(yt.float() + ma * F.relu(torch.tanh(pa.float())) * ytab.float() + mb * F.relu(torch.tanh(pb.float())) * yimg.float())
+
+
+def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, rows_per_b):
+    ma = (1 - no_table.float()).repeat_interleave(rows_per_b)[:, None]
+    mb = (1 - no_img.float()).repeat_interleave(rows_per_b)[:, None]
+    g = dout.float()
+    ta, tb = torch.tanh(pa.float()), torch.tanh(pb.float())
+    dytab.copy_(g * ma * F.relu(ta))
+    dyimg.copy_(g * mb * F.relu(tb))
+    dpa.copy_(torch.where(ta > 0, ma * g * ytab.float() * (1 - ta * ta), torch.zeros_like(g)))
+    dpb.copy_(torch.where(tb > 0, mb * g * yimg.float() * (1 - tb * tb), torch.zeros_like(g)))
+    dyt.copy_(g)
+
+
+def ls_loss(logits, target, row_loss, V, smoothing, gscale, write_grad=True):
+    x = logits[:, :V].float()
+    logp = x.log_softmax(-1)
+    eps_p = smoothing / (V - 1) if V > 1 else 0.0
+    td = torch.full_like(logp, eps_p)
+    td.scatter_(1, target.reshape(-1, 1), 1.0 - smoothing)
+    row_loss.copy_(-(td * logp).sum(-1))
+    if write_grad:
+        logits.zero_()
+        logits[:, :V] = gscale * (logp.exp() - td)
+
+
+def segment_sum(x, out, nseg, seg, scale):
+    out.copy_(x[:nseg * seg].double().view(nseg, seg).sum(-1).float() * scale)
+
+
+def l2norm_sq(g, out, accumulate=False):
+    s = (g.double() ** 2).sum().float()
+    out.copy_(out + s if accumulate else s.reshape(1))
+
+
+def _clip(norm_sq, max_norm):
+    if norm_sq is None or max_norm <= 0:
+        return 1.0
+    return min(1.0, max_norm / (float(norm_sq.sqrt()) + 1e-6))
+
+
+def adamw(p, g, m, v, shadow, hyper, norm_sq, beta1, beta2, eps):
+    step_size, lr_wd, max_norm = float(hyper[0]), float(hyper[1]), float(hyper[2])
+    gg = g * _clip(norm_sq, max_norm)
+    m.mul_(beta1).add_(gg, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    p.sub_(step_size * m / (v.sqrt() + eps))
+    p.sub_(lr_wd * p)
+    if shadow is not None:
+        shadow.copy_(p)
+
+
+def cast(dst, src):
+    dst.copy_(src)
+    return dst
+
+
+def scale_by_clip(g, norm_sq, max_norm):
+    g.mul_(_clip(norm_sq, max_norm))
+
+
+def im2col(x, col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
+    xi = x.float().view(N, H, W, C).permute(0, 3, 1, 2)
+    u = F.unfold(xi, (KH, KW), padding=pad, stride=stride)              # [N, C*KH*KW, L], rows (c, kh, kw)
+    u = u.view(N, C, KH * KW, Ho * Wo).permute(0, 3, 2, 1).reshape(N * Ho * Wo, KH * KW * C)
+    col.zero_()
+    col[:, :KH * KW * C] = u
+
+
+def col2im(dcol, dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
+    u = dcol[:, :KH * KW * C].float().view(N, Ho * Wo, KH * KW, C).permute(0, 3, 2, 1).reshape(N, C * KH * KW, Ho * Wo)
+    xi = F.fold(u, (H, W), (KH, KW), padding=pad, stride=stride)
+    dx.copy_(xi.permute(0, 2, 3, 1).reshape(N * H * W, C))
+
+
+def conv_weight_to_matrix(matrix, weight, Cout, Cin, KH, KW, Kpad):
+    matrix.zero_()
+    matrix[:, :KH * KW * Cin] = weight.view(Cout, Cin, KH, KW).permute(0, 2, 3, 1).reshape(Cout, -1)
+
+
+def conv_matrix_grad_to_weight(matrix_f32, dweight, Cout, Cin, KH, KW, Kpad, accumulate):
+    g = matrix_f32[:, :KH * KW * Cin].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+    if accumulate:
+        dweight.add_(g)
+    else:
+        dweight.copy_(g)
+
+
+def bn_reduce(x, sums):
+    C = x.shape[1]
+    sums[:C] = x.float().sum(0)
+    sums[C:] = (x.float() ** 2).sum(0)
+
+
+def _bn_stats(sums, R, C, eps):
+    mean = sums[:C] / R
+    var = (sums[C:] / R - mean * mean).clamp_min(0)
+    return mean, var, (var + eps).rsqrt()
+
+
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training):
+    R, C = x.shape
+    if training:
+        mean, var, rstd = _bn_stats(sums, R, C, eps)
+    else:
+        mean, var = running_mean, running_var
+        rstd = (var + eps).rsqrt()
+    o = (x.float() - mean) * rstd * gamma + beta
+    if residual is not None:
+        o = o + residual.float()
+    y.copy_(F.relu(o) if relu else o)
+    if training and running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(momentum * mean)
+        running_var.mul_(1 - momentum).add_(momentum * var * (R / (R - 1) if R > 1 else 1.0))
+
+
+def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu):
+    R, C = x.shape
+    mean, var, rstd = _bn_stats(sums, R, C, eps)
+    g = dy.float() * ((y.float() > 0) if relu else 1.0)
+    dsums[:C] = g.sum(0)
+    dsums[C:] = (g * (x.float() - mean) * rstd).sum(0)
+
+
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu):
+    R, C = x.shape
+    mean, var, rstd = _bn_stats(sums, R, C, eps)
+    g = dy.float() * ((y.float() > 0) if relu else 1.0)
+    xh = (x.float() - mean) * rstd
+    dx.copy_(gamma * rstd * (g - dsums[:C] / R - xh * dsums[C:] / R))
+    if dresidual is not None:
+        dresidual.copy_(g)
+    if dgamma is not None:
+        dbeta.add_(dsums[:C])
+        dgamma.add_(dsums[C:])
+
+
+def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):
+    y.copy_(F.max_pool2d(x.float().view(N, H, W, C).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, C))
+
+
+def nchw_to_nhwc(x, y, N, C, H, W):
+    y.copy_(x.permute(0, 2, 3, 1).reshape(-1, C))
+
+
+def table_gather(E, field, fv, w_rating, w_hours, out, mask, B, pad_id):
+    name, category, str_cat, str_bool, rating, hours = fv
+    Ef = E.float()
+
+    def msum(ids, dim):
+        return (Ef[ids] * ids.ne(pad_id).unsqueeze(-1).float()).sum(dim=dim)
+
+    names = msum(field, 1).unsqueeze(0).expand(B, -1, -1)
+    cat_valid = category.ne(pad_id).any(-1).unsqueeze(-1).float()
+    vals = torch.cat([msum(name, 1).unsqueeze(1),
+                      (msum(category, 2) * cat_valid).sum(1, keepdim=True) / (cat_valid.sum(1, keepdim=True) + 1e-6),
+                      msum(str_cat, 2), Ef[str_bool.squeeze(-1)] * str_bool.ne(pad_id).float(),
+                      F.linear(rating.float(), w_rating.float()).unsqueeze(1), F.linear(hours.float(), w_hours.float())], 1)
+    out.copy_(torch.cat([names, vals], -1).reshape(B * 47, -1))
+    ones = torch.ones(B, 1, dtype=torch.bool)
+    m = torch.cat([ones, category[:, :1, 0].ne(pad_id), str_cat[:, :, 0].ne(pad_id), str_bool[:, :, 0].ne(pad_id), ones,
+                   hours.sum(-1) != 0], 1)
+    mask.copy_(m.to(torch.uint8))
+
+
+def table_gather_bwd(dall, rating, hours, dw_rating, dw_hours, B, D):
+    dv = dall.float().view(B, 47, 2 * D)[:, :, D:]
+    dw_rating.add_(torch.einsum("bk,bd->dk", rating.float(), dv[:, 39]))
+    dw_hours.add_(torch.einsum("bjk,bjd->dk", hours.float(), dv[:, 40:47]))
+
+
+def install(monkeypatch):
+    """Route multimodalsum_amd.{engine,modules,optim}.kn to this module for the duration of a test."""
+    import sys
+    import multimodalsum_amd.engine as eng
+    import multimodalsum_amd.modules as mods
+    import multimodalsum_amd.optim as opt
+    me = sys.modules[__name__]
+    for m in (eng, mods, opt):
+        monkeypatch.setattr(m, "kn", me)

@@ -1,0 +1,209 @@
+"""CPU: the real engine / modules / optimiser code (kernel schedules, arena views, backward order,
+Q1 grouping) driven through tests/cpu_kernel_emu.py and compared with the oracle and the golden
+vectors.  Catches host-side mistakes before GPU minutes are spent; the HIP kernels themselves are
+checked on the GPU (tests/test_kernels_gpu.py, tests/test_modules_gpu.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from multimodalsum_amd import synthetic as syn
+from multimodalsum_amd.config import BartConfig
+from multimodalsum_amd.formula_init import formula_state_dict, formula_tensor
+from oracle import bart_oracle as bo
+from oracle import encoders_oracle as eo
+from oracle import step_oracle as so
+from tests import cpu_kernel_emu as emu
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err, ref = (a - b).abs().max().item(), b.abs().max().item()
+    assert err <= atol + rtol * ref, "%s: max err %.3e vs ref max %.3e" % (what, err, ref)
+
+
+def tiny_cfg(vocab=200, d=1024, ffn=64, layers=1, heads=16, maxpos=32, dropout=0.0):
+    return BartConfig(vocab_size=vocab, d_model=d, encoder_ffn_dim=ffn, decoder_ffn_dim=ffn, encoder_layers=layers,
+                      decoder_layers=layers, encoder_attention_heads=heads, decoder_attention_heads=heads,
+                      max_position_embeddings=maxpos, dropout=dropout)
+
+
+def oracle_cfg(cfg):
+    return bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim,
+                      encoder_layers=cfg.encoder_layers, decoder_layers=cfg.decoder_layers, heads=cfg.heads,
+                      max_position_embeddings=cfg.max_position_embeddings, dropout=cfg.dropout)
+
+
+def f3_state(ocfg):
+    shapes = bo.bart_param_shapes(ocfg, True, prefix="bart_model.")
+    shapes.update(eo.table_param_shapes())
+    sd = formula_state_dict(shapes, std=0.02)
+    sd.update(formula_state_dict(eo.resnet_param_shapes(1024), std=0.05))
+    return sd
+
+
+def test_multimodal_step_matches_oracle_and_golden(monkeypatch, golden_dir):
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import MultimodalSum
+    g = np.load(os.path.join(golden_dir, "f3_step.npz"))
+    cfg = tiny_cfg()
+    ocfg = oracle_cfg(cfg)
+    sd = f3_state(ocfg)
+    model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    assert all(("embed_tokens" in k or "bart_embedding" in k or "stage" in k or k.endswith("final_logits_bias")) for k in missing), missing
+    model.train()
+    b = syn.yelp_batch(int(g["B"]), int(g["NR"]), int(g["S"]), int(g["I"]), cfg.vocab_size, seed=int(g["seed"]), img_hw=int(g["img_hw"]))
+    loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+    _close(loss, torch.from_numpy(g["loss"]), 1e-5, 1e-6, "loss vs golden")
+    loss.backward()
+    named = dict(model.named_parameters())
+    P = "bart_model.model.decoder."
+    _close(named[P + "rating_embeddings"].grad, torch.from_numpy(g["g_rating"]), what="g_rating")
+    _close(named[P + "layers.0.encoder_attn.alpha_proj.weight"].grad[:32], torch.from_numpy(g["g_alpha"]), what="g_alpha")
+    _close(named[P + "layers.0.encoder_attn.beta_proj.bias"].grad, torch.from_numpy(g["g_beta_b"]), what="g_beta_b")
+    _close(named[P + "layers.0.encoder_attn.k_proj.weight"].grad[:32], torch.from_numpy(g["g_kproj"]), what="g_kproj")
+    _close(named["table_encoder.fc.weight"].grad[:16], torch.from_numpy(g["g_table_fc"]), what="g_table_fc")
+    _close(named["bart_model.model.shared.weight"].grad[:64], torch.from_numpy(g["g_shared"]), what="g_shared")
+    _close(named["img_encoder.linear.weight"].grad[:16], torch.from_numpy(g["g_img_lin"]), what="g_img_lin")
+    _close(named["bart_model.model.encoder.layers.0.self_attn.q_proj.weight"].grad[:16], torch.from_numpy(g["g_enc_q"]), what="g_enc_q")
+    # full comparison with the oracle's autograd on every parameter
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() > 0 and "running" not in k:
+            v.requires_grad_(True)
+    running = {}
+    ol = so.multimodal_step_loss(sd, ocfg, b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"],
+                                 b["img"], b["img_mask"], 0.1, training=True, running=running)
+    ol.backward()
+    n_checked = 0
+    for name, p in named.items():
+        ref = sd[name].grad
+        if ref is None:
+            assert p.grad is None, "%s must not receive a gradient" % name
+            continue
+        _close(p.grad, ref, 5e-4, 5e-6, name)
+        n_checked += 1
+    assert n_checked > 100
+    # BatchNorm running statistics are updated in train mode, also for the detached stages
+    for k, v in running.items():
+        _close(model._engine.buffers[k], v, 1e-3, 1e-6, k)   # variance via E[x^2]-mean^2 in f32
+    # state_dict exposes the reference's aliased keys
+    keys = set(model.state_dict().keys())
+    for k in ("bart_model.model.encoder.embed_tokens.weight", "bart_model.model.decoder.embed_tokens.weight",
+              "table_encoder.bart_embedding.weight", "img_encoder.stage1.0.weight", "img_encoder.stage3.0.22.bn3.running_var",
+              "img_encoder.resnet.fc.bias", "bart_model.final_logits_bias", "img_encoder.stage1.4.2.conv3.weight"):
+        assert k in keys, k
+
+
+def test_text_step_c1(monkeypatch, golden_dir):
+    """BASELINE config 1: text_pretrain plumbing (reviews [2,2,64], CrossEntropy)."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import TextSupervised
+    g = np.load(os.path.join(golden_dir, "c1_textstep.npz"))
+    cfg = tiny_cfg(vocab=150, d=256, ffn=128, layers=2, heads=4, maxpos=80)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.08)
+    model = TextSupervised(config=cfg, label_smoothing=None, device="cpu", dtype=torch.float32)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    b = syn.yelp_batch(2, 2, 64, 1, cfg.vocab_size, seed=int(g["seed"]), img_hw=8)
+    loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+    loss.backward()
+    for v in sd.values():
+        v.requires_grad_(True)
+    ol = so.text_step_loss(sd, ocfg, b["reviews"], b["reviews_mask"], b["reviews_rating"], None, training=True)
+    ol.backward()
+    _close(loss, ol, 1e-5, 1e-6, "loss")
+    for name, p in model.named_parameters():
+        _close(p.grad, sd[name].grad, 5e-4, 5e-6, name)
+
+
+def test_coarse_modules_match_oracle(monkeypatch):
+    """Un-fused drop-in path: encoder(...) -> bart_model(hiddens..., labels=) -> logits, like the
+    reference's own loop (multimodal_train.py:150-163), incl. gradients w.r.t. the hiddens."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
+    cfg = tiny_cfg(vocab=100, d=256, ffn=128, layers=2, heads=4, maxpos=64)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
+    model = BartForMultiEncConditionalGeneration(cfg, device="cpu", dtype=torch.float32)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    Bz, N, S, T = 2, 3, 8, 10
+    ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
+    labels = syn.token_batch(Bz, T, cfg.vocab_size, seed=12, min_len=4)
+    text_m = ids.ne(1).clone()
+    text_m[1, 2, :] = False
+    table_h = formula_tensor("t.table_h", (Bz, 1, 6, cfg.d_model), std=1.0).requires_grad_(True)
+    img_h = formula_tensor("t.img_h", (Bz, 2, 4, cfg.d_model), std=1.0).requires_grad_(True)
+    table_m = torch.ones(Bz, 1, 6, dtype=torch.bool)
+    table_m[1] = False
+    img_m = torch.ones(Bz, 2, 4, dtype=torch.bool)
+    img_m[0] = False
+    rd = torch.tensor([[0.5], [-1.25]])
+    enc = model.model.encoder(input_ids=ids.view(-1, S), attention_mask=ids.view(-1, S).ne(1))[0]
+    logits = model(enc.view(Bz, N, S, -1), text_m, table_h, table_m, img_h, img_m, rating_diff=rd, labels=labels)[0]
+    loss = bo.label_smoothing_loss(logits.view(-1, cfg.vocab_size), labels.view(-1), cfg.vocab_size, 0.1)
+    loss.backward()
+    for v in sd.values():
+        v.requires_grad_(True)
+    th2, ih2 = table_h.detach().clone().requires_grad_(True), img_h.detach().clone().requires_grad_(True)
+    oenc = bo.bart_encoder(sd, ocfg, ids.view(-1, S), ids.view(-1, S).ne(1), training=True)
+    ologits = bo.multienc_forward(sd, ocfg, oenc.view(Bz, N, S, -1), text_m, th2, table_m, ih2, img_m, rd, labels, training=True)
+    oloss = bo.label_smoothing_loss(ologits.view(-1, cfg.vocab_size), labels.view(-1), cfg.vocab_size, 0.1)
+    oloss.backward()
+    _close(enc, oenc, what="encoder out")
+    _close(logits, ologits, what="logits")
+    _close(table_h.grad, th2.grad, 5e-4, 1e-6, "d table_h")
+    _close(img_h.grad, ih2.grad, 5e-4, 1e-6, "d img_h")
+    for name, p in model.named_parameters():
+        _close(p.grad, sd[name].grad, 5e-4, 5e-6, name)
+
+
+def test_optimizer_q1_and_clip(monkeypatch):
+    """get_optimizer reproduces Q1 (empty no-decay group) and Q1b (their gradients keep accumulating and
+    keep entering the clip norm); FusedAdamW + fused clip == oracle AdamW + clip_grad_norm_ over 3 steps."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import TextSupervised
+    from multimodalsum_amd import optim
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.08)
+    model = TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    opt = optim.get_optimizer(1e-3, so.NO_DECAY, model.named_parameters(), None)
+    assert len(opt.param_groups[1]["params"]) == 0
+    sch = optim.get_linear_schedule_with_warmup(opt, 1, 6)
+    ref = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    groups = so.q1_param_groups(ref.items())
+    decay_ids = {id(p) for p in groups[0]["params"]}
+    state = {id(p): (torch.zeros_like(p), torch.zeros_like(p)) for p in groups[0]["params"]}
+    for step in range(3):
+        b = syn.yelp_batch(2, 3, 16, 1, cfg.vocab_size, seed=50 + step, img_hw=8)
+        loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+        opt.zero_grad()
+        loss.backward()
+        norm = optim.clip_grad_norm_(model.parameters(), 1.0, fused=True)
+        opt.step()
+        sch.step()
+        # oracle side
+        ol = so.text_step_loss(ref, ocfg, b["reviews"], b["reviews_mask"], b["reviews_rating"], 0.1, training=True)
+        for p in groups[0]["params"]:
+            p.grad = None
+        ol.backward()
+        onorm = so.clip_grad_norm([p.grad for p in ref.values()], 1.0)
+        lr = 1e-3 * so.linear_schedule_lambda(step, 1, 6)
+        with torch.no_grad():
+            for p in groups[0]["params"]:
+                m, v = state[id(p)]
+                so.adamw_step(p, p.grad, m, v, step + 1, lr, weight_decay=0.01)
+        _close(loss, ol, 1e-5, 1e-6, "loss step %d" % step)
+        _close(norm, onorm, 1e-4, 1e-6, "grad norm step %d" % step)
+    for name, p in model.named_parameters():
+        _close(p, ref[name], 1e-4, 1e-6, name)
+        if id(ref[name]) not in decay_ids:
+            _close(p.grad, ref[name].grad, 1e-3, 1e-6, name + " accumulated grad (Q1b)")
