@@ -9,23 +9,12 @@
 // two 64-byte slabs (64 bf16 / 32 f32); register-staged double buffering (global loads for tile
 // t+1 are issued before the MFMAs of tile t, the LDS writes after them); one barrier per K step.
 // Workgroup ids are remapped so that consecutive tiles (which share an A panel) land on one XCD.
-#include "mmsum_device.h"
-#include "mmsum_kernels.h"
+#include "gemm_common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, NSLAB = 2, THREADS = 256;
 constexpr int TILE_BYTES = BM * NSLAB * SLAB_BYTES;  // 16 KiB per operand per stage
-
-struct GemmArgs {
-    const void* A; const void* A2; const void* B; void* C; const float* bias; void* aux;
-    int M, N, K; long lda, lda2, ldb, ldc, ldaux; int ksplit; float alpha; int flags; int splitk;
-};
-
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
 
 template <typename T> struct NatRegs { u32x4_t v[4]; };
 
@@ -139,48 +128,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs p) {
         }
     }
 
-    // ---- epilogue ----------------------------------------------------------------------------
-    const int epi = (p.flags >> 3) & 7;
-    const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
-    const bool accum = p.flags & MMSUM_GEMM_ACCUM;
-    const bool out_f32 = p.flags & MMSUM_GEMM_OUT_F32;
-    const bool atomic = p.splitk > 1;
-    float* Cf = static_cast<float*>(p.C);
-    T* Ct = static_cast<T*>(p.C);
-    T* aux = static_cast<T*>(p.aux);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (col >= p.N) continue;
-        const float bv = has_bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + acc_row(r, lane);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] * p.alpha + bv;
-                if (epi == MMSUM_EPI_GELU) {
-                    if (aux) aux[(long)row * p.ldaux + col] = from_f32<T>(v);
-                    v = gelu_f(v);
-                } else if (epi == MMSUM_EPI_GELU_BWD) {
-                    v *= gelu_grad_f(to_f32(aux[(long)row * p.ldaux + col]));
-                } else if (epi == MMSUM_EPI_RELU) {
-                    v = fmaxf(v, 0.f);
-                } else if (epi == MMSUM_EPI_RELU_BWD) {
-                    v = (to_f32(aux[(long)row * p.ldaux + col]) > 0.f) ? v : 0.f;
-                }
-                const long o = (long)row * p.ldc + col;
-                if (atomic) {
-                    atomicAdd(Cf + o, v);
-                } else if (out_f32) {
-                    Cf[o] = accum ? Cf[o] + v : v;
-                } else {
-                    Ct[o] = from_f32<T>(accum ? to_f32(Ct[o]) + v : v);
-                }
-            }
-        }
-    }
+    gemm_epilogue<T, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, ks, lane);
 }
 
 template <typename T>
@@ -221,5 +169,6 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     if (bt && ((ldb * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
     GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
 }

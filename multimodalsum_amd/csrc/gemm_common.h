@@ -1,0 +1,70 @@
+// Shared by the generic and the LDS-DMA GEMM kernels: argument block and the fused epilogue.
+#pragma once
+#include "mmsum_device.h"
+#include "mmsum_kernels.h"
+
+struct GemmArgs {
+    const void* A; const void* A2; const void* B; void* C; const float* bias; void* aux;
+    int M, N, K; long lda, lda2, ldb, ldc, ldaux; int ksplit; float alpha; int flags; int splitk;
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+
+// Epilogue of one wave: acc[i][j] is the 32x32 tile at rows row0 + i*32, columns col0 + j*32.
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x16_t (&acc)[TM][TN], int row0, int col0, int ks, int lane) {
+    const int epi = (p.flags >> 3) & 7;
+    const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
+    const bool accum = p.flags & MMSUM_GEMM_ACCUM;
+    const bool out_f32 = p.flags & MMSUM_GEMM_OUT_F32;
+    const bool atomic = p.splitk > 1;
+    float* Cf = static_cast<float*>(p.C);
+    T* Ct = static_cast<T*>(p.C);
+    T* aux = static_cast<T*>(p.aux);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32 + (lane & 31);
+        if (col >= p.N) continue;
+        const float bv = has_bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + acc_row(r, lane);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] * p.alpha + bv;
+                if (epi == MMSUM_EPI_GELU) {
+                    if (aux) aux[(long)row * p.ldaux + col] = from_f32<T>(v);
+                    v = gelu_f(v);
+                } else if (epi == MMSUM_EPI_GELU_BWD) {
+                    v *= gelu_grad_f(to_f32(aux[(long)row * p.ldaux + col]));
+                } else if (epi == MMSUM_EPI_RELU) {
+                    v = fmaxf(v, 0.f);
+                } else if (epi == MMSUM_EPI_RELU_BWD) {
+                    v = (to_f32(aux[(long)row * p.ldaux + col]) > 0.f) ? v : 0.f;
+                }
+                const long o = (long)row * p.ldc + col;
+                if (atomic) {
+                    atomicAdd(Cf + o, v);
+                } else if (out_f32) {
+                    Cf[o] = accum ? Cf[o] + v : v;
+                } else {
+                    Ct[o] = from_f32<T>(accum ? to_f32(Ct[o]) + v : v);
+                }
+            }
+        }
+    }
+}
+
+// bijective XCD remap (blocks b and b+8 share an XCD): consecutive logical ids land on one XCD
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
+    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+}
+
+int launch_gemm_glds(const GemmArgs& a, hipStream_t stream);   // gemm_fast.hip
+bool gemm_glds_eligible(int dtype, const GemmArgs& a);
