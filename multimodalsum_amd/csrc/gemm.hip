@@ -41,7 +41,7 @@ __device__ __forceinline__ void nat_store(char* lds, const NatRegs<T>& r, int ti
     }
 }
 
-template <typename T, bool AT, bool BT>
+template <typename T, bool AT, bool BT, int EPI, int OUT>
 __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KC = ElemTraits<T>::kPerChunk;
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs p) {
     const int tiles = tiles_m * tiles_n;
     const int ks = wg / tiles;                 // split-K slice
     const int t = wg % tiles;
-    const int tm = t / tiles_n, tn = t % tiles_n;
+    int tm, tn;
+    tile_coords(t, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- K range of this slice ---------------------------------------------------------------
@@ -128,20 +129,31 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs p) {
         }
     }
 
-    gemm_epilogue<T, 2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, ks, lane);
+    gemm_epilogue<T, 2, 2, EPI, OUT>(p, acc, m0 + wm * 64, n0 + wn * 64, ks, lane);
+}
+
+template <typename T, bool AT, bool BT>
+int launch_layout(const GemmArgs& a, hipStream_t stream) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const dim3 grid(tiles * a.splitk), block(THREADS);
+    const size_t lds = 4 * TILE_BYTES;
+    const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
+#define GEMM_CASE(E, O) if (epi == E && out == O) { gemm_kernel<T, AT, BT, E, O><<<grid, block, lds, stream>>>(a); return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP; }
+    GEMM_CASE(MMSUM_EPI_NONE, OUT_T) GEMM_CASE(MMSUM_EPI_NONE, OUT_T_ACC) GEMM_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
+    GEMM_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) GEMM_CASE(MMSUM_EPI_NONE, OUT_F32)
+    GEMM_CASE(MMSUM_EPI_GELU, OUT_T) GEMM_CASE(MMSUM_EPI_GELU_BWD, OUT_T) GEMM_CASE(MMSUM_EPI_RELU, OUT_T) GEMM_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
+    GEMM_CASE(MMSUM_EPI_GELU, OUT_F32) GEMM_CASE(MMSUM_EPI_GELU_BWD, OUT_F32) GEMM_CASE(MMSUM_EPI_RELU, OUT_F32) GEMM_CASE(MMSUM_EPI_RELU_BWD, OUT_F32)
+#undef GEMM_CASE
+    return MMSUM_ERR_BAD_SHAPE;   // unsupported epilogue/output combination
 }
 
 template <typename T>
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const dim3 grid(tiles * a.splitk), block(THREADS);
-    const size_t lds = 4 * TILE_BYTES;
     const bool at = a.flags & MMSUM_GEMM_A_T, bt = a.flags & MMSUM_GEMM_B_T;
-    if (!at && !bt) hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, block, lds, stream, a);
-    else if (!at && bt) hipLaunchKernelGGL((gemm_kernel<T, false, true>), grid, block, lds, stream, a);
-    else if (at && bt) hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, block, lds, stream, a);
-    else hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, block, lds, stream, a);
-    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+    if (!at && !bt) return launch_layout<T, false, false>(a, stream);
+    if (!at && bt) return launch_layout<T, false, true>(a, stream);
+    if (at && bt) return launch_layout<T, true, true>(a, stream);
+    return launch_layout<T, true, false>(a, stream);
 }
 
 }  // namespace

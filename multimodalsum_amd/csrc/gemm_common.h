@@ -15,49 +15,67 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 
 
 // Epilogue of one wave: acc[i][j] is the 32x32 tile at rows row0 + i*32, columns col0 + j*32.
-template <typename T, int TM, int TN>
+// OUT selects the store form at compile time (the runtime-flag version costs ~250 instructions per
+// element): 0 = store T, 1 = T += , 2 = f32 += , 3 = f32 atomic += , 4 = store f32.
+enum { OUT_T = 0, OUT_T_ACC = 1, OUT_F32_ACC = 2, OUT_F32_ATOMIC = 3, OUT_F32 = 4 };
+
+template <typename T, int TM, int TN, int EPI, int OUT>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x16_t (&acc)[TM][TN], int row0, int col0, int ks, int lane) {
-    const int epi = (p.flags >> 3) & 7;
     const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
-    const bool accum = p.flags & MMSUM_GEMM_ACCUM;
-    const bool out_f32 = p.flags & MMSUM_GEMM_OUT_F32;
-    const bool atomic = p.splitk > 1;
     float* Cf = static_cast<float*>(p.C);
     T* Ct = static_cast<T*>(p.C);
     T* aux = static_cast<T*>(p.aux);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + j * 32 + (lane & 31);
-        if (col >= p.N) continue;
-        const float bv = has_bias ? p.bias[col] : 0.f;
+        const bool col_ok = col < p.N;
+        const float bv = (has_bias && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + i * 32 + acc_row(r, lane);
-                if (row >= p.M) continue;
+                if (!col_ok || row >= p.M) continue;
                 float v = acc[i][j][r] * p.alpha + bv;
-                if (epi == MMSUM_EPI_GELU) {
+                if constexpr (EPI == MMSUM_EPI_GELU) {
                     if (aux) aux[(long)row * p.ldaux + col] = from_f32<T>(v);
                     v = gelu_f(v);
-                } else if (epi == MMSUM_EPI_GELU_BWD) {
+                } else if constexpr (EPI == MMSUM_EPI_GELU_BWD) {
                     v *= gelu_grad_f(to_f32(aux[(long)row * p.ldaux + col]));
-                } else if (epi == MMSUM_EPI_RELU) {
+                } else if constexpr (EPI == MMSUM_EPI_RELU) {
                     v = fmaxf(v, 0.f);
-                } else if (epi == MMSUM_EPI_RELU_BWD) {
+                } else if constexpr (EPI == MMSUM_EPI_RELU_BWD) {
                     v = (to_f32(aux[(long)row * p.ldaux + col]) > 0.f) ? v : 0.f;
                 }
                 const long o = (long)row * p.ldc + col;
-                if (atomic) {
-                    atomicAdd(Cf + o, v);
-                } else if (out_f32) {
-                    Cf[o] = accum ? Cf[o] + v : v;
-                } else {
-                    Ct[o] = from_f32<T>(accum ? to_f32(Ct[o]) + v : v);
-                }
+                if constexpr (OUT == OUT_T) Ct[o] = from_f32<T>(v);
+                else if constexpr (OUT == OUT_T_ACC) Ct[o] = from_f32<T>(to_f32(Ct[o]) + v);
+                else if constexpr (OUT == OUT_F32_ACC) Cf[o] += v;
+                else if constexpr (OUT == OUT_F32_ATOMIC) atomicAdd(Cf + o, v);
+                else Cf[o] = v;
             }
         }
     }
+}
+
+inline int out_mode_of(const GemmArgs& a) {
+    const bool f32 = a.flags & MMSUM_GEMM_OUT_F32, acc = a.flags & MMSUM_GEMM_ACCUM;
+    if (a.splitk > 1) return OUT_F32_ATOMIC;
+    if (f32) return acc ? OUT_F32_ACC : OUT_F32;
+    return acc ? OUT_T_ACC : OUT_T;
+}
+
+// Grouped rasterisation: logical tile ids walk GROUP_M tile-rows at a time so that the tiles an
+// XCD works on concurrently share both A and B panels in its 4 MiB L2.
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * tiles_n;
+    const int g = t / per_group;
+    const int first_m = g * GROUP_M;
+    const int gm = min(GROUP_M, tiles_m - first_m);
+    const int in = t - g * per_group;
+    tm = first_m + in % gm;
+    tn = in / gm;
 }
 
 // bijective XCD remap (blocks b and b+8 share an XCD): consecutive logical ids land on one XCD

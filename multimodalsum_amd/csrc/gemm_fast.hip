@@ -44,7 +44,7 @@ __device__ __forceinline__ void dma_piece(char* tile, const bf16_t* __restrict__
     dma16(g + (long)grow * ld + k0 + slab * 32 + c * 8, tile + slab * (ROWS * SLAB_BYTES) + rb * 1024);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_glds_kernel(GemmArgs p) {
     using Cfg = FastCfg<BM, BN, WAVES_M, WAVES_N>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -57,7 +57,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_glds_kernel(Gem
     const int tiles = tiles_m * tiles_n;
     const int ks = wg / tiles;
     const int t = wg % tiles;
-    const int m0 = (t / tiles_n) * BM, n0 = (t % tiles_n) * BN;
+    int tm, tn;
+    tile_coords(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const int ktiles = p.K / 64;
     const int per = (ktiles + p.splitk - 1) / p.splitk;
@@ -112,22 +114,33 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_glds_kernel(Gem
             cur ^= 1;
         }
     }
-    gemm_epilogue<bf16_t, Cfg::TM, Cfg::TN>(p, acc, m0 + wm * (Cfg::TM * 32), n0 + wn * (Cfg::TN * 32), ks, lane);
+    gemm_epilogue<bf16_t, Cfg::TM, Cfg::TN, EPI, OUT>(p, acc, m0 + wm * (Cfg::TM * 32), n0 + wn * (Cfg::TN * 32), ks, lane);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+int launch_one(const GemmArgs& a, hipStream_t stream) {
     using Cfg = FastCfg<BM, BN, WAVES_M, WAVES_N>;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * Cfg::STAGE;
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<BM, BN, WAVES_M, WAVES_N>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         once = true;
     }
-    gemm_nt_glds_kernel<BM, BN, WAVES_M, WAVES_N><<<dim3(tiles * a.splitk), dim3(Cfg::THREADS), lds, stream>>>(a);
+    gemm_nt_glds_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT><<<dim3(tiles * a.splitk), dim3(Cfg::THREADS), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
+#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O>(a, stream);
+    FAST_CASE(MMSUM_EPI_NONE, OUT_T) FAST_CASE(MMSUM_EPI_NONE, OUT_T_ACC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
+    FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32)
+    FAST_CASE(MMSUM_EPI_GELU, OUT_T) FAST_CASE(MMSUM_EPI_GELU_BWD, OUT_T) FAST_CASE(MMSUM_EPI_RELU, OUT_T) FAST_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
+#undef FAST_CASE
+    return MMSUM_ERR_BAD_SHAPE;
 }
 
 inline double tile_score(int M, int N, int splitk, int bm, int bn, double eff) {
@@ -145,6 +158,8 @@ bool gemm_glds_eligible(int dtype, const GemmArgs& a) {
     if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) return false;
     if (a.K % 64) return false;
     if (a.A2 && (a.ksplit % 64)) return false;
+    const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
+    if (epi != MMSUM_EPI_NONE && out != OUT_T) return false;     // rare combinations stay on the generic kernel
     return true;
 }
 

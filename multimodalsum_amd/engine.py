@@ -133,6 +133,9 @@ class Engine:
         self._conv_dirty = "all"
         self.touched = set()
         self.Vpad = (cfg.vocab_size + 127) // 128 * 128
+        self.wt, self.wt_desc, self.conv_mats_t, self._tcache = {}, None, {}, {}
+        if compute_dtype == torch.bfloat16:
+            self._build_wt_table()
         self.post_backward_hooks = []      # run once when a whole backward pass has finished (DDP finalisation)
         self.segment_hooks = []            # run when a parameter segment's gradients are final (DDP overlap)
         for name, p in self.arena.params.items():   # lets optim.py / parallel.py find the arena from a parameter
@@ -157,6 +160,74 @@ class Engine:
         self.step_count += 1
         return (self.seed_base * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
 
+    # ---- transposed bf16 weight shadows: dgrad dx = dy W runs as the NT product dy (W^T)^T --------
+    def _wt_groups(self):
+        cfg, bp = self.cfg, self.bp
+        D, V = cfg.d_model, cfg.vocab_size
+        g = [(bp + "model.shared.weight", bp + "model.shared.weight", V, D, self.Vpad)]
+        for side, nl in (("encoder", cfg.encoder_layers), ("decoder", cfg.decoder_layers)):
+            for i in range(nl):
+                lb = bp + "model.%s.layers.%d." % (side, i)
+                q, k, v = self._attn_names(lb, "self_attn")
+                g.append((q + ".weight", v + ".weight", 3 * D, D, 3 * D))
+                g.append((lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.weight", D, D, D))
+                if side == "decoder":
+                    q, k, v = self._attn_names(lb, "encoder_attn")
+                    g.append((q + ".weight", q + ".weight", D, D, D))
+                    g.append((k + ".weight", v + ".weight", 2 * D, D, 2 * D))
+                    g.append((lb + "encoder_attn.out_proj.weight", lb + "encoder_attn.out_proj.weight", D, D, D))
+                    if self.multimodal:
+                        for pr in ("alpha_proj", "beta_proj"):
+                            g.append((lb + "encoder_attn.%s.weight" % pr, lb + "encoder_attn.%s.weight" % pr, D, 2 * D, D))
+                Fd = self.arena.shapes[lb + "fc1.weight"][0]
+                g.append((lb + "fc1.weight", lb + "fc1.weight", Fd, D, Fd))
+                g.append((lb + "fc2.weight", lb + "fc2.weight", D, Fd, D))
+        if self.with_table:
+            g.append(("table_encoder.fc.weight", "table_encoder.fc.weight", 1024, 2048, 1024))
+            g.append(("table_encoder.linear.weight", "table_encoder.linear.weight", 1024, 1024, 1024))
+        if self.with_img:
+            g.append(("img_encoder.linear.weight", "img_encoder.linear.weight", D, 1024, D))
+            for li, bi, inp, pl, stride, down in resnet_blocks():
+                if li == 3:
+                    b = "img_encoder.resnet.layer3.%d." % bi
+                    g.append((b + "conv1.weight", b + "conv1.weight", pl, inp, pl))
+                    g.append((b + "conv3.weight", b + "conv3.weight", pl * 4, pl, pl * 4))
+        return g
+
+    def _build_wt_table(self):
+        a = self.arena
+        rows_desc, off, max_tiles = [], 0, 1
+        for first, last, rows, cols, ld in self._wt_groups():
+            src_off = a.offsets[first]
+            assert a.offsets[last] + a.numel(last) - src_off == rows * cols, (first, last)
+            rows_desc.append([src_off, off, rows, cols, cols, ld])
+            self.wt[first] = (off, cols, ld, rows)
+            off += cols * ld
+            off = (off + 63) // 64 * 64
+            max_tiles = max(max_tiles, ((rows + 63) // 64) * ((cols + 63) // 64))
+        self.wt_buf = torch.zeros(off, dtype=torch.bfloat16, device=self.device)
+        self.wt_desc = torch.tensor(rows_desc, dtype=torch.int64, device=self.device)
+        self.wt_max_tiles = max_tiles
+        for k, (o, cols, ld, rows) in list(self.wt.items()):
+            self.wt[k] = self.wt_buf[o:o + cols * ld].view(cols, ld)
+
+    def dgrad(self, dy, key, w_natural, out, accumulate=False, epi=0, aux=None, rows=None):
+        """out (+)= dy @ W  (W natural = [N_out, K_in]); uses the transposed shadow when present."""
+        wt = self.wt.get(key)
+        if wt is not None:
+            kn.gemm(dy, wt if rows is None else wt[rows], out, accumulate=accumulate, epi=epi, aux=aux)
+        else:
+            kn.gemm(dy, w_natural, out, b_t=True, accumulate=accumulate, epi=epi, aux=aux)
+
+    def transposed(self, t, Mp, cache_key=None):
+        if cache_key is not None and cache_key in self._tcache:
+            return self._tcache[cache_key]
+        out = self.empty(t.shape[1], Mp)
+        kn.transpose(t, out, Mp)
+        if cache_key is not None:
+            self._tcache[cache_key] = out
+        return out
+
     def sync_weights(self):
         """Called at the start of every forward.  Parameters are ordinary f32 tensors that any
         optimiser may update in place, so the bf16 shadow and the conv weight matrices are rebuilt
@@ -166,6 +237,8 @@ class Engine:
             kn.cast(a.shadow, a.data)
         if self.with_img and self._conv_dirty:
             self._build_conv_mats(all_layers=(self._conv_dirty == "all"))
+        if self.wt_desc is not None and self.training:
+            kn.transpose_batched(a.shadow, self.wt_buf, self.wt_desc, self.wt_desc.shape[0], self.wt_max_tiles)
         a.shadow_dirty = True
         self._conv_dirty = "all"
 
@@ -186,9 +259,16 @@ class Engine:
         sk = max(1, min(16, 512 // max(tiles, 1), ktiles // 4))
         return sk
 
-    def wgrad(self, dy, x, gname=None, gview=None):
+    def wgrad(self, dy, x, gname=None, gview=None, x_cache_key=None):
         """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena."""
         out = gview if gview is not None else self.arena.g(gname)
+        if self.dtype == torch.bfloat16:
+            M = dy.shape[0]
+            Mp = (M + 63) // 64 * 64
+            dyT = self.transposed(dy, Mp)
+            xT = self.transposed(x, Mp, x_cache_key)
+            kn.gemm(dyT, xT, out, accumulate=True, splitk=self.splitk(dy.shape[1], x.shape[1], Mp))
+            return
         kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=self.splitk(dy.shape[1], x.shape[1], dy.shape[0]))
 
     def bgrad(self, dy, gname=None, gview=None):
@@ -276,13 +356,13 @@ class Engine:
         self.bgrad(do, lb + "self_attn.out_proj.bias")
         self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight")
         dattn = self.empty(R, D)
-        kn.gemm(do, a.w(lb + "self_attn.out_proj.weight"), dattn, b_t=True)
+        self.dgrad(do, lb + "self_attn.out_proj.weight", a.w(lb + "self_attn.out_proj.weight"), dattn)
         dqkv = self.empty(R, 3 * D)
         stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
         kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
         self.bgrad(dqkv, gview=a.gspan(q + ".bias", v + ".bias", (3 * D,)))
         self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)))
-        kn.gemm(dqkv, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), dx, b_t=True, accumulate=True)
+        self.dgrad(dqkv, q + ".weight", a.wspan(q + ".weight", v + ".weight", (3 * D, D)), dx, accumulate=True)
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias",
                    lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.bias", lb + "self_attn_layer_norm.weight",
                    lb + "self_attn_layer_norm.bias")
@@ -313,10 +393,10 @@ class Engine:
         self.bgrad(df, lb + "fc2.bias")
         self.wgrad(df, c.h, lb + "fc2.weight")
         du = self.empty(R, c.u.shape[1])
-        kn.gemm(df, a.w(lb + "fc2.weight"), du, b_t=True, epi=kn.EPI_GELU_BWD, aux=c.u)
+        self.dgrad(df, lb + "fc2.weight", a.w(lb + "fc2.weight"), du, epi=kn.EPI_GELU_BWD, aux=c.u)
         self.bgrad(du, lb + "fc1.bias")
         self.wgrad(du, c.x, lb + "fc1.weight")
-        kn.gemm(du, a.w(lb + "fc1.weight"), dx, b_t=True, accumulate=True)
+        self.dgrad(du, lb + "fc1.weight", a.w(lb + "fc1.weight"), dx, accumulate=True)
         self.touch(lb + "fc1.weight", lb + "fc1.bias", lb + "fc2.weight", lb + "fc2.bias", lb + "final_layer_norm.weight",
                    lb + "final_layer_norm.bias")
         return dx
@@ -455,15 +535,15 @@ class Engine:
                 self.bgrad(dp, name + ".bias")
                 self.wgrad(dp, yt, gview=gW[:, :D])
                 self.wgrad(dp, other, gview=gW[:, D:])
-                kn.gemm(dp, W[:, :D], dyt, b_t=True, accumulate=True)
-                kn.gemm(dp, W[:, D:], dother, b_t=True, accumulate=True)
+                self.dgrad(dp, name + ".weight", W[:, :D], dyt, accumulate=True, rows=slice(0, D))
+                self.dgrad(dp, name + ".weight", W[:, D:], dother, accumulate=True, rows=slice(D, 2 * D))
                 self.touch(name + ".weight", name + ".bias")
         else:
             dyy = dcv
         self.bgrad(dyy, pre + "out_proj.bias")
         self.wgrad(dyy, c.heads, pre + "out_proj.weight")
         dheads = self.empty(nm * Rq, D)
-        kn.gemm(dyy, a.w(pre + "out_proj.weight"), dheads, b_t=True)
+        self.dgrad(dyy, pre + "out_proj.weight", a.w(pre + "out_proj.weight"), dheads)
         dq = self.empty(Rq, D)
         dkv = self.empty(L.rows, 2 * D)
         for m, (N, S) in enumerate(L.mods):
@@ -471,11 +551,11 @@ class Engine:
             stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
             kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
         self.bgrad(dkv, gview=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
-        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)))
-        kn.gemm(dkv, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, b_t=True, accumulate=not first)
+        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), x_cache_key=("mem", dc.mem.data_ptr()))
+        self.dgrad(dkv, k + ".weight", a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, accumulate=not first)
         self.bgrad(dq, q + ".bias")
         self.wgrad(dq, c.x, q + ".weight")
-        kn.gemm(dq, a.w(q + ".weight"), dx, b_t=True, accumulate=True)
+        self.dgrad(dq, q + ".weight", a.w(q + ".weight"), dx, accumulate=True)
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias", pre + "out_proj.weight",
                    pre + "out_proj.bias", lb + "encoder_attn_layer_norm.weight", lb + "encoder_attn_layer_norm.bias")
         return dx
@@ -493,7 +573,10 @@ class Engine:
         """dlogits [Rq, Vpad] with zero padding columns.  -> dh; accumulates the tied-embedding gradient."""
         V, name = self.cfg.vocab_size, self.bp + "model.shared.weight"
         dh = self.empty(h.shape[0], h.shape[1])
-        kn.gemm(dlogits[:, :V], self.arena.w(name), dh, b_t=True)
+        if name in self.wt:
+            kn.gemm(dlogits, self.wt[name], dh)          # K = Vpad: padding columns of both operands are zero
+        else:
+            kn.gemm(dlogits[:, :V], self.arena.w(name), dh, b_t=True)
         self.wgrad(dlogits[:, :V], h, name)
         self.touch(name)
         return dh
@@ -535,11 +618,11 @@ class Engine:
         tp = "table_encoder."
         self.wgrad(dy, c.t1, tp + "linear.weight")
         dt1 = self.empty(c.B * 47, D)
-        kn.gemm(dy, a.w(tp + "linear.weight"), dt1, b_t=True, epi=kn.EPI_RELU_BWD, aux=c.t1)
+        self.dgrad(dy, tp + "linear.weight", a.w(tp + "linear.weight"), dt1, epi=kn.EPI_RELU_BWD, aux=c.t1)
         self.bgrad(dt1, tp + "fc.bias")
         self.wgrad(dt1, c.all, tp + "fc.weight")
         dall = self.empty(c.B * 47, 2 * D)
-        kn.gemm(dt1, a.w(tp + "fc.weight"), dall, b_t=True)
+        self.dgrad(dt1, tp + "fc.weight", a.w(tp + "fc.weight"), dall)
         kn.table_gather_bwd(dall, c.fv[4], c.fv[5], a.g(tp + "rating_embedding.weight"), a.g(tp + "hours_embedding.weight"), c.B, D)
         self.touch(tp + "linear.weight", tp + "fc.bias", tp + "fc.weight", tp + "rating_embedding.weight", tp + "hours_embedding.weight")
 
@@ -563,6 +646,12 @@ class Engine:
                 m = self.empty(co, Kpad)
                 self.conv_mats[name] = m
             kn.conv_weight_to_matrix(m, a.f32(name), co, ci, ks, ks, Kpad)
+            if self.dtype == torch.bfloat16 and ".layer3." in name:
+                mt = self.conv_mats_t.get(name)
+                if mt is None:
+                    mt = self.empty(Kpad, co)
+                    self.conv_mats_t[name] = mt
+                kn.transpose(m, mt)
 
     def _bn_fwd(self, name, x, relu, residual=None):
         a = self.arena
@@ -656,7 +745,7 @@ class Engine:
         self.wgrad(dy, c.feat, "img_encoder.linear.weight")
         self.touch("img_encoder.linear.weight")
         dx = self.empty(c.feat.shape[0], c.feat.shape[1])
-        kn.gemm(dy, a.w("img_encoder.linear.weight"), dx, b_t=True)
+        self.dgrad(dy, "img_encoder.linear.weight", a.w("img_encoder.linear.weight"), dx)
         for bc in reversed(c.blocks):
             b = bc.name
             first_block = bc.down      # block 0: its input is the detached stage-2 output (:33) -> no input gradient
@@ -666,14 +755,18 @@ class Engine:
             w3 = a.w(b + "conv3.weight")
             self.wgrad(dc3, bc.o2, gview=a.g(b + "conv3.weight", (w3.shape[0], w3.shape[1])))
             do2 = self.empty(R2, bc.pl)
-            kn.gemm(dc3, w3.view(w3.shape[0], w3.shape[1]), do2, b_t=True)
+            self.dgrad(dc3, b + "conv3.weight", w3.view(w3.shape[0], w3.shape[1]), do2)
             dc2 = self._bn_bwd(bc.bn2, do2)
             wm = self.conv_mats[b + "conv2.weight"]
             dwm = self.zeros(wm.shape[0], wm.shape[1], dtype=torch.float32)
-            kn.gemm(dc2, bc.col, dwm, a_t=True, b_t=True, accumulate=True, splitk=self.splitk(wm.shape[0], wm.shape[1], R2))
+            self.wgrad(dc2, bc.col, gview=dwm)
             kn.conv_matrix_grad_to_weight(dwm, a.g(b + "conv2.weight"), bc.pl, bc.pl, 3, 3, wm.shape[1], True)
             dcol = self.empty(R2, wm.shape[1])
-            kn.gemm(dc2, wm, dcol, b_t=True)
+            wmt = self.conv_mats_t.get(b + "conv2.weight")
+            if wmt is not None:
+                kn.gemm(dc2, wmt, dcol)
+            else:
+                kn.gemm(dc2, wm, dcol, b_t=True)
             do1 = self.empty(bc.o1.shape[0], bc.pl)
             Ho2, Wo2 = (bc.H + 2 - 3) // bc.stride + 1, (bc.W + 2 - 3) // bc.stride + 1
             kn.col2im(dcol, do1, n, bc.H, bc.W, bc.pl, 3, 3, bc.stride, 1, Ho2, Wo2, wm.shape[1])
@@ -688,5 +781,5 @@ class Engine:
                 self.touch(b + "downsample.0.weight")
                 dx = None
             else:
-                kn.gemm(dc1, w1.view(w1.shape[0], w1.shape[1]), didt, b_t=True, accumulate=True)
+                self.dgrad(dc1, b + "conv1.weight", w1.view(w1.shape[0], w1.shape[1]), didt, accumulate=True)
                 dx = didt

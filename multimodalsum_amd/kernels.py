@@ -179,6 +179,18 @@ def cast(dst, src):
     return dst
 
 
+def transpose(src, dst, rows_pad=None):
+    """dst[c, r] = src[r, c] (bf16); dst has >= rows_pad columns, [rows, rows_pad) zero filled."""
+    rows, cols = src.shape
+    rp = rows if rows_pad is None else rows_pad
+    check(lib.mmsum_transpose_bf16(_p(src), _ld(src), _p(dst), _ld(dst), rows, cols, rp, _stream()), "mmsum_transpose_bf16")
+    return dst
+
+
+def transpose_batched(src_base, dst_base, desc, n, max_tiles):
+    check(lib.mmsum_transpose_bf16_batched(_p(src_base), _p(dst_base), _p(desc), n, max_tiles, _stream()), "mmsum_transpose_bf16_batched")
+
+
 def scale_by_clip(g, norm_sq, max_norm):
     check(lib.mmsum_scale_by_clip(_p(g), g.numel(), _p(norm_sq), max_norm, _stream()), "mmsum_scale_by_clip")
 

@@ -238,6 +238,19 @@ def cast(dst, src):
     return dst
 
 
+def transpose(src, dst, rows_pad=None):
+    dst.zero_()
+    dst[:, :src.shape[0]] = src.t()
+    return dst
+
+
+def transpose_batched(src_base, dst_base, desc, n, max_tiles):
+    for i in range(n):
+        so, do, r, c, ls, ld = [int(v) for v in desc[i]]
+        src = torch.as_strided(src_base, (r, c), (ls, 1), so)
+        torch.as_strided(dst_base, (c, r), (ld, 1), do).copy_(src.t())
+
+
 def scale_by_clip(g, norm_sq, max_norm):
     g.mul_(_clip(norm_sq, max_norm))
 

@@ -207,3 +207,40 @@ def test_optimizer_q1_and_clip(monkeypatch):
         _close(p, ref[name], 1e-4, 1e-6, name)
         if id(ref[name]) not in decay_ids:
             _close(p.grad, ref[name].grad, 1e-3, 1e-6, name + " accumulated grad (Q1b)")
+
+
+def test_bf16_mode_schedules(monkeypatch, golden_dir):
+    """bf16 compute mode takes different host paths (bf16 weight shadow, transposed-weight table for dgrad,
+    activation transposes for wgrad).  Run them through the emulator and check against the f32 oracle at
+    bf16 accuracy: an indexing mistake there is an O(1) error, rounding is not."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import MultimodalSum
+    g = np.load(os.path.join(golden_dir, "f3_step.npz"))
+    cfg = tiny_cfg()
+    ocfg = oracle_cfg(cfg)
+    sd = f3_state(ocfg)
+    model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.bfloat16)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    b = syn.yelp_batch(int(g["B"]), int(g["NR"]), int(g["S"]), int(g["I"]), cfg.vocab_size, seed=int(g["seed"]), img_hw=int(g["img_hw"]))
+    loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() > 0 and "running" not in k:
+            v.requires_grad_(True)
+    ol = so.multimodal_step_loss(sd, ocfg, b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"],
+                                 b["img"], b["img_mask"], 0.1, training=True)
+    ol.backward()
+    worst = ("", 1.0)
+    for name, p in model.named_parameters():
+        ref = sd[name].grad
+        if ref is None:
+            assert p.grad is None, name
+            continue
+        if ref.numel() >= 1024 and ref.abs().max() > 1e-6:
+            a, r = p.grad.double().flatten(), ref.double().flatten()
+            cos = float((a @ r) / (a.norm() * r.norm() + 1e-30))
+            if cos < worst[1]:
+                worst = (name, cos)
+    assert worst[1] > 0.97, worst
