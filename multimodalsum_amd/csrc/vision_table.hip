@@ -116,50 +116,71 @@ __global__ __launch_bounds__(256) void matrix_to_weight_grad_kernel(const float*
 }
 
 // ---- BatchNorm ----------------------------------------------------------------------------------
-constexpr int BN_SPLITS = 64;
+constexpr int BN_SPLITS = 128;
 // MODE 0: sums of (x, x^2).  MODE 1: sums of (dy', dy'*xhat) for the backward pass.
+// block = 16 column groups (4 channels, vector loads) x 16 row lanes; grid (C/64, splits)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                                                          const float* __restrict__ sums, int R, int C, float eps, int relu,
                                                          float* __restrict__ part) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
+    __shared__ float red[2][16][64];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + cg * 4;
     const int rows_per = (R + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
-    float s0 = 0.f, s1 = 0.f;
+    f32x4_t s0 = f32x4_t{0, 0, 0, 0}, s1 = f32x4_t{0, 0, 0, 0};
     if (col < C) {
-        float mean = 0.f, rstd = 0.f;
+        f32x4_t mean = f32x4_t{0, 0, 0, 0}, rstd = f32x4_t{0, 0, 0, 0};
         if (MODE == 1) {
-            mean = sums[col] / R;
-            const float var = fmaxf(sums[C + col] / R - mean * mean, 0.f);
-            rstd = rsqrtf(var + eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mean[j] = sums[col + j] / R;
+                rstd[j] = rsqrtf(fmaxf(sums[C + col + j] / R - mean[j] * mean[j], 0.f) + eps);
+            }
         }
-        for (int r = r0 + rl; r < r1; r += 4) {
+        for (int r = r0 + rl; r < r1; r += 16) {
             const long o = (long)r * C + col;
             if (MODE == 0) {
-                const float v = to_f32(a[o]);
-                s0 += v; s1 += v * v;
+                const f32x4_t v = ld4<T>(a + o);
+                s0 = s0 + v;
+                s1 = s1 + v * v;
             } else {
-                float g = to_f32(a[o]);
-                if (relu && !(to_f32(y[o]) > 0.f)) g = 0.f;
-                s0 += g; s1 += g * (to_f32(x[o]) - mean) * rstd;
+                f32x4_t g = ld4<T>(a + o);
+                if (relu) {
+                    const f32x4_t yv = ld4<T>(y + o);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (!(yv[j] > 0.f)) g[j] = 0.f;
+                }
+                s0 = s0 + g;
+                s1 = s1 + g * (ld4<T>(x + o) - mean) * rstd;
             }
         }
     }
-    red[0][rl][cl] = s0; red[1][rl][cl] = s1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[0][rl][cg * 4 + j] = s0[j]; red[1][rl][cg * 4 + j] = s1[j]; }
     __syncthreads();
-    if (rl == 0 && col < C) {
-        part[(long)blockIdx.y * 2 * C + col] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        part[(long)blockIdx.y * 2 * C + C + col] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6, c = threadIdx.x & 63;
+        if (blockIdx.x * 64 + c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[w][k][c];
+            part[(long)blockIdx.y * 2 * C + w * C + blockIdx.x * 64 + c] = t;
+        }
     }
 }
-__global__ void bn_finish_kernel(const float* __restrict__ part, int splits, int C2, float* __restrict__ out) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= C2) return;
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ part, int splits, int C2, float* __restrict__ out) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[(long)k * C2 + col];
-    out[col] = s;
+    if (col < C2) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += 4) s += part[(long)k * C2 + col];
+    }
+    red[sl][cl] = s;
+    __syncthreads();
+    if (sl == 0 && col < C2) out[col] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
 template <typename T>
@@ -423,12 +444,12 @@ extern "C" long mmsum_bn_workspace(int C) { return (long)BN_SPLITS * 2 * C * siz
 extern "C" int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, void* stream) {
     if (R <= 0 || C <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int splits = R < BN_SPLITS * 8 ? max(1, R / 8) : BN_SPLITS;
+    const int splits = R < BN_SPLITS * 16 ? max(1, R / 16) : BN_SPLITS;
     const dim3 grid((C + 63) / 64, splits), block(256);
     float* part = (float*)workspace;
     DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 0><<<grid, block, 0, s>>>((const bf16_t*)x, nullptr, nullptr, nullptr, R, C, 0.f, 0, part)),
               (bn_partial_kernel<float, 0><<<grid, block, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, R, C, 0.f, 0, part)));
-    bn_finish_kernel<<<dim3((2 * C + 255) / 256), dim3(256), 0, s>>>(part, splits, 2 * C, sums);
+    bn_finish_kernel<<<dim3((2 * C + 63) / 64), dim3(256), 0, s>>>(part, splits, 2 * C, sums);
     return ok();
 }
 
@@ -449,12 +470,12 @@ extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, con
                                    int relu, float* dsums, void* workspace, void* stream) {
     if (R <= 0 || C <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int splits = R < BN_SPLITS * 8 ? max(1, R / 8) : BN_SPLITS;
+    const int splits = R < BN_SPLITS * 16 ? max(1, R / 16) : BN_SPLITS;
     const dim3 grid((C + 63) / 64, splits), block(256);
     float* part = (float*)workspace;
     DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, eps, relu, part)),
               (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, eps, relu, part)));
-    bn_finish_kernel<<<dim3((2 * C + 255) / 256), dim3(256), 0, s>>>(part, splits, 2 * C, dsums);
+    bn_finish_kernel<<<dim3((2 * C + 63) / 64), dim3(256), 0, s>>>(part, splits, 2 * C, dsums);
     return ok();
 }
 
