@@ -402,6 +402,364 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(mmsum_attn_de
     }
 }
 
+// =============================================================================================
+// Software-pipelined variants: the global loads of the NEXT entity (or query chunk) are issued into
+// registers before the MFMA/softmax work of the current one and committed to LDS afterwards, so a
+// workgroup pays one global round trip per kernel instead of two or three per entity.  K and V
+// (forward), K, V and K^T (dQ), Q, dO, Q^T and dO^T (dK/dV) live in separate LDS regions.
+// =============================================================================================
+__device__ __forceinline__ uint32_t valid_entities(const mmsum_attn_desc& d, int b, int excl) {
+    uint32_t m = 0;
+    for (int n = 0; n < d.N; ++n) {
+        if (n == excl) continue;
+        if (d.null_entity && d.null_entity[b * d.N + n]) continue;
+        m |= 1u << n;
+    }
+    return m;
+}
+
+template <typename T, int NKB>
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_pipe_kernel(mmsum_attn_desc d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+    constexpr int TILE = SPAD * HD * sizeof(T);
+    char* ktile = smem;
+    char* vtile = smem + TILE;
+    char* img = smem + 2 * TILE + (threadIdx.x >> 6) * ImageTraits<T>::kBytes;
+    uint8_t* maskb = reinterpret_cast<uint8_t*>(smem + 2 * TILE + 4 * ImageTraits<T>::kBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, qb = blockIdx.y;
+    const int b = qb / d.qpb;
+    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
+    uint32_t rem = valid_entities(d, b, excl);
+    const int cnt = __popc(rem);
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+    T* O = static_cast<T*>(d.out);
+
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+    Frag qf[NS];
+    {
+        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) qf[sl] = global_frag<T>(qrow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
+    }
+    f32x16_t oacc[2] = {zero_acc(), zero_acc()};
+
+    NatTile<T, SPAD, NS, ATT_THREADS> kreg;
+    TrTile<T, HD, NKB * AttnTraits<T>::kSlabsPer32, ATT_THREADS> vreg;
+    uint8_t mreg = 1;
+    auto prefetch = [&](int n) {
+        const long ent = (long)b * d.N + n;
+        const long row0 = ent * d.S;
+        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
+        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, 0, HD, 0, d.S, tid);
+        mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
+    };
+    if (rem) prefetch(__builtin_ctz(rem));
+    while (rem) {
+        rem &= rem - 1;
+        __syncthreads();
+        kreg.commit(ktile, tid);
+        vreg.commit(vtile, tid);
+        if (tid < SPAD) maskb[tid] = mreg;
+        __syncthreads();
+        if (rem) prefetch(__builtin_ctz(rem));
+        f32x16_t sacc[NKB];
+        float m, l;
+        scores_softmax<T, NKB>(sacc, ktile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * 32 < d.S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] *= norm;
+                acc_to_image<T>(img, sacc[kb], lane);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    mma_image<T>(oacc[db], img, vtile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + acc_row(r, lane);
+            if (qq < d.T) O[((long)qb * d.T + qq) * d.ldo + col] = from_f32<T>(oacc[db][r]);
+        }
+    }
+}
+
+template <typename T, int NKB>
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
+                                                                       T* __restrict__ dQ, long lddq, int accumulate_dq,
+                                                                       float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+    constexpr int TILE = SPAD * HD * sizeof(T);
+    char* ktile = smem;
+    char* vtile = smem + TILE;
+    char* kttile = smem + 2 * TILE;
+    char* img = smem + 3 * TILE + (threadIdx.x >> 6) * ImageTraits<T>::kBytes;
+    uint8_t* maskb = reinterpret_cast<uint8_t*>(smem + 3 * TILE + 4 * ImageTraits<T>::kBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, qb = blockIdx.y;
+    const int b = qb / d.qpb;
+    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
+    uint32_t rem = valid_entities(d, b, excl);
+    const int cnt = __popc(rem);
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+    Frag qf[NS], dof[NS];
+    {
+        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
+        const T* drow = dO + ((long)qb * d.T + qpos) * lddo + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            qf[sl] = global_frag<T>(qrow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
+            dof[sl] = global_frag<T>(drow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
+        }
+    }
+    f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
+
+    NatTile<T, SPAD, NS, ATT_THREADS> kreg, vreg;
+    TrTile<T, HD, NKB * AttnTraits<T>::kSlabsPer32, ATT_THREADS> ktreg;
+    uint8_t mreg = 1;
+    int cur_n = 0, next_n = 0;
+    auto prefetch = [&](int n) {
+        const long ent = (long)b * d.N + n;
+        const long row0 = ent * d.S;
+        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
+        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
+        ktreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, HD, 0, d.S, tid);
+        mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
+        next_n = n;
+    };
+    if (rem) prefetch(__builtin_ctz(rem));
+    while (rem) {
+        rem &= rem - 1;
+        __syncthreads();
+        kreg.commit(ktile, tid);
+        vreg.commit(vtile, tid);
+        ktreg.commit(kttile, tid);
+        if (tid < SPAD) maskb[tid] = mreg;
+        cur_n = next_n;
+        __syncthreads();
+        if (rem) prefetch(__builtin_ctz(rem));
+        f32x16_t p[NKB];
+        float m, l;
+        scores_softmax<T, NKB>(p, ktile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        const float invl = (l > 0.f) ? 1.f / l : 0.f;
+        f32x16_t dp[NKB];
+        float delta = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            dp[kb] = zero_acc();
+            if (kb * 32 < d.S) {
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const Frag a = lds_frag<T>(vtile + sl * (SPAD * SLAB_BYTES), kb * 32, lane);
+                    mma_slab<T>(dp[kb], a, dof[sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[kb][r] *= invl;
+                    dp[kb][r] *= inv_cnt;
+                    delta += p[kb][r] * dp[kb][r];
+                }
+            }
+        }
+        delta = wave_half_sum(delta);
+        if (lane < 32 && qvalid) {
+            float* st = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
+            st[0] = m + __logf(l);
+            st[1] = delta;
+        }
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * 32 < d.S) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p[kb][r] = p[kb][r] * (dp[kb][r] - delta) * d.scale;
+                acc_to_image<T>(img, p[kb], lane);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    mma_image<T>(dqacc[db], img, kttile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + acc_row(r, lane);
+            if (qq < d.T) {
+                T* o = dQ + ((long)qb * d.T + qq) * lddq + col;
+                const float v = dqacc[db][r] + (accumulate_dq ? to_f32(*o) : 0.f);
+                *o = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T, int NKB>
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
+                                                                        T* __restrict__ dK, long lddk, T* __restrict__ dV, long lddv,
+                                                                        const float* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+    constexpr int TQ = 64;
+    constexpr int NOWN = (NKB + 3) / 4;
+    constexpr int QT_TILE = TQ * HD * sizeof(T);
+    constexpr int NSQ = TQ * sizeof(T) / SLAB_BYTES;
+    char* qn = smem;
+    char* don = smem + QT_TILE;
+    char* qt = smem + 2 * QT_TILE;
+    char* dot = smem + 3 * QT_TILE;
+    char* imgP = smem + 4 * QT_TILE + (threadIdx.x >> 6) * 2 * ImageTraits<T>::kBytes;
+    char* imgS = imgP + ImageTraits<T>::kBytes;
+    float* st = reinterpret_cast<float*>(smem + 4 * QT_TILE + 8 * ImageTraits<T>::kBytes);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x;
+    const long ent = blockIdx.y;
+    const int b = (int)(ent / d.N), n = (int)(ent % d.N);
+    const long row0 = ent * d.S;
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+    const bool is_null = d.null_entity && d.null_entity[ent];
+
+    Frag kf[NOWN][NS], vf[NOWN][NS];
+    bool keymask[NOWN];
+    f32x16_t dkacc[NOWN][2], dvacc[NOWN][2];
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int key = (wave + 4 * o) * 32 + (lane & 31);
+        const bool kvalid = key < d.S;
+        keymask[o] = !kvalid || (d.pad && d.pad[ent * d.S + (kvalid ? key : 0)]);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            kf[o][sl] = global_frag<T>(K + (row0 + key) * d.ldk + h * HD + sl * ElemTraits<T>::kPerSlab, lane, kvalid);
+            vf[o][sl] = global_frag<T>(V + (row0 + key) * d.ldv + h * HD + sl * ElemTraits<T>::kPerSlab, lane, kvalid);
+        }
+        dkacc[o][0] = dkacc[o][1] = dvacc[o][0] = dvacc[o][1] = zero_acc();
+    }
+
+    const int nchunks = (d.T + TQ - 1) / TQ;
+    const int nqb = is_null ? 0 : (d.qpb - ((d.exclude_self && n < d.qpb) ? 1 : 0));
+    const int n_it = nqb * nchunks;
+    NatTile<T, TQ, NS, ATT_THREADS> qreg, doreg;
+    TrTile<T, HD, NSQ, ATT_THREADS> qtreg, dotreg;
+    float streg = 0.f;
+    auto coords = [&](int it, int& qb, int& qc, int& i) {
+        const int idx = it / nchunks;
+        i = idx + ((d.exclude_self && idx >= n) ? 1 : 0);
+        qb = b * d.qpb + i;
+        qc = (it % nchunks) * TQ;
+    };
+    auto prefetch = [&](int it) {
+        int qb, qc, i;
+        coords(it, qb, qc, i);
+        const T* qbase = Q + (long)qb * d.T * d.ldq + h * HD;
+        const T* dobase = dO + (long)qb * d.T * lddo + h * HD;
+        qreg.load(qbase, d.ldq, qc, d.T, 0, HD, tid);
+        doreg.load(dobase, lddo, qc, d.T, 0, HD, tid);
+        qtreg.load(qbase, d.ldq, 0, HD, qc, d.T, tid);
+        dotreg.load(dobase, lddo, 0, HD, qc, d.T, tid);
+        const float* sbase = stats + (((long)qb * d.N + n) * d.H + h) * d.T * 2;
+        streg = (tid < TQ * 2 && qc + (tid >> 1) < d.T) ? sbase[(long)qc * 2 + tid] : 0.f;
+    };
+    if (n_it > 0) prefetch(0);
+    for (int it = 0; it < n_it; ++it) {
+        int qb, qc, i;
+        coords(it, qb, qc, i);
+        const int cnt = __popc(valid_entities(d, b, d.exclude_self ? i : -1));
+        const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+        __syncthreads();
+        qreg.commit(qn, tid);
+        doreg.commit(don, tid);
+        qtreg.commit(qt, tid);
+        dotreg.commit(dot, tid);
+        if (tid < TQ * 2) st[tid] = streg;
+        __syncthreads();
+        if (it + 1 < n_it) prefetch(it + 1);
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const int kb = wave + 4 * o;
+            if (kb >= NKB || kb * 32 >= d.S) continue;
+            const int key = kb * 32 + (lane & 31);
+#pragma unroll
+            for (int qq = 0; qq < TQ / 32; ++qq) {
+                if (qc + qq * 32 >= d.T) continue;
+                f32x16_t s = zero_acc(), dp = zero_acc();
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const Frag aq = lds_frag<T>(qn + sl * (TQ * SLAB_BYTES), qq * 32, lane);
+                    mma_slab<T>(s, aq, kf[o][sl]);
+                    const Frag ad = lds_frag<T>(don + sl * (TQ * SLAB_BYTES), qq * 32, lane);
+                    mma_slab<T>(dp, ad, vf[o][sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ql = qq * 32 + acc_row(r, lane);
+                    const int qg = qc + ql;
+                    const bool masked = keymask[o] || qg >= d.T || (d.causal && key > qg);
+                    const float pr = masked ? 0.f : __expf(s[r] * d.scale - st[ql * 2]);
+                    dp[r] = pr * (dp[r] * inv_cnt - st[ql * 2 + 1]) * d.scale;
+                    s[r] = pr * inv_cnt;
+                }
+                acc_to_image<T>(imgP, s, lane);
+                acc_to_image<T>(imgS, dp, lane);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    mma_image<T>(dvacc[o][db], imgP, dot + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                    mma_image<T>(dkacc[o][db], imgS, qt + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int kb = wave + 4 * o;
+        if (kb >= NKB) continue;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + acc_row(r, lane);
+                if (key < d.S) {
+                    dK[(row0 + key) * lddk + col] = from_f32<T>(dkacc[o][db][r]);
+                    dV[(row0 + key) * lddv + col] = from_f32<T>(dvacc[o][db][r]);
+                }
+            }
+        }
+    }
+}
+
 __global__ void entity_null_kernel(const uint8_t* __restrict__ pad, uint8_t* __restrict__ null_entity, int S) {
     __shared__ int any_live;
     if (threadIdx.x == 0) any_live = 0;
@@ -430,10 +788,20 @@ inline void allow_lds(KernelT kernel, size_t bytes) {
 
 inline int nkb_for(int S) { return S <= 64 ? 2 : (S <= 128 ? 4 : 7); }
 
+constexpr size_t LDS_MAX = 160 * 1024;
+template <typename T> size_t pipe_lds(int nkb, int ntiles) { return (size_t)ntiles * nkb * 32 * HD * sizeof(T) + 4 * ImageTraits<T>::kBytes + nkb * 32 + 16; }
+
 template <typename T>
 int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
     const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
     const int nkb = nkb_for(d.S);
+    if (pipe_lds<T>(nkb, 2) <= LDS_MAX) {
+        const size_t lds = pipe_lds<T>(nkb, 2);
+        if (nkb == 2) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2>), grid, block, lds, s, d);
+        else if (nkb == 4) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 4>), grid, block, lds, s, d);
+        else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 7>), grid, block, lds, s, d);
+        return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+    }
     const size_t lds = fwd_lds<T>(nkb);
     if (nkb == 2) LAUNCH_LDS((attn_fwd_kernel<T, 2>), grid, block, lds, s, d);
     else if (nkb == 4) LAUNCH_LDS((attn_fwd_kernel<T, 4>), grid, block, lds, s, d);
@@ -445,7 +813,13 @@ template <typename T>
 int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, long lddq, int accumulate_dq, void* dk, long lddk,
                void* dv, long lddv, void* stats, hipStream_t s) {
     const int nkb = nkb_for(d.S);
-    {
+    if (pipe_lds<T>(nkb, 3) <= LDS_MAX) {
+        const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
+        const size_t lds = pipe_lds<T>(nkb, 3);
+        if (nkb == 2) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        else if (nkb == 4) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 4>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        else LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 7>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+    } else {
         const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
         const size_t lds = fwd_lds<T>(nkb);
         if (nkb == 2) LAUNCH_LDS((attn_bwd_dq_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
@@ -456,9 +830,9 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         const int n_ent = (d.n_qblocks / d.qpb) * d.N;
         const dim3 grid(d.H, n_ent), block(ATT_THREADS);
         const size_t lds = dkv_lds<T>();
-        if (nkb == 2) LAUNCH_LDS((attn_bwd_dkv_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
-        else if (nkb == 4) LAUNCH_LDS((attn_bwd_dkv_kernel<T, 4>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
-        else LAUNCH_LDS((attn_bwd_dkv_kernel<T, 7>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        if (nkb == 2) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        else if (nkb == 4) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 4>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        else LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 7>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
     }
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }

@@ -192,6 +192,63 @@ __device__ __forceinline__ void stage_transposed(char* lds, const T* __restrict_
     }
 }
 
+// Register-prefetched tiles: `load` issues the global loads of a tile into registers (they stay in
+// flight while the caller computes on the previous tile), `commit` writes them to LDS in the k-slab
+// format.  Same addressing as stage_natural / stage_transposed.
+template <typename T, int ROWS, int NSLAB, int THREADS>
+struct NatTile {
+    static constexpr int CPR = NSLAB * 4;
+    static constexpr int TOTAL = ROWS * CPR;
+    static constexpr int NIT = (TOTAL + THREADS - 1) / THREADS;
+    u32x4_t v[NIT];
+    __device__ __forceinline__ void load(const T* __restrict__ g, long ld, int row_lo, int R, int k0, int K, int tid) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * THREADS;
+            const int r = id / CPR, cc = id % CPR;
+            const int grow = row_lo + r, gk = k0 + cc * ElemTraits<T>::kPerChunk;
+            v[it] = u32x4_t{0, 0, 0, 0};
+            if (id < TOTAL && grow < R && gk < K) v[it] = *reinterpret_cast<const u32x4_t*>(g + (long)grow * ld + gk);
+        }
+    }
+    __device__ __forceinline__ void commit(char* lds, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * THREADS;
+            const int r = id / CPR, cc = id % CPR;
+            if (id < TOTAL) *reinterpret_cast<u32x4_t*>(lds + (cc >> 2) * (ROWS * SLAB_BYTES) + slab_off(r, cc & 3)) = v[it];
+        }
+    }
+};
+
+template <typename T, int ROWS, int NSLAB, int THREADS>
+struct TrTile {
+    static constexpr int KC = ElemTraits<T>::kPerChunk;
+    static constexpr int RG = ROWS / 4, KG = NSLAB * 4;
+    static constexpr int TOTAL = RG * KG;
+    static constexpr int NIT = (TOTAL + THREADS - 1) / THREADS;
+    TBlock<T> b[NIT];
+    int row_lo_, R_;
+    __device__ __forceinline__ void load(const T* __restrict__ g, long ld, int row_lo, int R, int k0, int K, int tid) {
+        row_lo_ = row_lo; R_ = R;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * THREADS;
+            const int rg = id % RG, kg = id / RG;
+            // out-of-range blocks (id >= TOTAL) load zeros: K guard with K = 0
+            load_tblock<T>(b[it], g, ld, row_lo + rg * 4, R, k0 + kg * KC, id < TOTAL ? K : 0);
+        }
+    }
+    __device__ __forceinline__ void commit(char* lds, int tid) const {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int id = tid + it * THREADS;
+            const int rg = id % RG, kg = id / RG;
+            if (id < TOTAL) store_tblock<T>(lds, ROWS, b[it], rg * 4, kg, row_lo_ + rg * 4, R_);
+        }
+    }
+};
+
 // --------------------------------------------------------------------------------------------
 // Accumulator -> LDS k-slab image, TRANSPOSED: image row = accumulator COLUMN (lane & 31),
 // image k = accumulator ROW.  This is the cheap direction (each lane owns 4 groups of 4
