@@ -130,32 +130,34 @@ __device__ __forceinline__ void stage_natural(char* lds, const T* __restrict__ g
 //     Row guard on LOADS has 4-element granularity: the allocation must be readable up to the
 //     next multiple of 4 rows (all call sites have R % 4 == 0 or a padded leading dimension);
 //     elements at rows >= R are zeroed before they reach LDS.
-template <typename T> struct TBlock { T e[ElemTraits<T>::kPerChunk][4]; };
+// The block is kept as RAW load results (one 8/16-byte vector per k line) so that issuing the loads
+// does not force a wait: unpacking happens in store_tblock, i.e. when the data is committed to LDS.
+template <typename T> struct RawVec;
+template <> struct RawVec<bf16_t> { typedef u32x2_t type; };
+template <> struct RawVec<float> { typedef u32x4_t type; };
+template <typename T> struct TBlock { typename RawVec<T>::type raw[ElemTraits<T>::kPerChunk]; };
 
 template <typename T>
 __device__ __forceinline__ void load_tblock(TBlock<T>& b, const T* __restrict__ g, long ld, int grow, int R, int gk0, int K) {
     constexpr int KC = ElemTraits<T>::kPerChunk;
+    typedef typename RawVec<T>::type V;
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
         const int gk = gk0 + kk;
-        if (grow < R && gk < K) {
-            if constexpr (sizeof(T) == 2) {
-                const u32x2_t v = *reinterpret_cast<const u32x2_t*>(g + (long)gk * ld + grow);
-                const bf16x4_t e = __builtin_bit_cast(bf16x4_t, v);
+        V v;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) b.e[kk][r] = e[r];
-            } else {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(g + (long)gk * ld + grow);
-                const f32x4_t e = __builtin_bit_cast(f32x4_t, v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) b.e[kk][r] = e[r];
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) b.e[kk][r] = from_f32<T>(0.f);
-        }
+        for (int j = 0; j < (int)(sizeof(V) / 4); ++j) v[j] = 0u;
+        if (grow < R && gk < K) v = *reinterpret_cast<const V*>(g + (long)gk * ld + grow);
+        b.raw[kk] = v;
     }
 }
+
+__device__ __forceinline__ bf16_t tblock_elem(const TBlock<bf16_t>& b, int kk, int r) {
+    const uint32_t w = b.raw[kk][r >> 1];
+    const uint16_t h = (r & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xFFFFu);
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float tblock_elem(const TBlock<float>& b, int kk, int r) { return __builtin_bit_cast(float, b.raw[kk][r]); }
 
 // tile_rows = rows of the LDS tile (slab stride = tile_rows*64); r0 = first of the 4 tile rows,
 // kg = chunk index along k (slab kg>>2, chunk kg&3).
@@ -166,7 +168,7 @@ __device__ __forceinline__ void store_tblock(char* lds, int tile_rows, const TBl
     for (int r = 0; r < 4; ++r) {
         T outv[KC];
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) outv[kk] = (grow + r < R) ? b.e[kk][r] : from_f32<T>(0.f);
+        for (int kk = 0; kk < KC; ++kk) outv[kk] = (grow + r < R) ? tblock_elem(b, kk, r) : from_f32<T>(0.f);
         u32x4_t w;
         __builtin_memcpy(&w, outv, 16);
         *reinterpret_cast<u32x4_t*>(lds + (kg >> 2) * (tile_rows * SLAB_BYTES) + slab_off(r0 + r, kg & 3)) = w;
