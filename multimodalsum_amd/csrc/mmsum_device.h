@@ -157,7 +157,10 @@ __device__ __forceinline__ bf16_t tblock_elem(const TBlock<bf16_t>& b, int kk, i
     const uint16_t h = (r & 1) ? (uint16_t)(w >> 16) : (uint16_t)(w & 0xFFFFu);
     return __builtin_bit_cast(bf16_t, h);
 }
-__device__ __forceinline__ float tblock_elem(const TBlock<float>& b, int kk, int r) { return __builtin_bit_cast(float, b.raw[kk][r]); }
+__device__ __forceinline__ float tblock_elem(const TBlock<float>& b, int kk, int r) {
+    const uint32_t w = b.raw[kk][r];   // bit_cast straight from a vector element reads element 0 (clang quirk)
+    return __builtin_bit_cast(float, w);
+}
 
 // tile_rows = rows of the LDS tile (slab stride = tile_rows*64); r0 = first of the 4 tile rows,
 // kg = chunk index along k (slab kg>>2, chunk kg&3).
