@@ -12,6 +12,7 @@
 // Two LDS stages: the DMA of K-tile t+1 is in flight while the MFMAs of tile t run; one
 // vmcnt(0)+barrier per K-tile.  Rows past M/N are clamped (their results are never stored).
 #include "gemm_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -165,9 +166,13 @@ bool gemm_glds_eligible(int dtype, const GemmArgs& a) {
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
     // pick the tile shape that keeps the 256 CUs busiest for this problem
+    // relative main-loop efficiency of the tile shapes: operand bytes per FLOP halve from 128^2 to
+    // 256^2 and the L2 -> LDS DMA rate, not the MFMA rate, bounds the small tiles
+    static const double e128 = getenv("MMSUM_E128") ? atof(getenv("MMSUM_E128")) : 0.50;
+    static const double e2x1 = getenv("MMSUM_E2X1") ? atof(getenv("MMSUM_E2X1")) : 0.72;
     const double s256 = tile_score(a.M, a.N, a.splitk, 256, 256, 1.00);
-    const double s128 = tile_score(a.M, a.N, a.splitk, 128, 128, 0.80);
-    const double s2x1 = tile_score(a.M, a.N, a.splitk, 256, 128, 0.92);
+    const double s128 = tile_score(a.M, a.N, a.splitk, 128, 128, e128);
+    const double s2x1 = tile_score(a.M, a.N, a.splitk, 256, 128, e2x1);
     if (s256 >= s128 && s256 >= s2x1) return launch_cfg<256, 256, 2, 4>(a, stream);
     if (s2x1 >= s128) return launch_cfg<256, 128, 4, 2>(a, stream);
     return launch_cfg<128, 128, 2, 2>(a, stream);

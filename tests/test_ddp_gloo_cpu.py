@@ -1,0 +1,89 @@
+"""CPU, world_size 2, gloo: the data-parallel path (parameter broadcast, segment-wise gradient all-reduce
+over the flat arena, mean over ranks) through the real DistributedDataParallel wrapper, with the kernel
+emulator standing in for the HIP library.  rank r trains on batch r; the averaged gradients must equal
+the mean of the two single-process gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(dtype=torch.float32):
+    from tests import cpu_kernel_emu as emu
+    import multimodalsum_amd.engine as eng
+    import multimodalsum_amd.modules as mods
+    import multimodalsum_amd.optim as opt
+    for m in (eng, mods, opt):
+        m.kn = emu
+    from multimodalsum_amd.modules import TextSupervised
+    from multimodalsum_amd.formula_init import formula_state_dict
+    from oracle import bart_oracle as bo
+    from tests.test_host_logic_cpu import tiny_cfg, oracle_cfg
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40)
+    sd = formula_state_dict(bo.bart_param_shapes(oracle_cfg(cfg), False, prefix="bart_model."), std=0.08)
+    model = TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=dtype)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    return cfg, model
+
+
+def _batch(cfg, rank):
+    from multimodalsum_amd import synthetic as syn
+    return syn.yelp_batch(2, 3, 16, 1, cfg.vocab_size, seed=70 + rank, img_hw=8)
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    cfg, model = _build()
+    if rank == 1:       # perturb rank 1: the wrapper must broadcast rank 0's parameters
+        with torch.no_grad():
+            model._engine.arena.data.add_(0.5)
+    from multimodalsum_amd.parallel import DistributedDataParallel, reduce_tensor
+    ddp = DistributedDataParallel(model, delay_allreduce=True)
+    b = _batch(cfg, rank)
+    loss = ddp(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+    loss.backward()
+    mean_loss = reduce_tensor(loss.detach().reshape(1), world)
+    torch.save({"grad": model._engine.arena.grad.clone(), "data": model._engine.arena.data.clone(), "loss": mean_loss,
+                "has_grad": [n for n, p in model.named_parameters() if p.grad is not None]}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_gloo(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["data"], r1["data"]), "parameters were not broadcast from rank 0"
+    assert torch.allclose(r0["grad"], r1["grad"], rtol=0, atol=0), "ranks disagree on the reduced gradient"
+    assert r0["has_grad"] == r1["has_grad"] and len(r0["has_grad"]) > 30
+    cfg, model = _build()
+    grads, losses = [], []
+    for rank in range(2):
+        b = _batch(cfg, rank)
+        for p in model.parameters():
+            p.grad = None
+        loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+        loss.backward()
+        grads.append(model._engine.arena.grad.clone())
+        losses.append(loss.detach())
+    ref = (grads[0] + grads[1]) / 2
+    err = (r0["grad"] - ref).abs().max().item()
+    assert err <= 1e-6 + 1e-5 * ref.abs().max().item(), err
+    assert abs(r0["loss"].item() - (losses[0] + losses[1]).item() / 2) < 1e-6

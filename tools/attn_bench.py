@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the entity-attention kernels at the training-step shapes (B=8)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodalsum_amd import kernels as kn
+
+CASES = [("cross_text", 8, 9, 9, 128, 128, True, False), ("self_causal", 72, 1, 1, 128, 128, False, True),
+         ("cross_img", 8, 9, 4, 196, 128, False, False), ("cross_table", 8, 9, 1, 47, 128, False, False)]
+
+
+def timeit(fn, iters=5):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    H, D, dt = 16, 1024, torch.bfloat16
+    for name, B, qpb, N, S, T, excl, causal in CASES:
+        if only and only != name:
+            continue
+        nq = B * qpb
+        q = torch.randn(nq * T, D, device="cuda").to(dt)
+        kv = torch.randn(B * N * S, 2 * D, device="cuda").to(dt)
+        k, v = kv[:, :D], kv[:, D:]
+        out = torch.empty(nq * T, D, device="cuda", dtype=dt)
+        pad = torch.zeros(B * N * S, dtype=torch.uint8, device="cuda")
+        null = torch.zeros(B * N, dtype=torch.uint8, device="cuda")
+        desc = kn.make_attn_desc(q, k, v, out, pad, null, nq, T, qpb, N, S, H, excl, causal, 0.125)
+        dout = torch.randn(nq * T, D, device="cuda").to(dt)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        stats = torch.empty(kn.attn_bwd_workspace(desc) // 4, device="cuda")
+        ents = (N - 1) if excl else N
+        fl = 4.0 * nq * T * S * 64 * H * ents
+        tf = timeit(lambda: kn.attn_fwd(desc, q))
+        tb = timeit(lambda: kn.attn_bwd(desc, dout, dq, False, dkv[:, :D], dkv[:, D:], stats))
+        print("%-12s fwd %7.0f us (%6.1f TF/s)   bwd %7.0f us (%6.1f TF/s)" % (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6), flush=True)
+
+
+if __name__ == "__main__":
+    main()
