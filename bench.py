@@ -127,7 +127,12 @@ def cpu_baseline(args, cfg):
     from multimodalsum_amd import synthetic as syn
     from multimodalsum_amd.formula_init import formula_state_dict
     from oracle import bart_oracle as bo, encoders_oracle as eo, step_oracle as so
-    torch.set_num_threads(os.cpu_count())
+    try:
+        cores = len(os.sched_getaffinity(0))       # cores this process may actually run on (cgroup/affinity aware)
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
     L = 1
     ocfg = bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim, encoder_layers=L,
                       decoder_layers=L, heads=cfg.heads, max_position_embeddings=cfg.max_position_embeddings, dropout=0.1)
@@ -167,11 +172,30 @@ def cpu_baseline(args, cfg):
 
     sample_flops = literal(L, I)
     full_flops = literal(cfg.encoder_layers, 4 if multimodal else 1)
-    return {"value": (sample_flops / dt) / full_flops, "unit": "businesses/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": (sample_flops / dt) / full_flops, "unit": "businesses/s", "cores": cores, "kind": "port",
             "sample": "CPU oracle (PyTorch fp32, literal reference algorithm) fwd+bwd of one B=1 step with 1+1 layers, "
                       "BART-large width/vocab, %d image: %.1f s measured (%.0f GFLOP/s); extrapolated to the 12+12-layer, "
                       "%d-image step by the reference-literal FLOP count" % (I, dt, sample_flops / dt / 1e9, 4 if multimodal else 1),
             "sample_seconds": dt}
+
+
+def cpu_baseline_bounded(args, budget_s=240):
+    """Runs cpu_baseline() in a child process (no GPU touched there) under a hard wall-clock budget."""
+    import subprocess
+    code = ("import sys, json, types; sys.path.insert(0, %r); import bench; from multimodalsum_amd.config import BartConfig; "
+            "cfg = BartConfig.from_json_file(%r); "
+            "print('CPUBASE ' + json.dumps(bench.cpu_baseline(types.SimpleNamespace(workload=%r), cfg)))"
+            % (ROOT, os.path.join(ROOT, "cfg", "bart-large.json"), args.workload))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s, env=env)
+        for line in r.stdout.splitlines():
+            if line.startswith("CPUBASE "):
+                return json.loads(line[8:])
+        return {"value": None, "unit": "businesses/s", "cores": None, "kind": "port", "sample": "cpu baseline failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "businesses/s", "cores": None, "kind": "port",
+                "sample": "cpu baseline exceeded its %d s budget on this host" % budget_s}
 
 
 def main():
@@ -239,7 +263,7 @@ def main():
                           "dropout": cfg.dropout},
                "final_loss": loss_val, "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, cfg)
+            out["cpu_baseline"] = cpu_baseline_bounded(args)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
