@@ -156,7 +156,8 @@ int mmsum_col2im(int dtype, const void* dcol, void* dx, int N, int H, int W, int
 int mmsum_conv_weight_permute(int dtype, void* matrix, float* weight, int Cout, int Cin, int KH, int KW, int Kpad,
                               int to_matrix, int accumulate, void* stream);
 /* BatchNorm2d (train mode, batch statistics over R = N*H*W rows of an [R, C] NHWC matrix).
- * stats: sums[2*C] f32 = {sum x, sum x^2} produced by mmsum_bn_reduce; bn_apply normalises with
+ * stats: sums[2*C] f32 = {mean, biased variance} produced by mmsum_bn_reduce (pivot-shifted sums, no
+ * catastrophic cancellation); bn_apply normalises with
  * them (y = relu?(gamma*(x-mean)*rstd + beta (+ residual))) and updates running stats (momentum,
  * unbiased variance) when running_mean != NULL. */
 long mmsum_bn_workspace(int C);

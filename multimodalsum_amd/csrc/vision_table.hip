@@ -134,14 +134,17 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                mean[j] = sums[col + j] / R;
-                rstd[j] = rsqrtf(fmaxf(sums[C + col + j] / R - mean[j] * mean[j], 0.f) + eps);
+                mean[j] = sums[col + j];
+                rstd[j] = rsqrtf(sums[C + col + j] + eps);
             }
         }
+        // MODE 0 accumulates around a per-channel pivot (row 0) so that var = E[(x-p)^2] - E[x-p]^2 does not
+        // cancel catastrophically when |mean| >> std
+        const f32x4_t pivot = (MODE == 0) ? ld4<T>(a + col) : f32x4_t{0, 0, 0, 0};
         for (int r = r0 + rl; r < r1; r += 16) {
             const long o = (long)r * C + col;
             if (MODE == 0) {
-                const f32x4_t v = ld4<T>(a + o);
+                const f32x4_t v = ld4<T>(a + o) - pivot;
                 s0 = s0 + v;
                 s1 = s1 + v * v;
             } else {
@@ -183,6 +186,29 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict_
     if (sl == 0 && col < C2) out[col] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
 }
 
+// forward statistics: shifted partial sums -> {mean, biased variance}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ part, int splits, int C, int R, const T* __restrict__ x,
+                                                              float* __restrict__ out) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < C) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += 4) { s0 += part[(long)k * 2 * C + col]; s1 += part[(long)k * 2 * C + C + col]; }
+    }
+    red[0][sl][cl] = s0; red[1][sl][cl] = s1;
+    __syncthreads();
+    if (sl == 0 && col < C) {
+        const float t0 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        const float t1 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        const float m = t0 / R;
+        out[col] = to_f32(x[col]) + m;
+        out[C + col] = fmaxf(t1 / R - m * m, 0.f);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual, T* __restrict__ y,
@@ -199,8 +225,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         for (int j = 0; j < 4; ++j) {
             float mean, var;
             if (training) {
-                mean = sums[c + j] / R;
-                var = fmaxf(sums[C + c + j] / R - mean * mean, 0.f);
+                mean = sums[c + j];
+                var = sums[C + c + j];
             } else {
                 mean = running_mean[c + j];
                 var = running_var[c + j];
@@ -220,8 +246,8 @@ __global__ void bn_running_kernel(const float* __restrict__ sums, float* __restr
                                   int R, int C, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mean = sums[c] / R;
-    const float var = fmaxf(sums[C + c] / R - mean * mean, 0.f);
+    const float mean = sums[c];
+    const float var = sums[C + c];
     const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
@@ -249,9 +275,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         f32x4_t out;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float mean = sums[c + j] * invR;
-            const float var = fmaxf(sums[C + c + j] * invR - mean * mean, 0.f);
-            const float rstd = rsqrtf(var + eps);
+            const float mean = sums[c + j];
+            const float rstd = rsqrtf(sums[C + c + j] + eps);
             const float xh = (xv[j] - mean) * rstd;
             out[j] = gamma[c + j] * rstd * (g[j] - dsums[c + j] * invR - xh * dsums[C + c + j] * invR);
         }
@@ -449,7 +474,8 @@ extern "C" int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* su
     float* part = (float*)workspace;
     DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 0><<<grid, block, 0, s>>>((const bf16_t*)x, nullptr, nullptr, nullptr, R, C, 0.f, 0, part)),
               (bn_partial_kernel<float, 0><<<grid, block, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, R, C, 0.f, 0, part)));
-    bn_finish_kernel<<<dim3((2 * C + 63) / 64), dim3(256), 0, s>>>(part, splits, 2 * C, sums);
+    DT_SWITCH(dtype, (bn_stats_finish_kernel<bf16_t><<<dim3((C + 63) / 64), dim3(256), 0, s>>>(part, splits, C, R, (const bf16_t*)x, sums)),
+              (bn_stats_finish_kernel<float><<<dim3((C + 63) / 64), dim3(256), 0, s>>>(part, splits, C, R, (const float*)x, sums)));
     return ok();
 }
 

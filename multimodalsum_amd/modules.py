@@ -518,6 +518,104 @@ class TextSupervised(nn.Module):
         e.segment_ready([e.bp + "model.encoder.", e.bp + "model.shared."])
 
 
+class _LossFn(torch.autograd.Function):
+    """LabelSmoothingLoss.forward (utils.py:32-38) on a logits tensor, fused HIP kernel (forward + gradient)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, classes, smoothing):
+        R = pred.shape[0]
+        work = pred.detach().to(torch.float32).contiguous().clone()
+        rows = torch.empty(R, dtype=torch.float32, device=pred.device)
+        kn.ls_loss(work, target.reshape(-1).contiguous(), rows, classes, float(smoothing), 1.0 / R, True)
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+        kn.segment_sum(rows, loss, 1, R, 1.0 / R)
+        ctx.save_for_backward(work)
+        ctx.in_dtype = pred.dtype
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (work,) = ctx.saved_tensors
+        return (work * g).to(ctx.in_dtype), None, None, None
+
+
+class LabelSmoothingLoss(nn.Module):
+    """Drop-in for /root/reference/src/utils.py:24-38 (pads are not ignored, quirk Q2)."""
+
+    def __init__(self, classes, smoothing=0.0, dim=-1):
+        super().__init__()
+        self.cls, self.smoothing = classes, smoothing
+
+    def forward(self, pred, target):
+        return _LossFn.apply(pred, target, self.cls, self.smoothing)
+
+
+class _SingleModality(nn.Module):
+    """Step-2 pretraining wrappers: one modality encoder feeds the text-only decoder
+    through the unimodal branch of the cross-attention (modeling_multimodalsum.py:746-749)."""
+
+    def __init__(self, bart_pretrained, config, label_smoothing, device, dtype, deterministic, with_img, with_table):
+        super().__init__()
+        cfg = config if isinstance(config, BartConfig) else BartConfig.from_json_file(config)
+        e = Engine(cfg, device=device, compute_dtype=dtype, multimodal=False, with_table=with_table, with_img=with_img,
+                   bart_prefix="bart_model.", deterministic=deterministic)
+        object.__setattr__(self, "_engine", e)
+        self.label_smoothing = label_smoothing
+        self.bart_model = BartForEncConditionalGeneration(cfg, engine=e, prefix="bart_model.")
+        if with_img:
+            self.img_encoder = Resnet(cfg.d_model, engine=e)
+        if with_table:
+            self.table_encoder = YelpTableEncoder(self.bart_model.model.shared, engine=e)
+        init_formula(self)
+        if bart_pretrained is not None and os.path.exists(os.path.join(str(bart_pretrained), "pytorch_model.bin")):
+            self.bart_model.load_state_dict(torch.load(os.path.join(str(bart_pretrained), "pytorch_model.bin"), map_location="cpu"), strict=False)
+        e.mark_weights_changed()
+
+    def train(self, mode=True):
+        super().train(mode)
+        self._engine.training = mode
+        return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._engine.mark_weights_changed()
+        return r
+
+    def _loss(self, hiddens, mask, labels):
+        bsz = hiddens.shape[0]
+        rating_diff = torch.zeros(bsz, 1, device=hiddens.device)
+        logits = self.bart_model(hiddens, rating_diff, mask, labels=labels)[0]
+        V = self.bart_model.config.vocab_size
+        return (LabelSmoothingLoss(V, self.label_smoothing or 0.0)(logits.view(-1, V), labels.reshape(-1)),)
+
+
+class ImgSupervised(_SingleModality):
+    """img_pretrain.py:85-141: forward(input_imgs [B,I,3,224,224], input_imgs_mask [B,I], labels=[B,T]) -> (loss,)."""
+
+    def __init__(self, bart_pretrained=None, config="cfg/bart-large.json", label_smoothing=0.1, device="cuda", dtype=torch.bfloat16,
+                 deterministic=False):
+        super().__init__(bart_pretrained, config, label_smoothing, device, dtype, deterministic, True, False)
+
+    def forward(self, input_imgs, input_imgs_mask=None, labels=None, **unused):
+        bsz, n = input_imgs.shape[:2]
+        h = self.img_encoder(input_imgs.reshape(-1, 3, input_imgs.shape[-2], input_imgs.shape[-1]))
+        h = h.reshape(bsz, n, -1, self.bart_model.config.d_model)
+        mask = None if input_imgs_mask is None else input_imgs_mask.unsqueeze(-1).repeat(1, 1, h.shape[2])
+        return self._loss(h, mask, labels)
+
+
+class TableSupervised(_SingleModality):
+    """table_pretrain.py:84-129: forward(field, field_value, labels=[B,T]) -> (loss,)."""
+
+    def __init__(self, bart_pretrained=None, config="cfg/bart-large.json", label_smoothing=0.1, device="cuda", dtype=torch.bfloat16,
+                 deterministic=False):
+        super().__init__(bart_pretrained, config, label_smoothing, device, dtype, deterministic, False, True)
+
+    def forward(self, field, field_value, labels=None, **unused):
+        h, m = self.table_encoder(field, field_value)
+        return self._loss(h.unsqueeze(1), m.unsqueeze(1), labels)
+
+
 def init_formula(module, std=0.02, prefix=None):
     """Fill every arena parameter / buffer with the RNG-free formula init (keyed by arena names)."""
     e = module._engine

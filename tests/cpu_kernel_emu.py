@@ -284,13 +284,12 @@ def conv_matrix_grad_to_weight(matrix_f32, dweight, Cout, Cin, KH, KW, Kpad, acc
 
 def bn_reduce(x, sums):
     C = x.shape[1]
-    sums[:C] = x.float().sum(0)
-    sums[C:] = (x.float() ** 2).sum(0)
+    sums[:C] = x.float().mean(0)
+    sums[C:] = x.float().var(0, unbiased=False)
 
 
 def _bn_stats(sums, R, C, eps):
-    mean = sums[:C] / R
-    var = (sums[C:] / R - mean * mean).clamp_min(0)
+    mean, var = sums[:C], sums[C:]
     return mean, var, (var + eps).rsqrt()
 
 
