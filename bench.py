@@ -131,7 +131,13 @@ def cpu_baseline(args, cfg):
         cores = len(os.sched_getaffinity(0))       # cores this process may actually run on (cgroup/affinity aware)
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
+    try:       # cgroup v2 CPU quota (containers often expose every host core but only a slice of CPU time)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    cores = max(1, min(cores, 32))
     torch.set_num_threads(cores)
     L = 1
     ocfg = bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim, encoder_layers=L,
