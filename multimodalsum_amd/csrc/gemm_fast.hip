@@ -28,6 +28,137 @@ struct FastCfg {
     static_assert(PA % NW == 0 && PB % NW == 0, "pieces must split evenly over the waves");
 };
 
+// ---------------------------------------------------------------------------------------------
+// Epilogue through LDS.  In the accumulator layout a lane owns ONE column and 16 scattered rows, so a
+// direct store is 16 two-byte stores per 32x32 tile (128 per lane for a 256x256 tile) and the store
+// issue, not the MFMAs, bounds every K<=4096 product.  Instead each 32-row band of the block tile is
+// staged in LDS as f32 [32][BN] (the operand stages are dead by now) and written back row-wise:
+// 8 consecutive columns per thread = one 16-byte store (two for f32 outputs), with the bias / GELU /
+// ReLU / accumulate work vectorised on the same 8 columns.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                                char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane) {
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int THREADS = WAVES_M * WAVES_N * 64;
+    constexpr int CPR = BN / 8;                       // 8-column chunks per row
+    constexpr int CHUNKS = 32 * CPR;
+    float* stage = reinterpret_cast<float*>(smem);
+    const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
+    bf16_t* Ct = static_cast<bf16_t*>(p.C);
+    float* Cf = static_cast<float*>(p.C);
+    bf16_t* aux = static_cast<bf16_t*>(p.aux);
+    constexpr bool kF32Out = (OUT == OUT_F32_ACC || OUT == OUT_F32_ATOMIC || OUT == OUT_F32);
+    const bool vec_ok = kF32Out ? ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 3) == 0)
+                                : ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 7) == 0);
+    const bool aux_vec = aux != nullptr && ((((uintptr_t)p.aux) & 15) == 0) && ((p.ldaux & 7) == 0);
+#pragma unroll
+    for (int sb = 0; sb < BM / 32; ++sb) {
+        __syncthreads();
+        if (wm == sb / TM) {
+            const int i = sb % TM;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * (TN * 32) + j * 32 + (lane & 31);
+#pragma unroll
+                for (int ii = 0; ii < TM; ++ii) {
+                    if (ii == i) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * BN + col] = acc[ii][j][r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < (CHUNKS + THREADS - 1) / THREADS; ++it) {
+            const int c = tid + it * THREADS;
+            if (c >= CHUNKS) break;
+            const int lr = c / CPR, cc = (c % CPR) * 8;
+            const int row = m0 + sb * 32 + lr, col = n0 + cc;
+            if (row >= p.M || col >= p.N) continue;
+            float v[8];
+            {
+                const f32x4_t a = *reinterpret_cast<const f32x4_t*>(stage + lr * BN + cc);
+                const f32x4_t b = *reinterpret_cast<const f32x4_t*>(stage + lr * BN + cc + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+            }
+            const int nvalid = min(8, p.N - col);
+            const bool full = nvalid == 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + ((has_bias && e < nvalid) ? p.bias[col + e] : 0.f);
+            const long o = (long)row * p.ldc + col;
+            if constexpr (EPI == MMSUM_EPI_GELU) {
+                if (aux) {
+                    const long oa = (long)row * p.ldaux + col;
+                    if (full && aux_vec) {
+                        bf16_t t[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+                        u32x4_t w;
+                        __builtin_memcpy(&w, t, 16);
+                        *reinterpret_cast<u32x4_t*>(aux + oa) = w;
+                    } else {
+                        for (int e = 0; e < nvalid; ++e) aux[oa + e] = (bf16_t)v[e];
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+            } else if constexpr (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD) {
+                const long oa = (long)row * p.ldaux + col;
+                bf16_t t[8];
+                if (full && aux_vec) {
+                    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(aux + oa);
+                    __builtin_memcpy(t, &w, 16);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (e < nvalid) ? aux[oa + e] : (bf16_t)0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (EPI == MMSUM_EPI_GELU_BWD) v[e] *= gelu_grad_f((float)t[e]);
+                    else v[e] = ((float)t[e] > 0.f) ? v[e] : 0.f;
+                }
+            } else if constexpr (EPI == MMSUM_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if constexpr (OUT == OUT_T || OUT == OUT_T_ACC) {
+                if (full && vec_ok) {
+                    bf16_t t[8];
+                    if constexpr (OUT == OUT_T_ACC) {
+                        const u32x4_t w0 = *reinterpret_cast<const u32x4_t*>(Ct + o);
+                        __builtin_memcpy(t, &w0, 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+                    u32x4_t w;
+                    __builtin_memcpy(&w, t, 16);
+                    *reinterpret_cast<u32x4_t*>(Ct + o) = w;
+                } else {
+                    for (int e = 0; e < nvalid; ++e) Ct[o + e] = (bf16_t)(OUT == OUT_T_ACC ? (float)Ct[o + e] + v[e] : v[e]);
+                }
+            } else if constexpr (OUT == OUT_F32_ATOMIC) {
+                for (int e = 0; e < nvalid; ++e) atomicAdd(Cf + o + e, v[e]);
+            } else {
+                if (full && vec_ok) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4_t w = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                        if constexpr (OUT == OUT_F32_ACC) w = w + *reinterpret_cast<const f32x4_t*>(Cf + o + 4 * h);
+                        *reinterpret_cast<f32x4_t*>(Cf + o + 4 * h) = w;
+                    }
+                } else {
+                    for (int e = 0; e < nvalid; ++e) Cf[o + e] = (OUT == OUT_F32_ACC ? Cf[o + e] : 0.f) + v[e];
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void dma16(const bf16_t* gsrc, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -115,11 +246,150 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_glds_kernel(Gem
             cur ^= 1;
         }
     }
-    gemm_epilogue<bf16_t, Cfg::TM, Cfg::TN, EPI, OUT>(p, acc, m0 + wm * (Cfg::TM * 32), n0 + wn * (Cfg::TN * 32), ks, lane);
+    if constexpr (OUT == OUT_F32_ATOMIC) {
+        // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
+        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+    } else {
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ring variant: 4 LDS stages of ONE 32-deep k-slab each; the DMA runs three slabs ahead and is
+// retired with counted s_waitcnt vmcnt(N) (never 0 in steady state) + a raw s_barrier, so a slab's
+// load latency is covered by three slabs of MFMA work instead of one (PMC on the 2-stage kernel:
+// 47 % of wave cycles parked at the vmcnt(0)+barrier, L2 hit rate 62 %).
+//   iteration s:  wait(own DMA of slab s landed) ; barrier ; issue DMA of slab s+3 into slot (s+3)&3
+//                 (that slot was last read in iteration s-1, which every wave finished before this
+//                 barrier) ; MFMAs of slab s.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct RingCfg {
+    static constexpr int NW = WAVES_M * WAVES_N;
+    static constexpr int THREADS = NW * 64;
+    static constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    static constexpr int A_BYTES = BM * SLAB_BYTES, B_BYTES = BN * SLAB_BYTES;
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int NSTAGE = 4;
+    static constexpr int PA = BM / 16, PB = BN / 16;
+    static constexpr int PPW = (PA + PB) / NW;                    // DMA instructions per wave per slab
+    static_assert(PA % NW == 0 && PB % NW == 0, "pieces must split evenly over the waves");
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(GemmArgs p) {
+    using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = tiles_m * tiles_n;
+    const int ks = wg / tiles;
+    const int t = wg % tiles;
+    int tm, tn;
+    tile_coords(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nslab_total = p.K / 32;
+    const int per = ((nslab_total + p.splitk - 1) / p.splitk + 1) & ~1;       // even number of slabs per split
+    const int s_beg = ks * per, s_end = min(nslab_total, s_beg + per);
+    const int ns = s_end - s_beg;
+
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* A2 = static_cast<const bf16_t*>(p.A2);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+
+    f32x16_t acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zero_acc();
+
+    // one slab piece: 16 rows x 64 B; lane -> (row = lane>>2, physical chunk = lane&3)
+    const int prow = lane >> 2;
+    auto issue = [&](int si) {          // si: slab index relative to s_beg
+        char* As = smem + (si & 3) * Cfg::STAGE;
+        char* Bs = As + Cfg::A_BYTES;
+        int k0 = (s_beg + si) * 32;
+        const int kb = k0;
+        const bf16_t* Ab = A;
+        long lda = p.lda;
+        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+#pragma unroll
+        for (int i = 0; i < Cfg::PPW; ++i) {
+            if (i * Cfg::NW < Cfg::PA) {
+                const int rb = i * Cfg::NW + wave;
+                const int row = rb * 16 + prow;
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                int grow = m0 + row;
+                grow = grow < p.M ? grow : p.M - 1;
+                dma16(Ab + (long)grow * lda + k0 + c * 8, As + rb * 1024);
+            } else {
+                const int rb = i * Cfg::NW - Cfg::PA + wave;
+                const int row = rb * 16 + prow;
+                const int c = (lane & 3) ^ ((row >> 2) & 3);
+                int grow = n0 + row;
+                grow = grow < p.N ? grow : p.N - 1;
+                dma16(B + (long)grow * p.ldb + kb + c * 8, Bs + rb * 1024);
+            }
+        }
+    };
+
+    if (ns > 0) {
+        issue(0);
+        if (ns > 1) issue(1);
+        if (ns > 2) issue(2);
+        for (int si = 0; si < ns; ++si) {
+            const int ahead = ns - 1 - si;                       // slabs issued after slab si (capped at 2)
+            if (ahead >= 2) wait_vmcnt<2 * Cfg::PPW>();
+            else if (ahead == 1) wait_vmcnt<Cfg::PPW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (si + 3 < ns) issue(si + 3);
+            const char* As = smem + (si & 3) * Cfg::STAGE;
+            const char* Bs = As + Cfg::A_BYTES;
+            Frag b[Cfg::TN];
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) {
+                const Frag a = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a, b[j]);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    if constexpr (OUT == OUT_F32_ATOMIC) {
+        // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
+        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+    } else {
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
+    static const bool use_ring = !(getenv("MMSUM_GEMM_RING") && atoi(getenv("MMSUM_GEMM_RING")) == 0);
+    if (use_ring) {
+        using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
+        const int tiles_r = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+        const size_t lds_r = R::NSTAGE * R::STAGE;
+        static bool once_r = false;
+        if (!once_r) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+            once_r = true;
+        }
+        gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT><<<dim3(tiles_r * a.splitk), dim3(R::THREADS), lds_r, stream>>>(a);
+        return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+    }
     using Cfg = FastCfg<BM, BN, WAVES_M, WAVES_N>;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = 2 * Cfg::STAGE;

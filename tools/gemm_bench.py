@@ -23,7 +23,10 @@ def timeit(fn, iters=10):
 
 def main():
     dt = torch.bfloat16
-    for M, N, K in SHAPES:
+    shapes = SHAPES
+    if len(sys.argv) > 3:
+        shapes = [tuple(int(v) for v in sys.argv[1:4])]
+    for M, N, K in shapes:
         a = torch.randn(M, K, device="cuda").to(dt)
         b = torch.randn(N, K, device="cuda").to(dt)
         ld = (N + 127) // 128 * 128
