@@ -36,6 +36,7 @@ enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_E
 #define MMSUM_GEMM_EPI(e)  ((e) << 3)
 #define MMSUM_GEMM_ACCUM   0x040  /* C += */
 #define MMSUM_GEMM_OUT_F32 0x080  /* C is f32 regardless of dtype */
+#define MMSUM_GEMM_SLABS   0x100  /* split-K without atomics: slice s writes its partial to C + s*M*ldc (f32) */
 
 int mmsum_abi_version(void);
 
@@ -43,11 +44,15 @@ int mmsum_abi_version(void);
  * on the path and their autograd (modeling_multimodalsum.py:302,304,783-792,885,738-739,2281;
  * table_encoder.py:62,65,71-73; img_encoder.py:40; 1x1 and im2col'ed convolutions of ResNet101).
  * A2/ksplit: for k >= ksplit the A operand continues in A2 (K split over two tensors: the
- * torch.cat([text, table]) of :738-739 without the concat).  splitk > 1 needs OUT_F32|ACCUM
- * (f32 atomics). */
+ * torch.cat([text, table]) of :738-739 without the concat).  splitk > 1 needs OUT_F32 and either ACCUM
+ * (f32 atomics into C) or SLABS (C = workspace of splitk partial slabs, summed by mmsum_slab_reduce:
+ * deterministic, and cheaper than atomics). */
 int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
                int flags, int splitk, void* stream);
+
+/* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
+int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
 
 /* out[c] (+)= sum_r X[r][c]  (bias gradients; BatchNorm reductions).  partial: f32 workspace of
  * mmsum_colsum_workspace(C) bytes. */

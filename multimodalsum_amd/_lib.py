@@ -17,7 +17,7 @@ ERRORS = {-1: "bad shape", -2: "bad dtype", -3: "bad alignment", -4: "workspace 
 
 GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
-GEMM_ACCUM, GEMM_OUT_F32 = 0x40, 0x80
+GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS = 0x40, 0x80, 0x100
 
 
 def gemm_epi(e):
@@ -37,6 +37,7 @@ SIGNATURES = {
     "mmsum_abi_version": (c_int, []),
     "mmsum_gemm": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
                            c_void_p, c_long, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+    "mmsum_slab_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_void_p]),
     "mmsum_colsum_workspace": (c_long, [c_int]),
     "mmsum_colsum": (c_int, [c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "mmsum_embed_ln_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

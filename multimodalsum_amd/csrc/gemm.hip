@@ -57,6 +57,7 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs p) {
     const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     const int tiles = tiles_m * tiles_n;
     const int ks = wg / tiles;                 // split-K slice
+    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
     const int t = wg % tiles;
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);
@@ -172,7 +173,8 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     if (!at && (K % kc) && lda < kround) return MMSUM_ERR_BAD_SHAPE;
     if (!bt && (K % kc) && ldb < kround) return MMSUM_ERR_BAD_SHAPE;
     if (A2 && (at || ksplit % bk || ksplit <= 0 || ksplit >= K)) return MMSUM_ERR_BAD_SHAPE;
-    if (splitk > 1 && !((flags & MMSUM_GEMM_OUT_F32) && (flags & MMSUM_GEMM_ACCUM))) return MMSUM_ERR_BAD_SHAPE;
+    if (splitk > 1 && !((flags & MMSUM_GEMM_OUT_F32) && ((flags & MMSUM_GEMM_ACCUM) || (flags & MMSUM_GEMM_SLABS)))) return MMSUM_ERR_BAD_SHAPE;
+    if ((flags & MMSUM_GEMM_SLABS) && (flags & (MMSUM_GEMM_ACCUM | MMSUM_GEMM_BIAS))) return MMSUM_ERR_BAD_SHAPE;
     const size_t es = (dtype == MMSUM_BF16) ? 2 : 4;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2) & 15) return MMSUM_ERR_BAD_ALIGN;
     if (!at && ((lda * es) & 15)) return MMSUM_ERR_BAD_ALIGN;
@@ -183,4 +185,31 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
+}
+
+namespace {
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ ws, int nslabs, int rows, int cols, float* __restrict__ out,
+                                                          long ldo, int accumulate) {
+    const int cv = cols >> 2;
+    const long total = (long)rows * cv;
+    const long slab = (long)rows * cols;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cv), c = (int)(i % cv) * 4;
+        f32x4_t s = *reinterpret_cast<const f32x4_t*>(ws + (long)r * cols + c);
+        for (int k = 1; k < nslabs; ++k) s = s + *reinterpret_cast<const f32x4_t*>(ws + k * slab + (long)r * cols + c);
+        float* o = out + (long)r * ldo + c;
+        if (accumulate) s = s + *reinterpret_cast<const f32x4_t*>(o);
+        *reinterpret_cast<f32x4_t*>(o) = s;
+    }
+}
+}  // namespace
+
+extern "C" int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream) {
+    if (nslabs < 1 || rows <= 0 || cols <= 0 || (cols & 3) || (ldo & 3)) return MMSUM_ERR_BAD_SHAPE;
+    if ((((uintptr_t)ws) | ((uintptr_t)out)) & 15) return MMSUM_ERR_BAD_ALIGN;
+    const long total = (long)rows * (cols >> 2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    slab_reduce_kernel<<<dim3((int)blocks), dim3(256), 0, (hipStream_t)stream>>>(ws, nslabs, rows, cols, out, ldo, accumulate);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }

@@ -60,7 +60,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x16_t 
 
 inline int out_mode_of(const GemmArgs& a) {
     const bool f32 = a.flags & MMSUM_GEMM_OUT_F32, acc = a.flags & MMSUM_GEMM_ACCUM;
-    if (a.splitk > 1) return OUT_F32_ATOMIC;
+    if (a.splitk > 1 && !(a.flags & MMSUM_GEMM_SLABS)) return OUT_F32_ATOMIC;
+    if (a.flags & MMSUM_GEMM_SLABS) return OUT_F32;
     if (f32) return acc ? OUT_F32_ACC : OUT_F32;
     return acc ? OUT_T_ACC : OUT_T;
 }

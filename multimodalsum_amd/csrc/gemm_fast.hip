@@ -188,6 +188,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_glds_kernel(Gem
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = tiles_m * tiles_n;
     const int ks = wg / tiles;
+    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
     const int t = wg % tiles;
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = tiles_m * tiles_n;
     const int ks = wg / tiles;
+    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
     const int t = wg % tiles;
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);

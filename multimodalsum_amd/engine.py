@@ -267,7 +267,14 @@ class Engine:
             Mp = (M + 63) // 64 * 64
             dyT = self.transposed(dy, Mp)
             xT = self.transposed(x, Mp, x_cache_key)
-            kn.gemm(dyT, xT, out, accumulate=True, splitk=self.splitk(dy.shape[1], x.shape[1], Mp))
+            sk = self.splitk(dy.shape[1], x.shape[1], Mp)
+            if sk > 1 and x.shape[1] % 4 == 0:
+                # split-K partial slabs + a deterministic reduce: cheaper than f32 atomics (1.3 TB/s chip-wide)
+                ws = self.empty(sk * dy.shape[1], x.shape[1], dtype=torch.float32)
+                kn.gemm(dyT, xT, ws, splitk=sk, slabs=True)
+                kn.slab_reduce(ws, sk, out, accumulate=True)
+            else:
+                kn.gemm(dyT, xT, out, accumulate=True, splitk=1)
             return
         kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=self.splitk(dy.shape[1], x.shape[1], dy.shape[0]))
 

@@ -39,7 +39,7 @@ def _ld(t):
 
 
 def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None,
-         splitk=1):
+         splitk=1, slabs=False):
     """out[M,N] = epi(alpha * A.B^T + bias) (+ out).  a: [M,K] (or [K,M] when a_t); b: [N,K] (or [K,N] when b_t);
     a2: optional second half of the K range ([M,K2], natural layout).  out may be f32 while a/b are bf16."""
     dt = _dt(a)
@@ -51,9 +51,9 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
         ksplit = K
         K = K + a2.shape[1]
     assert K == Kb, (K, Kb)
-    assert out.shape[0] == M and out.shape[1] == N, (out.shape, M, N)
+    assert out.shape[0] == (M * splitk if slabs else M) and out.shape[1] == N, (out.shape, M, N)
     flags = (_lib.GEMM_A_T if a_t else 0) | (_lib.GEMM_B_T if b_t else 0) | (_lib.GEMM_BIAS if bias is not None else 0)
-    flags |= _lib.gemm_epi(epi) | (_lib.GEMM_ACCUM if accumulate else 0)
+    flags |= _lib.gemm_epi(epi) | (_lib.GEMM_ACCUM if accumulate else 0) | (_lib.GEMM_SLABS if slabs else 0)
     if out.dtype == torch.float32 and dt == BF16:
         flags |= _lib.GEMM_OUT_F32
     elif out.dtype == torch.float32:
@@ -66,6 +66,12 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
                          _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, float(alpha), flags, splitk, _stream()),
           "mmsum_gemm")
     return out
+
+
+def slab_reduce(ws, nslabs, out, accumulate=True):
+    """out[rows, cols] (+)= sum of the nslabs f32 slabs stacked in ws [nslabs*rows, cols]."""
+    rows, cols = out.shape
+    check(lib.mmsum_slab_reduce(_p(ws), nslabs, rows, cols, _p(out), _ld(out), int(accumulate), _stream()), "mmsum_slab_reduce")
 
 
 _ws_cache = {}

@@ -22,7 +22,7 @@ def _keep_mask(shape, p, seed):
     return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
 
 
-def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None, splitk=1):
+def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None, splitk=1, slabs=False):
     A = a.float().t() if a_t else a.float()
     if a2 is not None:
         A = torch.cat([A, a2.float()], dim=1)
@@ -41,11 +41,24 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
         v = F.relu(v)
     elif epi == EPI_RELU_BWD:
         v = v * (aux.float() > 0)
+    if slabs:        # split-K partial slabs: emulate as 'slab 0 holds everything, the rest are zero'
+        out.zero_()
+        out[:v.shape[0]].copy_(v)
+        return out
     if accumulate:
         out.add_(v.to(out.dtype))
     else:
         out.copy_(v)
     return out
+
+
+def slab_reduce(ws, nslabs, out, accumulate=True):
+    rows = out.shape[0]
+    s = ws.view(nslabs, rows, -1).sum(0)
+    if accumulate:
+        out.add_(s)
+    else:
+        out.copy_(s)
 
 
 def colsum(x, out, accumulate=False):

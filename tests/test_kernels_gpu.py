@@ -86,6 +86,12 @@ def test_gemm_epilogues(dtype):
     o2 = acc.clone()
     kn.gemm(a, b, o2, accumulate=True, splitk=2)
     close(o2, ref, dtype, what="splitk")
+    # split-K into partial slabs + deterministic reduce (no atomics)
+    ws = torch.full((3 * M, N), float("nan"), device=DEV)
+    kn.gemm(a, b, ws, splitk=3, slabs=True)
+    o5 = acc.clone()
+    kn.slab_reduce(ws, 3, o5, accumulate=True)
+    close(o5, ref, dtype, what="splitk slabs")
     # K split over two A operands
     a2 = rnd(M, 64, dtype=dtype, seed=8, std=0.3)
     b2 = rnd(N, Kd + 64, dtype=dtype, seed=9, std=0.3)
