@@ -256,7 +256,7 @@ class Engine:
             return 1
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         ktiles = max(1, Kred // (64 if self.dtype == torch.bfloat16 else 32))
-        sk = max(1, min(16, 512 // max(tiles, 1), ktiles // 4))
+        sk = max(1, min(8, -(-768 // max(tiles, 1)), ktiles // 4))     # measured optimum: ~768/tiles slices (tools/wgrad_bench.py)
         return sk
 
     def wgrad(self, dy, x, gname=None, gview=None, x_cache_key=None):

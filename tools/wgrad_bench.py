@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""wgrad-shaped products (small output, long reduction): split-K slabs at several split counts."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multimodalsum_amd import kernels as kn
+from tools.gemm_bench import timeit
+
+for M, N, K in [(1024, 1024, 16128), (3072, 1024, 16128), (4096, 1024, 16128), (1024, 4096, 16128), (2048, 1024, 27776)]:
+    a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
+    out = torch.zeros(M, N, device="cuda")
+    line = "M=%5d N=%5d K=%6d " % (M, N, K)
+    for sk in (1, 2, 4, 8, 16):
+        ws = torch.empty(sk * M, N, device="cuda")
+        def f():
+            if sk == 1:
+                kn.gemm(a, b, out, accumulate=True)
+            else:
+                kn.gemm(a, b, ws, splitk=sk, slabs=True)
+                kn.slab_reduce(ws, sk, out, accumulate=True)
+        us = timeit(f) * 1e3
+        line += " sk%-2d %5.0fus %5.0fTF |" % (sk, us, 2.0 * M * N * K / us / 1e6)
+    print(line, flush=True)
