@@ -87,6 +87,63 @@ __device__ __forceinline__ void scores_softmax(f32x16_t (&sacc)[NKB], const char
     l_out = l;
 }
 
+// Leaner variant used by the pipelined kernels.  Works in the log2 domain (one FMA folds scale*log2(e) and
+// the key mask, which is an additive 0 / -inf vector read from LDS four keys at a time), exponentials
+// are v_exp_f32 (2^x), fragment addresses are hoisted, and for causal self-attention the key blocks above
+// the wave's diagonal block are skipped altogether.  Returns the row max / sum in the log2 domain.
+#define LOG2E_F 1.4426950408889634f
+#define LN2_F 0.6931471805599453f
+template <typename T, int NKB, bool CAUSAL>
+__device__ __forceinline__ void scores_softmax2(f32x16_t (&sacc)[NKB], const char* ktile, int spad, const Frag* qf, const float* biasf,
+                                                int S, float scale, int qpos, int wave, int lane, const FragOff& fo, float& m_out,
+                                                float& l_out) {
+    constexpr int NS = AttnTraits<T>::kSlabsHD;
+    const float c2 = scale * LOG2E_F;
+    const int h = lane >> 5;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const bool active = (kb * 32 < S) && (!CAUSAL || kb <= wave);
+        sacc[kb] = zero_acc();
+        if (active) {
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const Frag a = lds_frag_o(ktile + sl * (spad * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                mma_slab<T>(sacc[kb], a, qf[sl]);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(biasf + kb * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s = fmaf(sacc[kb][4 * g + j], c2, bias[j]);
+                    if (CAUSAL && kb == wave && (kb * 32 + 8 * g + 4 * h + j) > qpos) s = -INFINITY;
+                    sacc[kb][4 * g + j] = s;
+                    m = fmaxf(m, s);
+                }
+            }
+        }
+    }
+    m = wave_half_max(m);
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        const bool active = (kb * 32 < S) && (!CAUSAL || kb <= wave);
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - ms);
+                sacc[kb][r] = pv;
+                l += pv;
+            }
+        }
+    }
+    l = wave_half_sum(l);
+    m_out = ms;
+    l_out = l;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Forward
 // ---------------------------------------------------------------------------------------------
@@ -243,7 +300,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(mmsum_attn_des
         delta = wave_half_sum(delta);
         if (lane < 32 && qvalid) {
             float* st = stats + ((((long)qb * d.N + n) * d.H + h) * d.T + qpos) * 2;
-            st[0] = m + __logf(l);
+            st[0] = (m + __logf(l)) * LOG2E_F;   // log2 domain, as the dK/dV kernel expects
             st[1] = delta;
         }
         __syncthreads();
@@ -418,7 +475,7 @@ __device__ __forceinline__ uint32_t valid_entities(const mmsum_attn_desc& d, int
     return m;
 }
 
-template <typename T, int NKB>
+template <typename T, int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_pipe_kernel(mmsum_attn_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SPAD = NKB * 32;
@@ -427,9 +484,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_pipe_kernel(mmsum_attn_d
     char* ktile = smem;
     char* vtile = smem + TILE;
     char* img = smem + 2 * TILE + (threadIdx.x >> 6) * ImageTraits<T>::kBytes;
-    uint8_t* maskb = reinterpret_cast<uint8_t*>(smem + 2 * TILE + 4 * ImageTraits<T>::kBytes);
+    float* biasf = reinterpret_cast<float*>(smem + 2 * TILE + 4 * ImageTraits<T>::kBytes);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FragOff fo = frag_off<T>(lane);
     const int h = blockIdx.x, qb = blockIdx.y;
     const int b = qb / d.qpb;
     const int excl = d.exclude_self ? (qb % d.qpb) : -1;
@@ -468,23 +526,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_pipe_kernel(mmsum_attn_d
         __syncthreads();
         kreg.commit(ktile, tid);
         vreg.commit(vtile, tid);
-        if (tid < SPAD) maskb[tid] = mreg;
+        if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
         __syncthreads();
         if (rem) prefetch(__builtin_ctz(rem));
         f32x16_t sacc[NKB];
         float m, l;
-        scores_softmax<T, NKB>(sacc, ktile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        scores_softmax2<T, NKB, CAUSAL>(sacc, ktile, SPAD, qf, biasf, d.S, d.scale, qpos, wave, lane, fo, m, l);
         const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < d.S) {
+            if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[kb][r] *= norm;
                 acc_to_image<T>(img, sacc[kb], lane);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    mma_image<T>(oacc[db], img, vtile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                    mma_image_o<T>(oacc[db], img, vtile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES) + db * 32 * SLAB_BYTES, HD * SLAB_BYTES, fo);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -500,7 +558,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_pipe_kernel(mmsum_attn_d
     }
 }
 
-template <typename T, int NKB>
+template <typename T, int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
                                                                        T* __restrict__ dQ, long lddq, int accumulate_dq,
                                                                        float* __restrict__ stats) {
@@ -512,9 +570,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_att
     char* vtile = smem + TILE;
     char* kttile = smem + 2 * TILE;
     char* img = smem + 3 * TILE + (threadIdx.x >> 6) * ImageTraits<T>::kBytes;
-    uint8_t* maskb = reinterpret_cast<uint8_t*>(smem + 3 * TILE + 4 * ImageTraits<T>::kBytes);
+    float* biasf = reinterpret_cast<float*>(smem + 3 * TILE + 4 * ImageTraits<T>::kBytes);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FragOff fo = frag_off<T>(lane);
     const int h = blockIdx.x, qb = blockIdx.y;
     const int b = qb / d.qpb;
     const int excl = d.exclude_self ? (qb % d.qpb) : -1;
@@ -560,23 +619,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_att
         kreg.commit(ktile, tid);
         vreg.commit(vtile, tid);
         ktreg.commit(kttile, tid);
-        if (tid < SPAD) maskb[tid] = mreg;
+        if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
         cur_n = next_n;
         __syncthreads();
         if (rem) prefetch(__builtin_ctz(rem));
         f32x16_t p[NKB];
         float m, l;
-        scores_softmax<T, NKB>(p, ktile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        scores_softmax2<T, NKB, CAUSAL>(p, ktile, SPAD, qf, biasf, d.S, d.scale, qpos, wave, lane, fo, m, l);
         const float invl = (l > 0.f) ? 1.f / l : 0.f;
         f32x16_t dp[NKB];
         float delta = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             dp[kb] = zero_acc();
-            if (kb * 32 < d.S) {
+            if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
-                    const Frag a = lds_frag<T>(vtile + sl * (SPAD * SLAB_BYTES), kb * 32, lane);
+                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dp[kb], a, dof[sl]);
                 }
 #pragma unroll
@@ -590,19 +649,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_att
         delta = wave_half_sum(delta);
         if (lane < 32 && qvalid) {
             float* st = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
-            st[0] = m + __logf(l);
+            st[0] = m + __log2f(l);            // log-sum-exp in the log2 domain (dK/dV kernel uses exp2)
             st[1] = delta;
         }
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < d.S) {
+            if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) p[kb][r] = p[kb][r] * (dp[kb][r] - delta) * d.scale;
                 acc_to_image<T>(img, p[kb], lane);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    mma_image<T>(dqacc[db], img, kttile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                    mma_image_o<T>(dqacc[db], img, kttile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES) + db * 32 * SLAB_BYTES, HD * SLAB_BYTES, fo);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -622,7 +681,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_att
     }
 }
 
-template <typename T, int NKB>
+template <typename T, int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
                                                                         T* __restrict__ dK, long lddk, T* __restrict__ dV, long lddv,
                                                                         const float* __restrict__ stats) {
@@ -641,6 +700,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_pipe_kernel(mmsum_at
     float* st = reinterpret_cast<float*>(smem + 4 * QT_TILE + 8 * ImageTraits<T>::kBytes);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FragOff fo = frag_off<T>(lane);
+    const float c2 = d.scale * LOG2E_F;
+    const int hh = lane >> 5;
     const int h = blockIdx.x;
     const long ent = blockIdx.y;
     const int b = (int)(ent / d.N), n = (int)(ent % d.N);
@@ -688,7 +750,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_pipe_kernel(mmsum_at
         qtreg.load(qbase, d.ldq, 0, HD, qc, d.T, tid);
         dotreg.load(dobase, lddo, 0, HD, qc, d.T, tid);
         const float* sbase = stats + (((long)qb * d.N + n) * d.H + h) * d.T * 2;
-        streg = (tid < TQ * 2 && qc + (tid >> 1) < d.T) ? sbase[(long)qc * 2 + tid] : 0.f;
+        streg = (tid < TQ * 2 && qc + (tid >> 1) < d.T) ? sbase[(long)qc * 2 + tid] : 0.f;      // tid = 2*query + {0: lse, 1: delta}
     };
     if (n_it > 0) prefetch(0);
     for (int it = 0; it < n_it; ++it) {
@@ -701,7 +763,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_pipe_kernel(mmsum_at
         doreg.commit(don, tid);
         qtreg.commit(qt, tid);
         dotreg.commit(dot, tid);
-        if (tid < TQ * 2) st[tid] = streg;
+        if (tid < TQ * 2) st[(tid & 1) * TQ + (tid >> 1)] = streg;
         __syncthreads();
         if (it + 1 < n_it) prefetch(it + 1);
 #pragma unroll
@@ -712,30 +774,38 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_pipe_kernel(mmsum_at
 #pragma unroll
             for (int qq = 0; qq < TQ / 32; ++qq) {
                 if (qc + qq * 32 >= d.T) continue;
+                if (CAUSAL && kb * 32 > qc + qq * 32 + 31) continue;          // every key of the block lies above every query
                 f32x16_t s = zero_acc(), dp = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
-                    const Frag aq = lds_frag<T>(qn + sl * (TQ * SLAB_BYTES), qq * 32, lane);
+                    const Frag aq = lds_frag_o(qn + sl * (TQ * SLAB_BYTES) + qq * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(s, aq, kf[o][sl]);
-                    const Frag ad = lds_frag<T>(don + sl * (TQ * SLAB_BYTES), qq * 32, lane);
+                    const Frag ad = lds_frag_o(don + sl * (TQ * SLAB_BYTES) + qq * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dp, ad, vf[o][sl]);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ql = qq * 32 + acc_row(r, lane);
-                    const int qg = qc + ql;
-                    const bool masked = keymask[o] || qg >= d.T || (d.causal && key > qg);
-                    const float pr = masked ? 0.f : __expf(s[r] * d.scale - st[ql * 2]);
-                    dp[r] = pr * (dp[r] * inv_cnt - st[ql * 2 + 1]) * d.scale;
-                    s[r] = pr * inv_cnt;
+                for (int g = 0; g < 4; ++g) {
+                    const int ql0 = qq * 32 + 8 * g + 4 * hh;
+                    const f32x4_t lse4 = *reinterpret_cast<const f32x4_t*>(st + ql0);
+                    const f32x4_t del4 = *reinterpret_cast<const f32x4_t*>(st + TQ + ql0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g + j;
+                        const int qg = qc + ql0 + j;
+                        bool masked = keymask[o] || qg >= d.T;
+                        if (CAUSAL) masked = masked || key > qg;
+                        const float pr = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[j]));
+                        dp[r] = pr * (dp[r] * inv_cnt - del4[j]) * d.scale;
+                        s[r] = pr * inv_cnt;
+                    }
                 }
                 acc_to_image<T>(imgP, s, lane);
                 acc_to_image<T>(imgS, dp, lane);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    mma_image<T>(dvacc[o][db], imgP, dot + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
-                    mma_image<T>(dkacc[o][db], imgS, qt + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES), HD * SLAB_BYTES, db * 32, lane);
+                    mma_image_o<T>(dvacc[o][db], imgP, dot + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES) + db * 32 * SLAB_BYTES, HD * SLAB_BYTES, fo);
+                    mma_image_o<T>(dkacc[o][db], imgS, qt + qq * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES) + db * 32 * SLAB_BYTES, HD * SLAB_BYTES, fo);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -789,7 +859,7 @@ inline void allow_lds(KernelT kernel, size_t bytes) {
 inline int nkb_for(int S) { return S <= 64 ? 2 : (S <= 128 ? 4 : 7); }
 
 constexpr size_t LDS_MAX = 160 * 1024;
-template <typename T> size_t pipe_lds(int nkb, int ntiles) { return (size_t)ntiles * nkb * 32 * HD * sizeof(T) + 4 * ImageTraits<T>::kBytes + nkb * 32 + 16; }
+template <typename T> size_t pipe_lds(int nkb, int ntiles) { return (size_t)ntiles * nkb * 32 * HD * sizeof(T) + 4 * ImageTraits<T>::kBytes + nkb * 32 * sizeof(float) + 16; }
 
 template <typename T>
 int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
@@ -797,9 +867,9 @@ int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
     const int nkb = nkb_for(d.S);
     if (pipe_lds<T>(nkb, 2) <= LDS_MAX) {
         const size_t lds = pipe_lds<T>(nkb, 2);
-        if (nkb == 2) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2>), grid, block, lds, s, d);
-        else if (nkb == 4) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 4>), grid, block, lds, s, d);
-        else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 7>), grid, block, lds, s, d);
+        if (nkb == 2) if (d.causal) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2, true>), grid, block, lds, s, d); else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2, false>), grid, block, lds, s, d);
+        else if (nkb == 4) if (d.causal) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 4, true>), grid, block, lds, s, d); else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 4, false>), grid, block, lds, s, d);
+        else if (d.causal) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 7, true>), grid, block, lds, s, d); else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 7, false>), grid, block, lds, s, d);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     }
     const size_t lds = fwd_lds<T>(nkb);
@@ -816,9 +886,9 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
     if (pipe_lds<T>(nkb, 3) <= LDS_MAX) {
         const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
         const size_t lds = pipe_lds<T>(nkb, 3);
-        if (nkb == 2) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
-        else if (nkb == 4) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 4>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
-        else LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 7>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        if (nkb == 2) if (d.causal) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 2, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats); else LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 2, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        else if (nkb == 4) if (d.causal) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 4, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats); else LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 4, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        else if (d.causal) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 7, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats); else LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 7, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
     } else {
         const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
         const size_t lds = fwd_lds<T>(nkb);
@@ -830,9 +900,9 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         const int n_ent = (d.n_qblocks / d.qpb) * d.N;
         const dim3 grid(d.H, n_ent), block(ATT_THREADS);
         const size_t lds = dkv_lds<T>();
-        if (nkb == 2) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 2>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
-        else if (nkb == 4) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 4>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
-        else LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 7>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        if (nkb == 2) if (d.causal) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 2, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats); else LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 2, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        else if (nkb == 4) if (d.causal) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 4, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats); else LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 4, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        else if (d.causal) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 7, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats); else LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 7, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
     }
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }

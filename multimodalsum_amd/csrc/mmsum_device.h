@@ -59,6 +59,21 @@ __device__ __forceinline__ Frag lds_frag(const char* slab, int row0, int lane) {
     return f;
 }
 
+// Hoisted form: the per-lane part of the address is loop invariant, so kernels with many fragment reads
+// compute it once (row0 must be a multiple of 16: the swizzle term then depends on the lane only).
+struct FragOff { int o0, o1; };
+template <typename T>
+__device__ __forceinline__ FragOff frag_off(int lane) {
+    const int r = lane & 31, h = lane >> 5;
+    return FragOff{slab_off(r, lane_chunk<T>(h, 0)), slab_off(r, lane_chunk<T>(h, 1))};
+}
+__device__ __forceinline__ Frag lds_frag_o(const char* slab_row0, const FragOff& fo) {
+    Frag f;
+    f.c[0] = *reinterpret_cast<const u32x4_t*>(slab_row0 + fo.o0);
+    f.c[1] = *reinterpret_cast<const u32x4_t*>(slab_row0 + fo.o1);
+    return f;
+}
+
 // Same fragment straight from global memory (row-major, K-contiguous): `rowptr` points at this
 // lane's row, element 0 of the slab.  Used for operands a wave reads once (Q / dO / K / V rows).
 template <typename T>
@@ -286,6 +301,16 @@ template <typename T> struct ImageTraits { static constexpr int kSlabs = (32 * s
 // acc[i][j] += sum over the 32 k of an image A (32 rows) and an operand block B (32 rows) that
 // lives in a bigger tile: `b_slab0` is the first slab covering those 32 k, `b_slab_stride` the
 // byte distance between consecutive slabs of that tile.
+template <typename T>
+__device__ __forceinline__ void mma_image_o(f32x16_t& acc, const char* img, const char* b_slab0_row0, int b_slab_stride, const FragOff& fo) {
+#pragma unroll
+    for (int s = 0; s < ImageTraits<T>::kSlabs; ++s) {
+        const Frag a = lds_frag_o(img + s * (32 * SLAB_BYTES), fo);
+        const Frag b = lds_frag_o(b_slab0_row0 + s * b_slab_stride, fo);
+        mma_slab<T>(acc, a, b);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void mma_image(f32x16_t& acc, const char* img, const char* b_slab0, int b_slab_stride,
                                           int b_row0, int lane) {
