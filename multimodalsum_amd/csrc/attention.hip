@@ -476,7 +476,7 @@ __device__ __forceinline__ uint32_t valid_entities(const mmsum_attn_desc& d, int
 }
 
 template <typename T, int NKB, bool CAUSAL>
-__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_pipe_kernel(mmsum_attn_desc d) {
+__global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) void attn_fwd_pipe_kernel(mmsum_attn_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SPAD = NKB * 32;
     constexpr int NS = AttnTraits<T>::kSlabsHD;
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_pipe_kernel(mmsum_attn_d
 }
 
 template <typename T, int NKB, bool CAUSAL>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
+__global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dq_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
                                                                        T* __restrict__ dQ, long lddq, int accumulate_dq,
                                                                        float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -627,26 +627,26 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_att
         float m, l;
         scores_softmax2<T, NKB, CAUSAL>(p, ktile, SPAD, qf, biasf, d.S, d.scale, qpos, wave, lane, fo, m, l);
         const float invl = (l > 0.f) ? 1.f / l : 0.f;
-        f32x16_t dp[NKB];
+        // dP^T = V dO^T is computed TWICE (delta pass, then dS pass) instead of being kept for all key blocks: the
+        // matrix pipe is mostly idle here and 48 fewer live registers buy a second resident workgroup per CU.
         float delta = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            dp[kb] = zero_acc();
             if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
+                f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
                     const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-                    mma_slab<T>(dp[kb], a, dof[sl]);
+                    mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    p[kb][r] *= invl;
-                    dp[kb][r] *= inv_cnt;
-                    delta += p[kb][r] * dp[kb][r];
+                    p[kb][r] *= invl;                 // normalised probability
+                    delta += p[kb][r] * dpk[r];
                 }
             }
         }
-        delta = wave_half_sum(delta);
+        delta = wave_half_sum(delta) * inv_cnt;       // dO_e = dO / count
         if (lane < 32 && qvalid) {
             float* st = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
             st[0] = m + __log2f(l);            // log-sum-exp in the log2 domain (dK/dV kernel uses exp2)
@@ -655,9 +655,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_att
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
+                f32x16_t dpk = zero_acc();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) p[kb][r] = p[kb][r] * (dp[kb][r] - delta) * d.scale;
-                acc_to_image<T>(img, p[kb], lane);
+                for (int sl = 0; sl < NS; ++sl) {
+                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    mma_slab<T>(dpk, a, dof[sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpk[r] = p[kb][r] * (dpk[r] * inv_cnt - delta) * d.scale;   // dS^T
+                acc_to_image<T>(img, dpk, lane);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_pipe_kernel(mmsum_att
 }
 
 template <typename T, int NKB, bool CAUSAL>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
+__global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dkv_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
                                                                         T* __restrict__ dK, long lddk, T* __restrict__ dV, long lddv,
                                                                         const float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
