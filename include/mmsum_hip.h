@@ -141,9 +141,11 @@ int mmsum_cast(int dtype_dst, void* dst, int dtype_src, const void* src, long n,
 int mmsum_scale_by_clip(float* g, long n, const float* norm_sq, float max_norm, void* stream);
 
 /* bf16 transposes feeding the NT GEMM: dst[c][r] = src[r][c]; dst columns [rows, rows_pad) are zero
- * filled (reduction padding for wgrad).  Batched form: desc[i] = {src_off, dst_off, rows, cols, ld_src,
+ * filled (reduction padding for wgrad); colsum (may be NULL): colsum[c] += sum_r src[r][c] (the bias gradient comes
+ * for free while dy is being transposed for its weight-gradient product).  Batched form: desc[i] = {src_off, dst_off, rows, cols, ld_src,
  * ld_dst} in elements (device memory), one matrix per entry (all 2-D weights after an optimiser step). */
-int mmsum_transpose_bf16(const void* src, long ld_src, void* dst, long ld_dst, int rows, int cols, int rows_pad, void* stream);
+int mmsum_transpose_bf16(const void* src, long ld_src, void* dst, long ld_dst, int rows, int cols, int rows_pad, float* colsum,
+                         void* stream);
 int mmsum_transpose_bf16_batched(const void* src_base, void* dst_base, const long* desc, int n, int max_tiles, void* stream);
 
 /* ---- ResNet101 stages (img_encoder.py:21-24,31-41; torchvision 0.6.1 resnet101) -------------

@@ -184,6 +184,7 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
+    if (gemm_tn_eligible(dtype, a)) return launch_gemm_tn(a, s);
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
 }
 

@@ -376,6 +376,173 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// "TN" ring kernel: C[m][n] = sum_k A[k][m] * B[k][n] with BOTH operands reduction-major (A [K,M],
+// B [K,N], row-major).  This is the weight-gradient product dW = dy^T x taken straight from the
+// activations as the forward/backward passes left them (dy [rows, N_out], x [rows, K_in]): no
+// transposed copies.  Same 4-stage DMA ring as above; a stage is 32 reduction rows x BM (and x BN)
+// columns kept ROW-major in LDS, and the MFMA operands (8 consecutive k per lane) are gathered by the
+// gfx950 transposing LDS read ds_read_b64_tr_b16 (guide T10): a 16-lane group reads a 4(k) x 16(m)
+// block and lane i receives column i.  A 32-lane half therefore touches 4 k-rows x 64 B per
+// instruction; the 64-byte chunks of a row are XOR-ed with (k & 3) (on the DMA SOURCE address, the
+// LDS destination of global_load_lds is linear) so the four rows fall in four different bank groups.
+// Rows past K and columns past M/N are fetched from a 16-byte zero page instead of being clamped,
+// so any K works (zeros add nothing to the reduction).
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[4];
+
+#include "gemm_tn_slab.inc"
+
+template <int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void tn_slab(f32x16_t (&acc)[TM][TN], const uint32_t (&addrA)[TM], const uint32_t (&addrB)[TN]) {
+    if constexpr (BM == 256 && BN == 256) { TN_SLAB_4x2_256_256(acc, addrA, addrB); }
+    else if constexpr (BM == 256 && BN == 128) { TN_SLAB_2x2_256_128(acc, addrA, addrB); }
+    else { TN_SLAB_2x2_128_128(acc, addrA, addrB); }
+}
+
+// per-lane source of one 1-KiB DMA piece of a [32 k][BW] stage (1024/(2 BW) reduction rows per piece)
+struct TnPiece { const bf16_t* src; int k; bool col_ok; };
+template <int BW>
+__device__ __forceinline__ TnPiece tn_piece(const bf16_t* __restrict__ g, long ld, int c0, int C, int k0, int piece, int lane) {
+    constexpr int ROWB = BW * 2, CPR = ROWB / 16, RPP = 1024 / ROWB;
+    const int r = piece * RPP + lane / CPR;
+    const int pc = lane % CPR;
+    const int c64 = (pc >> 2) ^ (r & 3);
+    const int col = c0 + (c64 * 4 + (pc & 3)) * 8;
+    TnPiece t;
+    t.k = k0 + r;
+    t.col_ok = col < C;
+    t.src = g + (long)t.k * ld + (t.col_ok ? col : 0);
+    return t;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_ring_kernel(GemmArgs p) {
+    using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N>;
+    constexpr int ROWB_A = BM * 2, ROWB_B = BN * 2;
+    static_assert((Cfg::TM == 4 && Cfg::TN == 2 && BM == 256 && BN == 256) || (Cfg::TM == 2 && Cfg::TN == 2), "no slab schedule for this tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = tiles_m * tiles_n;
+    const int ks = wg / tiles;
+    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
+    const int t = wg % tiles;
+    int tm, tn;
+    tile_coords(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nslab_total = (p.K + 31) / 32;
+    const int per = (nslab_total + p.splitk - 1) / p.splitk;
+    const int s_beg = ks * per, s_end = min(nslab_total, s_beg + per);
+    const int ns = s_end - s_beg;
+
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+
+    f32x16_t acc[Cfg::TM][Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zero_acc();
+
+    // transposing-read lane geometry: group g = lane>>4 -> (16-column half g&1, k half g>>1); lane 4q+p of the
+    // group addresses row q, columns 4p..4p+3 of its 4 x 16 block
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    uint32_t offA[Cfg::TM], offB[Cfg::TN];
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i) offA[i] = lds0 + (8 * (g >> 1) + q) * ROWB_A + (((wm * Cfg::TM + i) ^ q) * 64) + 32 * (g & 1) + 8 * pp;
+#pragma unroll
+    for (int j = 0; j < Cfg::TN; ++j)
+        offB[j] = lds0 + Cfg::A_BYTES + (8 * (g >> 1) + q) * ROWB_B + (((wn * Cfg::TN + j) ^ q) * 64) + 32 * (g & 1) + 8 * pp;
+
+    // DMA sources: pointer + reduction row per piece, advanced by 32 rows per issued slab (issue order is sequential)
+    TnPiece pc[Cfg::PPW];
+#pragma unroll
+    for (int i = 0; i < Cfg::PPW; ++i) {
+        if (i * Cfg::NW < Cfg::PA) pc[i] = tn_piece<BM>(A, p.lda, m0, p.M, s_beg * 32, i * Cfg::NW + wave, lane);
+        else pc[i] = tn_piece<BN>(B, p.ldb, n0, p.N, s_beg * 32, i * Cfg::NW - Cfg::PA + wave, lane);
+    }
+    const long stepA = 32 * p.lda, stepB = 32 * p.ldb;
+    const uintptr_t zero_page = (uintptr_t)g_zero_page;
+    auto issue = [&](int si) {
+        char* As = smem + (si & 3) * Cfg::STAGE;
+        char* Bs = As + Cfg::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < Cfg::PPW; ++i) {
+            const bool ok = pc[i].col_ok && pc[i].k < p.K;
+            const uintptr_t src = ok ? (uintptr_t)pc[i].src : zero_page;
+            if (i * Cfg::NW < Cfg::PA) {
+                dma16(reinterpret_cast<const bf16_t*>(src), As + (i * Cfg::NW + wave) * 1024);
+                pc[i].src += stepA;
+            } else {
+                dma16(reinterpret_cast<const bf16_t*>(src), Bs + (i * Cfg::NW - Cfg::PA + wave) * 1024);
+                pc[i].src += stepB;
+            }
+            pc[i].k += 32;
+        }
+    };
+
+    if (ns > 0) {
+        issue(0);
+        if (ns > 1) issue(1);
+        if (ns > 2) issue(2);
+        for (int si = 0; si < ns; ++si) {
+            const int ahead = ns - 1 - si;
+            if (ahead >= 2) wait_vmcnt<2 * Cfg::PPW>();
+            else if (ahead == 1) wait_vmcnt<Cfg::PPW>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (si + 3 < ns) issue(si + 3);
+            const uint32_t stage = (uint32_t)((si & 3) * Cfg::STAGE);
+            uint32_t addrA[Cfg::TM], addrB[Cfg::TN];
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) addrA[i] = offA[i] + stage;
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) addrB[j] = offB[j] + stage;
+            tn_slab<BM, BN, Cfg::TM, Cfg::TN>(acc, addrA, addrB);
+        }
+        // the MFMAs were issued from inline asm: the compiler does not know results are still in the pipeline
+        asm volatile("s_nop 15\n s_nop 15" ::: "memory");
+    }
+    if constexpr (OUT == OUT_F32_ATOMIC) {
+        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+    } else {
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
+int launch_tn_one(const GemmArgs& a, hipStream_t stream) {
+    using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const size_t lds = R::NSTAGE * R::STAGE;
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<BM, BN, WAVES_M, WAVES_N, MMSUM_EPI_NONE, OUT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        once = true;
+    }
+    gemm_tn_ring_kernel<BM, BN, WAVES_M, WAVES_N, MMSUM_EPI_NONE, OUT><<<dim3(tiles * a.splitk), dim3(R::THREADS), lds, stream>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+int launch_tn_cfg(const GemmArgs& a, hipStream_t stream) {
+    switch (out_mode_of(a)) {
+        case OUT_T: return launch_tn_one<BM, BN, WAVES_M, WAVES_N, OUT_T>(a, stream);
+        case OUT_F32_ACC: return launch_tn_one<BM, BN, WAVES_M, WAVES_N, OUT_F32_ACC>(a, stream);
+        case OUT_F32_ATOMIC: return launch_tn_one<BM, BN, WAVES_M, WAVES_N, OUT_F32_ATOMIC>(a, stream);
+        case OUT_F32: return launch_tn_one<BM, BN, WAVES_M, WAVES_N, OUT_F32>(a, stream);
+        default: return MMSUM_ERR_BAD_SHAPE;
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
     static const bool use_ring = !(getenv("MMSUM_GEMM_RING") && atoi(getenv("MMSUM_GEMM_RING")) == 0);
@@ -434,6 +601,28 @@ bool gemm_glds_eligible(int dtype, const GemmArgs& a) {
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
     if (epi != MMSUM_EPI_NONE && out != OUT_T) return false;     // rare combinations stay on the generic kernel
     return true;
+}
+
+// A [K,M] and B [K,N] reduction-major bf16 (flags A_T | B_T): the weight-gradient layout
+bool gemm_tn_eligible(int dtype, const GemmArgs& a) {
+    if (dtype != MMSUM_BF16) return false;
+    if ((a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) != (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) return false;
+    if (a.A2 != nullptr || (a.flags & MMSUM_GEMM_BIAS) || ((a.flags >> 3) & 7) != MMSUM_EPI_NONE || a.aux != nullptr) return false;
+    if ((a.M & 7) || (a.N & 7) || (a.lda & 7) || (a.ldb & 7)) return false;
+    if ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15) return false;
+    static const bool off = getenv("MMSUM_GEMM_TN") && atoi(getenv("MMSUM_GEMM_TN")) == 0;
+    return !off;
+}
+
+int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
+    static const double e128 = getenv("MMSUM_E128") ? atof(getenv("MMSUM_E128")) : 0.50;
+    static const double e2x1 = getenv("MMSUM_E2X1") ? atof(getenv("MMSUM_E2X1")) : 0.72;
+    const double s256 = tile_score(a.M, a.N, a.splitk, 256, 256, 1.00);
+    const double s128 = tile_score(a.M, a.N, a.splitk, 128, 128, e128);
+    const double s2x1 = tile_score(a.M, a.N, a.splitk, 256, 128, e2x1);
+    if (s256 >= s128 && s256 >= s2x1) return launch_tn_cfg<256, 256, 2, 4>(a, stream);
+    if (s2x1 >= s128) return launch_tn_cfg<256, 128, 4, 2>(a, stream);
+    return launch_tn_cfg<128, 128, 2, 2>(a, stream);
 }
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {

@@ -259,24 +259,21 @@ class Engine:
         sk = max(1, min(8, -(-768 // max(tiles, 1)), ktiles // 4))     # measured optimum: ~768/tiles slices (tools/wgrad_bench.py)
         return sk
 
-    def wgrad(self, dy, x, gname=None, gview=None, x_cache_key=None):
+    def wgrad(self, dy, x, gname=None, gview=None, x_cache_key=None, bias_g=None):
         """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena."""
         out = gview if gview is not None else self.arena.g(gname)
-        if self.dtype == torch.bfloat16:
-            M = dy.shape[0]
-            Mp = (M + 63) // 64 * 64
-            dyT = self.transposed(dy, Mp)
-            xT = self.transposed(x, Mp, x_cache_key)
-            sk = self.splitk(dy.shape[1], x.shape[1], Mp)
-            if sk > 1 and x.shape[1] % 4 == 0:
-                # split-K partial slabs + a deterministic reduce: cheaper than f32 atomics (1.3 TB/s chip-wide)
-                ws = self.empty(sk * dy.shape[1], x.shape[1], dtype=torch.float32)
-                kn.gemm(dyT, xT, ws, splitk=sk, slabs=True)
-                kn.slab_reduce(ws, sk, out, accumulate=True)
-            else:
-                kn.gemm(dyT, xT, out, accumulate=True, splitk=1)
+        if bias_g is not None:
+            kn.colsum(dy, bias_g, accumulate=True)
+        R = dy.shape[0]
+        sk = self.splitk(dy.shape[1], x.shape[1], R)
+        if self.dtype == torch.bfloat16 and sk > 1 and x.shape[1] % 4 == 0:
+            # reduction-major product straight from the activations (gemm_tn_ring_kernel: transposing LDS reads);
+            # split-K partial slabs + a deterministic reduce: cheaper than f32 atomics (1.3 TB/s chip-wide)
+            ws = self.empty(sk * dy.shape[1], x.shape[1], dtype=torch.float32)
+            kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+            kn.slab_reduce(ws, sk, out, accumulate=True)
             return
-        kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=self.splitk(dy.shape[1], x.shape[1], dy.shape[0]))
+        kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=sk)
 
     def bgrad(self, dy, gname=None, gview=None):
         kn.colsum(dy, gview if gview is not None else self.arena.g(gname), accumulate=True)
@@ -360,15 +357,13 @@ class Engine:
         do, dx = self.empty(R, D), self.empty(R, D)
         kn.add_ln_bwd(dy, c.o, c.x, a.f32(lb + "self_attn_layer_norm.weight"), c.mean, c.rstd, do, dx, False,
                       a.g(lb + "self_attn_layer_norm.weight"), a.g(lb + "self_attn_layer_norm.bias"), c.p, c.seed)
-        self.bgrad(do, lb + "self_attn.out_proj.bias")
-        self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight")
+        self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight", bias_g=a.g(lb + "self_attn.out_proj.bias"))
         dattn = self.empty(R, D)
         self.dgrad(do, lb + "self_attn.out_proj.weight", a.w(lb + "self_attn.out_proj.weight"), dattn)
         dqkv = self.empty(R, 3 * D)
         stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
         kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
-        self.bgrad(dqkv, gview=a.gspan(q + ".bias", v + ".bias", (3 * D,)))
-        self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)))
+        self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)), bias_g=a.gspan(q + ".bias", v + ".bias", (3 * D,)))
         self.dgrad(dqkv, q + ".weight", a.wspan(q + ".weight", v + ".weight", (3 * D, D)), dx, accumulate=True)
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias",
                    lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.bias", lb + "self_attn_layer_norm.weight",
@@ -397,12 +392,10 @@ class Engine:
         df, dx = self.empty(R, D), self.empty(R, D)
         kn.add_ln_bwd(dy, c.f, c.x, a.f32(lb + "final_layer_norm.weight"), c.mean, c.rstd, df, dx, False,
                       a.g(lb + "final_layer_norm.weight"), a.g(lb + "final_layer_norm.bias"), c.p, c.seed)
-        self.bgrad(df, lb + "fc2.bias")
-        self.wgrad(df, c.h, lb + "fc2.weight")
+        self.wgrad(df, c.h, lb + "fc2.weight", bias_g=a.g(lb + "fc2.bias"))
         du = self.empty(R, c.u.shape[1])
         self.dgrad(df, lb + "fc2.weight", a.w(lb + "fc2.weight"), du, epi=kn.EPI_GELU_BWD, aux=c.u)
-        self.bgrad(du, lb + "fc1.bias")
-        self.wgrad(du, c.x, lb + "fc1.weight")
+        self.wgrad(du, c.x, lb + "fc1.weight", bias_g=a.g(lb + "fc1.bias"))
         self.dgrad(du, lb + "fc1.weight", a.w(lb + "fc1.weight"), dx, accumulate=True)
         self.touch(lb + "fc1.weight", lb + "fc1.bias", lb + "fc2.weight", lb + "fc2.bias", lb + "final_layer_norm.weight",
                    lb + "final_layer_norm.bias")
@@ -547,8 +540,7 @@ class Engine:
                 self.touch(name + ".weight", name + ".bias")
         else:
             dyy = dcv
-        self.bgrad(dyy, pre + "out_proj.bias")
-        self.wgrad(dyy, c.heads, pre + "out_proj.weight")
+        self.wgrad(dyy, c.heads, pre + "out_proj.weight", bias_g=a.g(pre + "out_proj.bias"))
         dheads = self.empty(nm * Rq, D)
         self.dgrad(dyy, pre + "out_proj.weight", a.w(pre + "out_proj.weight"), dheads)
         dq = self.empty(Rq, D)
@@ -557,11 +549,9 @@ class Engine:
             rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
             stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
             kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
-        self.bgrad(dkv, gview=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
-        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), x_cache_key=("mem", dc.mem.data_ptr()))
+        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), x_cache_key=("mem", dc.mem.data_ptr()), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
         self.dgrad(dkv, k + ".weight", a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, accumulate=not first)
-        self.bgrad(dq, q + ".bias")
-        self.wgrad(dq, c.x, q + ".weight")
+        self.wgrad(dq, c.x, q + ".weight", bias_g=a.g(q + ".bias"))
         self.dgrad(dq, q + ".weight", a.w(q + ".weight"), dx, accumulate=True)
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias", pre + "out_proj.weight",
                    pre + "out_proj.bias", lb + "encoder_attn_layer_norm.weight", lb + "encoder_attn_layer_norm.bias")
@@ -626,8 +616,7 @@ class Engine:
         self.wgrad(dy, c.t1, tp + "linear.weight")
         dt1 = self.empty(c.B * 47, D)
         self.dgrad(dy, tp + "linear.weight", a.w(tp + "linear.weight"), dt1, epi=kn.EPI_RELU_BWD, aux=c.t1)
-        self.bgrad(dt1, tp + "fc.bias")
-        self.wgrad(dt1, c.all, tp + "fc.weight")
+        self.wgrad(dt1, c.all, tp + "fc.weight", bias_g=a.g(tp + "fc.bias"))
         dall = self.empty(c.B * 47, 2 * D)
         self.dgrad(dt1, tp + "fc.weight", a.w(tp + "fc.weight"), dall)
         kn.table_gather_bwd(dall, c.fv[4], c.fv[5], a.g(tp + "rating_embedding.weight"), a.g(tp + "hours_embedding.weight"), c.B, D)

@@ -185,11 +185,12 @@ def cast(dst, src):
     return dst
 
 
-def transpose(src, dst, rows_pad=None):
-    """dst[c, r] = src[r, c] (bf16); dst has >= rows_pad columns, [rows, rows_pad) zero filled."""
+def transpose(src, dst, rows_pad=None, colsum=None):
+    """dst[c, r] = src[r, c] (bf16); dst has >= rows_pad columns, [rows, rows_pad) zero filled;
+    colsum (f32 [cols], optional) += column sums of src."""
     rows, cols = src.shape
     rp = rows if rows_pad is None else rows_pad
-    check(lib.mmsum_transpose_bf16(_p(src), _ld(src), _p(dst), _ld(dst), rows, cols, rp, _stream()), "mmsum_transpose_bf16")
+    check(lib.mmsum_transpose_bf16(_p(src), _ld(src), _p(dst), _ld(dst), rows, cols, rp, _p(colsum), _stream()), "mmsum_transpose_bf16")
     return dst
 
 

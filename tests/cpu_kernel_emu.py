@@ -251,9 +251,11 @@ def cast(dst, src):
     return dst
 
 
-def transpose(src, dst, rows_pad=None):
+def transpose(src, dst, rows_pad=None, colsum=None):
     dst.zero_()
     dst[:, :src.shape[0]] = src.t()
+    if colsum is not None:
+        colsum.add_(src.float().sum(0))
     return dst
 
 

@@ -105,12 +105,62 @@ def test_gemm_epilogues(dtype):
     close(o4, wide[:, Kd:2 * Kd].float() @ b.float().t(), dtype, what="strided A")
 
 
+@pytest.mark.parametrize("rows,n_out,k_in,sk", [(512, 256, 256, 1), (1000, 1024, 512, 4), (2066, 2048, 1024, 8), (96, 136, 72, 1),
+                                               (16128, 1024, 1024, 8), (18, 256, 128, 1), (4000, 3072, 1024, 3)])
+def test_gemm_wgrad_layout(rows, n_out, k_in, sk):
+    """dW[n_out,k_in] = dy[rows,n_out]^T x[rows,k_in] straight from reduction-major bf16 operands
+    (gemm_tn_ring_kernel): bf16 result, f32 accumulate, atomics and split-K slabs; any row count."""
+    dy = rnd(rows, n_out, dtype=torch.bfloat16, seed=11, std=0.5)
+    x = rnd(rows, k_in, dtype=torch.bfloat16, seed=12, std=0.5)
+    ref = dy.double().t() @ x.double()
+    scale = math.sqrt(max(rows, 64) / 64)
+    acc = rnd(n_out, k_in, seed=13)
+    o1 = acc.clone()
+    kn.gemm(dy, x, o1, a_t=True, b_t=True, accumulate=True)
+    close(o1, acc.double() + ref, torch.float32, scale=4 * scale, what="tn accumulate")
+    o2 = torch.full((n_out, k_in), float("nan"), device=DEV, dtype=torch.bfloat16)
+    kn.gemm(dy, x, o2, a_t=True, b_t=True)
+    close(o2, ref, torch.bfloat16, scale=scale, what="tn bf16 out")
+    if sk > 1:
+        ws = torch.full((sk * n_out, k_in), float("nan"), device=DEV)
+        kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+        o3 = acc.clone()
+        kn.slab_reduce(ws, sk, o3, accumulate=True)
+        close(o3, acc.double() + ref, torch.float32, scale=4 * scale, what="tn slabs")
+        o4 = acc.clone()
+        kn.gemm(dy, x, o4, a_t=True, b_t=True, accumulate=True, splitk=sk)
+        close(o4, acc.double() + ref, torch.float32, scale=4 * scale, what="tn atomics")
+    # strided operands (column windows of wider buffers, as the fused q/k/v gradients are)
+    wide = rnd(rows, n_out + 64, dtype=torch.bfloat16, seed=14, std=0.5)
+    o5 = torch.zeros(n_out, k_in, device=DEV)
+    kn.gemm(wide[:, 64:], x, o5, a_t=True, b_t=True, accumulate=True)
+    close(o5, wide[:, 64:].double().t() @ x.double(), torch.float32, scale=4 * scale, what="tn strided")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_colsum(dtype):
     x = rnd(1000, 200, dtype=dtype, seed=1)
     out = torch.ones(200, device=DEV)
     kn.colsum(x, out, accumulate=True)
     close(out, 1 + x.float().sum(0), dtype, scale=4, what="colsum")
+
+
+@pytest.mark.parametrize("rows,cols,ld_extra", [(64, 64, 0), (200, 136, 0), (333, 1024, 0), (130, 72, 8), (1000, 3072, 0), (77, 40, 0)])
+def test_transpose_colsum(rows, cols, ld_extra):
+    """mmsum_transpose_bf16: bit-exact transpose, zero padding up to rows_pad, fused column sums (+=)."""
+    src_full = rnd(rows, cols + ld_extra, dtype=torch.bfloat16, seed=rows + cols)
+    src = src_full[:, :cols]
+    rp = (rows + 63) // 64 * 64
+    dst = torch.full((cols, rp), 7.0, device=DEV, dtype=torch.bfloat16)
+    kn.transpose(src, dst, rp)
+    assert torch.equal(dst[:, :rows], src.t())
+    assert (dst[:, rows:] == 0).all()
+    dst2 = torch.full((cols, rp), 7.0, device=DEV, dtype=torch.bfloat16)
+    cs = torch.ones(cols, device=DEV, dtype=torch.float32)
+    kn.transpose(src, dst2, rp, colsum=cs)
+    assert torch.equal(dst2, dst)
+    ref = 1.0 + src.double().sum(0)
+    assert (cs.double() - ref).abs().max().item() <= 1e-4 * (1 + ref.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

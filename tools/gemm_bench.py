@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodalsum_amd import kernels as kn
 
+SHAPES14 = [(16128, 1024, 1024), (16128, 3072, 1024), (16128, 4096, 1024), (16128, 1024, 4096), (16128, 1024, 2048), (27762, 2048, 1024),
+            (48384, 1024, 1024), (16128, 50265, 1024), (16128, 1024, 50304)]
 SHAPES = [(9216, 1024, 1024), (9216, 3072, 1024), (9216, 4096, 1024), (9216, 1024, 4096), (15864, 2048, 1024),
           (27648, 1024, 1024), (9216, 50265, 1024), (1024, 1024, 9216), (4096, 1024, 9216), (50265, 1024, 9216)]
 
@@ -23,7 +25,7 @@ def timeit(fn, iters=10):
 
 def main():
     dt = torch.bfloat16
-    shapes = SHAPES
+    shapes = SHAPES14 if (len(sys.argv) > 1 and sys.argv[1] == 'b14') else SHAPES
     if len(sys.argv) > 3:
         shapes = [tuple(int(v) for v in sys.argv[1:4])]
     for M, N, K in shapes:

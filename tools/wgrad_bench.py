@@ -22,3 +22,17 @@ for M, N, K in [(1024, 1024, 16128), (3072, 1024, 16128), (4096, 1024, 16128), (
         us = timeit(f) * 1e3
         line += " sk%-2d %5.0fus %5.0fTF |" % (sk, us, 2.0 * M * N * K / us / 1e6)
     print(line, flush=True)
+    # the same product straight from reduction-major operands (TN kernel, no transposed copies)
+    at, bt = a.t().contiguous(), b.t().contiguous()
+    line = "   TN (dy[K,M], x[K,N])      "
+    for sk in (1, 2, 4, 8, 16):
+        ws = torch.empty(sk * M, N, device="cuda")
+        def g():
+            if sk == 1:
+                kn.gemm(at, bt, out, a_t=True, b_t=True, accumulate=True)
+            else:
+                kn.gemm(at, bt, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+                kn.slab_reduce(ws, sk, out, accumulate=True)
+        us = timeit(g) * 1e3
+        line += " sk%-2d %5.0fus %5.0fTF |" % (sk, us, 2.0 * M * N * K / us / 1e6)
+    print(line, flush=True)
