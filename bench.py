@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="capture the step into a HIP graph")
+    ap.add_argument("--no-graphs", action="store_true", help="issue every kernel from Python instead of replaying captured HIP graphs")
     return ap.parse_args()
 
 
@@ -232,6 +232,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    priming = 0
+    if not args.no_graphs:
+        model.enable_step_graphs()
+        priming = 2                         # un-timed: one eager step, one that captures the HIP graphs
+        for i in range(priming):
+            run_step(args, runner, opt, sch, batches[i % len(batches)])
     for i in range(args.warmup):
         run_step(args, runner, opt, sch, batches[i % len(batches)])
     sync()
@@ -267,6 +273,7 @@ def main():
                           if multimodal else "text_pretrain.py BART-large text-only step, 9 reviews x 128 tok",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "dropout": cfg.dropout},
+               "launch": "eager" if args.no_graphs else "hip-graph replay (fwd + 3 bwd segments), %d priming steps before warmup" % priming,
                "final_loss": loss_val, "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_bounded(args)

@@ -71,6 +71,14 @@ int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids, const void
                        const float* rstd, float* dE, float* dP, float* drvec, float* dgamma, float* dbeta, int nseq,
                        int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, void* stream);
 
+/* Dropout salt for captured HIP graphs.  The reference draws fresh dropout masks every step from the torch
+ * generator (F.dropout, modeling_multimodalsum.py:294,305,371,458,474,486,596); here masks are a hash of
+ * (seed argument, element index).  A captured graph replays the same seed arguments, so a device-resident 64-bit
+ * salt can be registered: every dropout kernel then uses seed + salt * golden-ratio constant, and
+ * mmsum_bump_u64 (a one-thread kernel, capturable) advances it once per step.  NULL unregisters. */
+int mmsum_set_dropout_salt(const void* dev_u64);
+int mmsum_bump_u64(void* dev_u64, unsigned long long inc, void* stream);
+
 /* K4/K6/K21: y = LN(res + dropout(x))  (modeling_multimodalsum.py:294-297,305-308,458-461,474-477,486-489;
  * apex FusedLayerNorm :972-980). */
 int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,

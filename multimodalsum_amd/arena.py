@@ -98,9 +98,19 @@ class ParamArena:
         none = [n for n, p in self.params.items() if p.grad is None]
         if len(none) == len(self.params):
             self.grad.zero_()
-        else:
-            for n in none:
-                self.g(n).zero_()
+            return
+        # one fill per run of adjacent parameters (the arena is [decay | no-decay], so under Q1 this is ONE launch
+        # instead of one per weight); alignment padding between neighbours is zeroed along with them
+        runs, names = [], list(self.offsets)
+        nxt = {n: (self.offsets[names[i + 1]] if i + 1 < len(names) else self.total) for i, n in enumerate(names)}
+        for n in none:
+            lo, hi = self.offsets[n], nxt[n]
+            if runs and runs[-1][1] == lo:
+                runs[-1][1] = hi
+            else:
+                runs.append([lo, hi])
+        for lo, hi in runs:
+            self.grad[lo:hi].zero_()
 
     def attach_grads(self, names=None):
         for n in (names if names is not None else self.params):

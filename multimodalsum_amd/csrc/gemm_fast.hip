@@ -104,7 +104,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
             } else if constexpr (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD) {
                 const long oa = (long)row * p.ldaux + col;
                 bf16_t t[8];
@@ -117,7 +117,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    if constexpr (EPI == MMSUM_EPI_GELU_BWD) v[e] *= gelu_grad_f((float)t[e]);
+                    if constexpr (EPI == MMSUM_EPI_GELU_BWD) v[e] *= gelu_grad_fast_f((float)t[e]);
                     else v[e] = ((float)t[e] > 0.f) ? v[e] : 0.f;
                 }
             } else if constexpr (EPI == MMSUM_EPI_RELU) {
@@ -608,7 +608,8 @@ bool gemm_tn_eligible(int dtype, const GemmArgs& a) {
     if (dtype != MMSUM_BF16) return false;
     if ((a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) != (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) return false;
     if (a.A2 != nullptr || (a.flags & MMSUM_GEMM_BIAS) || ((a.flags >> 3) & 7) != MMSUM_EPI_NONE || a.aux != nullptr) return false;
-    if ((a.M & 7) || (a.N & 7) || (a.lda & 7) || (a.ldb & 7)) return false;
+    // 16-byte column chunks: a ragged last chunk must still lie inside the row (leading dimension padded)
+    if ((a.lda & 7) || (a.ldb & 7) || a.lda < ((a.M + 7) & ~7) || a.ldb < ((a.N + 7) & ~7)) return false;
     if ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15) return false;
     static const bool off = getenv("MMSUM_GEMM_TN") && atoi(getenv("MMSUM_GEMM_TN")) == 0;
     return !off;

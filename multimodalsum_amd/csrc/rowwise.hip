@@ -19,6 +19,15 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4_t v)
     *reinterpret_cast<bf16x4_t*>(p) = bf16x4_t{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
 }
 
+// Dropout salt: an optional device-resident step counter mixed into every dropout seed.  A captured HIP graph bakes
+// the seed ARGUMENT into its kernel nodes; bumping the salt (mmsum_bump_u64, itself a graph node) gives every replay
+// fresh masks while forward and backward of one step still agree.  NULL (default) = seeds used as passed.
+const uint64_t* g_dropout_salt = nullptr;
+__device__ __forceinline__ uint64_t salted_seed(uint64_t seed, const uint64_t* salt) {
+    return salt != nullptr ? seed + *salt * 0x9E3779B97F4A7C15ull : seed;
+}
+__global__ void bump_u64_kernel(uint64_t* p, uint64_t inc) { *p += inc; }
+
 __device__ __forceinline__ uint32_t keep_threshold(float p_drop) {
     if (p_drop <= 0.f) return 0xFFFFFFFFu;
     const double t = (1.0 - (double)p_drop) * 4294967296.0;
@@ -47,7 +56,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          T* __restrict__ y, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, int R, int D, float eps,
-                                                         float p_drop, uint64_t seed) {
+                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ salt) {
+    seed = salted_seed(seed, salt);
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const uint32_t thr = keep_threshold(p_drop);
@@ -89,7 +99,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          T* __restrict__ dx, T* __restrict__ dres, int accumulate_dres,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int D,
-                                                         float p_drop, uint64_t seed) {
+                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ salt) {
+    seed = salted_seed(seed, salt);
     __shared__ float red[4][VPL * 256 * 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -163,7 +174,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
                                                            const float* __restrict__ beta, T* __restrict__ y,
                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                            int R, int T_len, int D, int pos_offset, float eps, float p_drop,
-                                                           uint64_t seed) {
+                                                           uint64_t seed, const uint64_t* __restrict__ salt) {
+    seed = salted_seed(seed, salt);
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const uint32_t thr = keep_threshold(p_drop);
@@ -208,7 +220,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const T* __restrict__
                                                            float* __restrict__ dP, float* __restrict__ drvec,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int nseq,
                                                            int T_len, int D, int pos_offset, int pad_id, float p_drop,
-                                                           uint64_t seed) {
+                                                           uint64_t seed, const uint64_t* __restrict__ salt) {
+    seed = salted_seed(seed, salt);
     __shared__ float red[4][VPL * 256 * 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -559,7 +572,7 @@ int add_ln_fwd_t(const void* x, const void* res, const void* gamma, const void* 
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
         add_ln_fwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)x, (const T*)res, (const float*)gamma, (const float*)beta,
-                                                                  (T*)y, mean, rstd, R, D, eps, p_drop, seed);
+                                                                  (T*)y, mean, rstd, R, D, eps, p_drop, seed, g_dropout_salt);
     });
 }
 template <typename T>
@@ -572,7 +585,7 @@ int add_ln_bwd_t(const void* dy, const void* x, const void* res, const void* gam
         constexpr int VPL = decltype(vpl)::value;
         add_ln_bwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)dy, (const T*)x, (const T*)res, (const float*)gamma, mean,
                                                                   rstd, (T*)dx, (T*)dres, accumulate_dres, dgamma, dbeta, R, D, p_drop,
-                                                                  seed);
+                                                                  seed, g_dropout_salt);
     });
 }
 template <typename T>
@@ -584,7 +597,7 @@ int embed_ln_fwd_t(const int64_t* ids, const void* E, const void* P, const float
         constexpr int VPL = decltype(vpl)::value;
         embed_ln_fwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>(ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
                                                                     (const float*)gamma, (const float*)beta, (T*)y, mean, rstd, R,
-                                                                    T_len, D, pos_offset, eps, p_drop, seed);
+                                                                    T_len, D, pos_offset, eps, p_drop, seed, g_dropout_salt);
     });
 }
 template <typename T>
@@ -595,7 +608,7 @@ int embed_ln_bwd_t(const void* dy, const int64_t* ids, const void* E, const void
         constexpr int VPL = decltype(vpl)::value;
         embed_ln_bwd_kernel<T, VPL><<<dim3(T_len), dim3(256), 0, s>>>((const T*)dy, ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
                                                                      (const float*)gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta,
-                                                                     nseq, T_len, D, pos_offset, pad_id, p_drop, seed);
+                                                                     nseq, T_len, D, pos_offset, pad_id, p_drop, seed, g_dropout_salt);
     });
 }
 
@@ -735,4 +748,15 @@ extern "C" int mmsum_cast(int dtype_dst, void* dst, int dtype_src, const void* s
     else if (dtype_dst == MMSUM_BF16 && dtype_src == MMSUM_BF16) hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (bf16_t*)dst, (const bf16_t*)src, n);
     else return MMSUM_ERR_BAD_DTYPE;
     return ok();
+}
+
+extern "C" int mmsum_set_dropout_salt(const void* dev_u64) {
+    g_dropout_salt = static_cast<const uint64_t*>(dev_u64);
+    return MMSUM_OK;
+}
+
+extern "C" int mmsum_bump_u64(void* dev_u64, unsigned long long inc, void* stream) {
+    if (dev_u64 == nullptr || (((uintptr_t)dev_u64) & 7)) return MMSUM_ERR_BAD_ALIGN;
+    bump_u64_kernel<<<dim3(1), dim3(1), 0, (hipStream_t)stream>>>(static_cast<uint64_t*>(dev_u64), (uint64_t)inc);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }

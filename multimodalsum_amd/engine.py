@@ -122,9 +122,17 @@ class Engine:
         if with_img:
             live, frozen, bufs = resnet_specs(cfg.d_model)
             specs += live
+            # BatchNorm step counters live in one vector (layers the hot path runs first) so that a forward bumps
+            # them with one launch instead of one per layer
+            nbt = [n for n, _ in bufs if n.endswith("num_batches_tracked")]
+            nbt.sort(key=lambda n: ".layer4." in n)
+            self._nbt_all = torch.zeros(len(nbt), dtype=torch.int64, device=self.device)
+            self._nbt_live = sum(1 for n in nbt if ".layer4." not in n)
+            for i, n in enumerate(nbt):
+                self.buffers[n] = self._nbt_all[i]
             for name, shape in bufs:
                 if name.endswith("num_batches_tracked"):
-                    self.buffers[name] = torch.zeros((), dtype=torch.int64, device=self.device)
+                    continue
                 else:
                     self.buffers[name] = (torch.ones if name.endswith("running_var") else torch.zeros)(shape, device=self.device)
         self.frozen_names = [n for n, _ in frozen]
@@ -658,7 +666,6 @@ class Engine:
         training = self.training
         if training:
             kn.bn_reduce(x, c.sums)
-            self.buffers[name + ".num_batches_tracked"] += 1
         kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, self.buffers[name + ".running_mean"],
                     self.buffers[name + ".running_var"], 1e-5, 0.1, relu, training)
         return c.y, c
@@ -688,6 +695,8 @@ class Engine:
         c = NS(n=n, blocks=[])
         x = self.empty(n * Hh * Ww, 3)
         kn.nchw_to_nhwc(img.contiguous(), x, n, 3, Hh, Ww)
+        if self.training:
+            self._nbt_all[:self._nbt_live] += 1          # BatchNorm num_batches_tracked of every layer this pass runs
         Ho, Wo = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
         wm = self.conv_mats[r + "conv1.weight"]
         col = self.empty(n * Ho * Wo, wm.shape[1])

@@ -1,0 +1,130 @@
+"""HIP-graph replay of the fused training step.
+
+The fused step is ~2,600 kernel launches of 10-300 us each; issued one by one from Python it is only as fast as
+the host can issue them, and on a slow or busy host the GPU idles between kernels.  The step's launch sequence
+is static for given batch shapes, so it is captured once into HIP graphs (torch.cuda.CUDAGraph is a thin wrapper
+over hipGraph) and replayed:
+
+  forward  : one graph  (salt bump, encoders, leave-one-out decoder, LM head + loss)
+  backward : one graph per gradient segment (decoder | image+table encoders | text encoder + embeddings), so the
+             data-parallel all-reduce of a finished segment (parallel.DistributedDataParallel) still overlaps the
+             next segment's kernels -- the collectives stay outside the graphs, on their own stream.
+
+What stays eager: weight shadow refresh (engine.sync_weights), gradient-buffer preparation, clipping and the
+optimiser (a handful of launches whose scalars -- lr, bias corrections -- change every step).
+
+Dropout: a captured graph replays the seed arguments it was captured with; the kernels mix in a device-resident
+salt that the forward graph bumps first (include/mmsum_hip.h: mmsum_set_dropout_salt), so every replay draws
+fresh masks and the backward graphs of the same step see the same ones.
+
+Shapes: one set of graphs per distinct (input shapes, dtypes, training flag); the first call with new shapes runs
+eagerly (warm-up), the second captures, later ones replay.
+"""
+import torch
+
+from . import kernels as kn
+from ._lib import check, lib
+
+
+def _flatten(batch):
+    flat, spec = [], []
+    for x in batch:
+        if isinstance(x, (list, tuple)):
+            spec.append(len(x))
+            flat.extend(x)
+        else:
+            spec.append(None)
+            flat.append(x)
+    return flat, spec
+
+
+def _unflatten(flat, spec):
+    out, i = [], 0
+    for n in spec:
+        if n is None:
+            out.append(flat[i])
+            i += 1
+        else:
+            out.append(list(flat[i:i + n]))
+            i += n
+    return tuple(out)
+
+
+class _Entry:
+    __slots__ = ("state", "static", "fwd", "bwd", "saved")
+
+    def __init__(self):
+        self.state, self.static, self.fwd, self.bwd, self.saved = 0, None, None, [], None
+
+
+class StepGraphs:
+    """Owned by a step module (MultimodalSum / TextSupervised); used by modules._StepFn."""
+
+    def __init__(self, model, max_shapes=8):
+        self.model = model
+        self.engine = model._engine
+        self.entries = {}
+        self.pool = None
+        self.max_shapes = max_shapes
+        self.salt = torch.zeros(1, dtype=torch.int64, device=self.engine.device)
+
+    def _key(self, flat):
+        e = self.engine
+        return tuple((tuple(t.shape), t.dtype) for t in flat) + (e.training, e.p_drop())
+
+    def forward(self, batch):
+        """Returns the entry whose .saved holds this step's forward state, or None (caller runs eagerly)."""
+        flat, spec = _flatten(batch)
+        if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in flat):
+            return None
+        key = self._key(flat)
+        ent = self.entries.get(key)
+        if ent is None:
+            if len(self.entries) >= self.max_shapes:
+                return None                      # too many distinct shapes: stay eager rather than hoard graph memory
+            self.entries[key] = _Entry()
+            return None                          # first sight of these shapes: eager warm-up
+        if ent.state == 0:
+            self._capture(ent, flat, spec)
+        else:
+            for dst, src in zip(ent.static, flat):
+                if dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+        ent.fwd.replay()
+        return ent
+
+    def _capture(self, ent, flat, spec):
+        e, m = self.engine, self.model
+        ent.static = [t.clone() for t in flat]
+        torch.cuda.synchronize()
+        check(lib.mmsum_set_dropout_salt(self.salt.data_ptr()), "mmsum_set_dropout_salt")
+        try:
+            ent.fwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ent.fwd, pool=self.pool):
+                check(lib.mmsum_bump_u64(self.salt.data_ptr(), 1, kn._stream()), "mmsum_bump_u64")
+                ent.saved = m._step_fwd(*_unflatten(ent.static, spec))
+            if self.pool is None:
+                self.pool = ent.fwd.pool()
+            # the backward graphs are captured here too (capture records, it does not execute): autograd would
+            # otherwise run the capture on its worker thread
+            keep_touched, keep_cache = e.touched, e._tcache
+            e._tcache = {}
+            for fn, prefixes in m._step_bwd_segments(ent.saved, release=False):
+                e.touched = set()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool):
+                    fn()
+                ent.bwd.append((g, frozenset(e.touched), prefixes))
+            e.touched, e._tcache = keep_touched, keep_cache
+        finally:
+            check(lib.mmsum_set_dropout_salt(None), "mmsum_set_dropout_salt")
+        ent.state = 1
+
+    def backward(self, ent, begin_backward, end_backward):
+        e = self.engine
+        begin_backward(e)
+        for g, touched, prefixes in ent.bwd:
+            g.replay()
+            e.touched = set(touched)
+            end_backward(e)
+            e.segment_ready(prefixes)

@@ -355,17 +355,42 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, batch):
         ctx.model = model
+        graphs = getattr(model, "_step_graphs", None)
+        ctx.entry = graphs.forward(batch) if (graphs is not None and model._engine.training) else None
+        if ctx.entry is not None:
+            ctx.saved = None
+            return ctx.entry.saved.loss.reshape(()).clone()      # the graph's loss buffer is overwritten by the next replay
         ctx.saved = model._step_fwd(*batch)
         return ctx.saved.loss.reshape(())
 
     @staticmethod
     def backward(ctx, dloss):
         # the fused step assumes loss.backward() with unit upstream gradient (multimodal_train.py:360)
-        ctx.model._step_bwd(ctx.saved)
+        if ctx.entry is not None:
+            ctx.model._step_graphs.backward(ctx.entry, _begin_backward, _end_backward)
+        else:
+            ctx.model._step_bwd(ctx.saved)
         return None, None, None
 
 
-class MultimodalSum(nn.Module):
+def _run_segments(engine, segments):
+    _begin_backward(engine)
+    for fn, prefixes in segments:
+        fn()
+        _end_backward(engine)
+        engine.segment_ready(prefixes)
+
+
+class _StepGraphMixin:
+    """enable_step_graphs(): replay the fused step from captured HIP graphs (graphs.StepGraphs)."""
+
+    def enable_step_graphs(self, enabled=True, max_shapes=8):
+        from .graphs import StepGraphs
+        object.__setattr__(self, "_step_graphs", StepGraphs(self, max_shapes) if enabled else None)
+        return self
+
+
+class MultimodalSum(_StepGraphMixin, nn.Module):
     """MultimodalSum(bart_pretrained, table_pretrained, img_pretrained, TableEncoder)  (multimodal_train.py:111-122).
 
     forward(reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask) -> (loss,)
@@ -445,25 +470,33 @@ class MultimodalSum(nn.Module):
         s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
         return s
 
-    def _step_bwd(self, s):
+    def _step_bwd_segments(self, s, release=True):
+        """The backward schedule as (callable, finished-parameter prefixes) segments, in execution order."""
         e = self._engine
-        _begin_backward(e)
         o1, o2 = s.layout.offs[1], s.layout.offs[2]
-        dh = e.lm_head_bwd(s.hL, s.dlogits)
-        s.dlogits = None
-        dmem = e.decoder_bwd(s.dec, dh)
-        _end_backward(e)
-        e.segment_ready([e.bp + "model.decoder."])
-        e.img_bwd(s.img, dmem[o2:])
-        e.table_bwd(s.tab, dmem[o1:o2])
-        _end_backward(e)
-        e.segment_ready(["img_encoder.", "table_encoder."])
-        e.encoder_bwd(s.enc, dmem[:o1])
-        _end_backward(e)
-        e.segment_ready([e.bp + "model.encoder.", e.bp + "model.shared."])
+        st = {}
+
+        def decoder():
+            dh = e.lm_head_bwd(s.hL, s.dlogits)
+            if release:
+                s.dlogits = None
+            st["dmem"] = e.decoder_bwd(s.dec, dh)
+
+        def side_encoders():
+            e.img_bwd(s.img, st["dmem"][o2:])
+            e.table_bwd(s.tab, st["dmem"][o1:o2])
+
+        def text_encoder():
+            e.encoder_bwd(s.enc, st["dmem"][:o1])
+
+        return [(decoder, [e.bp + "model.decoder."]), (side_encoders, ["img_encoder.", "table_encoder."]),
+                (text_encoder, [e.bp + "model.encoder.", e.bp + "model.shared."])]
+
+    def _step_bwd(self, s):
+        _run_segments(self._engine, self._step_bwd_segments(s))
 
 
-class TextSupervised(nn.Module):
+class TextSupervised(_StepGraphMixin, nn.Module):
     """TextSupervised (text_pretrain.py:66-113): text-only leave-one-out step, fused the same way."""
 
     def __init__(self, bart_pretrained=None, config="cfg/bart-large.json", label_smoothing=None, device="cuda",
@@ -505,17 +538,23 @@ class TextSupervised(nn.Module):
         s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(s.hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
         return s
 
-    def _step_bwd(self, s):
+    def _step_bwd_segments(self, s, release=True):
         e = self._engine
-        _begin_backward(e)
-        dh = e.lm_head_bwd(s.hL, s.dlogits)
-        s.dlogits = None
-        dmem = e.decoder_bwd(s.dec, dh)
-        _end_backward(e)
-        e.segment_ready([e.bp + "model.decoder."])
-        e.encoder_bwd(s.enc, dmem)
-        _end_backward(e)
-        e.segment_ready([e.bp + "model.encoder.", e.bp + "model.shared."])
+        st = {}
+
+        def decoder():
+            dh = e.lm_head_bwd(s.hL, s.dlogits)
+            if release:
+                s.dlogits = None
+            st["dmem"] = e.decoder_bwd(s.dec, dh)
+
+        def text_encoder():
+            e.encoder_bwd(s.enc, st["dmem"])
+
+        return [(decoder, [e.bp + "model.decoder."]), (text_encoder, [e.bp + "model.encoder.", e.bp + "model.shared."])]
+
+    def _step_bwd(self, s):
+        _run_segments(self._engine, self._step_bwd_segments(s))
 
 
 class _LossFn(torch.autograd.Function):
