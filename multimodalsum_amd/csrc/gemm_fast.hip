@@ -264,14 +264,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_glds_kernel(Gem
 //                 (that slot was last read in iteration s-1, which every wave finished before this
 //                 barrier) ; MFMAs of slab s.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE_ = 4>
 struct RingCfg {
     static constexpr int NW = WAVES_M * WAVES_N;
     static constexpr int THREADS = NW * 64;
     static constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     static constexpr int A_BYTES = BM * SLAB_BYTES, B_BYTES = BN * SLAB_BYTES;
     static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int NSTAGE = 4;
+    static constexpr int NSTAGE = NSTAGE_;
     static constexpr int PA = BM / 16, PB = BN / 16;
     static constexpr int PPW = (PA + PB) / NW;                    // DMA instructions per wave per slab
     static_assert(PA % NW == 0 && PB % NW == 0, "pieces must split evenly over the waves");
@@ -279,9 +279,9 @@ struct RingCfg {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(GemmArgs p) {
-    using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N>;
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_ring_kernel(GemmArgs p) {
+    using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
     // one slab piece: 16 rows x 64 B; lane -> (row = lane>>2, physical chunk = lane&3)
     const int prow = lane >> 2;
     auto issue = [&](int si) {          // si: slab index relative to s_beg
-        char* As = smem + (si & 3) * Cfg::STAGE;
+        char* As = smem + (si % NSTAGE) * Cfg::STAGE;
         char* Bs = As + Cfg::A_BYTES;
         int k0 = (s_beg + si) * 32;
         const int kb = k0;
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             if (si + 3 < ns) issue(si + 3);
-            const char* As = smem + (si & 3) * Cfg::STAGE;
+            const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
             const char* Bs = As + Cfg::A_BYTES;
             Frag b[Cfg::TN];
 #pragma unroll
@@ -543,20 +543,20 @@ int launch_tn_cfg(const GemmArgs& a, hipStream_t stream) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
     static const bool use_ring = !(getenv("MMSUM_GEMM_RING") && atoi(getenv("MMSUM_GEMM_RING")) == 0);
-    if (use_ring) {
-        using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
+    if (use_ring || NSTAGE != 4) {
+        using R = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
         const int tiles_r = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
         const size_t lds_r = R::NSTAGE * R::STAGE;
         static bool once_r = false;
         if (!once_r) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
             once_r = true;
         }
-        gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT><<<dim3(tiles_r * a.splitk), dim3(R::THREADS), lds_r, stream>>>(a);
+        gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU><<<dim3(tiles_r * a.splitk), dim3(R::THREADS), lds_r, stream>>>(a);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     }
     using Cfg = FastCfg<BM, BN, WAVES_M, WAVES_N>;
@@ -572,10 +572,10 @@ int launch_one(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE = 4, int MIN_WAVES_EU = 1>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
-#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O>(a, stream);
+#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O, NSTAGE, MIN_WAVES_EU>(a, stream);
     FAST_CASE(MMSUM_EPI_NONE, OUT_T) FAST_CASE(MMSUM_EPI_NONE, OUT_T_ACC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
     FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32)
     FAST_CASE(MMSUM_EPI_GELU, OUT_T) FAST_CASE(MMSUM_EPI_GELU_BWD, OUT_T) FAST_CASE(MMSUM_EPI_RELU, OUT_T) FAST_CASE(MMSUM_EPI_RELU_BWD, OUT_T)

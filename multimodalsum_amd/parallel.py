@@ -26,7 +26,8 @@ def reduce_tensor(tensor, world_size):
 
 
 class DistributedDataParallel(nn.Module):
-    def __init__(self, module, delay_allreduce=True, bucket_elems=64 * 1024 * 1024, overlap=True, process_group=None):
+    def __init__(self, module, delay_allreduce=True, bucket_elems=64 * 1024 * 1024, overlap=True, process_group=None,
+                 always_reduce=False):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -38,7 +39,7 @@ class DistributedDataParallel(nn.Module):
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
         self._done = set()
         self._pending = []
-        if self.world_size > 1:
+        if self.world_size > 1 or (always_reduce and dist.is_initialized()):      # always_reduce: exercise the path at world size 1
             dist.broadcast(self.arena.data, 0, group=self.group)          # C2: parameters from rank 0
             for b in self.engine.buffers.values():
                 if b.is_floating_point():
