@@ -627,8 +627,11 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
         float m, l;
         scores_softmax2<T, NKB, CAUSAL>(p, ktile, SPAD, qf, biasf, d.S, d.scale, qpos, wave, lane, fo, m, l);
         const float invl = (l > 0.f) ? 1.f / l : 0.f;
-        // dP^T = V dO^T is computed TWICE (delta pass, then dS pass) instead of being kept for all key blocks: the
-        // matrix pipe is mostly idle here and 48 fewer live registers buy a second resident workgroup per CU.
+        // dP^T = V dO^T.  With two resident workgroups per CU (NKB <= 2) the registers to keep it for all key blocks
+        // are not there, so it is computed twice (delta pass, then dS pass); the text entities (NKB 3..4, one
+        // workgroup per CU) keep it.
+        constexpr bool KEEP_DP = (sizeof(T) == 2 && NKB >= 3 && NKB <= 4);
+        f32x16_t dpkeep[KEEP_DP ? NKB : 1];
         float delta = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -644,6 +647,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
                     p[kb][r] *= invl;                 // normalised probability
                     delta += p[kb][r] * dpk[r];
                 }
+                if constexpr (KEEP_DP) dpkeep[kb] = dpk;
             }
         }
         delta = wave_half_sum(delta) * inv_cnt;       // dO_e = dO / count
@@ -655,11 +659,16 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
-                f32x16_t dpk = zero_acc();
+                f32x16_t dpk;
+                if constexpr (KEEP_DP) {
+                    dpk = dpkeep[kb];
+                } else {
+                    dpk = zero_acc();
 #pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-                    mma_slab<T>(dpk, a, dof[sl]);
+                    for (int sl = 0; sl < NS; ++sl) {
+                        const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                        mma_slab<T>(dpk, a, dof[sl]);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) dpk[r] = p[kb][r] * (dpk[r] * inv_cnt - delta) * d.scale;   // dS^T

@@ -36,14 +36,20 @@ struct FastCfg {
 // 8 consecutive columns per thread = one 16-byte store (two for f32 outputs), with the bias / GELU /
 // ReLU / accumulate work vectorised on the same 8 columns.
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                 char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr int CPR = BN / 8;                       // 8-column chunks per row
-    constexpr int CHUNKS = 32 * CPR;
-    float* stage = reinterpret_cast<float*>(smem);
+    constexpr int BAND = 32 * BN;                     // floats per staged 32-row band
+    constexpr int CHUNKS = WAVES_M * 32 * CPR;        // per pass: one band of every wave row
+    // pass i stages tile row i of EVERY wave row (WAVES_M bands side by side); with room for two sets of bands the
+    // passes alternate between them and one barrier per pass orders everything (the readers of a set are two
+    // barriers behind its next writers), otherwise a second barrier guards the reuse
+    constexpr int NSETS = (LDS_BYTES >= 2 * WAVES_M * BAND * 4) ? 2 : 1;
+    static_assert(LDS_BYTES >= WAVES_M * BAND * 4, "epilogue staging does not fit the kernel's LDS");
+    float* stage0 = reinterpret_cast<float*>(smem);
     const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
     bf16_t* Ct = static_cast<bf16_t*>(p.C);
     float* Cf = static_cast<float*>(p.C);
@@ -52,21 +58,18 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     const bool vec_ok = kF32Out ? ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 3) == 0)
                                 : ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 7) == 0);
     const bool aux_vec = aux != nullptr && ((((uintptr_t)p.aux) & 15) == 0) && ((p.ldaux & 7) == 0);
+    __syncthreads();                                  // every wave is done reading the operand stages
 #pragma unroll
-    for (int sb = 0; sb < BM / 32; ++sb) {
-        __syncthreads();
-        if (wm == sb / TM) {
-            const int i = sb % TM;
+    for (int i = 0; i < TM; ++i) {
+        float* set = stage0 + (NSETS == 2 ? (i & 1) * (WAVES_M * BAND) : 0);
+        if (NSETS == 1 && i > 0) __syncthreads();
+        {
+            float* stage = set + wm * BAND;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = wn * (TN * 32) + j * 32 + (lane & 31);
 #pragma unroll
-                for (int ii = 0; ii < TM; ++ii) {
-                    if (ii == i) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * BN + col] = acc[ii][j][r];
-                    }
-                }
+                for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * BN + col] = acc[i][j][r];
             }
         }
         __syncthreads();
@@ -74,8 +77,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
         for (int it = 0; it < (CHUNKS + THREADS - 1) / THREADS; ++it) {
             const int c = tid + it * THREADS;
             if (c >= CHUNKS) break;
-            const int lr = c / CPR, cc = (c % CPR) * 8;
-            const int row = m0 + sb * 32 + lr, col = n0 + cc;
+            const int wr = c / (32 * CPR), lr = (c / CPR) % 32, cc = (c % CPR) * 8;
+            const float* stage = set + wr * BAND;
+            const int row = m0 + wr * (TM * 32) + i * 32 + lr, col = n0 + cc;
             if (row >= p.M || col >= p.N) continue;
             float v[8];
             {
@@ -277,6 +281,16 @@ struct RingCfg {
     static_assert(PA % NW == 0 && PB % NW == 0, "pieces must split evenly over the waves");
 };
 
+inline int cu_count() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v & ~7;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
@@ -288,10 +302,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = tiles_m * tiles_n;
+    const int total = tiles * p.splitk;
+    void* const C0 = p.C;
+    // persistent: a workgroup walks virtual ids blockIdx.x, +gridDim.x, ... (the grid is a multiple of 8, so every id
+    // of a workgroup lands on its own XCD's chunk of the tile order)
+    for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
+    const int wg = xcd_remap(vid, total);
     const int ks = wg / tiles;
-    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
+    p.C = (p.flags & MMSUM_GEMM_SLABS) ? static_cast<void*>(static_cast<float*>(C0) + (long)ks * p.M * p.ldc) : C0;
     const int t = wg % tiles;
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);
@@ -372,9 +391,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
         // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
         gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+    }
+    __syncthreads();          // the staging reads are done before the next tile's DMA lands in the same LDS
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // "TN" ring kernel: C[m][n] = sum_k A[k][m] * B[k][n] with BOTH operands reduction-major (A [K,M],
@@ -556,7 +578,12 @@ int launch_one(const GemmArgs& a, hipStream_t stream) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
             once_r = true;
         }
-        gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU><<<dim3(tiles_r * a.splitk), dim3(R::THREADS), lds_r, stream>>>(a);
+        // persistent workgroups: one per CU walks the tile list (measured +0..8 % on multi-round shapes: no relaunch
+        // between a CU's tiles); MMSUM_GEMM_PERSIST=0 restores one workgroup per tile
+        static const int persist = getenv("MMSUM_GEMM_PERSIST") ? atoi(getenv("MMSUM_GEMM_PERSIST")) : cu_count();
+        int grid = tiles_r * a.splitk;
+        if (persist > 0 && grid > persist) grid = persist;
+        gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     }
     using Cfg = FastCfg<BM, BN, WAVES_M, WAVES_N>;
