@@ -1,0 +1,155 @@
+"""CPU restatement of the reference's beam-search generation (TEST INFRASTRUCTURE ONLY).
+
+Follows BartForMultiEncConditionalGeneration.generate / _generate_beam_search
+(/root/reference/src/transformer/modeling_multimodalsum.py:2295-2693, 2803-3067), the score post-processing
+and n-gram ban of /root/reference/src/transformer/generation_utils.py:57-98, 848-868, BeamHypotheses
+(:948-993) and the logits adjustment (:3084-3102), for the greedy (do_sample=False) beam-search branch that
+`src/test.py:156-158` uses.  The reference decodes one token at a time with cached keys/values; the cached step is
+algebraically the last row of a causal decoder pass over the whole prefix, which is what this restatement runs
+(bart_oracle.bart_decoder), so no cache logic is needed here.
+
+Pinned by tests/golden/g1_beam.npz (token ids produced by the reference itself, oracle/make_golden.py).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this package.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import bart_oracle as bo
+
+
+class Hypotheses:
+    """n-best list of finished hypotheses of one batch entry (generation_utils.py:948-993)."""
+
+    def __init__(self, num_beams, max_length, length_penalty, early_stopping):
+        self.num_beams, self.length_penalty, self.early_stopping = num_beams, length_penalty, early_stopping
+        self.max_length = max_length - 1
+        self.items = []                      # (score, tokens)
+        self.worst = 1e9
+
+    def __len__(self):
+        return len(self.items)
+
+    def add(self, tokens, sum_logprobs):
+        score = sum_logprobs / len(tokens) ** self.length_penalty
+        if len(self.items) < self.num_beams or score > self.worst:
+            self.items.append((score, tokens))
+            if len(self.items) > self.num_beams:
+                order = sorted((s, i) for i, (s, _) in enumerate(self.items))
+                del self.items[order[0][1]]
+                self.worst = order[1][0]
+            else:
+                self.worst = min(score, self.worst)
+
+    def is_done(self, best_sum_logprobs, cur_len):
+        if len(self.items) < self.num_beams:
+            return False
+        if self.early_stopping:
+            return True
+        return self.worst >= best_sum_logprobs / cur_len ** self.length_penalty
+
+
+def banned_ngram_tokens(rows, n, cur_len):
+    """Tokens that would complete an n-gram already present in the hypothesis (generation_utils.py:848-868)."""
+    if cur_len + 1 < n:
+        return [[] for _ in rows]
+    out = []
+    for toks in rows:
+        seen = {}
+        for i in range(len(toks) - n + 1):
+            seen.setdefault(tuple(toks[i:i + n - 1]), []).append(toks[i + n - 1])
+        out.append(seen.get(tuple(toks[cur_len + 1 - n:cur_len]), []))
+    return out
+
+
+def next_token_logits(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, prefix):
+    """Logits of the next token for every hypothesis row: last row of a causal pass over the prefix."""
+    T = input_ids.shape[1]
+    causal = torch.triu(torch.full((T, T), float("-inf")), 1)
+    h = bo.bart_decoder(sd, cfg, input_ids, hiddens, masks, None, causal, rating_diff, multimodal, False, prefix)
+    return F.linear(h[:, -1, :], sd[prefix + "model.shared.weight"])
+
+
+def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max_length, min_length=0,
+                no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.0, decoder_start_token_id=None, prefix=""):
+    """hiddens/masks: list of [B,N,S,D] / [B,N,S] (multimodal) or single tensors.  Returns LongTensor [B, L]."""
+    pad, bos, eos, V = cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id, cfg.vocab_size
+    start = bos if decoder_start_token_id is None else decoder_start_token_id
+    first = hiddens[0] if multimodal else hiddens
+    B = first.shape[0]
+    rep = lambda t: None if t is None else t.repeat_interleave(num_beams, dim=0)      # noqa: E731  (:2599-2627)
+    if multimodal:
+        hid, msk = [rep(h) for h in hiddens], [rep(m) for m in masks]
+    else:
+        hid, msk = rep(hiddens), rep(masks)
+    rd = rep(rating_diff)
+    input_ids = torch.full((B * num_beams, 1), start, dtype=torch.long)
+    hyps = [Hypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
+    beam_scores = torch.zeros(B, num_beams)
+    beam_scores[:, 1:] = -1e9                                                          # (:2848-2850)
+    beam_scores = beam_scores.view(-1)
+    done = [False] * B
+    cur_len = 1
+    next_scores = next_tokens = None
+    while cur_len < max_length:
+        logits = next_token_logits(sd, cfg, input_ids, hid, msk, rd, multimodal, prefix)
+        if cur_len == 1:                                                               # (:3084-3102)
+            keep = logits[:, bos].clone()
+            logits.fill_(float("-inf"))
+            logits[:, bos] = keep
+        if cur_len == max_length - 1 and eos is not None:
+            keep = logits[:, eos].clone()
+            logits.fill_(float("-inf"))
+            logits[:, eos] = keep
+        scores = F.log_softmax(logits, dim=-1)
+        if eos is not None and cur_len < min_length:
+            scores[:, eos] = float("-inf")
+        if no_repeat_ngram_size > 0:
+            for i, banned in enumerate(banned_ngram_tokens(input_ids.tolist(), no_repeat_ngram_size, cur_len)):
+                scores[i, banned] = float("-inf")
+        cand = (scores + beam_scores[:, None]).view(B, num_beams * V)
+        next_scores, next_tokens = torch.topk(cand, 2 * num_beams, dim=1, largest=True, sorted=True)
+        nxt = []
+        for b in range(B):
+            if done[b]:
+                nxt.extend([(0.0, pad, 0)] * num_beams)
+                continue
+            sent = []
+            for rank, (tok_id, sc) in enumerate(zip(next_tokens[b].tolist(), next_scores[b].tolist())):
+                beam, tok = tok_id // V, tok_id % V
+                row = b * num_beams + beam
+                if eos is not None and tok == eos:
+                    if rank >= num_beams:
+                        continue
+                    hyps[b].add(input_ids[row].clone(), sc)
+                else:
+                    sent.append((sc, tok, row))
+                if len(sent) == num_beams:
+                    break
+            done[b] = done[b] or hyps[b].is_done(next_scores[b].max().item(), cur_len)
+            assert len(sent) == num_beams
+            nxt.extend(sent)
+        if all(done):
+            break
+        beam_scores = torch.tensor([x[0] for x in nxt], dtype=torch.float32)
+        beam_tokens = torch.tensor([x[1] for x in nxt], dtype=torch.long)
+        beam_idx = torch.tensor([x[2] for x in nxt], dtype=torch.long)
+        input_ids = torch.cat([input_ids[beam_idx], beam_tokens[:, None]], dim=1)
+        cur_len += 1
+        # every hypothesis row of a batch entry shares its encoder tensors: reordering them is a no-op
+    for b in range(B):
+        if done[b]:
+            continue
+        for beam in range(num_beams):
+            row = b * num_beams + beam
+            hyps[b].add(input_ids[row], beam_scores[row].item())
+    best = [sorted(h.items, key=lambda x: x[0])[-1][1] for h in hyps]
+    lens = [len(t) for t in best]
+    if min(lens) != max(lens):
+        L = min(max(lens) + 1, max_length)
+        out = torch.full((B, L), pad, dtype=torch.long)
+        for i, t in enumerate(best):
+            out[i, :lens[i]] = t
+            if lens[i] < max_length:
+                out[i, lens[i]] = eos
+        return out
+    return torch.stack(best).long()

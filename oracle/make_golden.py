@@ -198,6 +198,19 @@ def main():
         rating_diff=rating_diff, enc_out=enc_out, logits=logits, loss=loss, g_table_h=table_h.grad,
         g_img_h=img_h.grad, **gsel)
 
+    # ---- G1: beam-search generation with the same tiny model (test.py:153-158 call shape) -----------------------
+    model.eval()
+    with torch.no_grad():
+        enc_eval = model.model.encoder(input_ids=ids.view(-1, S), attention_mask=ids.view(-1, S).ne(1))[0].view(Bz, N, S, -1)
+        zeros = torch.zeros(Bz, 1)
+        gen_a = model.generate(enc_eval, text_m, table_h.detach(), table_m, img_h.detach(), img_m, rating_diff=zeros, num_beams=4,
+                               length_penalty=1.0, max_length=14, no_repeat_ngram_size=3, early_stopping=True)
+        gen_b = model.generate(enc_eval, text_m, table_h.detach(), table_m, img_h.detach(), img_m, rating_diff=rating_diff, num_beams=2,
+                               length_penalty=2.0, max_length=10, min_length=4, no_repeat_ngram_size=2, early_stopping=False)
+    npz(G("g1_beam.npz"), ids=ids, text_m=text_m, table_m=table_m, img_m=img_m, rating_diff=rating_diff, enc_eval=enc_eval,
+        gen_a=gen_a, gen_b=gen_b)
+    model.train()
+
     # text-only variant (BartForEncConditionalGeneration) on the same weights ------------------
     tmodel = mm.BartForEncConditionalGeneration(cfg)
     load_formula(tmodel, prefix="f2.", std=0.08)

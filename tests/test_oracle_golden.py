@@ -117,6 +117,28 @@ def test_f2_decoder_pass(golden_dir):
             _close(sd[name].grad, g[k], **TOL)
 
 
+def test_g1_beam_search(golden_dir):
+    """Beam-search restatement (oracle/generate_oracle.py) against token ids produced by the reference's own
+    generate() on the F2 model: the test.py call shape (4 beams, 3-gram ban, early stopping) and a variant with
+    min_length, length penalty 2, 2-gram ban and the non-early-stopping is_done branch."""
+    from oracle import generate_oracle as go
+    g = _load(golden_dir, "f2_decoder.npz")
+    gg = _load(golden_dir, "g1_beam.npz")
+    cfg, sd, table_h, img_h = f2_setup(g)
+    ids = gg["ids"]
+    Bz, N, S = ids.shape
+    with torch.no_grad():
+        enc = bo.bart_encoder(sd, cfg, ids.view(-1, S), ids.view(-1, S).ne(1), prefix="f2.").view(Bz, N, S, -1)
+        _close(enc, gg["enc_eval"], **TOL)
+        hid, msk = [enc, table_h, img_h], [gg["text_m"], gg["table_m"], gg["img_m"]]
+        a = go.beam_search(sd, cfg, hid, msk, torch.zeros(Bz, 1), True, num_beams=4, max_length=14, no_repeat_ngram_size=3,
+                           early_stopping=True, length_penalty=1.0, prefix="f2.")
+        b = go.beam_search(sd, cfg, hid, msk, gg["rating_diff"], True, num_beams=2, max_length=10, min_length=4,
+                           no_repeat_ngram_size=2, early_stopping=False, length_penalty=2.0, prefix="f2.")
+    assert torch.equal(a, gg["gen_a"]), (a, gg["gen_a"])
+    assert torch.equal(b, gg["gen_b"]), (b, gg["gen_b"])
+
+
 def test_f2_text_only(golden_dir):
     g = _load(golden_dir, "f2_decoder.npz")
     gt = _load(golden_dir, "f2_textonly.npz")
