@@ -9,7 +9,8 @@ class BartConfig:
                  dropout=0.1, attention_dropout=0.0, activation_dropout=0.0, activation_function="gelu", init_std=0.02,
                  pad_token_id=1, bos_token_id=0, eos_token_id=2, decoder_start_token_id=2, extra_pos_embeddings=2,
                  normalize_before=False, normalize_embedding=True, scale_embedding=False,
-                 static_position_embeddings=False, add_final_layer_norm=False, **unused):
+                 static_position_embeddings=False, add_final_layer_norm=False, max_length=20, min_length=0, num_beams=1,
+                 early_stopping=False, length_penalty=1.0, no_repeat_ngram_size=0, **unused):
         self.vocab_size = vocab_size
         self.d_model = d_model
         self.encoder_ffn_dim = encoder_ffn_dim
@@ -34,6 +35,9 @@ class BartConfig:
         self.scale_embedding = scale_embedding
         self.static_position_embeddings = static_position_embeddings
         self.add_final_layer_norm = add_final_layer_norm
+        # generation defaults (transformers PretrainedConfig defaults; generate() arguments override them)
+        self.max_length, self.min_length, self.num_beams = max_length, min_length, num_beams
+        self.early_stopping, self.length_penalty, self.no_repeat_ngram_size = early_stopping, length_penalty, no_repeat_ngram_size
         self.validate()
 
     def validate(self):

@@ -256,7 +256,8 @@ class _BartBase(nn.Module):
         _new_forward(e)
         cfg = self.config
         if labels is None:
-            raise NotImplementedError("generation (use_cache) path: SURVEY.md section 8f rank 1, not built yet")
+            raise NotImplementedError("single cached decoder steps are driven by generate() (multimodalsum_amd/generation.py); "
+                                      "forward() implements the labels (training / scoring) path")
         if decoder_input_ids is None:
             decoder_input_ids = shift_tokens_right_batched(labels, labels[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id)
         if decoder_attention_mask is None:
@@ -269,8 +270,53 @@ class _BartBase(nn.Module):
         return _DecoderLogitsFn.apply(_anchor(e), e, decoder_input_ids, dec_pad, rd, pads, 1, False, *hs)
 
 
+    @torch.no_grad()
+    def _generate(self, hiddens, masks, rating_diff, input_ids=None, max_length=None, min_length=None, do_sample=None,
+                  early_stopping=None, num_beams=None, temperature=None, top_k=None, top_p=None, repetition_penalty=None,
+                  bad_words_ids=None, bos_token_id=None, pad_token_id=None, eos_token_id=None, length_penalty=None,
+                  no_repeat_ngram_size=None, num_return_sequences=None, decoder_start_token_id=None, use_cache=None, **unused):
+        """generate() of the reference (modeling_multimodalsum.py:2295-2693 / :1398-1700): greedy beam search as
+        test.py:156-158 calls it.  Sampling, repetition penalty, bad-word lists, prompts and num_beams == 1 are
+        not part of the scoped path and raise."""
+        from .generation import beam_search
+        cfg, e = self.config, self._engine
+        pick = lambda v, d: d if v is None else v                                    # noqa: E731
+        max_length, min_length = pick(max_length, cfg.max_length), pick(min_length, cfg.min_length)
+        num_beams, early_stopping = pick(num_beams, cfg.num_beams), pick(early_stopping, cfg.early_stopping)
+        length_penalty = pick(length_penalty, cfg.length_penalty)
+        no_repeat_ngram_size = pick(no_repeat_ngram_size, cfg.no_repeat_ngram_size)
+        start = pick(decoder_start_token_id, cfg.decoder_start_token_id)
+        start = cfg.bos_token_id if start is None else start
+        if do_sample or (repetition_penalty not in (None, 1.0)) or bad_words_ids or input_ids is not None \
+                or (num_return_sequences not in (None, 1)) or num_beams < 2:
+            raise NotImplementedError("generate(): only greedy beam search (num_beams >= 2, one returned sequence, no prompt, "
+                                      "no sampling / repetition penalty / bad words) is built")
+        assert max_length > 1 and min_length >= 0 and length_penalty > 0 and no_repeat_ngram_size >= 0
+        was_training = e.training
+        e.training = False
+        try:
+            _new_forward(e)
+            D = cfg.d_model
+            B = hiddens[0].shape[0]
+            layout = e.make_memory(B, [(h.shape[1], h.shape[2]) for h in hiddens])
+            mem = e.empty(layout.rows, D)
+            for m, h in enumerate(hiddens):
+                n = h.shape[0] * h.shape[1] * h.shape[2]
+                mem[layout.offs[m]:layout.offs[m] + n].copy_(h.reshape(n, D))
+            pads = [m.eq(0).to(torch.uint8).contiguous() for m in masks]
+            return beam_search(e, mem, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size,
+                               bool(early_stopping), float(length_penalty), int(start))
+        finally:
+            e.training = was_training
+
+
 class BartForMultiEncConditionalGeneration(_BartBase):
     multimodal = True
+
+    def generate(self, text_hiddens, text_attention_mask, table_hiddens, table_attention_mask, img_hiddens, img_attention_mask,
+                 input_ids=None, rating_diff=None, **kw):
+        return self._generate([text_hiddens, table_hiddens, img_hiddens], [text_attention_mask, table_attention_mask, img_attention_mask],
+                              rating_diff, input_ids=input_ids, **kw)
 
     def forward(self, text_hiddens, text_attention_mask, table_hiddens, table_attention_mask, img_hiddens, img_attention_mask,
                 rating_diff=None, decoder_input_ids=None, decoder_attention_mask=None, decoder_past_key_values=None, labels=None,
@@ -283,6 +329,11 @@ class BartForMultiEncConditionalGeneration(_BartBase):
 
 class BartForEncConditionalGeneration(_BartBase):
     multimodal = False
+
+    def generate(self, encoder_hiddens, attention_mask=None, input_ids=None, rating_diff=None, **kw):
+        if attention_mask is None:
+            attention_mask = torch.ones(encoder_hiddens.shape[:3], dtype=torch.bool, device=encoder_hiddens.device)
+        return self._generate([encoder_hiddens], [attention_mask], rating_diff, input_ids=input_ids, **kw)
 
     def forward(self, encoder_hiddens, rating_diff=None, encoder_attention_mask=None, decoder_input_ids=None,
                 decoder_attention_mask=None, decoder_past_key_values=None, labels=None, use_cache=None, output_attentions=False,

@@ -380,11 +380,12 @@ def table_gather_bwd(dall, rating, hours, dw_rating, dw_hours, B, D):
 
 
 def install(monkeypatch):
-    """Route multimodalsum_amd.{engine,modules,optim}.kn to this module for the duration of a test."""
+    """Route multimodalsum_amd.{engine,modules,optim,generation}.kn to this module for the duration of a test."""
     import sys
     import multimodalsum_amd.engine as eng
     import multimodalsum_amd.modules as mods
     import multimodalsum_amd.optim as opt
+    import multimodalsum_amd.generation as gen
     me = sys.modules[__name__]
-    for m in (eng, mods, opt):
+    for m in (eng, mods, opt, gen):
         monkeypatch.setattr(m, "kn", me)

@@ -319,3 +319,49 @@ def test_single_modality_wrappers(monkeypatch):
     # scheduling mistake is an O(1) relative error on the parameters it touches
     assert rel_eng.median() <= 3 * rel_o32.median() + 1e-4, (rel_eng.median(), rel_o32.median())
     assert rel_eng.max() <= max(10 * rel_o32.max().item(), 1e-3), (rel_eng.max(), rel_o32.max())
+
+
+@pytest.mark.parametrize("case", ["test_py", "variant", "text_only"])
+def test_beam_search_host_logic(monkeypatch, case):
+    """generate(): the KV-cached decode schedule, cache append / reorder and the beam bookkeeping of
+    multimodalsum_amd/generation.py (through the kernel emulator) give the oracle's token ids."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration, BartForEncConditionalGeneration
+    from oracle import generate_oracle as go
+    multimodal = case != "text_only"
+    cfg = tiny_cfg(vocab=100, d=256, ffn=128, layers=2, heads=4, maxpos=64)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, multimodal, prefix=""), std=0.08)
+    cls = BartForMultiEncConditionalGeneration if multimodal else BartForEncConditionalGeneration
+    model = cls(cfg, device="cpu", dtype=torch.float32)
+    model.load_state_dict(sd, strict=False)
+    model.eval()
+    Bz, N, S = 3, 3, 8
+    ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
+    text_m = ids.ne(1).clone()
+    text_m[1, 2, :] = False
+    table_h = formula_tensor("t.table_h", (Bz, 1, 6, cfg.d_model), std=1.0)
+    img_h = formula_tensor("t.img_h", (Bz, 2, 4, cfg.d_model), std=1.0)
+    table_m = torch.ones(Bz, 1, 6, dtype=torch.bool)
+    table_m[1] = False
+    img_m = torch.ones(Bz, 2, 4, dtype=torch.bool)
+    img_m[0] = False
+    img_m[2, 1] = False
+    kw = dict(num_beams=4, max_length=14, no_repeat_ngram_size=3, early_stopping=True, length_penalty=1.0)
+    rd = torch.zeros(Bz, 1)
+    if case == "variant":
+        kw = dict(num_beams=2, max_length=10, min_length=4, no_repeat_ngram_size=2, early_stopping=False, length_penalty=2.0)
+        rd = torch.tensor([[0.5], [-1.25], [2.0]])
+    with torch.no_grad():
+        enc = model.model.encoder(input_ids=ids.view(-1, S), attention_mask=ids.view(-1, S).ne(1))[0].view(Bz, N, S, -1)
+        oenc = bo.bart_encoder(sd, ocfg, ids.view(-1, S), ids.view(-1, S).ne(1)).view(Bz, N, S, -1)
+        if multimodal:
+            out = model.generate(enc, text_m, table_h, table_m, img_h, img_m, rating_diff=rd, decoder_start_token_id=cfg.bos_token_id, **kw)
+            ref = go.beam_search(sd, ocfg, [oenc, table_h, img_h], [text_m, table_m, img_m], rd, True,
+                                 decoder_start_token_id=cfg.bos_token_id, **kw)
+        else:
+            out = model.generate(enc, text_m, rating_diff=rd, decoder_start_token_id=cfg.bos_token_id, **kw)
+            ref = go.beam_search(sd, ocfg, oenc, text_m, rd, False, decoder_start_token_id=cfg.bos_token_id, **kw)
+    assert torch.equal(out, ref), (out, ref)
+    with pytest.raises(NotImplementedError):
+        model.generate(*([enc, text_m, table_h, table_m, img_h, img_m] if multimodal else [enc, text_m]), num_beams=1, max_length=5)
