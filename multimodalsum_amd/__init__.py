@@ -9,3 +9,4 @@ from .modules import (BartForEncConditionalGeneration, BartForMultiEncConditiona
                       LabelSmoothingLoss, MultimodalSum, Resnet, TableSupervised, TextSupervised, YelpTableEncoder)
 from .optim import FusedAdamW, clip_grad_norm_, get_linear_schedule_with_warmup, get_optimizer  # noqa: F401
 from .parallel import DistributedDataParallel, reduce_tensor  # noqa: F401
+from .prefetch import amazon_data_prefetcher, data_prefetcher, yelp_data_prefetcher  # noqa: F401

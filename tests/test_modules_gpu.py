@@ -307,3 +307,25 @@ def test_beam_search_generation_token_ids(case):
             ref = go.beam_search(sd, ocfg, oenc, text_m, rd, False, decoder_start_token_id=cfg.bos_token_id, **kw)
     assert out.shape == ref.shape and torch.equal(out.cpu(), ref), (out.cpu(), ref)
     assert out.shape[1] > 3
+
+
+def test_prefetcher_yields_loader_batches_in_order():
+    """yelp_data_prefetcher: side-stream copies, reference return grouping, Nones at the end (multimodal_train.py:196-268)."""
+    from multimodalsum_amd import yelp_data_prefetcher, data_prefetcher
+    cfg = tiny_cfg()
+    host = []
+    for i in range(3):
+        b = syn.yelp_batch(2, 3, 16, 2, cfg.vocab_size, seed=70 + i, img_hw=32)
+        fv = b["field_value"]
+        host.append((b["reviews"], b["reviews_mask"], b["reviews_rating"], fv[0], fv[1], fv[2], fv[3], fv[4], fv[5], b["img"], b["img_mask"]))
+    pf = yelp_data_prefetcher(host)
+    for i in range(3):
+        reviews, mask, rating, fv, img, img_mask = pf.next()
+        assert reviews.is_cuda and torch.equal(reviews.cpu(), host[i][0]) and torch.equal(mask.cpu(), host[i][1])
+        assert torch.equal(rating.cpu(), host[i][2]) and len(fv) == 6
+        assert all(torch.equal(a.cpu(), b) for a, b in zip(fv, host[i][3:9]))
+        assert torch.equal(img.cpu(), host[i][9]) and torch.equal(img_mask.cpu(), host[i][10])
+    reviews, mask, rating, fv, img, img_mask = pf.next()
+    assert reviews is None and img is None and fv == [None] * 6
+    pt = data_prefetcher([h[:3] for h in host])
+    assert torch.equal(pt.next()[0].cpu(), host[0][0])
