@@ -203,6 +203,18 @@ int mmsum_table_gather(int dtype, const void* E, const int64_t* field, const int
 int mmsum_table_gather_bwd(int dtype, const void* dall, const int64_t* rating, const int64_t* hours, float* dw_rating,
                            float* dw_hours, int B, int D, void* stream);
 
+/* ---- Amazon table encoder (table_encoder.py:86-167) ----------------------------------------------
+ * all_embeddings [B,133,2D] = [field-name embedding (field [6], the last repeated 128x) | value] with values
+ * price = Linear(11->D), rating = Linear(4->D), brand / name = masked token sums, category [B,3,8,12] = token sums
+ * averaged over valid rows then over valid groups, description = 128 raw token embeddings; mask [B,133] (:160-166). */
+int mmsum_amazon_table_gather(int dtype, const void* E, const int64_t* field, const int64_t* price, const int64_t* rating,
+                              const int64_t* brand, const int64_t* name, const int64_t* category, const int64_t* description,
+                              const void* w_price, const void* w_rating, void* out, uint8_t* mask, int B, int D, int pad_id,
+                              void* stream);
+/* d w_price [D,11] += sum_b price[b,k] * dvalue[b,0,d]; d w_rating [D,4] += sum_b rating[b,k] * dvalue[b,1,d]. */
+int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* price, const int64_t* rating, float* dw_price,
+                                  float* dw_rating, int B, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

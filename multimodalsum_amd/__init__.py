@@ -5,7 +5,7 @@ include/mmsum_hip.h); there is no CPU or PyTorch-op fallback for the compute pat
 """
 from . import _lib  # noqa: F401  (raises if the HIP library is missing)
 from .config import BartConfig  # noqa: F401
-from .modules import (BartForEncConditionalGeneration, BartForMultiEncConditionalGeneration, ImgSupervised,  # noqa: F401
+from .modules import (AmazonTableEncoder, BartForEncConditionalGeneration, BartForMultiEncConditionalGeneration, ImgSupervised,  # noqa: F401
                       LabelSmoothingLoss, MultimodalSum, Resnet, TableSupervised, TextSupervised, YelpTableEncoder)
 from .optim import FusedAdamW, clip_grad_norm_, get_linear_schedule_with_warmup, get_optimizer  # noqa: F401
 from .parallel import DistributedDataParallel, reduce_tensor  # noqa: F401

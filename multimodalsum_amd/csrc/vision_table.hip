@@ -416,6 +416,91 @@ __global__ __launch_bounds__(256) void table_gather_bwd_kernel(const T* __restri
     for (int k = 0; k < 4; ++k) { dw_rating[(long)dcol * 4 + k] += gr[k]; dw_hours[(long)dcol * 4 + k] += gh[k]; }
 }
 
+// ---- Amazon table encoder gather (table_encoder.py:86-167): 133 positions = price, rating, brand, name, category, 128 description tokens
+template <typename T>
+__global__ __launch_bounds__(256) void amazon_gather_kernel(const T* __restrict__ E, const int64_t* __restrict__ field,
+                                                            const int64_t* __restrict__ price, const int64_t* __restrict__ rating,
+                                                            const int64_t* __restrict__ brand, const int64_t* __restrict__ name,
+                                                            const int64_t* __restrict__ category, const int64_t* __restrict__ description,
+                                                            const T* __restrict__ w_price, const T* __restrict__ w_rating,
+                                                            T* __restrict__ out, uint8_t* __restrict__ mask, int D, int pad_id) {
+    const int f = blockIdx.x, b = blockIdx.y;
+    T* orow = out + ((long)b * 133 + f) * 2 * D;
+    if (threadIdx.x == 0) {                                   // masks (:160-166)
+        uint8_t m = 1;
+        if (f == 0) {
+            long s = 0;
+            for (int k = 0; k < 11; ++k) s += price[(long)b * 11 + k];
+            m = s != 0;
+        } else if (f == 2) m = brand[(long)b * 12] != pad_id;
+        else if (f == 3) m = name[(long)b * 32] != pad_id;
+        else if (f >= 5) m = description[(long)b * 128 + (f - 5)] != pad_id;
+        mask[(long)b * 133 + f] = m;
+    }
+    const long fid = field[f < 5 ? f : 5];                    // single-token field names, the last one repeated (:109-111)
+    for (int dv = threadIdx.x * 4; dv < D; dv += 256 * 4) {
+        st4<T>(orow + dv, ld4<T>(E + fid * D + dv));
+        f32x4_t v = f32x4_t{0, 0, 0, 0};
+        if (f <= 1) {                                         // price / rating: Linear(11 | 4 -> D, no bias) (:116-117)
+            const int nb = f == 0 ? 11 : 4;
+            const int64_t* bits = f == 0 ? price + (long)b * 11 : rating + (long)b * 4;
+            const T* w = f == 0 ? w_price : w_rating;
+            for (int k = 0; k < nb; ++k) {
+                const float x = (float)bits[k];
+                if (x != 0.f)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += x * to_f32(w[(long)(dv + j) * nb + k]);
+            }
+        } else if (f == 2 || f == 3) {                        // brand / name: masked token sum (:120-129)
+            const int nt = f == 2 ? 12 : 32;
+            const int64_t* ids = f == 2 ? brand + (long)b * 12 : name + (long)b * 32;
+            for (int j = 0; j < nt; ++j)
+                if (ids[j] != pad_id) v = v + ld4<T>(E + ids[j] * D + dv);
+        } else if (f == 4) {                                  // category [3][8][12]: token sum, mean over valid rows, mean over valid groups (:132-145)
+            float ngroups = 0.f;
+            for (int g = 0; g < 3; ++g) {
+                f32x4_t gv = f32x4_t{0, 0, 0, 0};
+                float nrows = 0.f;
+                for (int r = 0; r < 8; ++r) {
+                    bool any = false;
+                    for (int j = 0; j < 12; ++j) {
+                        const long id = category[(((long)b * 3 + g) * 8 + r) * 12 + j];
+                        if (id != pad_id) { gv = gv + ld4<T>(E + id * D + dv); any = true; }
+                    }
+                    nrows += any ? 1.f : 0.f;
+                }
+                if (nrows > 0.f) {
+                    v = v + gv * (1.f / (nrows + 1e-6f));
+                    ngroups += 1.f;
+                }
+            }
+            v = v * (1.f / (ngroups + 1e-6f));
+        } else {                                              // description tokens, NOT masked here (:148-150)
+            v = ld4<T>(E + description[(long)b * 128 + (f - 5)] * D + dv);
+        }
+        st4<T>(orow + D + dv, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void amazon_gather_bwd_kernel(const T* __restrict__ dall, const int64_t* __restrict__ price,
+                                                                const int64_t* __restrict__ rating, float* __restrict__ dw_price,
+                                                                float* __restrict__ dw_rating, int B, int D) {
+    const int dcol = blockIdx.x * 256 + threadIdx.x;
+    if (dcol >= D) return;
+    float gp[11], gr[4];
+    for (int k = 0; k < 11; ++k) gp[k] = 0.f;
+    for (int k = 0; k < 4; ++k) gr[k] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float g0 = to_f32(dall[((long)b * 133 + 0) * 2 * D + D + dcol]);
+        const float g1 = to_f32(dall[((long)b * 133 + 1) * 2 * D + D + dcol]);
+        for (int k = 0; k < 11; ++k) gp[k] += (float)price[(long)b * 11 + k] * g0;
+        for (int k = 0; k < 4; ++k) gr[k] += (float)rating[(long)b * 4 + k] * g1;
+    }
+    for (int k = 0; k < 11; ++k) dw_price[(long)dcol * 11 + k] += gp[k];
+    for (int k = 0; k < 4; ++k) dw_rating[(long)dcol * 4 + k] += gr[k];
+}
+
 }  // namespace
 
 #define DT_SWITCH(dtype, CALL_BF16, CALL_F32)               \
@@ -553,5 +638,27 @@ extern "C" int mmsum_table_gather_bwd(int dtype, const void* dall, const int64_t
     const dim3 grid((D + 255) / 256), block(256);
     DT_SWITCH(dtype, (table_gather_bwd_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dall, rating, hours, dw_rating, dw_hours, B, D)),
               (table_gather_bwd_kernel<float><<<grid, block, 0, s>>>((const float*)dall, rating, hours, dw_rating, dw_hours, B, D)));
+    return ok();
+}
+
+extern "C" int mmsum_amazon_table_gather(int dtype, const void* E, const int64_t* field, const int64_t* price, const int64_t* rating,
+                                         const int64_t* brand, const int64_t* name, const int64_t* category, const int64_t* description,
+                                         const void* w_price, const void* w_rating, void* out, uint8_t* mask, int B, int D, int pad_id,
+                                         void* stream) {
+    if (B <= 0 || D % 4) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(133, B), block(256);
+    DT_SWITCH(dtype, (amazon_gather_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)E, field, price, rating, brand, name, category, description, (const bf16_t*)w_price, (const bf16_t*)w_rating, (bf16_t*)out, mask, D, pad_id)),
+              (amazon_gather_kernel<float><<<grid, block, 0, s>>>((const float*)E, field, price, rating, brand, name, category, description, (const float*)w_price, (const float*)w_rating, (float*)out, mask, D, pad_id)));
+    return ok();
+}
+
+extern "C" int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* price, const int64_t* rating, float* dw_price,
+                                             float* dw_rating, int B, int D, void* stream) {
+    if (B <= 0) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((D + 255) / 256), block(256);
+    DT_SWITCH(dtype, (amazon_gather_bwd_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dall, price, rating, dw_price, dw_rating, B, D)),
+              (amazon_gather_bwd_kernel<float><<<grid, block, 0, s>>>((const float*)dall, price, rating, dw_price, dw_rating, B, D)));
     return ok();
 }

@@ -57,9 +57,14 @@ def bart_specs(cfg, multimodal, prefix):
     return s
 
 
-def table_specs(prefix="table_encoder."):
-    return [(prefix + "rating_embedding.weight", (1024, 4)), (prefix + "hours_embedding.weight", (1024, 4)),
-            (prefix + "fc.weight", (1024, 2048)), (prefix + "fc.bias", (1024,)), (prefix + "linear.weight", (1024, 1024))]
+def table_specs(prefix="table_encoder.", kind="yelp"):
+    """YelpTableEncoder (table_encoder.py:5-12) or AmazonTableEncoder (:86-93) parameters."""
+    first = [(prefix + "rating_embedding.weight", (1024, 4)), (prefix + "hours_embedding.weight", (1024, 4))] if kind == "yelp" else \
+            [(prefix + "price_embedding.weight", (1024, 11)), (prefix + "rating_embedding.weight", (1024, 4))]
+    return first + [(prefix + "fc.weight", (1024, 2048)), (prefix + "fc.bias", (1024,)), (prefix + "linear.weight", (1024, 1024))]
+
+
+TABLE_POSITIONS = {"yelp": 47, "amazon": 133}
 
 
 def resnet_blocks():
@@ -108,7 +113,9 @@ class Engine:
         self.device = torch.device(device)
         self.dtype = compute_dtype
         self.multimodal = multimodal
-        self.with_table, self.with_img = with_table, with_img
+        self.with_table, self.with_img = bool(with_table), with_img
+        self.table_kind = None if not with_table else ("amazon" if with_table == "amazon" else "yelp")
+        self.table_positions = TABLE_POSITIONS.get(self.table_kind, 0)
         self.bp = bart_prefix
         self.deterministic = deterministic
         self.training = True
@@ -118,7 +125,7 @@ class Engine:
         self.buffers = {bart_prefix + "final_logits_bias": torch.zeros(1, cfg.vocab_size, device=self.device)}
         frozen = []
         if with_table:
-            specs += table_specs()
+            specs += table_specs(kind=self.table_kind)
         if with_img:
             live, frozen, bufs = resnet_specs(cfg.d_model)
             specs += live
@@ -605,30 +612,41 @@ class Engine:
         a = self.arena
         B = fv[0].shape[0]
         D = self.cfg.d_model
+        P = self.table_positions
         tp = "table_encoder."
         c = NS(B=B, fv=[t.contiguous() for t in fv])
-        c.all = self.empty(B * 47, 2 * D)
-        c.mask = self.empty(B, 47, dtype=torch.uint8)
-        kn.table_gather(a.w(self.bp + "model.shared.weight"), field.contiguous(), c.fv, a.w(tp + "rating_embedding.weight"),
-                        a.w(tp + "hours_embedding.weight"), c.all, c.mask, B, self.cfg.pad_token_id)
-        c.t1 = self.empty(B * 47, D)
+        c.all = self.empty(B * P, 2 * D)
+        c.mask = self.empty(B, P, dtype=torch.uint8)
+        if self.table_kind == "yelp":
+            kn.table_gather(a.w(self.bp + "model.shared.weight"), field.contiguous(), c.fv, a.w(tp + "rating_embedding.weight"),
+                            a.w(tp + "hours_embedding.weight"), c.all, c.mask, B, self.cfg.pad_token_id)
+        else:
+            kn.amazon_table_gather(a.w(self.bp + "model.shared.weight"), field.contiguous(), c.fv, a.w(tp + "price_embedding.weight"),
+                                   a.w(tp + "rating_embedding.weight"), c.all, c.mask, B, self.cfg.pad_token_id)
+        c.t1 = self.empty(B * P, D)
         kn.gemm(c.all, a.w(tp + "fc.weight"), c.t1, bias=a.f32(tp + "fc.bias"), epi=kn.EPI_RELU)
-        y = out if out is not None else self.empty(B * 47, D)
+        y = out if out is not None else self.empty(B * P, D)
         kn.gemm(c.t1, a.w(tp + "linear.weight"), y)
         return y, c
 
     def table_bwd(self, c, dy):
         a = self.arena
         D = self.cfg.d_model
+        P = self.table_positions
         tp = "table_encoder."
         self.wgrad(dy, c.t1, tp + "linear.weight")
-        dt1 = self.empty(c.B * 47, D)
+        dt1 = self.empty(c.B * P, D)
         self.dgrad(dy, tp + "linear.weight", a.w(tp + "linear.weight"), dt1, epi=kn.EPI_RELU_BWD, aux=c.t1)
         self.wgrad(dt1, c.all, tp + "fc.weight", bias_g=a.g(tp + "fc.bias"))
-        dall = self.empty(c.B * 47, 2 * D)
+        dall = self.empty(c.B * P, 2 * D)
         self.dgrad(dt1, tp + "fc.weight", a.w(tp + "fc.weight"), dall)
-        kn.table_gather_bwd(dall, c.fv[4], c.fv[5], a.g(tp + "rating_embedding.weight"), a.g(tp + "hours_embedding.weight"), c.B, D)
-        self.touch(tp + "linear.weight", tp + "fc.bias", tp + "fc.weight", tp + "rating_embedding.weight", tp + "hours_embedding.weight")
+        if self.table_kind == "yelp":
+            kn.table_gather_bwd(dall, c.fv[4], c.fv[5], a.g(tp + "rating_embedding.weight"), a.g(tp + "hours_embedding.weight"), c.B, D)
+            self.touch(tp + "rating_embedding.weight", tp + "hours_embedding.weight")
+        else:
+            kn.amazon_table_gather_bwd(dall, c.fv[0], c.fv[1], a.g(tp + "price_embedding.weight"), a.g(tp + "rating_embedding.weight"), c.B, D)
+            self.touch(tp + "price_embedding.weight", tp + "rating_embedding.weight")
+        self.touch(tp + "linear.weight", tp + "fc.bias", tp + "fc.weight")
 
     # =============================================================================================
     # ResNet101 stages 1-3 + projection  (img_encoder.py:31-41; torchvision 0.6.1 resnet101)

@@ -263,3 +263,15 @@ def table_gather(E, field, fv, w_rating, w_hours, out, mask, B, pad_id):
 def table_gather_bwd(dall, rating, hours, dw_rating, dw_hours, B, D):
     check(lib.mmsum_table_gather_bwd(_dt(dall), _p(dall), _p(rating), _p(hours), _p(dw_rating), _p(dw_hours), B, D, _stream()),
           "mmsum_table_gather_bwd")
+
+
+def amazon_table_gather(E, field, fv, w_price, w_rating, out, mask, B, pad_id):
+    price, rating, brand, name, category, description = fv
+    D = E.shape[1]
+    check(lib.mmsum_amazon_table_gather(_dt(E), _p(E), _p(field), _p(price), _p(rating), _p(brand), _p(name), _p(category), _p(description),
+                                        _p(w_price), _p(w_rating), _p(out), _p(mask), B, D, pad_id, _stream()), "mmsum_amazon_table_gather")
+
+
+def amazon_table_gather_bwd(dall, price, rating, dw_price, dw_rating, B, D):
+    check(lib.mmsum_amazon_table_gather_bwd(_dt(dall), _p(dall), _p(price), _p(rating), _p(dw_price), _p(dw_rating), B, D, _stream()),
+          "mmsum_amazon_table_gather_bwd")

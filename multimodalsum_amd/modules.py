@@ -98,7 +98,7 @@ class _TableFn(torch.autograd.Function):
         y, c = engine.table_fwd(field, list(fv))
         ctx.engine, ctx.c = engine, c
         ctx.mark_non_differentiable(c.mask)
-        return y.view(c.B, 47, -1), c.mask
+        return y.view(c.B, engine.table_positions, -1), c.mask
 
     @staticmethod
     def backward(ctx, dy, _dmask):
@@ -347,11 +347,14 @@ class BartForEncConditionalGeneration(_BartBase):
 
 class YelpTableEncoder(nn.Module):
     """TableEncoder(bart_model.model.shared): must alias the embedding Parameter (multimodal_train.py:117)."""
+    kind = "yelp"
 
     def __init__(self, bart_embedding, engine=None):
         super().__init__()
         if engine is None:
-            raise RuntimeError("YelpTableEncoder needs the engine that owns the aliased embedding (build it through MultimodalSum)")
+            raise RuntimeError("the table encoder needs the engine that owns the aliased embedding (build it through MultimodalSum)")
+        if engine.table_kind != self.kind:
+            raise RuntimeError("engine was built for the %s table encoder, not %s" % (engine.table_kind, self.kind))
         object.__setattr__(self, "_engine", engine)
         emb = _Node()
         emb.register_parameter("weight", bart_embedding.weight if hasattr(bart_embedding, "weight") else bart_embedding)
@@ -365,6 +368,13 @@ class YelpTableEncoder(nn.Module):
         _new_forward(e)
         y, mask = _TableFn.apply(_anchor(e), e, field, *field_value)
         return y, mask.bool()
+
+
+class AmazonTableEncoder(YelpTableEncoder):
+    """AmazonTableEncoder(bart_model.model.shared) (table_encoder.py:86-167): field [6,1], field_value = [price [B,11],
+    rating [B,4], brand [B,12], name [B,32], category [B,3,8,12], description [B,128]] -> ([B,133,D], [B,133] bool).
+    Needs an engine built for it: MultimodalSum(..., TableEncoder=AmazonTableEncoder)."""
+    kind = "amazon"
 
 
 class Resnet(nn.Module):
@@ -451,7 +461,7 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
                  config="cfg/bart-large.json", label_smoothing=0.1, device="cuda", dtype=torch.bfloat16, deterministic=False):
         super().__init__()
         cfg = config if isinstance(config, BartConfig) else BartConfig.from_json_file(config)
-        e = Engine(cfg, device=device, compute_dtype=dtype, multimodal=True, with_table=True, with_img=True,
+        e = Engine(cfg, device=device, compute_dtype=dtype, multimodal=True, with_table=getattr(TableEncoder, "kind", "yelp"), with_img=True,
                    bart_prefix="bart_model.", deterministic=deterministic)
         object.__setattr__(self, "_engine", e)
         self.label_smoothing = label_smoothing
@@ -503,13 +513,14 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
             hw = ((hw[0] + 2 - 3) // 2 + 1, (hw[1] + 2 - 3) // 2 + 1)
         P = hw[0] * hw[1]
         s = type("Saved", (), {})()
-        s.layout = e.make_memory(B, [(NR, S), (1, 47), (I, P)])
+        TP = e.table_positions
+        s.layout = e.make_memory(B, [(NR, S), (1, TP), (I, P)])
         s.mem = e.empty(s.layout.rows, D)
         o1, o2 = s.layout.offs[1], s.layout.offs[2]
         _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1])
         _, s.tab = e.table_fwd(field, field_value, out=s.mem[o1:o2])
         _, s.img = e.img_fwd(imgs, out=s.mem[o2:])
-        pads = [reviews_mask.eq(0).to(torch.uint8).contiguous(), (1 - s.tab.mask).view(B, 1, 47).contiguous(),
+        pads = [reviews_mask.eq(0).to(torch.uint8).contiguous(), (1 - s.tab.mask).view(B, 1, TP).contiguous(),
                 img_mask.eq(0).to(torch.uint8).unsqueeze(-1).expand(B, I, P).contiguous()]
         dec_in = shift_tokens_right_batched(reviews, reviews[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id)
         dec_in = dec_in.reshape(B * NR, S)
@@ -655,7 +666,7 @@ class _SingleModality(nn.Module):
         if with_img:
             self.img_encoder = Resnet(cfg.d_model, engine=e)
         if with_table:
-            self.table_encoder = YelpTableEncoder(self.bart_model.model.shared, engine=e)
+            self.table_encoder = (AmazonTableEncoder if with_table == "amazon" else YelpTableEncoder)(self.bart_model.model.shared, engine=e)
         init_formula(self)
         if bart_pretrained is not None and os.path.exists(os.path.join(str(bart_pretrained), "pytorch_model.bin")):
             self.bart_model.load_state_dict(torch.load(os.path.join(str(bart_pretrained), "pytorch_model.bin"), map_location="cpu"), strict=False)
@@ -698,8 +709,9 @@ class TableSupervised(_SingleModality):
     """table_pretrain.py:84-129: forward(field, field_value, labels=[B,T]) -> (loss,)."""
 
     def __init__(self, bart_pretrained=None, config="cfg/bart-large.json", label_smoothing=0.1, device="cuda", dtype=torch.bfloat16,
-                 deterministic=False):
-        super().__init__(bart_pretrained, config, label_smoothing, device, dtype, deterministic, False, True)
+                 deterministic=False, TableEncoder=None):
+        super().__init__(bart_pretrained, config, label_smoothing, device, dtype, deterministic, False,
+                         getattr(TableEncoder, "kind", "yelp") if TableEncoder is not None else True)
 
     def forward(self, field, field_value, labels=None, **unused):
         h, m = self.table_encoder(field, field_value)

@@ -61,6 +61,30 @@ def table_batch(B, vocab, seed, g=None):
     return field, [name, category, str_cat, str_bool, rating, hours]
 
 
+def amazon_table_batch(B, vocab, seed, g=None):
+    """field [6,1] + the six Amazon field_value tensors (data_utils.py:90-116): price one-hot over 11 bins (all-zero =
+    unknown), rating 4 bits, brand [B,12], name [B,32], category [B,3,8,12] (groups / rows trailing-padded), description
+    [B,128]; the last business has no brand, no category and no description."""
+    g = g or _gen(seed)
+    field = torch.randint(3, vocab, (6, 1), generator=_gen(978))
+    price = torch.nn.functional.one_hot(torch.randint(0, 11, (B,), generator=g), 11).long()
+    price = torch.where((torch.rand(B, generator=g) < 0.25).unsqueeze(-1), torch.zeros_like(price), price)
+    rating = (torch.rand(B, 4, generator=g) < 0.5).long()
+    brand = _trailing_pad((B, 12), vocab, g, min_real=1)
+    name = _trailing_pad((B, 32), vocab, g, min_real=1)
+    category = _trailing_pad((B, 3, 8, 12), vocab, g, min_real=1)
+    rows_real = torch.randint(1, 9, (B, 3), generator=g)
+    category = torch.where((torch.arange(8).view(1, 1, 8) >= rows_real.unsqueeze(-1)).unsqueeze(-1), torch.full_like(category, PAD), category)
+    groups_real = torch.randint(1, 4, (B,), generator=g)
+    category = torch.where((torch.arange(3).view(1, 3) >= groups_real.unsqueeze(-1)).view(B, 3, 1, 1), torch.full_like(category, PAD), category)
+    description = _trailing_pad((B, 128), vocab, g, min_real=0)
+    if B > 1:
+        brand[B - 1] = PAD
+        category[B - 1] = PAD
+        description[B - 1] = PAD
+    return field, [price, rating, brand, name, category, description]
+
+
 def yelp_batch(B, NR, S, I, vocab, seed, img_hw=224, mean_len=None, std_len=None, min_len=None):
     """One step's inputs, row 0 of SURVEY.md section 8a.  Real sizes: NR=9, S=128, I=4, img_hw=224,
     review length ~ clamp(round(N(75,20)),32,128)."""

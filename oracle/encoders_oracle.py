@@ -64,6 +64,50 @@ def yelp_table_encoder(sd, emb_weight, field, field_value, prefix="table_encoder
     return x, mask
 
 
+def amazon_table_param_shapes(prefix="table_encoder."):
+    return {
+        prefix + "price_embedding.weight": (1024, 11),
+        prefix + "rating_embedding.weight": (1024, 4),
+        prefix + "fc.weight": (1024, 2048),
+        prefix + "fc.bias": (1024,),
+        prefix + "linear.weight": (1024, 1024),
+    }
+
+
+def amazon_table_encoder(sd, emb_weight, field, field_value, prefix="table_encoder."):
+    """AmazonTableEncoder.forward (/root/reference/src/table_encoder.py:94-167).  field [6,1] int64; field_value =
+    [price [B,11], rating [B,4], brand [B,12], name [B,32], category [B,3,8,12], description [B,128]].
+    -> ([B,133,1024], [B,133] bool)."""
+    price, rating, brand, name, category, description = field_value
+    E = emb_weight.detach()                                               # embedding reads are under no_grad (:108,119,125,131,147)
+
+    def msum(ids, dim):
+        return (F.embedding(ids, E) * ids.ne(1).unsqueeze(-1).float()).sum(dim=dim)
+
+    fn = F.embedding(field, E).squeeze(1)                                 # [6,D]
+    field_name = torch.cat([fn[:-1], fn[-1:].repeat(128, 1)])             # [133,D]  (:110)
+    price_e = F.linear(price.float(), sd[prefix + "price_embedding.weight"]).unsqueeze(1)
+    rating_e = F.linear(rating.float(), sd[prefix + "rating_embedding.weight"]).unsqueeze(1)
+    brand_e = msum(brand, 1).unsqueeze(1)
+    name_e = msum(name, 1).unsqueeze(1)
+    rows = msum(category, 3)                                              # [B,3,8,D]
+    row_valid = category.ne(1).any(dim=-1)                                # [B,3,8]
+    rv = row_valid.unsqueeze(-1).float()
+    groups = (rows * rv).sum(dim=2) / (rv.sum(dim=2) + 1e-6)              # [B,3,D]
+    gv = row_valid.any(dim=-1).unsqueeze(-1).float()                      # [B,3,1]
+    cat_e = (groups * gv).sum(dim=1, keepdim=True) / (gv.sum(dim=1, keepdim=True) + 1e-6)
+    desc_e = F.embedding(description, E)                                  # not masked (:148)
+    B = price.shape[0]
+    names = field_name.unsqueeze(0).expand(B, -1, -1)
+    values = torch.cat([price_e, rating_e, brand_e, name_e, cat_e, desc_e], dim=1)       # [B,133,D]
+    x = torch.cat([names, values], dim=-1)
+    x = F.linear(x, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
+    x = F.linear(torch.relu(x), sd[prefix + "linear.weight"])
+    ones = torch.ones(B, 1, dtype=torch.bool)
+    mask = torch.cat([price.sum(dim=1, keepdim=True) != 0, ones, brand[:, :1].ne(1), name[:, :1].ne(1), ones, description.ne(1)], dim=1)
+    return x, mask
+
+
 # --------------------------------------------------------------------------------------------
 # ResNet101 (torchvision 0.6.1 definition), stages 1-3 + projection
 # --------------------------------------------------------------------------------------------

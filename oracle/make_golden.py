@@ -235,6 +235,18 @@ def main():
         g_fc_w=tenc.fc.weight.grad[:64], g_fc_b=tenc.fc.bias.grad, g_linear=tenc.linear.weight.grad[:64],
         emb_grad_is_none=np.bool_(emb.weight.grad is None))
 
+    # ---- Amazon table encoder (table_encoder.py:86-167) --------------------------------------------------
+    aenc = te.AmazonTableEncoder(emb)
+    load_formula(aenc, prefix="table_encoder.", std=0.02)
+    emb.weight.data.copy_(formula_tensor("bart_model.model.shared.weight", (200, 1024), 0.02))
+    afield, afv = syn.amazon_table_batch(3, 200, seed=22)
+    ah, am = aenc(afield, afv)
+    ah.backward(formula_tensor("table.gout.amazon", ah.shape, std=1.0))
+    npz(G("table_amazon.npz"), field=afield, price=afv[0], rating=afv[1], brand=afv[2], name=afv[3], category=afv[4],
+        description=afv[5], hiddens=ah[:, :12], hiddens_tail=ah[:, -3:], hiddens_checksum=ah.double().abs().sum(), mask=am,
+        g_price=aenc.price_embedding.weight.grad, g_rating=aenc.rating_embedding.weight.grad,
+        g_fc_w=aenc.fc.weight.grad[:64], g_fc_b=aenc.fc.bias.grad, g_linear=aenc.linear.weight.grad[:64])
+
     # ---- F3: leave-one-out multimodal step (MultimodalSum.forward) ---------------------------
     cfg3 = tiny_cfg(BartConfig, vocab=200, d=1024, ffn=64, layers=1, heads=16, maxpos=32)
     ms = mt.MultimodalSum.__new__(mt.MultimodalSum)

@@ -379,6 +379,34 @@ def table_gather_bwd(dall, rating, hours, dw_rating, dw_hours, B, D):
     dw_hours.add_(torch.einsum("bjk,bjd->dk", hours.float(), dv[:, 40:47]))
 
 
+def amazon_table_gather(E, field, fv, w_price, w_rating, out, mask, B, pad_id):
+    price, rating, brand, name, category, description = fv
+    Ef = E.float()
+
+    def msum(ids, dim):
+        return (Ef[ids] * ids.ne(pad_id).unsqueeze(-1).float()).sum(dim=dim)
+
+    fn = Ef[field.reshape(-1)]
+    names = torch.cat([fn[:5], fn[5:6].expand(128, -1)], 0).unsqueeze(0).expand(B, -1, -1)
+    rows = msum(category, 3)                                             # [B,3,8,D]
+    rv = category.ne(pad_id).any(-1)                                     # [B,3,8]
+    grp = (rows * rv.unsqueeze(-1).float()).sum(2) / (rv.float().sum(2, keepdim=True) + 1e-6)
+    gv = rv.any(-1)                                                      # [B,3]
+    cat = (grp * gv.unsqueeze(-1).float()).sum(1, keepdim=True) / (gv.float().sum(1, keepdim=True).unsqueeze(-1) + 1e-6)
+    vals = torch.cat([F.linear(price.float(), w_price.float()).unsqueeze(1), F.linear(rating.float(), w_rating.float()).unsqueeze(1),
+                      msum(brand, 1).unsqueeze(1), msum(name, 1).unsqueeze(1), cat, Ef[description]], 1)
+    out.copy_(torch.cat([names, vals], -1).reshape(B * 133, -1))
+    ones = torch.ones(B, 1, dtype=torch.bool)
+    m = torch.cat([price.sum(1, keepdim=True) != 0, ones, brand[:, :1].ne(pad_id), name[:, :1].ne(pad_id), ones, description.ne(pad_id)], 1)
+    mask.copy_(m.to(torch.uint8))
+
+
+def amazon_table_gather_bwd(dall, price, rating, dw_price, dw_rating, B, D):
+    dv = dall.float().view(B, 133, 2 * D)[:, :, D:]
+    dw_price.add_(torch.einsum("bk,bd->dk", price.float(), dv[:, 0]))
+    dw_rating.add_(torch.einsum("bk,bd->dk", rating.float(), dv[:, 1]))
+
+
 def install(monkeypatch):
     """Route multimodalsum_amd.{engine,modules,optim,generation}.kn to this module for the duration of a test."""
     import sys

@@ -365,3 +365,38 @@ def test_beam_search_host_logic(monkeypatch, case):
     assert torch.equal(out, ref), (out, ref)
     with pytest.raises(NotImplementedError):
         model.generate(*([enc, text_m, table_h, table_m, img_h, img_m] if multimodal else [enc, text_m]), num_beams=1, max_length=5)
+
+
+def test_amazon_table_encoder_module(monkeypatch):
+    """AmazonTableEncoder drop-in (table_encoder.py:86-167) through TableSupervised(TableEncoder=AmazonTableEncoder):
+    133-position gather, fc/relu/linear, unimodal decoder branch, loss and every gradient against the oracle."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import TableSupervised, AmazonTableEncoder
+    cfg = tiny_cfg(vocab=200, d=1024, ffn=64, layers=1, heads=16, maxpos=32)
+    ocfg = oracle_cfg(cfg)
+    labels = syn.token_batch(2, 12, cfg.vocab_size, seed=5, min_len=4)
+    shapes = bo.bart_param_shapes(ocfg, False, prefix="bart_model.")
+    shapes.update(eo.amazon_table_param_shapes())
+    sd = formula_state_dict(shapes, std=0.02)
+    tm = TableSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32, TableEncoder=AmazonTableEncoder)
+    tm.load_state_dict(sd, strict=False)
+    tm.train()
+    field, fv = syn.amazon_table_batch(2, cfg.vocab_size, seed=9)
+    h, m = tm.table_encoder(field, fv)
+    assert h.shape == (2, 133, 1024) and m.dtype == torch.bool
+    loss = tm(field, fv, labels=labels)[0]
+    loss.backward()
+    for v in sd.values():
+        v.requires_grad_(True)
+    th, tmask = eo.amazon_table_encoder(sd, sd["bart_model.model.shared.weight"], field, fv)
+    assert torch.equal(m, tmask)
+    _close(h, th, what="amazon table hiddens")
+    logits = bo.enc_forward(sd, ocfg, th.unsqueeze(1), torch.zeros(2, 1), tmask.unsqueeze(1), labels, training=True, prefix="bart_model.")
+    ol = bo.label_smoothing_loss(logits.view(-1, cfg.vocab_size), labels.view(-1), cfg.vocab_size, 0.1)
+    ol.backward()
+    _close(loss, ol, 1e-5, 1e-6, "amazon table loss")
+    for name, p in tm.named_parameters():
+        if sd[name].grad is None:
+            assert p.grad is None, name
+        else:
+            _close(p.grad, sd[name].grad, 5e-4, 5e-6, name)

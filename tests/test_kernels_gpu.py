@@ -512,3 +512,41 @@ def test_table_gather(dtype):
     dv = dall.float().cpu().view(B, 47, 2 * D)[:, :, D:]
     close(dwr, torch.einsum("bk,bd->dk", rating.float(), dv[:, 39]), dtype, what="dw_rating")
     close(dwh, torch.einsum("bjk,bjd->dk", hours.float(), dv[:, 40:47]), dtype, scale=2, what="dw_hours")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_amazon_table_gather(dtype):
+    """mmsum_amazon_table_gather(_bwd) against the oracle's statement of AmazonTableEncoder's gather (table_encoder.py:106-166)."""
+    from multimodalsum_amd import synthetic as syn
+    B, V, D = 3, 200, 1024
+    field, fv = syn.amazon_table_batch(B, V, seed=22)
+    E = rnd(V, D, dtype=dtype, seed=1, std=0.05)
+    wp, wr = rnd(D, 11, dtype=dtype, seed=2), rnd(D, 4, dtype=dtype, seed=3)
+    Ef = E.float().cpu()
+    price, rating, brand, name, category, description = fv
+
+    def msum(ids, dim):
+        return (F.embedding(ids, Ef) * ids.ne(1).unsqueeze(-1).float()).sum(dim=dim)
+
+    fn = F.embedding(field, Ef).squeeze(1)
+    names = torch.cat([fn[:-1], fn[-1:].repeat(128, 1)]).unsqueeze(0).expand(B, -1, -1)
+    rv = category.ne(1).any(-1)
+    groups = (msum(category, 3) * rv.unsqueeze(-1).float()).sum(2) / (rv.float().sum(2, keepdim=True) + 1e-6)
+    gv = rv.any(-1).unsqueeze(-1).float()
+    cat = (groups * gv).sum(1, keepdim=True) / (gv.sum(1, keepdim=True) + 1e-6)
+    vals = torch.cat([F.linear(price.float(), wp.float().cpu()).unsqueeze(1), F.linear(rating.float(), wr.float().cpu()).unsqueeze(1),
+                      msum(brand, 1).unsqueeze(1), msum(name, 1).unsqueeze(1), cat, F.embedding(description, Ef)], 1)
+    ref = torch.cat([names, vals], -1)
+    ones = torch.ones(B, 1, dtype=torch.bool)
+    mref = torch.cat([price.sum(1, keepdim=True) != 0, ones, brand[:, :1].ne(1), name[:, :1].ne(1), ones, description.ne(1)], 1)
+    out = torch.empty(B * 133, 2 * D, device=DEV, dtype=dtype)
+    mask = torch.empty(B, 133, dtype=torch.uint8, device=DEV)
+    kn.amazon_table_gather(E, field.to(DEV), [t.to(DEV).contiguous() for t in fv], wp, wr, out, mask, B, 1)
+    close(out, ref.reshape(B * 133, 2 * D), dtype, what="amazon table gather")
+    assert torch.equal(mask.bool().cpu(), mref)
+    dall = rnd(B * 133, 2 * D, dtype=dtype, seed=4)
+    dwp, dwr = torch.ones(D, 11, device=DEV), torch.ones(D, 4, device=DEV)
+    kn.amazon_table_gather_bwd(dall, price.to(DEV), rating.to(DEV), dwp, dwr, B, D)
+    dv = dall.float().cpu().view(B, 133, 2 * D)[:, :, D:]
+    close(dwp, 1 + torch.einsum("bk,bd->dk", price.float(), dv[:, 0]), dtype, what="d price weight")
+    close(dwr, 1 + torch.einsum("bk,bd->dk", rating.float(), dv[:, 1]), dtype, what="d rating weight")

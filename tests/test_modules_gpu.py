@@ -329,3 +329,44 @@ def test_prefetcher_yields_loader_batches_in_order():
     assert reviews is None and img is None and fv == [None] * 6
     pt = data_prefetcher([h[:3] for h in host])
     assert torch.equal(pt.next()[0].cpu(), host[0][0])
+
+
+def test_amazon_table_encoder_f32():
+    """AmazonTableEncoder on the HIP path (TableSupervised step: 133-position gather kernel, fc/relu/linear GEMMs,
+    unimodal decoder, loss) against the oracle, and the fused multimodal step runs with it (I=1 as in the Amazon set)."""
+    from multimodalsum_amd.modules import TableSupervised, AmazonTableEncoder, MultimodalSum
+    from oracle import encoders_oracle as eo
+    cfg = tiny_cfg(vocab=200, d=1024, ffn=64, layers=1, heads=16, maxpos=32)
+    ocfg = oracle_cfg(cfg)
+    labels = syn.token_batch(2, 12, cfg.vocab_size, seed=5, min_len=4)
+    shapes = bo.bart_param_shapes(ocfg, False, prefix="bart_model.")
+    shapes.update(eo.amazon_table_param_shapes())
+    sd = formula_state_dict(shapes, std=0.02)
+    tm = TableSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, TableEncoder=AmazonTableEncoder, deterministic=True)
+    tm.load_state_dict(sd, strict=False)
+    tm.train()
+    field, fv = syn.amazon_table_batch(2, cfg.vocab_size, seed=9)
+    loss = tm(field.to(DEV), [t.to(DEV) for t in fv], labels=labels.to(DEV))[0]
+    loss.backward()
+    for v in sd.values():
+        v.requires_grad_(True)
+    th, tmask = eo.amazon_table_encoder(sd, sd["bart_model.model.shared.weight"], field, fv)
+    logits = bo.enc_forward(sd, ocfg, th.unsqueeze(1), torch.zeros(2, 1), tmask.unsqueeze(1), labels, training=True, prefix="bart_model.")
+    ol = bo.label_smoothing_loss(logits.view(-1, cfg.vocab_size), labels.view(-1), cfg.vocab_size, 0.1)
+    ol.backward()
+    close(loss, ol, TOL_F32, 1e-6, "amazon table loss")
+    for name, p in tm.named_parameters():
+        if sd[name].grad is None:
+            assert p.grad is None, name
+        else:
+            close(p.grad, sd[name].grad, TOL_F32, 5e-6, name)
+    # fused step with the Amazon table encoder (bf16): finite loss and gradients for the encoder's own weights
+    model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.bfloat16, TableEncoder=AmazonTableEncoder)
+    model.train()
+    b = to_dev(syn.yelp_batch(2, 3, 16, 1, cfg.vocab_size, seed=41, img_hw=64))
+    l2 = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], field.to(DEV), [t.to(DEV) for t in fv], b["img"], b["img_mask"])[0]
+    l2.backward()
+    assert torch.isfinite(l2)
+    named = dict(model.named_parameters())
+    for n in ("table_encoder.price_embedding.weight", "table_encoder.rating_embedding.weight", "table_encoder.fc.weight"):
+        assert named[n].grad is not None and torch.isfinite(named[n].grad).all() and named[n].grad.abs().sum() > 0, n

@@ -250,3 +250,26 @@ def test_f4_optimizer(golden_dir):
                 m, v = state[id(p)]
                 so.adamw_step(p, p.grad, m, v, step + 1, lr, weight_decay=0.01)
         _close(torch.cat([p.detach().flatten() for p in params]), g["params"][step], 1e-5, 1e-6)
+
+
+def test_amazon_table_encoder(golden_dir):
+    """AmazonTableEncoder restatement against the reference run (133 positions, nested category means, masks, grads)."""
+    g = _load(golden_dir, "table_amazon.npz")
+    sd = formula_state_dict(eo.amazon_table_param_shapes(), std=0.02)
+    for v in sd.values():
+        v.requires_grad_(True)
+    emb = formula_tensor("bart_model.model.shared.weight", (200, 1024), 0.02)
+    fv = [g["price"], g["rating"], g["brand"], g["name"], g["category"], g["description"]]
+    field, fv2 = syn.amazon_table_batch(3, 200, seed=22)
+    assert torch.equal(field, g["field"]) and all(torch.equal(a, b) for a, b in zip(fv, fv2))
+    h, m = eo.amazon_table_encoder(sd, emb, g["field"], fv)
+    assert torch.equal(m, g["mask"]) and h.shape == (3, 133, 1024)
+    _close(h[:, :12], g["hiddens"], **TOL)
+    _close(h[:, -3:], g["hiddens_tail"], **TOL)
+    _close(h.double().abs().sum(), g["hiddens_checksum"], 1e-5, 1e-3)
+    h.backward(formula_tensor("table.gout.amazon", h.shape, std=1.0))
+    _close(sd["table_encoder.price_embedding.weight"].grad, g["g_price"], **TOL)
+    _close(sd["table_encoder.rating_embedding.weight"].grad, g["g_rating"], **TOL)
+    _close(sd["table_encoder.fc.weight"].grad[:64], g["g_fc_w"], **TOL)
+    _close(sd["table_encoder.fc.bias"].grad, g["g_fc_b"], **TOL)
+    _close(sd["table_encoder.linear.weight"].grad[:64], g["g_linear"], **TOL)
