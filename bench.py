@@ -121,6 +121,17 @@ def kernel_probe(dtype, batch=14):
             "shape": [M, N, K], "avg_launch_ms": ms, "flops_per_launch": fl, "achieved": fl / ms / 1e9, "unit": "TFLOP/s"}
 
 
+def pmc_traffic(shape):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE doubled per
+    the gfx950 correction + WRITE_SIZE); None when no profile of this exact shape is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_dominant_gemm_pmc.json")) as f:
+            prof = json.load(f)
+        return prof["hbm_bytes_per_launch"] if list(prof["shape"]) == list(shape) else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, cfg):
     """The reference algorithm (CPU oracle, literal: 9 sequential passes, K/V re-projected per pass)
     on the host cores.  Bounded sample: B=1, BART-large width/vocab, 1 encoder + 1 decoder layer,
@@ -268,11 +279,17 @@ def main():
                                  4 if multimodal else 1, multimodal=multimodal)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = value / world * fpb / 1e12
-        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                "flops_per_business": fpb, "scope": "whole training step per GPU (algorithmic FLOPs of SURVEY.md 8d / step time)"}
-        if not args.no_kernel_probe:
-            roof["dominant_kernel"] = kernel_probe(torch.bfloat16 if args.dtype == "bf16" else torch.float32, args.batch)
-            roof["dominant_kernel"]["frac"] = roof["dominant_kernel"]["achieved"] / peak
+        step_roof = {"achieved": achieved, "frac": achieved / peak, "flops_per_business": fpb,
+                     "scope": "whole training step per GPU (algorithmic FLOPs of SURVEY.md 8d / step time)"}
+        if args.no_kernel_probe:
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                    "scope": step_roof["scope"], "flops_per_business": fpb}
+        else:
+            # the dominant kernel, timed live with HIP events on its launch stream; traffic from the committed PMC profile
+            dk = kernel_probe(torch.bfloat16 if args.dtype == "bf16" else torch.float32, args.batch)
+            roof = {"bound": "mfma", "achieved": dk["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dk["achieved"] / peak,
+                    "traffic": pmc_traffic(dk["shape"]), "kernel": dk["kernel"], "shape": dk["shape"], "avg_launch_ms": dk["avg_launch_ms"],
+                    "flops_per_launch": dk["flops_per_launch"], "step": step_roof}
         out = {"metric": "training samples/sec (businesses/sec) BART-large multimodal" if multimodal else
                "training samples/sec (businesses/sec) BART-large text-only",
                "value": value, "unit": "businesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -282,7 +299,7 @@ def main():
                           if multimodal else "text_pretrain.py BART-large text-only step, 9 reviews x 128 tok",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "dropout": cfg.dropout},
-               "launch": "eager" if args.no_graphs else "hip-graph replay (fwd + 3 bwd segments), %d priming steps before warmup" % priming,
+               "launch": "eager" if args.no_graphs else "hip-graph replay (1 forward graph + 1 graph per backward gradient segment), %d priming steps before warmup" % priming,
                "final_loss": loss_val, "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_bounded(args)

@@ -168,6 +168,13 @@ class Engine:
     def zeros(self, *shape, dtype=None):
         return torch.zeros(*shape, dtype=dtype or self.dtype, device=self.device)
 
+    def side_stream(self):
+        """Second HIP stream for the image/table branch of the fused step (None when MMSUM_SIDE_STREAM=0)."""
+        if not hasattr(self, "_side_stream"):
+            import os
+            self._side_stream = None if os.environ.get("MMSUM_SIDE_STREAM") == "0" else torch.cuda.Stream(device=self.device)
+        return self._side_stream
+
     def p_drop(self):
         return float(self.cfg.dropout) if self.training else 0.0
 

@@ -5,10 +5,12 @@ the host can issue them, and on a slow or busy host the GPU idles between kernel
 is static for given batch shapes, so it is captured once into HIP graphs (torch.cuda.CUDAGraph is a thin wrapper
 over hipGraph) and replayed:
 
-  forward  : one graph  (salt bump, encoders, leave-one-out decoder, LM head + loss)
-  backward : one graph per gradient segment (decoder | image+table encoders | text encoder + embeddings), so the
-             data-parallel all-reduce of a finished segment (parallel.DistributedDataParallel) still overlaps the
-             next segment's kernels -- the collectives stay outside the graphs, on their own stream.
+  forward  : one graph  (salt bump, text encoder with the table/image encoders on a parallel branch, leave-one-out
+             decoder, LM head + loss)
+  backward : one graph per gradient segment (decoder | text encoder + embeddings with the image/table backward on a
+             parallel branch), so the data-parallel all-reduce of the decoder's gradients
+             (parallel.DistributedDataParallel) overlaps the encoders' backward -- the collectives stay outside the
+             graphs, on their own stream.
 
 What stays eager: weight shadow refresh (engine.sync_weights), gradient-buffer preparation, clipping and the
 optimiser (a handful of launches whose scalars -- lr, bias corrections -- change every step).

@@ -78,7 +78,7 @@ _ws_cache = {}
 
 
 def _workspace(nbytes, device, key):
-    k = (key, str(device))
+    k = (key, str(device), _stream())        # per stream: the image branch of the step runs beside the text encoder
     w = _ws_cache.get(k)
     if w is None or w.numel() < nbytes:
         w = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
