@@ -37,6 +37,8 @@ enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_E
 #define MMSUM_GEMM_ACCUM   0x040  /* C += */
 #define MMSUM_GEMM_OUT_F32 0x080  /* C is f32 regardless of dtype */
 #define MMSUM_GEMM_SLABS   0x100  /* split-K without atomics: slice s writes its partial to C + s*M*ldc (f32) */
+#define MMSUM_GEMM_COLSUM  0x200  /* bf16 NT fast path only: `bias` is an OUTPUT, bias[n] += sum_m C[m][n] of the stored result
+                                    (the bias gradient of the layer that produced the GEMM's input gradient) */
 
 int mmsum_abi_version(void);
 
@@ -83,10 +85,11 @@ int mmsum_bump_u64(void* dev_u64, unsigned long long inc, void* stream);
  * apex FusedLayerNorm :972-980). */
 int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,
                      float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, void* stream);
-/* dres <- dz (or += if accumulate_dres), dx <- dz * dropmask/(1-p); dgamma/dbeta += (f32). */
+/* dres <- dz (or += if accumulate_dres), dx <- dz * dropmask/(1-p); dgamma/dbeta += (f32);
+ * dxsum (f32 [D], may be NULL) += column sums of dx = the bias gradient of the Linear that produced x (:302,304,885). */
 int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, const void* gamma, const float* mean,
                      const float* rstd, void* dx, void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R,
-                     int D, float p_drop, uint64_t seed, void* stream);
+                     int D, float p_drop, uint64_t seed, float* dxsum, void* stream);
 
 /* Entity attention (K3, K8, K11; modeling_multimodalsum.py:752-875).  One description covers
  * encoder self-attention, causal decoder self-attention and the per-entity cross-attention with

@@ -183,6 +183,10 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     if (bt && ((ldb * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
     GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk};
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & MMSUM_GEMM_COLSUM) {      // epilogue column sums exist on the LDS-DMA NT path with a bf16 result only
+        if (!gemm_glds_eligible(dtype, a) || (flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS)) || splitk != 1 || !bias)
+            return MMSUM_ERR_BAD_SHAPE;
+    }
     if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
     if (gemm_tn_eligible(dtype, a)) return launch_gemm_tn(a, s);
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);

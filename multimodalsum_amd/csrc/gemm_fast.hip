@@ -50,7 +50,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     constexpr int NSETS = (LDS_BYTES >= 2 * WAVES_M * BAND * 4) ? 2 : 1;
     static_assert(LDS_BYTES >= WAVES_M * BAND * 4, "epilogue staging does not fit the kernel's LDS");
     float* stage0 = reinterpret_cast<float*>(smem);
-    const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
+    const bool do_colsum = (p.flags & MMSUM_GEMM_COLSUM) != 0;     // bias slot = f32 output: += column sums of the stored tile
+    const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0) && !do_colsum;
+    static_assert(THREADS % CPR == 0, "a thread must own one 8-column chunk for the column sums");
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bf16_t* Ct = static_cast<bf16_t*>(p.C);
     float* Cf = static_cast<float*>(p.C);
     bf16_t* aux = static_cast<bf16_t*>(p.aux);
@@ -128,6 +131,10 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+            if (do_colsum) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) csum[e] += (e < nvalid) ? (float)(bf16_t)v[e] : 0.f;     // what a separate pass over the bf16 result would add
+            }
             if constexpr (OUT == OUT_T || OUT == OUT_T_ACC) {
                 if (full && vec_ok) {
                     bf16_t t[8];
@@ -159,6 +166,21 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
                     for (int e = 0; e < nvalid; ++e) Cf[o + e] = (OUT == OUT_F32_ACC ? Cf[o + e] : 0.f) + v[e];
                 }
             }
+        }
+    }
+    if (do_colsum) {
+        // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+        constexpr int NPART = THREADS / CPR;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = csum[e];
+        __syncthreads();
+        for (int c = tid; c < BN; c += THREADS) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPART; ++k) t += red[k * BN + c];
+            if (n0 + c < p.N) atomicAdd(const_cast<float*>(p.bias) + n0 + c, t);
         }
     }
 }

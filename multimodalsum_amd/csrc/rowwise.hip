@@ -99,16 +99,17 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
                                                          T* __restrict__ dx, T* __restrict__ dres, int accumulate_dres,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int D,
-                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ salt) {
+                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
+                                                         float* __restrict__ dxsum) {
     seed = salted_seed(seed, salt);
-    __shared__ float red[4][VPL * 256 * 2];
+    __shared__ float red[4][VPL * 256 * 3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
     const uint32_t thr = keep_threshold(p_drop);
     const float dscale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
-    f32x4_t ag[VPL], ab[VPL];
+    f32x4_t ag[VPL], ab[VPL], ax[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) { ag[i] = f32x4_t{0, 0, 0, 0}; ab[i] = f32x4_t{0, 0, 0, 0}; }
+    for (int i = 0; i < VPL; ++i) { ag[i] = f32x4_t{0, 0, 0, 0}; ab[i] = f32x4_t{0, 0, 0, 0}; ax[i] = f32x4_t{0, 0, 0, 0}; }
     for (int row = blockIdx.x * wpb + wave; row < R; row += gridDim.x * wpb) {
         const float mean = mean_in[row], rstd = rstd_in[row];
         f32x4_t xh[VPL], gdy[VPL];
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                 dz[j] = rstd * (gdy[i][j] - s1 - xh[i][j] * s2);
                 dxv[j] = keep[i][j] ? dz[j] * dscale : 0.f;
             }
+            ax[i] = ax[i] + dxv;                       // column sums of dx = bias gradient of the linear layer that produced x
             store4<T>(dx + (long)row * D + c, dxv);
             if (accumulate_dres) dz = dz + load4<T>(dres + (long)row * D + c);
             store4<T>(dres + (long)row * D + c, dz);
@@ -156,13 +158,15 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
             const int c = (i * 64 + lane) * 4 + j;
             red[wave][c] = ag[i][j];
             red[wave][VPL * 256 + c] = ab[i][j];
+            red[wave][2 * VPL * 256 + c] = ax[i][j];
         }
     __syncthreads();
     for (int c = threadIdx.x; c < D; c += blockDim.x) {
-        float g = 0.f, b = 0.f;
-        for (int w = 0; w < wpb; ++w) { g += red[w][c]; b += red[w][VPL * 256 + c]; }
+        float g = 0.f, b = 0.f, xs = 0.f;
+        for (int w = 0; w < wpb; ++w) { g += red[w][c]; b += red[w][VPL * 256 + c]; xs += red[w][2 * VPL * 256 + c]; }
         atomicAdd(dgamma + c, g);
         atomicAdd(dbeta + c, b);
+        if (dxsum != nullptr) atomicAdd(dxsum + c, xs);
     }
 }
 
@@ -578,14 +582,14 @@ int add_ln_fwd_t(const void* x, const void* res, const void* gamma, const void* 
 template <typename T>
 int add_ln_bwd_t(const void* dy, const void* x, const void* res, const void* gamma, const float* mean, const float* rstd, void* dx,
                  void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R, int D, float p_drop, uint64_t seed,
-                 hipStream_t s) {
+                 float* dxsum, hipStream_t s) {
     int grid = (R + 15) / 16;
     grid = grid > 1024 ? 1024 : grid;
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
         add_ln_bwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)dy, (const T*)x, (const T*)res, (const float*)gamma, mean,
                                                                   rstd, (T*)dx, (T*)dres, accumulate_dres, dgamma, dbeta, R, D, p_drop,
-                                                                  seed, g_dropout_salt);
+                                                                  seed, g_dropout_salt, dxsum);
     });
 }
 template <typename T>
@@ -627,11 +631,11 @@ extern "C" int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const
 
 extern "C" int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, const void* gamma, const float* mean,
                                 const float* rstd, void* dx, void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R,
-                                int D, float p_drop, uint64_t seed, void* stream) {
+                                int D, float p_drop, uint64_t seed, float* dxsum, void* stream) {
     if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MMSUM_BF16) return add_ln_bwd_t<bf16_t>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, s);
-    if (dtype == MMSUM_F32) return add_ln_bwd_t<float>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, s);
+    if (dtype == MMSUM_BF16) return add_ln_bwd_t<bf16_t>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, dxsum, s);
+    if (dtype == MMSUM_F32) return add_ln_bwd_t<float>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, dxsum, s);
     return MMSUM_ERR_BAD_DTYPE;
 }
 

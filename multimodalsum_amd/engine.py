@@ -233,13 +233,20 @@ class Engine:
         for k, (o, cols, ld, rows) in list(self.wt.items()):
             self.wt[k] = self.wt_buf[o:o + cols * ld].view(cols, ld)
 
-    def dgrad(self, dy, key, w_natural, out, accumulate=False, epi=0, aux=None, rows=None):
-        """out (+)= dy @ W  (W natural = [N_out, K_in]); uses the transposed shadow when present."""
+    def dgrad(self, dy, key, w_natural, out, accumulate=False, epi=0, aux=None, rows=None, colsum=None):
+        """out (+)= dy @ W  (W natural = [N_out, K_in]); uses the transposed shadow when present.
+        colsum (f32 [K_in], optional) += column sums of out: the bias gradient of the layer below, taken in the GEMM
+        epilogue when the fast path allows it and by the column-sum kernel otherwise."""
         wt = self.wt.get(key)
         if wt is not None:
-            kn.gemm(dy, wt if rows is None else wt[rows], out, accumulate=accumulate, epi=epi, aux=aux)
+            fuse = colsum is not None and not accumulate and not self.deterministic and kn.gemm_colsum_fusable(dy)
+            kn.gemm(dy, wt if rows is None else wt[rows], out, accumulate=accumulate, epi=epi, aux=aux, colsum=colsum if fuse else None)
+            if colsum is not None and not fuse:
+                kn.colsum(out, colsum, accumulate=True)
         else:
             kn.gemm(dy, w_natural, out, b_t=True, accumulate=accumulate, epi=epi, aux=aux)
+            if colsum is not None:
+                kn.colsum(out, colsum, accumulate=True)
 
     def transposed(self, t, Mp, cache_key=None):
         if cache_key is not None and cache_key in self._tcache:
@@ -378,8 +385,9 @@ class Engine:
         q, k, v = self._attn_names(lb, "self_attn")
         do, dx = self.empty(R, D), self.empty(R, D)
         kn.add_ln_bwd(dy, c.o, c.x, a.f32(lb + "self_attn_layer_norm.weight"), c.mean, c.rstd, do, dx, False,
-                      a.g(lb + "self_attn_layer_norm.weight"), a.g(lb + "self_attn_layer_norm.bias"), c.p, c.seed)
-        self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight", bias_g=a.g(lb + "self_attn.out_proj.bias"))
+                      a.g(lb + "self_attn_layer_norm.weight"), a.g(lb + "self_attn_layer_norm.bias"), c.p, c.seed,
+                      dxsum=a.g(lb + "self_attn.out_proj.bias"))         # out_proj's bias gradient = column sums of do
+        self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight")
         dattn = self.empty(R, D)
         self.dgrad(do, lb + "self_attn.out_proj.weight", a.w(lb + "self_attn.out_proj.weight"), dattn)
         dqkv = self.empty(R, 3 * D)
@@ -413,11 +421,12 @@ class Engine:
         R, D = dy.shape
         df, dx = self.empty(R, D), self.empty(R, D)
         kn.add_ln_bwd(dy, c.f, c.x, a.f32(lb + "final_layer_norm.weight"), c.mean, c.rstd, df, dx, False,
-                      a.g(lb + "final_layer_norm.weight"), a.g(lb + "final_layer_norm.bias"), c.p, c.seed)
-        self.wgrad(df, c.h, lb + "fc2.weight", bias_g=a.g(lb + "fc2.bias"))
+                      a.g(lb + "final_layer_norm.weight"), a.g(lb + "final_layer_norm.bias"), c.p, c.seed,
+                      dxsum=a.g(lb + "fc2.bias"))                       # fc2's bias gradient = column sums of df
+        self.wgrad(df, c.h, lb + "fc2.weight")
         du = self.empty(R, c.u.shape[1])
-        self.dgrad(df, lb + "fc2.weight", a.w(lb + "fc2.weight"), du, epi=kn.EPI_GELU_BWD, aux=c.u)
-        self.wgrad(du, c.x, lb + "fc1.weight", bias_g=a.g(lb + "fc1.bias"))
+        self.dgrad(df, lb + "fc2.weight", a.w(lb + "fc2.weight"), du, epi=kn.EPI_GELU_BWD, aux=c.u, colsum=a.g(lb + "fc1.bias"))
+        self.wgrad(du, c.x, lb + "fc1.weight")
         self.dgrad(du, lb + "fc1.weight", a.w(lb + "fc1.weight"), dx, accumulate=True)
         self.touch(lb + "fc1.weight", lb + "fc1.bias", lb + "fc2.weight", lb + "fc2.bias", lb + "final_layer_norm.weight",
                    lb + "final_layer_norm.bias")

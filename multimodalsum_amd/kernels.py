@@ -38,8 +38,13 @@ def _ld(t):
     return t.stride(0)
 
 
+def gemm_colsum_fusable(a, a_t=False, b_t=False, a2=None):
+    """True when mmsum_gemm can add the output's column sums in its epilogue (bf16 LDS-DMA NT path)."""
+    return a.dtype == torch.bfloat16 and not a_t and not b_t and a2 is None and a.shape[1] % 64 == 0
+
+
 def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None,
-         splitk=1, slabs=False):
+         splitk=1, slabs=False, colsum=None):
     """out[M,N] = epi(alpha * A.B^T + bias) (+ out).  a: [M,K] (or [K,M] when a_t); b: [N,K] (or [K,N] when b_t);
     a2: optional second half of the K range ([M,K2], natural layout).  out may be f32 while a/b are bf16."""
     dt = _dt(a)
@@ -54,6 +59,10 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
     assert out.shape[0] == (M * splitk if slabs else M) and out.shape[1] == N, (out.shape, M, N)
     flags = (_lib.GEMM_A_T if a_t else 0) | (_lib.GEMM_B_T if b_t else 0) | (_lib.GEMM_BIAS if bias is not None else 0)
     flags |= _lib.gemm_epi(epi) | (_lib.GEMM_ACCUM if accumulate else 0) | (_lib.GEMM_SLABS if slabs else 0)
+    if colsum is not None:            # f32 [N] += column sums of the stored result (bias slot becomes an output)
+        assert bias is None and colsum.dtype == torch.float32 and gemm_colsum_fusable(a, a_t, b_t, a2)
+        flags |= _lib.GEMM_COLSUM
+        bias = colsum
     if out.dtype == torch.float32 and dt == BF16:
         flags |= _lib.GEMM_OUT_F32
     elif out.dtype == torch.float32:
@@ -113,10 +122,11 @@ def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed):
                                _stream()), "mmsum_add_ln_fwd")
 
 
-def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed):
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None):
+    """dxsum (f32 [D], optional) += column sums of dx: the bias gradient of the Linear that produced x."""
     R, D = x.shape
     check(lib.mmsum_add_ln_bwd(_dt(x), _p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres),
-                               int(accumulate_dres), _p(dgamma), _p(dbeta), R, D, p_drop, seed, _stream()), "mmsum_add_ln_bwd")
+                               int(accumulate_dres), _p(dgamma), _p(dbeta), R, D, p_drop, seed, _p(dxsum), _stream()), "mmsum_add_ln_bwd")
 
 
 def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale):

@@ -22,7 +22,12 @@ def _keep_mask(shape, p, seed):
     return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
 
 
-def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None, splitk=1, slabs=False):
+def gemm_colsum_fusable(a, a_t=False, b_t=False, a2=None):
+    return a.dtype == torch.bfloat16 and not a_t and not b_t and a2 is None and a.shape[1] % 64 == 0
+
+
+def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None, splitk=1, slabs=False,
+         colsum=None):
     A = a.float().t() if a_t else a.float()
     if a2 is not None:
         A = torch.cat([A, a2.float()], dim=1)
@@ -49,6 +54,8 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
         out.add_(v.to(out.dtype))
     else:
         out.copy_(v)
+    if colsum is not None:
+        colsum.add_(out.float().sum(0))
     return out
 
 
@@ -111,7 +118,7 @@ def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed):
     y.copy_((z - mu[:, None]) * rs[:, None] * gamma + beta)
 
 
-def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed):
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None):
     km = _keep_mask(x.shape, p_drop, seed)
     z = x.float() * km + res.float()
     xh = (z - mean[:, None]) * rstd[:, None]
@@ -121,6 +128,8 @@ def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma,
     dgamma.add_((g * xh).sum(0))
     dbeta.add_(g.sum(0))
     dx.copy_(dz * km)
+    if dxsum is not None:
+        dxsum.add_((dz * km).sum(0))
     if accumulate_dres:
         dres.add_(dz)
     else:

@@ -92,6 +92,22 @@ def test_gemm_epilogues(dtype):
     o5 = acc.clone()
     kn.slab_reduce(ws, 3, o5, accumulate=True)
     close(o5, ref, dtype, what="splitk slabs")
+    # epilogue column sums (bias gradient of the layer below) on the bf16 fast path; rejected elsewhere
+    if dtype == torch.bfloat16:
+        for (Mc, Nc) in ((160, 200), (1000, 520)):
+            ac, bc = rnd(Mc, Kd, dtype=dtype, seed=30, std=0.3), rnd(Nc, Kd, dtype=dtype, seed=31, std=0.3)
+            uc = rnd(Mc, Nc, dtype=dtype, seed=32)
+            oc = torch.empty(Mc, Nc, device=DEV, dtype=dtype)
+            cs = torch.ones(Nc, device=DEV)
+            kn.gemm(ac, bc, oc, epi=kn.EPI_GELU_BWD, aux=uc, colsum=cs)
+            ref_o = torch.empty(Mc, Nc, device=DEV, dtype=dtype)
+            kn.gemm(ac, bc, ref_o, epi=kn.EPI_GELU_BWD, aux=uc)
+            assert torch.equal(oc, ref_o)
+            refc = 1.0 + ref_o.double().sum(0)
+            assert (cs.double() - refc).abs().max().item() <= 1e-4 * (1 + refc.abs().max().item())
+    else:
+        with pytest.raises(AssertionError):
+            kn.gemm(a, b, torch.empty(M, N, device=DEV, dtype=dtype), colsum=torch.zeros(N, device=DEV))
     # K split over two A operands
     a2 = rnd(M, 64, dtype=dtype, seed=8, std=0.3)
     b2 = rnd(N, Kd + 64, dtype=dtype, seed=9, std=0.3)
@@ -189,6 +205,11 @@ def test_add_ln(dtype, D):
     close(dres, rf.grad, dtype, what="ln dres")
     close(dg, gf.grad, dtype, scale=4, what="ln dgamma")
     close(db, bf.grad, dtype, scale=4, what="ln dbeta")
+    # fused column sums of dx (the bias gradient of the Linear that produced x), with dropout
+    dxs = torch.ones(D, device=DEV)
+    kn.add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, False, dg, db, 0.25, 77, dxsum=dxs)
+    close(dxs, 1.0 + dx.double().sum(0), dtype, scale=4, what="ln dx column sums")
+    kn.add_ln_fwd(x, res, gamma, beta, y, mean, rstd, 1e-5, 0.0, 0)
     # dropout: statistical + fwd/bwd mask consistency
     kn.add_ln_fwd(x, torch.zeros_like(res), torch.ones_like(gamma), torch.zeros_like(beta), y, mean, rstd, 1e-5, 0.5, 1234)
     kn.add_ln_bwd(dy, x, torch.zeros_like(res), torch.ones_like(gamma), mean, rstd, dx, dres, False, dg, db, 0.5, 1234)
