@@ -357,18 +357,66 @@ __device__ __forceinline__ void online_merge(float& m, float& s, float m2, float
     m = mn;
 }
 
-template <typename T>
+// 16-byte chunks of a logits row (8 bf16 / 4 f32); rows start 16-byte aligned when ld * sizeof(T) is a multiple of 16.
+template <typename T> struct RowChunk;
+template <> struct RowChunk<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        const u32x4_t w = *reinterpret_cast<const u32x4_t*>(p);
+        bf16_t t[8];
+        __builtin_memcpy(t, &w, 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        bf16_t t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[j];
+        u32x4_t w;
+        __builtin_memcpy(&w, t, 16);
+        *reinterpret_cast<u32x4_t*>(p) = w;
+    }
+};
+template <> struct RowChunk<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        const f32x4_t w = *reinterpret_cast<const f32x4_t*>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = w[j];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]}; }
+};
+
+// One workgroup per row, 16-byte accesses (VEC) or scalar ones (unaligned rows); pass 1: online max / sum-exp / sum of
+// logits; pass 2 (the row is L2-resident by then): dlogits in place.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void ls_loss_kernel(T* __restrict__ logits, long ld, const int64_t* __restrict__ target,
                                                       float* __restrict__ row_loss, int V, float smoothing, float gscale,
                                                       int write_grad) {
     __shared__ float sm[4], ss[4], sx[4];
+    constexpr int CN = RowChunk<T>::N;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T* x = logits + (long)row * ld;
     float m = -INFINITY, s = 0.f, sumx = 0.f;
-    for (int c = tid; c < V; c += 256) {
-        const float v = to_f32(x[c]);
-        sumx += v;
-        if (v > m) { s = s * __expf(m - v) + 1.f; m = v; } else { s += __expf(v - m); }
+    if constexpr (VEC) {
+        for (int c = tid * CN; c < V; c += 256 * CN) {
+            float v[CN];
+            RowChunk<T>::load(x + c, v);
+            float cm = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < CN; ++j)
+                if (c + j < V) { cm = fmaxf(cm, v[j]); sumx += v[j]; }
+            if (cm > m) { s *= __expf(m - cm); m = cm; }
+#pragma unroll
+            for (int j = 0; j < CN; ++j)
+                if (c + j < V) s += __expf(v[j] - m);
+        }
+    } else {
+        for (int c = tid; c < V; c += 256) {
+            const float v = to_f32(x[c]);
+            sumx += v;
+            if (v > m) { s = s * __expf(m - v) + 1.f; m = v; } else { s += __expf(v - m); }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -391,13 +439,24 @@ __global__ __launch_bounds__(256) void ls_loss_kernel(T* __restrict__ logits, lo
     }
     if (write_grad) {
         __syncthreads();
-        for (int c = tid; c < (int)ld; c += 256) {
-            float g = 0.f;
-            if (c < V) {
-                const float pr = __expf(to_f32(x[c]) - lse);
-                g = gscale * (pr - (c == y ? conf : eps_p));
+        if constexpr (VEC) {
+            for (int c = tid * CN; c < (int)ld; c += 256 * CN) {
+                float v[CN];
+                if (c < V) RowChunk<T>::load(x + c, v);
+#pragma unroll
+                for (int j = 0; j < CN; ++j)
+                    v[j] = (c + j < V) ? gscale * (__expf(v[j] - lse) - ((c + j) == y ? conf : eps_p)) : 0.f;
+                RowChunk<T>::store(x + c, v);
             }
-            x[c] = from_f32<T>(g);
+        } else {
+            for (int c = tid; c < (int)ld; c += 256) {
+                float g = 0.f;
+                if (c < V) {
+                    const float pr = __expf(to_f32(x[c]) - lse);
+                    g = gscale * (pr - (c == y ? conf : eps_p));
+                }
+                x[c] = from_f32<T>(g);
+            }
         }
     }
 }
@@ -690,9 +749,16 @@ extern "C" int mmsum_ls_loss(int dtype, void* logits, long ld, const int64_t* ta
                              float smoothing, float gscale, int write_grad, void* stream) {
     if (R <= 0 || V <= 0 || ld < V) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((ls_loss_kernel<bf16_t>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
-    else if (dtype == MMSUM_F32) hipLaunchKernelGGL((ls_loss_kernel<float>), dim3(R), dim3(256), 0, s, (float*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
-    else return MMSUM_ERR_BAD_DTYPE;
+    const size_t es = dtype == MMSUM_BF16 ? 2 : 4;
+    // 16-byte path: aligned rows whose padded length is a whole number of chunks (the engine pads V to 128 columns)
+    const bool vec = (((uintptr_t)logits) & 15) == 0 && ((ld * es) & 15) == 0;
+    if (dtype == MMSUM_BF16) {
+        if (vec) hipLaunchKernelGGL((ls_loss_kernel<bf16_t, true>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+        else hipLaunchKernelGGL((ls_loss_kernel<bf16_t, false>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+    } else if (dtype == MMSUM_F32) {
+        if (vec) hipLaunchKernelGGL((ls_loss_kernel<float, true>), dim3(R), dim3(256), 0, s, (float*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+        else hipLaunchKernelGGL((ls_loss_kernel<float, false>), dim3(R), dim3(256), 0, s, (float*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+    } else return MMSUM_ERR_BAD_DTYPE;
     return ok();
 }
 

@@ -63,50 +63,101 @@ def _banned_ngram_tokens(rows, n, cur_len):
 
 
 class DecodeSession:
-    """KV-cached single-token decoder over an engine's weights.  rows = B * rows_per_business hypotheses."""
+    """KV-cached single-token decoder over an engine's weights; rows = B * rows_per_business hypotheses.
 
-    def __init__(self, engine, mem, layout, pads, rows_per_business, max_length, rating_diff):
-        e, cfg, a = engine, engine.cfg, engine.arena
-        self.e, self.L, self.pads, self.qpb, self.Tmax = e, layout, pads, rows_per_business, max_length
+    Every buffer is static (memory matrix, masks, cross K/V of all layers, two ping-pong sets of self-attention
+    caches, token / beam-index inputs, logits), so a decode step at position t is the same launch sequence on the
+    same addresses in every generate() call: on the GPU it is captured once per position into a HIP graph
+    (first use) and replayed afterwards -- a step is ~250 launches of a few microseconds each, i.e. purely
+    launch-bound when issued from Python.  Sessions are cached on the engine per (memory layout, beams, max_length)."""
+
+    def __init__(self, engine, layout, rows_per_business, max_length, has_rating):
+        e, cfg = engine, engine.cfg
         if max_length > 224:
             raise ValueError("max_length > 224 exceeds the attention kernel's key tile")
-        D = cfg.d_model
-        self.rows = layout.B * rows_per_business
-        self.rd = rating_diff
-        b = e.bp + "model.decoder."
-        self.nulls = []
-        for (N, S), pad in zip(layout.mods, pads):
-            nul = e.empty(layout.B * N, dtype=torch.uint8)
-            kn.entity_null(pad, nul, layout.B * N, S)
-            self.nulls.append(nul)
-        if e.multimodal:
-            self.no_table = self.nulls[1]
-            N2, S2 = layout.mods[2]
-            self.no_img = e.empty(layout.B, dtype=torch.uint8)
-            kn.entity_null(pads[2], self.no_img, layout.B, N2 * S2)
-        # cross-attention K/V of every layer, once (:810-815 caches them after the first step)
-        self.kv = []
-        for i in range(cfg.decoder_layers):
-            lb = b + "layers.%d." % i
-            _, k, v = e._attn_names(lb, "encoder_attn")
-            kv = e.empty(layout.rows, 2 * D)
-            kn.gemm(mem, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), kv, bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)))
-            self.kv.append(kv)
-        # self-attention caches: zero-filled (masked keys carry probability 0, so they must stay finite)
-        self.kc = [e.zeros(self.rows * max_length, D) for _ in range(cfg.decoder_layers)]
-        self.vc = [e.zeros(self.rows * max_length, D) for _ in range(cfg.decoder_layers)]
-        self.self_pad = torch.ones(self.rows, max_length, dtype=torch.uint8, device=e.device)
-        self.mean = e.empty(self.rows, dtype=torch.float32)
-        self.rstd = e.empty(self.rows, dtype=torch.float32)
+        self.e, self.L, self.qpb, self.Tmax = e, layout, rows_per_business, max_length
+        D, R = cfg.d_model, layout.B * rows_per_business
+        self.rows = R
+        dev = e.device
+        self.mem = e.empty(layout.rows, D)
+        self.pads = [torch.empty(layout.B, N, S, dtype=torch.uint8, device=dev) for (N, S) in layout.mods]
+        self.nulls = [e.empty(layout.B * N, dtype=torch.uint8) for (N, S) in layout.mods]
+        self.no_table = self.nulls[1] if e.multimodal else None
+        self.no_img = e.empty(layout.B, dtype=torch.uint8) if e.multimodal else None
+        self.rd = e.empty(R, dtype=torch.float32) if has_rating else None
+        self.kv = [e.empty(layout.rows, 2 * D) for _ in range(cfg.decoder_layers)]
+        # self-attention caches, two sets: step t reads/extends set t & 1 after gathering it from set (t-1) & 1 by beam index;
+        # zero-filled once (masked keys carry probability 0, so whatever they hold must stay finite)
+        self.kc = [[e.zeros(R * max_length, D) for _ in range(cfg.decoder_layers)] for _ in range(2)]
+        self.vc = [[e.zeros(R * max_length, D) for _ in range(cfg.decoder_layers)] for _ in range(2)]
+        self.self_pad = torch.ones(R, max_length, dtype=torch.uint8, device=dev)
+        self.mean, self.rstd = e.empty(R, dtype=torch.float32), e.empty(R, dtype=torch.float32)
+        self.tokens = torch.zeros(R, 1, dtype=torch.long, device=dev)
+        self.beam_idx = torch.arange(R, dtype=torch.long, device=dev)
+        self.logits = e.empty(R, e.Vpad)
+        self.use_graphs = dev.type == "cuda" and __import__("os").environ.get("MMSUM_DECODE_GRAPHS") != "0"
+        self.graphs, self.pool, self.warm = {}, None, False
 
-    def step(self, tokens, t):
-        """tokens [rows] int64 = the token at position t of every hypothesis.  -> next-token logits [rows, V] f32."""
+    def begin(self, hiddens, pads, rating_diff):
+        """New generate() call: load the memory, masks and rating difference, project the cross-attention K/V."""
+        e, cfg, a, L = self.e, self.e.cfg, self.e.arena, self.L
+        D = cfg.d_model
+        for m, h in enumerate(hiddens):
+            n = h.shape[0] * h.shape[1] * h.shape[2]
+            self.mem[L.offs[m]:L.offs[m] + n].copy_(h.reshape(n, D))
+        for dst, src in zip(self.pads, pads):
+            dst.copy_(src.reshape(dst.shape))
+        if self.rd is not None:
+            self.rd.copy_(rating_diff.reshape(L.B, 1).float().repeat_interleave(self.qpb, dim=0).reshape(-1))
+        for (N, S), pad, nul in zip(L.mods, self.pads, self.nulls):
+            kn.entity_null(pad, nul, L.B * N, S)
+        if e.multimodal:
+            N2, S2 = L.mods[2]
+            kn.entity_null(self.pads[2], self.no_img, L.B, N2 * S2)
+        b = e.bp + "model.decoder."
+        for i in range(cfg.decoder_layers):                     # (:810-815 caches them after the first step)
+            _, k, v = e._attn_names(b + "layers.%d." % i, "encoder_attn")
+            kn.gemm(self.mem, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), self.kv[i],
+                    bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)))
+        self.self_pad.fill_(1)
+
+    def step(self, tokens, beam_idx, t):
+        """tokens [rows] int64 = token at position t of every hypothesis, which continues hypothesis beam_idx[row] of the
+        previous step (None at t = 0).  -> next-token logits [rows, V] f32."""
+        self.tokens.copy_(tokens.view(-1, 1))
+        if beam_idx is not None:
+            self.beam_idx.copy_(beam_idx)
+        if not self.use_graphs:
+            self._step(t)
+        else:
+            if not self.warm:                                    # one eager pass first: lazy kernel attributes, allocator warm-up
+                self._step(t)
+                self.warm = True
+            g = self.graphs.get(t)
+            if g is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool):
+                    self._step(t)
+                if self.pool is None:
+                    self.pool = g.pool()
+                self.graphs[t] = g
+            g.replay()
+        return self.logits[:, :self.e.cfg.vocab_size].float()
+
+    def _step(self, t):
         e, cfg, a = self.e, self.e.cfg, self.e.arena
         D, H, R, Tm = cfg.d_model, cfg.heads, self.rows, self.Tmax
         b = e.bp + "model.decoder."
         scale = 64 ** -0.5
+        cur, prev = t & 1, (t - 1) & 1
+        kc, vc = self.kc[cur], self.vc[cur]
+        if t > 0:                                                # beam reorder (:2996-3003, _reorder_cache) = gather into the other cache set
+            for i in range(cfg.decoder_layers):
+                torch.index_select(self.kc[prev][i].view(R, Tm, D), 0, self.beam_idx, out=kc[i].view(R, Tm, D))
+                torch.index_select(self.vc[prev][i].view(R, Tm, D), 0, self.beam_idx, out=vc[i].view(R, Tm, D))
         x = e.empty(R, D)
-        kn.embed_ln_fwd(tokens.view(R, 1).contiguous(), a.w(e.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), self.rd,
+        kn.embed_ln_fwd(self.tokens, a.w(e.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), self.rd,
                         a.w(b + "rating_embeddings") if self.rd is not None else None, a.f32(b + "layernorm_embedding.weight"),
                         a.f32(b + "layernorm_embedding.bias"), x, self.mean, self.rstd, R, 1, cfg.extra_pos_embeddings + t, 1e-5, 0.0, 0)
         self.self_pad[:, t] = 0
@@ -117,10 +168,10 @@ class DecodeSession:
             q, k, v = e._attn_names(lb, "self_attn")
             qkv = e.empty(R, 3 * D)
             kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)))
-            self.kc[i].view(R, Tm, D)[:, t].copy_(qkv[:, D:2 * D])
-            self.vc[i].view(R, Tm, D)[:, t].copy_(qkv[:, 2 * D:])
+            kc[i].view(R, Tm, D)[:, t].copy_(qkv[:, D:2 * D])
+            vc[i].view(R, Tm, D)[:, t].copy_(qkv[:, 2 * D:])
             att = e.empty(R, D)
-            d = kn.make_attn_desc(qkv[:, :D], self.kc[i], self.vc[i], att, self.self_pad, None, R, 1, 1, 1, Tm, H, False, False, scale)
+            d = kn.make_attn_desc(qkv[:, :D], kc[i], vc[i], att, self.self_pad, None, R, 1, 1, 1, Tm, H, False, False, scale)
             kn.attn_fwd(d, x)
             o = e.empty(R, D)
             kn.gemm(att, a.w(lb + "self_attn.out_proj.weight"), o, bias=a.f32(lb + "self_attn.out_proj.bias"))
@@ -164,22 +215,22 @@ class DecodeSession:
             kn.add_ln_fwd(f, x, a.f32(lb + "final_layer_norm.weight"), a.f32(lb + "final_layer_norm.bias"), y, self.mean, self.rstd, 1e-5,
                           0.0, 0)
             x = y
-        logits = e.empty(R, e.Vpad)
-        kn.gemm(x, a.w(e.bp + "model.shared.weight"), logits[:, :cfg.vocab_size],
+        kn.gemm(x, a.w(e.bp + "model.shared.weight"), self.logits[:, :cfg.vocab_size],
                 bias=e.buffers[e.bp + "final_logits_bias"].reshape(-1))                                      # :2281
-        return logits[:, :cfg.vocab_size].float()
 
-    def reorder(self, beam_idx):
-        """Hypothesis row r continues hypothesis beam_idx[r] (:2996-3003, _reorder_cache)."""
-        R, Tm = self.rows, self.Tmax
-        for i in range(len(self.kc)):
-            D = self.kc[i].shape[1]
-            self.kc[i] = self.kc[i].view(R, Tm, D).index_select(0, beam_idx).view(R * Tm, D)
-            self.vc[i] = self.vc[i].view(R, Tm, D).index_select(0, beam_idx).view(R * Tm, D)
+
+def _session(engine, layout, num_beams, max_length, has_rating):
+    key = (tuple(layout.mods), layout.B, num_beams, max_length, has_rating)
+    cache = engine.__dict__.setdefault("_decode_sessions", {})
+    if key not in cache:
+        if len(cache) >= 4:                          # static buffers + graphs per shape: keep only a few
+            cache.pop(next(iter(cache)))
+        cache[key] = DecodeSession(engine, layout, num_beams, max_length, has_rating)
+    return cache[key]
 
 
 @torch.no_grad()
-def beam_search(engine, mem, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size, early_stopping,
+def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size, early_stopping,
                 length_penalty, decoder_start_token_id):
     """Greedy beam search (_generate_beam_search :2803-3067).  Returns LongTensor [B, L] on the engine's device."""
     cfg = engine.cfg
@@ -187,8 +238,9 @@ def beam_search(engine, mem, layout, pads, rating_diff, num_beams, max_length, m
     dev = engine.device
     B = layout.B
     R = B * num_beams
-    rd = None if rating_diff is None else rating_diff.reshape(B, 1).float().repeat_interleave(num_beams, dim=0).reshape(-1).contiguous()
-    sess = DecodeSession(engine, mem, layout, pads, num_beams, max_length, rd)
+    sess = _session(engine, layout, num_beams, max_length, rating_diff is not None)
+    sess.begin(hiddens, pads, rating_diff)
+    beam_idx_dev = None
     rows = [[decoder_start_token_id] for _ in range(R)]                    # host copy of input_ids
     last = torch.full((R,), decoder_start_token_id, dtype=torch.long, device=dev)
     hyps = [_Hypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
@@ -200,7 +252,7 @@ def beam_search(engine, mem, layout, pads, rating_diff, num_beams, max_length, m
     cur_len = 1
     neg_inf = float("-inf")
     while cur_len < max_length:
-        logits = sess.step(last, cur_len - 1)
+        logits = sess.step(last, beam_idx_dev, cur_len - 1)
         if cur_len == 1:                                                   # force BOS (:3084-3086)
             keep = logits[:, bos].clone()
             logits.fill_(neg_inf)
@@ -248,8 +300,7 @@ def beam_search(engine, mem, layout, pads, rating_diff, num_beams, max_length, m
         beam_idx = [x[2] for x in nxt]
         rows = [rows[j] + [x[1]] for j, x in zip(beam_idx, nxt)]
         last = torch.tensor([x[1] for x in nxt], dtype=torch.long, device=dev)
-        if beam_idx != list(range(R)):
-            sess.reorder(torch.tensor(beam_idx, dtype=torch.long, device=dev))
+        beam_idx_dev = torch.tensor(beam_idx, dtype=torch.long, device=dev)
         cur_len += 1
     for b in range(B):
         if done[b]:

@@ -296,15 +296,10 @@ class _BartBase(nn.Module):
         e.training = False
         try:
             _new_forward(e)
-            D = cfg.d_model
             B = hiddens[0].shape[0]
             layout = e.make_memory(B, [(h.shape[1], h.shape[2]) for h in hiddens])
-            mem = e.empty(layout.rows, D)
-            for m, h in enumerate(hiddens):
-                n = h.shape[0] * h.shape[1] * h.shape[2]
-                mem[layout.offs[m]:layout.offs[m] + n].copy_(h.reshape(n, D))
             pads = [m.eq(0).to(torch.uint8).contiguous() for m in masks]
-            return beam_search(e, mem, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size,
+            return beam_search(e, hiddens, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size,
                                bool(early_stopping), float(length_penalty), int(start))
         finally:
             e.training = was_training
