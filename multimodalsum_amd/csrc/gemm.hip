@@ -187,6 +187,7 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
         if (!gemm_glds_eligible(dtype, a) || (flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS)) || splitk != 1 || !bias)
             return MMSUM_ERR_BAD_SHAPE;
     }
+    if (gemm_skinny_eligible(dtype, a)) return launch_gemm_skinny(a, s);
     if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
     if (gemm_tn_eligible(dtype, a)) return launch_gemm_tn(a, s);
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);

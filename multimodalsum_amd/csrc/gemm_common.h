@@ -106,5 +106,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream);   // gemm_fast.hip
 bool gemm_glds_eligible(int dtype, const GemmArgs& a);
+int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);   // gemm_skinny.hip: M <= 64 (decode step)
+bool gemm_skinny_eligible(int dtype, const GemmArgs& a);
 int launch_gemm_tn(const GemmArgs& a, hipStream_t stream);     // gemm_fast.hip: A [K,M], B [K,N] (weight gradients)
 bool gemm_tn_eligible(int dtype, const GemmArgs& a);

@@ -53,6 +53,25 @@ def test_gemm_layouts(dtype, a_t, b_t, M, N, K):
     close(out, ref, dtype, scale=math.sqrt(K / 64), what="gemm")
 
 
+@pytest.mark.parametrize("M,N,K", [(32, 1024, 1024), (12, 3072, 1024), (64, 1024, 4096), (33, 4096, 1024), (1, 256, 128)])
+def test_gemm_skinny_decode_shapes(M, N, K):
+    """gemm_skinny_kernel (M <= 64 bf16: the decode step's weight-streaming products): bias, GELU, K split over two operands."""
+    dt = torch.bfloat16
+    x, w = rnd(M, K, dtype=dt, seed=50, std=0.5), rnd(N, K, dtype=dt, seed=51, std=0.5)
+    bias = rnd(N, seed=52)
+    ref = x.float() @ w.float().t() + bias
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=dt)
+    kn.gemm(x, w, out, bias=bias)
+    close(out, ref, dt, scale=math.sqrt(K / 64), what="skinny bias")
+    kn.gemm(x, w, out, bias=bias, epi=kn.EPI_GELU, alpha=0.125)
+    close(out, F.gelu((x.float() @ w.float().t()) * 0.125 + bias), dt, scale=math.sqrt(K / 64), what="skinny gelu")
+    if K >= 256:
+        x2 = rnd(M, 128, dtype=dt, seed=53, std=0.5)
+        w2 = rnd(N, K + 128, dtype=dt, seed=54, std=0.5)
+        kn.gemm(x, w2, out, a2=x2, bias=bias)
+        close(out, torch.cat([x.float(), x2.float()], 1) @ w2.float().t() + bias, dt, scale=math.sqrt(K / 64), what="skinny a2")
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_epilogues(dtype):
     M, N, Kd = 160, 200, 128
