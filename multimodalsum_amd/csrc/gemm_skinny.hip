@@ -1,5 +1,5 @@
 // Skinny bf16 GEMM for the single-token decode step of generation (multimodalsum_amd/generation.py):
-//   out[M, N] = epi(alpha * x[M, K] . W[N, K]^T + bias),  M <= 64 hypothesis rows, N, K = model dimensions.
+//   out[M, N] = epi(alpha * x[M, K] . W[N, K]^T + bias),  M <= 128 hypothesis rows, N, K = model dimensions.
 // The product is a weight stream: W (2 N K bytes) is read once, x (<= 64 rows) stays in L2.  The tiled kernels put
 // one workgroup on a 128- or 256-column tile, i.e. 8 workgroups for N = 1024 -- 3 % of the chip pulling the
 // weights (measured 26 us per product, half of a decode step).  Here a workgroup owns 32 output columns, its four
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 }  // namespace
 
 bool gemm_skinny_eligible(int dtype, const GemmArgs& a) {
-    if (dtype != MMSUM_BF16 || a.M > 64 || a.splitk != 1) return false;
+    if (dtype != MMSUM_BF16 || a.M > 128 || a.splitk != 1) return false;
     if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_ACCUM | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS | MMSUM_GEMM_COLSUM)) return false;
     const int epi = (a.flags >> 3) & 7;
     if (!(epi == MMSUM_EPI_NONE || (epi == MMSUM_EPI_GELU && a.aux == nullptr))) return false;
@@ -79,12 +79,15 @@ bool gemm_skinny_eligible(int dtype, const GemmArgs& a) {
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7;
     const dim3 grid((a.N + 31) / 32), block(256);
-    if (a.M <= 32) {
-        if (epi == MMSUM_EPI_GELU) gemm_skinny_kernel<1, MMSUM_EPI_GELU><<<grid, block, 0, stream>>>(a);
-        else gemm_skinny_kernel<1, MMSUM_EPI_NONE><<<grid, block, 0, stream>>>(a);
-    } else {
-        if (epi == MMSUM_EPI_GELU) gemm_skinny_kernel<2, MMSUM_EPI_GELU><<<grid, block, 0, stream>>>(a);
-        else gemm_skinny_kernel<2, MMSUM_EPI_NONE><<<grid, block, 0, stream>>>(a);
-    }
+#define SKINNY(MT)                                                                                         \
+    do {                                                                                                   \
+        if (epi == MMSUM_EPI_GELU) gemm_skinny_kernel<MT, MMSUM_EPI_GELU><<<grid, block, 0, stream>>>(a);   \
+        else gemm_skinny_kernel<MT, MMSUM_EPI_NONE><<<grid, block, 0, stream>>>(a);                         \
+    } while (0)
+    if (a.M <= 32) SKINNY(1);
+    else if (a.M <= 64) SKINNY(2);
+    else if (a.M <= 96) SKINNY(3);
+    else SKINNY(4);
+#undef SKINNY
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }

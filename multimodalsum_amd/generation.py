@@ -187,8 +187,10 @@ class DecodeSession:
             heads = e.empty(nm * R, D)
             for m, ((N, S), pad) in enumerate(zip(self.L.mods, self.pads)):
                 rows = slice(self.L.offs[m], self.L.offs[m] + self.L.B * N * S)
+                # the hypotheses of a business are consecutive rows: one query block of `qpb` rows per business reads the
+                # business's K/V once for all of them
                 d = kn.make_attn_desc(cq, self.kv[i][rows, :D], self.kv[i][rows, D:], heads[m * R:(m + 1) * R], pad, self.nulls[m],
-                                      R, 1, self.qpb, N, S, H, False, False, scale)
+                                      self.L.B, self.qpb, 1, N, S, H, False, False, scale)
                 kn.attn_fwd(d, x)
             yy = e.empty(nm * R, D)
             kn.gemm(heads, a.w(pre + "out_proj.weight"), yy, bias=a.f32(pre + "out_proj.bias"))

@@ -53,9 +53,9 @@ def test_gemm_layouts(dtype, a_t, b_t, M, N, K):
     close(out, ref, dtype, scale=math.sqrt(K / 64), what="gemm")
 
 
-@pytest.mark.parametrize("M,N,K", [(32, 1024, 1024), (12, 3072, 1024), (64, 1024, 4096), (33, 4096, 1024), (1, 256, 128)])
+@pytest.mark.parametrize("M,N,K", [(32, 1024, 1024), (12, 3072, 1024), (64, 1024, 4096), (33, 4096, 1024), (1, 256, 128), (96, 1024, 1024), (128, 2048, 1024)])
 def test_gemm_skinny_decode_shapes(M, N, K):
-    """gemm_skinny_kernel (M <= 64 bf16: the decode step's weight-streaming products): bias, GELU, K split over two operands."""
+    """gemm_skinny_kernel (M <= 128 bf16: the decode step's weight-streaming products): bias, GELU, K split over two operands."""
     dt = torch.bfloat16
     x, w = rnd(M, K, dtype=dt, seed=50, std=0.5), rnd(N, K, dtype=dt, seed=51, std=0.5)
     bias = rnd(N, seed=52)
