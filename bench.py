@@ -79,7 +79,10 @@ def make_batches(args, cfg, device, rank, n=2):
     for i in range(n):
         b = syn.yelp_batch(args.batch, 9, 128, 4 if args.workload == "multimodal" else 1, cfg.vocab_size,
                            seed=1234 + 1000 * rank + i, img_hw=224 if args.workload == "multimodal" else 8)
-        out.append(syn.batch_to(b, device))
+        dev = syn.batch_to(b, device)
+        # what a loader-side prefetcher does on the host copy (multimodalsum_amd/prefetch.py): the number of non-padding review tokens
+        dev["reviews_mask"]._mmsum_valid_rows = int(b["reviews_mask"].ne(0).sum())
+        out.append(dev)
     return out
 
 

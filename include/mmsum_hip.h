@@ -73,6 +73,14 @@ int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids, const void
                        const float* rstd, float* dE, float* dP, float* drvec, float* dgamma, float* dbeta, int nseq,
                        int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, void* stream);
 
+/* Padding-free text encoder (MI355X-side restructuring, results identical): encoder rows that are padding never reach a
+ * result (their keys are masked, :836-837; their outputs are masked again in the decoder's cross-attention, :858-866), so
+ * the fused step runs the encoder's GEMM / LayerNorm work on the valid rows only and moves rows between the padded
+ * layout the attention kernel reads and the compact one with this gather:
+ *   dst[i, :] = map[i] >= 0 ? src[map[i], :] : 0   (i < nrows; row_bytes multiple of 16; pitches in bytes). */
+int mmsum_rows_gather(const void* src, long src_pitch, int src_rows, void* dst, long dst_pitch, const int64_t* map, int nrows,
+                      int row_bytes, void* stream);
+
 /* Dropout salt for captured HIP graphs.  The reference draws fresh dropout masks every step from the torch
  * generator (F.dropout, modeling_multimodalsum.py:294,305,371,458,474,486,596); here masks are a hash of
  * (seed argument, element index).  A captured graph replays the same seed arguments, so a device-resident 64-bit

@@ -66,6 +66,7 @@ SIGNATURES = {
                             c_float, c_void_p]),
     "mmsum_cast": (c_int, [c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "mmsum_scale_by_clip": (c_int, [c_void_p, c_long, c_void_p, c_float, c_void_p]),
+    "mmsum_rows_gather": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
     "mmsum_set_dropout_salt": (c_int, [c_void_p]),
     "mmsum_bump_u64": (c_int, [c_void_p, ctypes.c_ulonglong, c_void_p]),
     "mmsum_transpose_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -820,6 +820,35 @@ extern "C" int mmsum_cast(int dtype_dst, void* dst, int dtype_src, const void* s
     return ok();
 }
 
+namespace {
+// Row compaction / expansion for the padding-free text encoder: dst[i] = src[map[i]] (zeros where map[i] < 0), 16-byte pieces.
+__global__ __launch_bounds__(256) void rows_gather_kernel(const char* __restrict__ src, long src_pitch, char* __restrict__ dst, long dst_pitch,
+                                                          const int64_t* __restrict__ map, int nrows, int row_bytes, int src_rows) {
+    const int chunks = row_bytes >> 4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)nrows * chunks; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / chunks), c = (int)(i % chunks);
+        const long m = map[r];
+        u32x4_t v = u32x4_t{0, 0, 0, 0};
+        if (m >= 0 && m < src_rows) v = *reinterpret_cast<const u32x4_t*>(src + m * src_pitch + (long)c * 16);
+        *reinterpret_cast<u32x4_t*>(dst + (long)r * dst_pitch + (long)c * 16) = v;
+    }
+}
+}  // namespace
+
+/* dst[i, :] = map[i] >= 0 ? src[map[i], :] : 0 for i < nrows; rows are row_bytes long (multiple of 16), pitches in bytes.
+ * One kernel serves both directions: compact (map = compact -> padded row) and expand (map = padded -> compact row). */
+extern "C" int mmsum_rows_gather(const void* src, long src_pitch, int src_rows, void* dst, long dst_pitch, const int64_t* map, int nrows,
+                                 int row_bytes, void* stream) {
+    if (nrows <= 0 || row_bytes <= 0 || (row_bytes & 15) || (src_pitch & 15) || (dst_pitch & 15)) return MMSUM_ERR_BAD_SHAPE;
+    if ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) return MMSUM_ERR_BAD_ALIGN;
+    const long items = (long)nrows * (row_bytes >> 4);
+    long blocks = (items + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    rows_gather_kernel<<<dim3((int)blocks), dim3(256), 0, (hipStream_t)stream>>>((const char*)src, src_pitch, (char*)dst, dst_pitch, map, nrows,
+                                                                              row_bytes, src_rows);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
 extern "C" int mmsum_set_dropout_salt(const void* dev_u64) {
     g_dropout_salt = static_cast<const uint64_t*>(dev_u64);
     return MMSUM_OK;

@@ -316,8 +316,25 @@ class Engine:
     def _attn_names(self, lb, a):
         return [lb + a + "." + p for p in ("q_proj", "k_proj", "v_proj")]
 
-    def encoder_fwd(self, ids, attention_mask, out=None):
-        """ids [Bn,S] int64, attention_mask [Bn,S] (1 = keep).  -> hidden [Bn*S, D] (batch-major rows)."""
+    def row_maps(self, attention_mask, capacity):
+        """Index maps of the padding-free encoder: c2p [capacity] = padded row of compact row i (-1 for the filler rows up
+        to the capacity), p2c [rows] = compact row of padded row r (-1 for padding).  Device-side, static shapes."""
+        flat = attention_mask.reshape(-1).ne(0)
+        R = flat.numel()
+        pos = torch.cumsum(flat.to(torch.int64), 0) - 1
+        p2c = torch.where(flat, pos, torch.full_like(pos, -1))
+        ar = torch.arange(R, dtype=torch.int64, device=flat.device)
+        # one spare slot swallows every padding row (all write -1 there) and any row beyond the capacity
+        c2p = torch.full((capacity + 1,), -1, dtype=torch.int64, device=flat.device)
+        c2p.index_put_((torch.where(flat, pos, torch.full_like(pos, capacity)).clamp_(max=capacity),),
+                       torch.where(flat, ar, torch.full_like(ar, -1)))
+        p2c = torch.where(p2c < capacity, p2c, torch.full_like(p2c, -1))
+        return NS(c2p=c2p[:capacity].contiguous(), p2c=p2c.contiguous(), capacity=capacity)
+
+    def encoder_fwd(self, ids, attention_mask, out=None, capacity=None):
+        """ids [Bn,S] int64, attention_mask [Bn,S] (1 = keep).  -> hidden [Bn*S, D] (batch-major rows).
+        capacity (fused step only): run the layers on the valid rows only, `capacity` >= their number (rows that are
+        padding come out as zeros; nothing downstream reads them: they are masked keys of the cross-attention)."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
         Bn, S = ids.shape
@@ -332,11 +349,17 @@ class Engine:
                         a.f32(b + "layernorm_embedding.weight"), a.f32(b + "layernorm_embedding.bias"), x, c.mean0, c.rstd0,
                         Bn, S, cfg.extra_pos_embeddings, 1e-5, c.p, c.seed0)
         c.x0 = x
+        c.maps = None
+        if capacity is not None and capacity < R:
+            c.maps = self.row_maps(attention_mask, capacity)
+            x = kn.rows_gather(x, self.empty(capacity, D), c.maps.c2p)
         for i in range(cfg.encoder_layers):
             last = i == cfg.encoder_layers - 1
-            x, lc = self._self_block_fwd(b + "layers.%d." % i, x, c.pad, Bn, S, causal=False)
-            x, fc = self._ffn_block_fwd(b + "layers.%d." % i, x, out if last else None)
+            x, lc = self._self_block_fwd(b + "layers.%d." % i, x, c.pad, Bn, S, causal=False, maps=c.maps)
+            x, fc = self._ffn_block_fwd(b + "layers.%d." % i, x, out if (last and c.maps is None) else None)
             c.layers.append((lc, fc))
+        if c.maps is not None:
+            x = kn.rows_gather(x, out if out is not None else self.empty(R, D), c.maps.p2c)
         c.out = x
         return x, c
 
@@ -345,10 +368,14 @@ class Engine:
         cfg, a = self.cfg, self.arena
         b = self.bp + "model.encoder."
         dx = dout
+        if c.maps is not None:
+            dx = kn.rows_gather(dout, self.empty(c.maps.capacity, cfg.d_model), c.maps.c2p)
         for i in reversed(range(cfg.encoder_layers)):
             lc, fc = c.layers[i]
             dx = self._ffn_block_bwd(b + "layers.%d." % i, fc, dx)
             dx = self._self_block_bwd(b + "layers.%d." % i, lc, dx)
+        if c.maps is not None:
+            dx = kn.rows_gather(dx, self.empty(c.Bn * c.S, cfg.d_model), c.maps.p2c)
         kn.embed_ln_bwd(dx, c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), None, None,
                         a.f32(b + "layernorm_embedding.weight"), c.mean0, c.rstd0, a.g(self.bp + "model.shared.weight"),
                         a.g(b + "embed_positions.weight"), None, a.g(b + "layernorm_embedding.weight"),
@@ -357,19 +384,24 @@ class Engine:
                    b + "layernorm_embedding.bias")
 
     # ---- shared blocks ----------------------------------------------------------------------------
-    def _self_block_fwd(self, lb, x, pad, Bn, T, causal):
-        """x -> LN(x + drop(out_proj(self_attention(x))))   (:288-297 / :442-461)."""
+    def _self_block_fwd(self, lb, x, pad, Bn, T, causal, maps=None):
+        """x -> LN(x + drop(out_proj(self_attention(x))))   (:288-297 / :442-461).
+        maps (padding-free encoder): x holds the valid rows only ([capacity, D]); q/k/v are expanded to the padded
+        [Bn*T, 3D] layout the attention kernel reads (zeros at padding) and its output is compacted again."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
         R = x.shape[0]
         q, k, v = self._attn_names(lb, "self_attn")
-        c = NS(x=x, pad=pad, Bn=Bn, T=T, causal=causal, p=self.p_drop(), seed=self.next_seed())
+        c = NS(x=x, pad=pad, Bn=Bn, T=T, causal=causal, p=self.p_drop(), seed=self.next_seed(), maps=maps)
         c.qkv = self.empty(R, 3 * D)
         kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), c.qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)))
-        c.attn = self.empty(R, D)
-        c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], c.attn, pad, None, Bn, T, 1, 1, T, H,
+        if maps is not None:
+            c.qkv = kn.rows_gather(c.qkv, self.empty(Bn * T, 3 * D), maps.p2c)
+        attn = self.empty(Bn * T, D)
+        c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn, pad, None, Bn, T, 1, 1, T, H,
                                    False, causal, 64 ** -0.5)
         kn.attn_fwd(c.desc, x)
+        c.attn = attn if maps is None else kn.rows_gather(attn, self.empty(R, D), maps.c2p)
         c.o = self.empty(R, D)
         kn.gemm(c.attn, a.w(lb + "self_attn.out_proj.weight"), c.o, bias=a.f32(lb + "self_attn.out_proj.bias"))
         y = self.empty(R, D)
@@ -390,9 +422,14 @@ class Engine:
         self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight")
         dattn = self.empty(R, D)
         self.dgrad(do, lb + "self_attn.out_proj.weight", a.w(lb + "self_attn.out_proj.weight"), dattn)
-        dqkv = self.empty(R, 3 * D)
+        Rp = c.Bn * c.T
+        if c.maps is not None:
+            dattn = kn.rows_gather(dattn, self.empty(Rp, D), c.maps.p2c)
+        dqkv = self.empty(Rp, 3 * D)
         stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
         kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
+        if c.maps is not None:
+            dqkv = kn.rows_gather(dqkv, self.empty(R, 3 * D), c.maps.c2p)
         self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)), bias_g=a.gspan(q + ".bias", v + ".bias", (3 * D,)))
         self.dgrad(dqkv, q + ".weight", a.wspan(q + ".weight", v + ".weight", (3 * D, D)), dx, accumulate=True)
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias",

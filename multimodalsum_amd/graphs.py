@@ -19,7 +19,7 @@ Dropout: a captured graph replays the seed arguments it was captured with; the k
 salt that the forward graph bumps first (include/mmsum_hip.h: mmsum_set_dropout_salt), so every replay draws
 fresh masks and the backward graphs of the same step see the same ones.
 
-Shapes: one set of graphs per distinct (input shapes, dtypes, training flag); the first call with new shapes runs
+Shapes: one set of graphs per distinct (input shapes, dtypes, training flag, row capacity of the padding-free encoder); the first call with new shapes runs
 eagerly (warm-up), the second captures, later ones replay.
 """
 import torch
@@ -70,16 +70,16 @@ class StepGraphs:
         self.max_shapes = max_shapes
         self.salt = torch.zeros(1, dtype=torch.int64, device=self.engine.device)
 
-    def _key(self, flat):
+    def _key(self, flat, extra):
         e = self.engine
-        return tuple((tuple(t.shape), t.dtype) for t in flat) + (e.training, e.p_drop())
+        return tuple((tuple(t.shape), t.dtype) for t in flat) + (e.training, e.p_drop(), extra)
 
-    def forward(self, batch):
+    def forward(self, batch, extra=None):
         """Returns the entry whose .saved holds this step's forward state, or None (caller runs eagerly)."""
         flat, spec = _flatten(batch)
         if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in flat):
             return None
-        key = self._key(flat)
+        key = self._key(flat, extra)
         ent = self.entries.get(key)
         if ent is None:
             if len(self.entries) >= self.max_shapes:
@@ -87,7 +87,7 @@ class StepGraphs:
             self.entries[key] = _Entry()
             return None                          # first sight of these shapes: eager warm-up
         if ent.state == 0:
-            self._capture(ent, flat, spec)
+            self._capture(ent, flat, spec, extra)
         else:
             for dst, src in zip(ent.static, flat):
                 if dst.data_ptr() != src.data_ptr():
@@ -95,7 +95,7 @@ class StepGraphs:
         ent.fwd.replay()
         return ent
 
-    def _capture(self, ent, flat, spec):
+    def _capture(self, ent, flat, spec, extra):
         e, m = self.engine, self.model
         ent.static = [t.clone() for t in flat]
         torch.cuda.synchronize()
@@ -104,7 +104,7 @@ class StepGraphs:
             ent.fwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ent.fwd, pool=self.pool):
                 check(lib.mmsum_bump_u64(self.salt.data_ptr(), 1, kn._stream()), "mmsum_bump_u64")
-                ent.saved = m._step_fwd(*_unflatten(ent.static, spec))
+                ent.saved = m._step_fwd(*_unflatten(ent.static, spec), capacity=extra)
             if self.pool is None:
                 self.pool = ent.fwd.pool()
             # the backward graphs are captured here too (capture records, it does not execute): autograd would

@@ -285,3 +285,12 @@ def amazon_table_gather(E, field, fv, w_price, w_rating, out, mask, B, pad_id):
 def amazon_table_gather_bwd(dall, price, rating, dw_price, dw_rating, B, D):
     check(lib.mmsum_amazon_table_gather_bwd(_dt(dall), _p(dall), _p(price), _p(rating), _p(dw_price), _p(dw_rating), B, D, _stream()),
           "mmsum_amazon_table_gather_bwd")
+
+
+def rows_gather(src, dst, row_map):
+    """dst[i] = src[row_map[i]] (zeros where row_map[i] < 0).  src [Rs, C], dst [Rd, C] (unit inner stride), row_map int64 [Rd]."""
+    assert src.dtype == dst.dtype and src.shape[1] == dst.shape[1] and row_map.dtype == torch.int64 and row_map.numel() == dst.shape[0]
+    es = src.element_size()
+    check(lib.mmsum_rows_gather(_p(src), _ld(src) * es, src.shape[0], _p(dst), _ld(dst) * es, _p(row_map), dst.shape[0], src.shape[1] * es,
+                                _stream()), "mmsum_rows_gather")
+    return dst

@@ -412,11 +412,12 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, anchor, model, batch):
         ctx.model = model
         graphs = getattr(model, "_step_graphs", None)
-        ctx.entry = graphs.forward(batch) if (graphs is not None and model._engine.training) else None
+        capacity = _encoder_capacity(model, batch[1])
+        ctx.entry = graphs.forward(batch, capacity) if (graphs is not None and model._engine.training) else None
         if ctx.entry is not None:
             ctx.saved = None
             return ctx.entry.saved.loss.reshape(()).clone()      # the graph's loss buffer is overwritten by the next replay
-        ctx.saved = model._step_fwd(*batch)
+        ctx.saved = model._step_fwd(*batch, capacity=capacity)
         return ctx.saved.loss.reshape(())
 
     @staticmethod
@@ -427,6 +428,23 @@ class _StepFn(torch.autograd.Function):
         else:
             ctx.model._step_bwd(ctx.saved)
         return None, None, None
+
+
+def _encoder_capacity(model, reviews_mask):
+    """Row capacity of the padding-free text encoder for this batch (None = run padded).  The number of valid tokens
+    comes from `reviews_mask._mmsum_valid_rows` when the loader side attached it (prefetch.py counts on the host copy,
+    bench.py at batch creation); otherwise one device->host read.  Rounded up to a bucket so that HIP graphs (keyed by
+    it) are reused across batches."""
+    e = model._engine
+    if not getattr(model, "compact_encoder", True) or not e.training:
+        return None
+    n = getattr(reviews_mask, "_mmsum_valid_rows", None)
+    if n is None:
+        n = int(reviews_mask.ne(0).sum().item())
+    R = reviews_mask.numel()
+    g = getattr(model, "encoder_row_granule", None) or (1024 if R >= 16384 else 256)
+    cap = (int(n) + g - 1) // g * g
+    return cap if cap + g <= R else None          # nothing to gain when (almost) no row is padding
 
 
 def _run_segments(engine, segments):
@@ -497,7 +515,7 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
         return NR, text_h, reviews_mask, table_h.unsqueeze(1), table_m.unsqueeze(1), img_h, img_m
 
     # ---- fused step -------------------------------------------------------------------------------
-    def _step_fwd(self, reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask):
+    def _step_fwd(self, reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask, capacity=None):
         e, cfg = self._engine, self._engine.cfg
         B, NR, S = reviews.shape
         I = img.shape[1]
@@ -522,7 +540,7 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
             with torch.cuda.stream(side):
                 _, s.tab = e.table_fwd(field, field_value, out=s.mem[o1:o2])
                 _, s.img = e.img_fwd(imgs, out=s.mem[o2:])
-        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1])
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1], capacity=capacity)
         if side is not None:
             main.wait_stream(side)
         else:
@@ -601,13 +619,13 @@ class TextSupervised(_StepGraphMixin, nn.Module):
         _new_forward(e)
         return (_StepFn.apply(_anchor(e), self, (reviews, reviews_mask, reviews_rating)),)
 
-    def _step_fwd(self, reviews, reviews_mask, reviews_rating):
+    def _step_fwd(self, reviews, reviews_mask, reviews_rating, capacity=None):
         e, cfg = self._engine, self._engine.cfg
         B, NR, S = reviews.shape
         s = type("Saved", (), {})()
         s.layout = e.make_memory(B, [(NR, S)])
         s.mem = e.empty(s.layout.rows, cfg.d_model)
-        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem)
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem, capacity=capacity)
         pads = [reviews_mask.eq(0).to(torch.uint8).contiguous()]
         dec_in = shift_tokens_right_batched(reviews, reviews[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id).reshape(B * NR, S)
         dec_pad = dec_in.eq(cfg.pad_token_id).to(torch.uint8).contiguous()

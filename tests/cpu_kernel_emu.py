@@ -416,6 +416,13 @@ def amazon_table_gather_bwd(dall, price, rating, dw_price, dw_rating, B, D):
     dw_rating.add_(torch.einsum("bk,bd->dk", rating.float(), dv[:, 1]))
 
 
+def rows_gather(src, dst, row_map):
+    ok = row_map >= 0
+    dst.zero_()
+    dst[ok] = src[row_map[ok]]
+    return dst
+
+
 def install(monkeypatch):
     """Route multimodalsum_amd.{engine,modules,optim,generation}.kn to this module for the duration of a test."""
     import sys

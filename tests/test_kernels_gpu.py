@@ -592,3 +592,26 @@ def test_amazon_table_gather(dtype):
     dv = dall.float().cpu().view(B, 133, 2 * D)[:, :, D:]
     close(dwp, 1 + torch.einsum("bk,bd->dk", price.float(), dv[:, 0]), dtype, what="d price weight")
     close(dwr, 1 + torch.einsum("bk,bd->dk", rating.float(), dv[:, 1]), dtype, what="d rating weight")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_rows_gather(dtype):
+    """mmsum_rows_gather: compact (valid rows first, filler rows zero) and expand (padding rows zero), strided operands."""
+    R, C, cap = 300, 1024, 200
+    g = torch.Generator().manual_seed(3)
+    mask = torch.rand(R, generator=g) < 0.6
+    n = int(mask.sum())
+    assert n <= cap
+    src_wide = rnd(R, C + 64, dtype=dtype, seed=9)
+    src = src_wide[:, 64:]
+    pos = torch.cumsum(mask.long(), 0) - 1
+    p2c = torch.where(mask, pos, torch.full_like(pos, -1)).to(DEV)
+    c2p = torch.full((cap,), -1, dtype=torch.long)
+    c2p[:n] = torch.nonzero(mask).flatten()
+    c2p = c2p.to(DEV)
+    comp = torch.full((cap, C), 7.0, device=DEV, dtype=dtype)
+    kn.rows_gather(src, comp, c2p)
+    assert torch.equal(comp[:n], src[mask.to(DEV)]) and (comp[n:] == 0).all()
+    back = torch.full((R, C), 7.0, device=DEV, dtype=dtype)
+    kn.rows_gather(comp, back, p2c)
+    assert torch.equal(back[mask.to(DEV)], src[mask.to(DEV)]) and (back[~mask.to(DEV)] == 0).all()
