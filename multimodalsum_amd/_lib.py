@@ -9,7 +9,7 @@ import os
 from ctypes import c_float, c_int, c_int64, c_long, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmsum_hip.so")
+LIB_PATH = os.environ.get("MMSUM_LIB") or os.path.join(_HERE, "csrc", "libmmsum_hip.so")     # MMSUM_LIB: A/B a second build
 
 F32, BF16 = 0, 1
 OK = 0

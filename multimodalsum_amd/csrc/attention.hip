@@ -92,6 +92,22 @@ __device__ __forceinline__ void scores_softmax(f32x16_t (&sacc)[NKB], const char
 // the key mask, which is an additive 0 / -inf vector read from LDS four keys at a time), exponentials
 // are v_exp_f32 (2^x), fragment addresses are hoisted, and for causal self-attention the key blocks above
 // the wave's diagonal block are skipped altogether.  Returns the row max / sum in the log2 domain.
+// Number of keys of the staged entity up to its last unmasked one (all waves agree after the next barrier): the key blocks
+// past it are pure padding (probability exactly 0) and their matrix products are skipped -- a 75-token review uses 3 of 4.
+__device__ __forceinline__ void publish_key_extent(int* slots, uint8_t masked, int S, int tid) {
+    int e = (tid < S && !masked) ? tid + 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) e = max(e, __shfl_xor(e, o));
+    if ((tid & 63) == 0) slots[tid >> 6] = e;
+}
+template <int NWAVES>
+__device__ __forceinline__ int read_key_extent(const int* slots) {
+    int e = 0;
+#pragma unroll
+    for (int w = 0; w < NWAVES; ++w) e = max(e, slots[w]);
+    return e;
+}
+
 #define LOG2E_F 1.4426950408889634f
 #define LN2_F 0.6931471805599453f
 template <typename T, int NKB, bool CAUSAL>
@@ -528,15 +544,17 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
         kreg.commit(ktile, tid);
         vreg.commit(vtile, tid);
         if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
+        publish_key_extent(reinterpret_cast<int*>(biasf + SPAD), mreg, d.S, tid);
         __syncthreads();
+        const int slen = read_key_extent<ATT_THREADS / 64>(reinterpret_cast<const int*>(biasf + SPAD));
         if (rem) prefetch(__builtin_ctz(rem));
         f32x16_t sacc[NKB];
         float m, l;
-        scores_softmax2<T, NKB, CAUSAL>(sacc, ktile, SPAD, qf, biasf, d.S, d.scale, qpos, wave, lane, fo, m, l);
+        scores_softmax2<T, NKB, CAUSAL>(sacc, ktile, SPAD, qf, biasf, slen, d.scale, qpos, wave, lane, fo, m, l);
         const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
+            if (kb * 32 < slen && (!CAUSAL || kb <= wave)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[kb][r] *= norm;
                 acc_to_image<T>(img, sacc[kb], lane);
@@ -621,12 +639,14 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
         vreg.commit(vtile, tid);
         ktreg.commit(kttile, tid);
         if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
+        publish_key_extent(reinterpret_cast<int*>(biasf + SPAD), mreg, d.S, tid);
         cur_n = next_n;
         __syncthreads();
+        const int slen = read_key_extent<ATT_THREADS / 64>(reinterpret_cast<const int*>(biasf + SPAD));
         if (rem) prefetch(__builtin_ctz(rem));
         f32x16_t p[NKB];
         float m, l;
-        scores_softmax2<T, NKB, CAUSAL>(p, ktile, SPAD, qf, biasf, d.S, d.scale, qpos, wave, lane, fo, m, l);
+        scores_softmax2<T, NKB, CAUSAL>(p, ktile, SPAD, qf, biasf, slen, d.scale, qpos, wave, lane, fo, m, l);
         const float invl = (l > 0.f) ? 1.f / l : 0.f;
         // dP^T = V dO^T.  With two resident workgroups per CU (NKB <= 2) the registers to keep it for all key blocks
         // are not there, so it is computed twice (delta pass, then dS pass); the text entities (NKB 3..4, one
@@ -636,7 +656,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
         float delta = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
+            if (kb * 32 < slen && (!CAUSAL || kb <= wave)) {
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
@@ -659,7 +679,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
         }
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < d.S && (!CAUSAL || kb <= wave)) {
+            if (kb * 32 < slen && (!CAUSAL || kb <= wave)) {
                 f32x16_t dpk;
                 if constexpr (KEEP_DP) {
                     dpk = dpkeep[kb];
@@ -775,8 +795,10 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
         vreg.commit(vtile, tid);
         ktreg.commit(kttile, tid);
         if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
+        publish_key_extent(reinterpret_cast<int*>(xch + 2 * 3 * 2 * 128), mreg, d.S, tid);
         cur_n = next_n;
         __syncthreads();
+        const int slen = read_key_extent<KS_THREADS / 64>(reinterpret_cast<const int*>(xch + 2 * 3 * 2 * 128));
         if (rem) prefetch(__builtin_ctz(rem));
         float* xm = xch + parity * (3 * 2 * 128);
         float* xl = xm + 2 * 128;
@@ -788,7 +810,7 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
 #pragma unroll
         for (int kl = 0; kl < KB0; ++kl) {
             const int kb = kb_lo + kl;
-            const bool active = kb < kb_hi && (kb * 32 < d.S) && (!CAUSAL || kb <= qw);
+            const bool active = kb < kb_hi && (kb * 32 < slen) && (!CAUSAL || kb <= qw);
             p[kl] = zero_acc();
             if (active) {
 #pragma unroll
@@ -834,7 +856,7 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
 #pragma unroll
         for (int kl = 0; kl < KB0; ++kl) {
             const int kb = kb_lo + kl;
-            if (kb < kb_hi && kb * 32 < d.S && (!CAUSAL || kb <= qw)) {
+            if (kb < kb_hi && kb * 32 < slen && (!CAUSAL || kb <= qw)) {
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
@@ -861,7 +883,7 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
 #pragma unroll
         for (int kl = 0; kl < KB0; ++kl) {
             const int kb = kb_lo + kl;
-            if (kb < kb_hi && kb * 32 < d.S && (!CAUSAL || kb <= qw)) {
+            if (kb < kb_hi && kb * 32 < slen && (!CAUSAL || kb <= qw)) {
                 f32x16_t dpk;
                 if constexpr (KEEP_DP) {
                     dpk = dpkeep[kl];
@@ -911,7 +933,7 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
     }
 }
 
-template <typename T> size_t ks_lds(int nkb) { return (size_t)3 * nkb * 32 * HD * sizeof(T) + 8 * ImageTraits<T>::kBytes + nkb * 32 * sizeof(float) + 2 * 3 * 2 * 128 * sizeof(float) + 16; }
+template <typename T> size_t ks_lds(int nkb) { return (size_t)3 * nkb * 32 * HD * sizeof(T) + 8 * ImageTraits<T>::kBytes + nkb * 32 * sizeof(float) + 2 * 3 * 2 * 128 * sizeof(float) + 48; }
 
 template <typename T, int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dkv_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,

@@ -32,6 +32,10 @@ def main():
         k, v = kv[:, :D], kv[:, D:]
         out = torch.empty(nq * T, D, device="cuda", dtype=dt)
         pad = torch.zeros(B * N * S, dtype=torch.uint8, device="cuda")
+        if os.environ.get("ATTN_BENCH_PADS") == "1" and name == "cross_text":      # review lengths ~ clamp(N(75,20),32,128): trailing pads
+            g = torch.Generator().manual_seed(0)
+            lens = (torch.randn(B * N, generator=g) * 20 + 75).round().clamp(32, S).long()
+            pad = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).to(torch.uint8).reshape(-1).cuda()
         null = torch.zeros(B * N, dtype=torch.uint8, device="cuda")
         desc = kn.make_attn_desc(q, k, v, out, pad, null, nq, T, qpb, N, S, H, excl, causal, 0.125)
         dout = torch.randn(nq * T, D, device="cuda").to(dt)
