@@ -303,7 +303,7 @@ def main():
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "dropout": cfg.dropout},
                "launch": "eager" if args.no_graphs else "hip-graph replay (1 forward graph + 1 graph per backward gradient segment), %d priming steps before warmup" % priming,
-               "final_loss": loss_val, "roofline": roof}
+               "final_loss": loss_val, "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1), "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_bounded(args)
     if world > 1 or force_ddp:

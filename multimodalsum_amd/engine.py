@@ -148,7 +148,7 @@ class Engine:
         self._conv_dirty = "all"
         self.touched = set()
         self.Vpad = (cfg.vocab_size + 127) // 128 * 128
-        self.wt, self.wt_desc, self.conv_mats_t, self._tcache = {}, None, {}, {}
+        self.wt, self.wt_desc, self.conv_mats_t = {}, None, {}
         if compute_dtype == torch.bfloat16:
             self._build_wt_table()
         self.post_backward_hooks = []      # run once when a whole backward pass has finished (DDP finalisation)
@@ -248,15 +248,6 @@ class Engine:
             if colsum is not None:
                 kn.colsum(out, colsum, accumulate=True)
 
-    def transposed(self, t, Mp, cache_key=None):
-        if cache_key is not None and cache_key in self._tcache:
-            return self._tcache[cache_key]
-        out = self.empty(t.shape[1], Mp)
-        kn.transpose(t, out, Mp)
-        if cache_key is not None:
-            self._tcache[cache_key] = out
-        return out
-
     def sync_weights(self):
         """Called at the start of every forward.  Parameters are ordinary f32 tensors that any
         optimiser may update in place, so the bf16 shadow and the conv weight matrices are rebuilt
@@ -288,7 +279,7 @@ class Engine:
         sk = max(1, min(8, -(-768 // max(tiles, 1)), ktiles // 4))     # measured optimum: ~768/tiles slices (tools/wgrad_bench.py)
         return sk
 
-    def wgrad(self, dy, x, gname=None, gview=None, x_cache_key=None, bias_g=None):
+    def wgrad(self, dy, x, gname=None, gview=None, bias_g=None):
         """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena."""
         out = gview if gview is not None else self.arena.g(gname)
         if bias_g is not None:
@@ -617,7 +608,7 @@ class Engine:
             rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
             stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
             kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
-        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), x_cache_key=("mem", dc.mem.data_ptr()), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
+        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
         self.dgrad(dkv, k + ".weight", a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, accumulate=not first)
         self.wgrad(dq, c.x, q + ".weight", bias_g=a.g(q + ".bias"))
         self.dgrad(dq, q + ".weight", a.w(q + ".weight"), dx, accumulate=True)

@@ -109,15 +109,14 @@ class StepGraphs:
                 self.pool = ent.fwd.pool()
             # the backward graphs are captured here too (capture records, it does not execute): autograd would
             # otherwise run the capture on its worker thread
-            keep_touched, keep_cache = e.touched, e._tcache
-            e._tcache = {}
+            keep_touched = e.touched
             for fn, prefixes in m._step_bwd_segments(ent.saved, release=False):
                 e.touched = set()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self.pool):
                     fn()
                 ent.bwd.append((g, frozenset(e.touched), prefixes))
-            e.touched, e._tcache = keep_touched, keep_cache
+            e.touched = keep_touched
         finally:
             check(lib.mmsum_set_dropout_salt(None), "mmsum_set_dropout_salt")
         ent.state = 1

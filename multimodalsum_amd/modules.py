@@ -57,7 +57,6 @@ def _begin_backward(engine):
     if not getattr(engine, "_grads_ready", False):
         engine.arena.prepare_grads()
         engine.touched = set()
-        engine._tcache = {}
         engine._grads_ready = True
         if engine.post_backward_hooks:
             # fires once, after the LAST node of this backward pass (what torch DDP uses as well)
