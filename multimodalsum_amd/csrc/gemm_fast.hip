@@ -315,8 +315,11 @@ inline int cu_count() {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
+// ABLATE (tools/gemm_ablate.py only; results are wrong by construction): 1 = no DMA after the first ring fill, 2 = no MFMA,
+// 3 = no epilogue; the timing differences attribute the launch time to DMA wait, matrix pipe and epilogue.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1, int ABLATE = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_ring_kernel(GemmArgs p) {
+    static_assert(NSTAGE == 4, "the wait counts below are written for a 4-stage ring");
     using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
             else if (ahead == 1) wait_vmcnt<Cfg::PPW>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (si + 3 < ns) issue(si + 3);
+            if (si + 3 < ns && ABLATE != 1) issue(si + 3);                          // ablation 1: only the first ring fill
             const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
             const char* Bs = As + Cfg::A_BYTES;
             Frag b[Cfg::TN];
@@ -403,6 +406,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
                 const Frag a = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
+                if (ABLATE == 2) {                                                  // ablation 2: operands read, no MFMA
+                    acc[i][0][0] += __builtin_bit_cast(float, a.c[0][0] ^ b[0].c[0][0] ^ b[1].c[1][1] ^ a.c[1][2]);
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a, b[j]);
             }
@@ -413,7 +420,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
         // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
         gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+        if (ABLATE != 3) epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+        else if (acc[0][0][0] == 12345.678f) static_cast<float*>(p.C)[0] = acc[1][1][3] + acc[3][0][7] + acc[2][1][9];      // keep the accumulators alive
     }
     __syncthreads();          // the staging reads are done before the next tile's DMA lands in the same LDS
     }
@@ -605,6 +613,23 @@ int launch_one(const GemmArgs& a, hipStream_t stream) {
         static const int persist = getenv("MMSUM_GEMM_PERSIST") ? atoi(getenv("MMSUM_GEMM_PERSIST")) : cu_count();
         int grid = tiles_r * a.splitk;
         if (persist > 0 && grid > persist) grid = persist;
+        if constexpr (BM == 256 && BN == 256 && EPI == MMSUM_EPI_NONE && OUT == OUT_T && NSTAGE == 4) {
+            static const int ablate = getenv("MMSUM_GEMM_ABLATE") ? atoi(getenv("MMSUM_GEMM_ABLATE")) : 0;
+            if (ablate) {
+                static bool once_a = false;
+                auto set = [&](const void* f) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r); };
+                if (!once_a) {
+                    set(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 1>));
+                    set(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 2>));
+                    set(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 3>));
+                    once_a = true;
+                }
+                if (ablate == 1) gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 1><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
+                else if (ablate == 2) gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 2><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
+                else gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 3><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
+                return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+            }
+        }
         gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     }
