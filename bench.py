@@ -310,6 +310,11 @@ def main():
         dist.destroy_process_group()          # RCCL prints its library banner on teardown: keep the JSON line last
     if rank == 0:
         sys.stdout.flush()
+        try:                                   # RCCL's banner sits in the C stdio buffer until exit: push it out first
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
 

@@ -354,17 +354,26 @@ class Engine:
         c.out = x
         return x, c
 
-    def encoder_bwd(self, c, dout):
-        """dout [Bn*S, D] (consumed).  Accumulates every encoder parameter gradient."""
+    def encoder_bwd(self, c, dout, split=None):
+        """dout [Bn*S, D] (consumed).  Accumulates every encoder parameter gradient.
+        split=(lo, hi, carry): run layers hi-1 .. lo only (the fused step cuts the encoder backward in two gradient segments
+        so that the data-parallel all-reduce of the upper layers overlaps the lower ones); `carry` is the input gradient
+        handed from the upper part (None for the part that starts at the top) and the function returns it for the next."""
         cfg, a = self.cfg, self.arena
         b = self.bp + "model.encoder."
-        dx = dout
-        if c.maps is not None:
-            dx = kn.rows_gather(dout, self.empty(c.maps.capacity, cfg.d_model), c.maps.c2p)
-        for i in reversed(range(cfg.encoder_layers)):
+        lo, hi, carry = (0, cfg.encoder_layers, None) if split is None else split
+        if carry is None:
+            dx = dout
+            if c.maps is not None:
+                dx = kn.rows_gather(dout, self.empty(c.maps.capacity, cfg.d_model), c.maps.c2p)
+        else:
+            dx = carry
+        for i in reversed(range(lo, hi)):
             lc, fc = c.layers[i]
             dx = self._ffn_block_bwd(b + "layers.%d." % i, fc, dx)
             dx = self._self_block_bwd(b + "layers.%d." % i, lc, dx)
+        if lo > 0:
+            return dx
         if c.maps is not None:
             dx = kn.rows_gather(dx, self.empty(c.Bn * c.S, cfg.d_model), c.maps.p2c)
         kn.embed_ln_bwd(dx, c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), None, None,
@@ -373,6 +382,7 @@ class Engine:
                         a.g(b + "layernorm_embedding.bias"), c.Bn, c.S, cfg.extra_pos_embeddings, cfg.pad_token_id, c.p, c.seed0)
         self.touch(self.bp + "model.shared.weight", b + "embed_positions.weight", b + "layernorm_embedding.weight",
                    b + "layernorm_embedding.bias")
+        return None
 
     # ---- shared blocks ----------------------------------------------------------------------------
     def _self_block_fwd(self, lb, x, pad, Bn, T, causal, maps=None):

@@ -7,10 +7,10 @@ over hipGraph) and replayed:
 
   forward  : one graph  (salt bump, text encoder with the table/image encoders on a parallel branch, leave-one-out
              decoder, LM head + loss)
-  backward : one graph per gradient segment (decoder | text encoder + embeddings with the image/table backward on a
-             parallel branch), so the data-parallel all-reduce of the decoder's gradients
-             (parallel.DistributedDataParallel) overlaps the encoders' backward -- the collectives stay outside the
-             graphs, on their own stream.
+  backward : one graph per gradient segment (decoder | upper half of the text encoder with the image/table backward on
+             a parallel branch | lower half + embeddings), so the data-parallel all-reduce of a finished segment
+             (parallel.DistributedDataParallel) overlaps the next segment's kernels and only the last ~0.4 GB of
+             gradients is reduced in the open -- the collectives stay outside the graphs, on their own stream.
 
 What stays eager: weight shadow refresh (engine.sync_weights), gradient-buffer preparation, clipping and the
 optimiser (a handful of launches whose scalars -- lr, bias corrections -- change every step).

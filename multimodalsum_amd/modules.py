@@ -569,7 +569,11 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
                 s.dlogits = None
             st["dmem"] = e.decoder_bwd(s.dec, dh)
 
-        def encoders():
+        L = e.cfg.encoder_layers
+        cut = L // 2 if L >= 4 else 0                   # two encoder segments: the all-reduce of the upper half overlaps the lower half
+        enc = e.bp + "model.encoder."
+
+        def encoders_upper():
             # image + table backward (layer3 and the projections only: small, sequential kernels) beside the text encoder's
             main = torch.cuda.current_stream() if st["dmem"].is_cuda else None
             side = e.side_stream() if main is not None else None
@@ -578,15 +582,21 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
                 with torch.cuda.stream(side):
                     e.img_bwd(s.img, st["dmem"][o2:])
                     e.table_bwd(s.tab, st["dmem"][o1:o2])
-                e.encoder_bwd(s.enc, st["dmem"][:o1])
+                st["dx"] = e.encoder_bwd(s.enc, st["dmem"][:o1], split=(cut, L, None))
                 main.wait_stream(side)
             else:
                 e.img_bwd(s.img, st["dmem"][o2:])
                 e.table_bwd(s.tab, st["dmem"][o1:o2])
-                e.encoder_bwd(s.enc, st["dmem"][:o1])
+                st["dx"] = e.encoder_bwd(s.enc, st["dmem"][:o1], split=(cut, L, None))
 
-        return [(decoder, [e.bp + "model.decoder."]),
-                (encoders, ["img_encoder.", "table_encoder.", e.bp + "model.encoder.", e.bp + "model.shared."])]
+        def encoder_lower():
+            e.encoder_bwd(s.enc, None, split=(0, cut, st["dx"]))
+
+        upper = ["img_encoder.", "table_encoder."] + [enc + "layers.%d." % i for i in range(cut, L)]
+        lower = [enc + "layers.%d." % i for i in range(cut)] + [enc + "embed", enc + "layernorm_embedding", e.bp + "model.shared."]
+        if cut == 0:
+            return [(decoder, [e.bp + "model.decoder."]), (encoders_upper, upper + lower)]
+        return [(decoder, [e.bp + "model.decoder."]), (encoders_upper, upper), (encoder_lower, lower)]
 
     def _step_bwd(self, s):
         _run_segments(self._engine, self._step_bwd_segments(s))
