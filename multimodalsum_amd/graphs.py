@@ -86,8 +86,20 @@ class StepGraphs:
                 return None                      # too many distinct shapes: stay eager rather than hoard graph memory
             self.entries[key] = _Entry()
             return None                          # first sight of these shapes: eager warm-up
+        if ent.state == -1:
+            return None                          # capture failed for these shapes before: stay eager
         if ent.state == 0:
-            self._capture(ent, flat, spec, extra)
+            try:
+                self._capture(ent, flat, spec, extra)
+            except Exception as exc:             # a failed capture must not take the training run down: fall back to eager launches
+                import warnings
+                warnings.warn("multimodalsum_amd: HIP-graph capture of the step failed (%r); continuing with eager launches" % (exc,))
+                ent.state, ent.fwd, ent.bwd, ent.saved = -1, None, [], None
+                try:
+                    torch.cuda.synchronize()
+                except Exception:
+                    pass
+                return None
         else:
             for dst, src in zip(ent.static, flat):
                 if dst.data_ptr() != src.data_ptr():
