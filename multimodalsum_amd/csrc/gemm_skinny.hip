@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
     f32x16_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = zero_acc();
-#pragma unroll 4
+#pragma unroll 8
     for (int s = s0; s < s1; ++s) {
         int k0 = s * 32;
         const Frag b = global_frag<bf16_t>(brow + k0, lane, true);
