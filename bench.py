@@ -82,6 +82,7 @@ def make_batches(args, cfg, device, rank, n=2):
         dev = syn.batch_to(b, device)
         # what a loader-side prefetcher does on the host copy (multimodalsum_amd/prefetch.py): the number of non-padding review tokens
         dev["reviews_mask"]._mmsum_valid_rows = int(b["reviews_mask"].ne(0).sum())
+        dev["img_mask"]._mmsum_valid_rows = int(b["img_mask"].ne(0).sum())
         out.append(dev)
     return out
 

@@ -482,9 +482,12 @@ class Engine:
             off += B * N * S
         return NS(B=B, mods=list(mods), offs=offs, rows=off)
 
-    def decoder_fwd(self, dec_ids, dec_pad, rating_diff, mem, layout, pads, qpb, exclude_self):
+    def decoder_fwd(self, dec_ids, dec_pad, rating_diff, mem, layout, pads, qpb, exclude_self, mem_capacity=None):
         """dec_ids [Bd,T]; dec_pad [Bd,T] uint8 or None; rating_diff [Bd] f32 or None; mem [Rmem,D];
-        pads: per-modality uint8 [B,N,S] (1 = padded key).  Bd = B*qpb."""
+        pads: per-modality uint8 [B,N,S] (1 = padded key).  Bd = B*qpb.
+        mem_capacity (fused step): the cross-attention K/V projections (and their gradients) run on the memory rows that
+        are not masked keys only, at most `mem_capacity` of them; K/V are expanded to the padded layout the attention
+        kernel reads (masked rows zero) once per layer."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
         Bd, T = dec_ids.shape
@@ -492,7 +495,11 @@ class Engine:
         b = self.bp + "model.decoder."
         nm = len(layout.mods)
         c = NS(Bd=Bd, T=T, ids=dec_ids.contiguous(), rd=rating_diff, mem=mem, layout=layout, pads=pads, qpb=qpb,
-               exclude_self=exclude_self, layers=[], p=self.p_drop(), seed0=self.next_seed(), dec_pad=dec_pad)
+               exclude_self=exclude_self, layers=[], p=self.p_drop(), seed0=self.next_seed(), dec_pad=dec_pad, mem_maps=None, mem_c=mem)
+        if mem_capacity is not None and mem_capacity < layout.rows:
+            keep = torch.cat([pd.reshape(-1) for pd in pads]).eq(0)            # rows that are real keys, memory-row order
+            c.mem_maps = self.row_maps(keep, mem_capacity)
+            c.mem_c = kn.rows_gather(mem, self.empty(mem_capacity, D), c.mem_maps.c2p)
         # null-entity flags per modality (:858) and the per-business no-table / no-image flags (:732-736)
         c.nulls = []
         for (N, S), pad in zip(layout.mods, pads):
@@ -523,7 +530,7 @@ class Engine:
         """dout [Rq, D] (consumed) -> dmem [Rmem, D]; accumulates decoder parameter gradients."""
         cfg, a = self.cfg, self.arena
         b = self.bp + "model.decoder."
-        dmem = self.empty(c.layout.rows, cfg.d_model)
+        dmem = self.empty(c.mem_c.shape[0], cfg.d_model)              # compact rows when the K/V projections run padding-free
         dx = dout
         for i in reversed(range(cfg.decoder_layers)):
             lb = b + "layers.%d." % i
@@ -541,6 +548,8 @@ class Engine:
                    b + "layernorm_embedding.bias")
         if has_r:
             self.touch(b + "rating_embeddings")
+        if c.mem_maps is not None:
+            dmem = kn.rows_gather(dmem, self.empty(c.layout.rows, cfg.d_model), c.mem_maps.p2c)
         return dmem
 
     def _cross_block_fwd(self, lb, x, dc):
@@ -554,9 +563,11 @@ class Engine:
         c = NS(x=x, p=self.p_drop(), seed=self.next_seed())
         c.q = self.empty(Rq, D)
         kn.gemm(x, a.w(q + ".weight"), c.q, bias=a.f32(q + ".bias"))                                     # :783 (scale folded into the kernel)
-        c.kv = self.empty(L.rows, 2 * D)
-        kn.gemm(dc.mem, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), c.kv,
+        c.kv = self.empty(dc.mem_c.shape[0], 2 * D)
+        kn.gemm(dc.mem_c, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), c.kv,
                 bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)))                                  # :788-789, hoisted
+        if dc.mem_maps is not None:
+            c.kv = kn.rows_gather(c.kv, self.empty(L.rows, 2 * D), dc.mem_maps.p2c)
         c.heads = self.empty(nm * Rq, D)
         c.descs = []
         for m, ((N, S), pad) in enumerate(zip(L.mods, dc.pads)):
@@ -618,7 +629,9 @@ class Engine:
             rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
             stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
             kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
-        self.wgrad(dkv, dc.mem, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
+        if dc.mem_maps is not None:
+            dkv = kn.rows_gather(dkv, self.empty(dc.mem_maps.capacity, 2 * D), dc.mem_maps.c2p)
+        self.wgrad(dkv, dc.mem_c, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
         self.dgrad(dkv, k + ".weight", a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, accumulate=not first)
         self.wgrad(dq, c.x, q + ".weight", bias_g=a.g(q + ".bias"))
         self.dgrad(dq, q + ".weight", a.w(q + ".weight"), dx, accumulate=True)

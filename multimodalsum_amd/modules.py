@@ -411,7 +411,7 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, anchor, model, batch):
         ctx.model = model
         graphs = getattr(model, "_step_graphs", None)
-        capacity = _encoder_capacity(model, batch[1])
+        capacity = _encoder_capacity(model, batch)
         ctx.entry = graphs.forward(batch, capacity) if (graphs is not None and model._engine.training) else None
         if ctx.entry is not None:
             ctx.saved = None
@@ -429,21 +429,47 @@ class _StepFn(torch.autograd.Function):
         return None, None, None
 
 
-def _encoder_capacity(model, reviews_mask):
-    """Row capacity of the padding-free text encoder for this batch (None = run padded).  The number of valid tokens
-    comes from `reviews_mask._mmsum_valid_rows` when the loader side attached it (prefetch.py counts on the host copy,
-    bench.py at batch creation); otherwise one device->host read.  Rounded up to a bucket so that HIP graphs (keyed by
-    it) are reused across batches."""
+def _valid_count(mask):
+    """Non-zero entries of a mask: the loader side attaches it (`_mmsum_valid_rows`, counted on the host copy by prefetch.py /
+    bench.py); otherwise one device->host read."""
+    n = getattr(mask, "_mmsum_valid_rows", None)
+    return int(mask.ne(0).sum().item()) if n is None else int(n)
+
+
+def _bucket(n, total, granule):
+    cap = (n + granule - 1) // granule * granule
+    return cap if cap + granule <= total else None          # nothing to gain when (almost) no row is padding
+
+
+def _encoder_capacity(model, batch):
+    """Row capacities of the padding-free parts of the fused step for this batch: (text-encoder rows, memory rows of the
+    cross-attention K/V projections), each None = run padded.  Counts are rounded up to a bucket so that HIP graphs
+    (keyed by them) are reused across batches."""
     e = model._engine
+    reviews_mask = batch[1]
     if not getattr(model, "compact_encoder", True) or not e.training:
         return None
-    n = getattr(reviews_mask, "_mmsum_valid_rows", None)
-    if n is None:
-        n = int(reviews_mask.ne(0).sum().item())
+    n_text = _valid_count(reviews_mask)
     R = reviews_mask.numel()
     g = getattr(model, "encoder_row_granule", None) or (1024 if R >= 16384 else 256)
-    cap = (int(n) + g - 1) // g * g
-    return cap if cap + g <= R else None          # nothing to gain when (almost) no row is padding
+    enc_cap = _bucket(n_text, R, g)
+    mem_cap = None
+    if len(batch) >= 7 and enc_cap is not None:               # multimodal step: + table rows (all counted) + rows of valid images
+        img, img_mask = batch[5], batch[6]
+        B, I = img.shape[0], img.shape[1]
+        hw = ((img.shape[-2] + 6 - 7) // 2 + 1, (img.shape[-1] + 6 - 7) // 2 + 1)
+        for _ in range(3):
+            hw = ((hw[0] + 2 - 3) // 2 + 1, (hw[1] + 2 - 3) // 2 + 1)
+        P = hw[0] * hw[1]
+        n_img = getattr(img_mask, "_mmsum_valid_rows", None)
+        n_img = B * I if n_img is None else int(n_img)       # no count at hand: every image slot counts (no device read for it)
+        total = R + B * e.table_positions + B * I * P
+        mem_cap = _bucket(n_text + B * e.table_positions + n_img * P, total, g)
+    elif enc_cap is not None:
+        mem_cap = enc_cap                                      # text-only step: the memory is the text rows
+    if os.environ.get("MMSUM_COMPACT_MEM") == "0":
+        mem_cap = None
+    return (enc_cap, mem_cap)
 
 
 def _run_segments(engine, segments):
@@ -539,7 +565,8 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
             with torch.cuda.stream(side):
                 _, s.tab = e.table_fwd(field, field_value, out=s.mem[o1:o2])
                 _, s.img = e.img_fwd(imgs, out=s.mem[o2:])
-        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1], capacity=capacity)
+        enc_cap, mem_cap = capacity if capacity is not None else (None, None)
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1], capacity=enc_cap)
         if side is not None:
             main.wait_stream(side)
         else:
@@ -552,7 +579,7 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
         dec_pad = dec_in.eq(cfg.pad_token_id).to(torch.uint8).contiguous()
         r = reviews_rating.float()
         rating_diff = (r - (r.sum(dim=1, keepdim=True) - r) / (NR - 1)).reshape(-1).contiguous()     # multimodal_train.py:153-156
-        hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True)
+        hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True, mem_capacity=mem_cap)
         s.hL = hL
         s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
         return s
@@ -634,13 +661,14 @@ class TextSupervised(_StepGraphMixin, nn.Module):
         s = type("Saved", (), {})()
         s.layout = e.make_memory(B, [(NR, S)])
         s.mem = e.empty(s.layout.rows, cfg.d_model)
-        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem, capacity=capacity)
+        enc_cap, mem_cap = capacity if capacity is not None else (None, None)
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem, capacity=enc_cap)
         pads = [reviews_mask.eq(0).to(torch.uint8).contiguous()]
         dec_in = shift_tokens_right_batched(reviews, reviews[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id).reshape(B * NR, S)
         dec_pad = dec_in.eq(cfg.pad_token_id).to(torch.uint8).contiguous()
         r = reviews_rating.float()
         rating_diff = (r - (r.sum(dim=1, keepdim=True) - r) / (NR - 1)).reshape(-1).contiguous()
-        s.hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True)
+        s.hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True, mem_capacity=mem_cap)
         s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(s.hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
         return s
 
