@@ -62,7 +62,8 @@ class _Entry:
 class StepGraphs:
     """Owned by a step module (MultimodalSum / TextSupervised); used by modules._StepFn."""
 
-    def __init__(self, model, max_shapes=8):
+    def __init__(self, model, max_shapes=8, max_live=4):
+        self.max_live = max_live                  # captured graph sets kept at once: each pins its own activations in HBM
         self.model = model
         self.engine = model._engine
         self.entries = {}
@@ -89,6 +90,10 @@ class StepGraphs:
         if ent.state == -1:
             return None                          # capture failed for these shapes before: stay eager
         if ent.state == 0:
+            live = [k for k, en in self.entries.items() if en.state == 1]
+            while len(live) >= self.max_live:     # least recently used set goes (dicts keep insertion order; replays re-insert)
+                old = self.entries[live.pop(0)]
+                old.state, old.fwd, old.bwd, old.saved, old.static = 0, None, [], None, None
             try:
                 self._capture(ent, flat, spec, extra)
             except Exception as exc:             # a failed capture must not take the training run down: fall back to eager launches
@@ -104,6 +109,7 @@ class StepGraphs:
             for dst, src in zip(ent.static, flat):
                 if dst.data_ptr() != src.data_ptr():
                     dst.copy_(src)
+        self.entries[key] = self.entries.pop(key)          # most recently used last
         ent.fwd.replay()
         return ent
 

@@ -451,7 +451,7 @@ def _encoder_capacity(model, batch):
         return None
     n_text = _valid_count(reviews_mask)
     R = reviews_mask.numel()
-    g = getattr(model, "encoder_row_granule", None) or (1024 if R >= 16384 else 256)
+    g = getattr(model, "encoder_row_granule", None) or (2048 if R >= 16384 else 256)     # coarse buckets: few graph sets
     enc_cap = _bucket(n_text, R, g)
     mem_cap = None
     if len(batch) >= 7 and enc_cap is not None:               # multimodal step: + table rows (all counted) + rows of valid images
@@ -464,7 +464,7 @@ def _encoder_capacity(model, batch):
         n_img = getattr(img_mask, "_mmsum_valid_rows", None)
         n_img = B * I if n_img is None else int(n_img)       # no count at hand: every image slot counts (no device read for it)
         total = R + B * e.table_positions + B * I * P
-        mem_cap = _bucket(n_text + B * e.table_positions + n_img * P, total, g)
+        mem_cap = _bucket(n_text + B * e.table_positions + n_img * P, total, 4 * g)     # image counts vary more: coarser bucket
     elif enc_cap is not None:
         mem_cap = enc_cap                                      # text-only step: the memory is the text rows
     if os.environ.get("MMSUM_COMPACT_MEM") == "0":
