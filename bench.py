@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=28,
-                    help="businesses per GPU per step (14: 9*14*128 rows = 63 x 256-row GEMM tiles, ~1.0 waves of 256 CUs per N=1024 slab)")
+                    help="businesses per GPU per step (28: 9*28*128 decoder rows = 126 x 256-row GEMM tiles, two full rounds of 256 CUs per N=1024 product)")
     ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
