@@ -125,6 +125,20 @@ def kernel_probe(dtype, batch=14):
             "shape": [M, N, K], "avg_launch_ms": ms, "flops_per_launch": fl, "achieved": fl / ms / 1e9, "unit": "TFLOP/s"}
 
 
+def padding_note(args, model, b):
+    """What the padding-free encoder / K-V projections skip in this run (results identical; the FLOP count used for the
+    roofline fraction stays the reference's padded one)."""
+    from multimodalsum_amd.modules import _encoder_capacity
+    batch = ((b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])
+             if args.workload == "multimodal" else (b["reviews"], b["reviews_mask"], b["reviews_rating"]))
+    cap = _encoder_capacity(model, batch)
+    if cap is None or cap[0] is None:
+        return None
+    R = b["reviews_mask"].numel()
+    return {"encoder_rows_computed": cap[0], "encoder_rows_padded": R, "memory_rows_projected": cap[1],
+            "note": "rows that are padding never reach a result; roofline.step keeps the padded FLOP count of SURVEY 8d"}
+
+
 def pmc_traffic(shape):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE doubled per
     the gfx950 correction + WRITE_SIZE); None when no profile of this exact shape is committed."""
@@ -303,6 +317,7 @@ def main():
                           if multimodal else "text_pretrain.py BART-large text-only step, 9 reviews x 128 tok",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "dropout": cfg.dropout},
+               "padding_free": padding_note(args, model, batches[0]),
                "launch": "eager" if args.no_graphs else "hip-graph replay (1 forward graph + 1 graph per backward gradient segment), %d priming steps before warmup" % priming,
                "final_loss": loss_val, "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1), "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
