@@ -94,6 +94,8 @@ class StepGraphs:
             while len(live) >= self.max_live:     # least recently used set goes (dicts keep insertion order; replays re-insert)
                 old = self.entries[live.pop(0)]
                 old.state, old.fwd, old.bwd, old.saved, old.static = 0, None, [], None, None
+            if not live:
+                self.pool = None                  # the allocator drops a graph pool with its last graph: start a new one
             try:
                 self._capture(ent, flat, spec, extra)
             except Exception as exc:             # a failed capture must not take the training run down: fall back to eager launches

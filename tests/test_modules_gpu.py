@@ -444,3 +444,36 @@ def test_padding_free_encoder_equals_padded(dtype):
             assert torch.isfinite(g1[n]).all(), n
             if g0[n].numel() >= 1024 and g0[n].abs().max() > 1e-6:
                 assert cosine(g1[n], g0[n]) > 0.98, (n, cosine(g1[n], g0[n]))
+
+
+def test_step_graph_sets_are_evicted_and_recaptured():
+    """At most `max_live` captured graph sets stay resident (each pins its activations); a batch whose set was evicted is
+    captured again and still reproduces the eager result."""
+    from multimodalsum_amd.modules import TextSupervised
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40, dropout=0.0)
+    model = TextSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    model.train()
+    model.encoder_row_granule = 8
+    batches = [to_dev(syn.yelp_batch(2, 3, 32, 1, cfg.vocab_size, seed=s, img_hw=8)) for s in (5, 6, 7)]
+
+    def step(b):
+        for p in model.parameters():
+            p.grad = None
+        loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone()
+
+    eager = [step(b) for b in batches]
+    import warnings
+    for max_live in (1, 2):
+        model.enable_step_graphs()
+        model._step_graphs.max_live = max_live
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")            # a failed capture only warns and falls back to eager launches
+            for rep in range(3):
+                for b, le in zip(batches, eager):
+                    assert torch.equal(step(b), le), (max_live, rep)
+        states = [en.state for en in model._step_graphs.entries.values()]
+        assert -1 not in states and states.count(1) == max_live, states
+        model.enable_step_graphs(False)
