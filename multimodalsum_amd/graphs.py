@@ -53,10 +53,10 @@ def _unflatten(flat, spec):
 
 
 class _Entry:
-    __slots__ = ("state", "static", "fwd", "bwd", "saved")
+    __slots__ = ("state", "static", "fwd", "bwd", "saved", "serial")
 
     def __init__(self):
-        self.state, self.static, self.fwd, self.bwd, self.saved = 0, None, None, [], None
+        self.state, self.static, self.fwd, self.bwd, self.saved, self.serial = 0, None, None, [], None, 0
 
 
 class StepGraphs:
@@ -113,6 +113,7 @@ class StepGraphs:
                     dst.copy_(src)
         self.entries[key] = self.entries.pop(key)          # most recently used last
         ent.fwd.replay()
+        ent.serial += 1
         return ent
 
     def _capture(self, ent, flat, spec, extra):
@@ -141,8 +142,13 @@ class StepGraphs:
             check(lib.mmsum_set_dropout_salt(None), "mmsum_set_dropout_salt")
         ent.state = 1
 
-    def backward(self, ent, begin_backward, end_backward):
+    def backward(self, ent, begin_backward, end_backward, serial=None):
         e = self.engine
+        if ent.state != 1 or (serial is not None and serial != ent.serial):
+            # the set's activation buffers belong to its latest forward replay; the training loop this path serves
+            # (multimodal_train.py:355-373) always runs backward before the next forward
+            raise RuntimeError("multimodalsum_amd: backward of a step whose captured forward state was overwritten by a later "
+                               "forward (or evicted); call backward before the next forward, or enable_step_graphs(False)")
         begin_backward(e)
         for g, touched, prefixes in ent.bwd:
             g.replay()

@@ -414,7 +414,7 @@ class _StepFn(torch.autograd.Function):
         capacity = _encoder_capacity(model, batch)
         ctx.entry = graphs.forward(batch, capacity) if (graphs is not None and model._engine.training) else None
         if ctx.entry is not None:
-            ctx.saved = None
+            ctx.saved, ctx.serial = None, ctx.entry.serial
             return ctx.entry.saved.loss.reshape(()).clone()      # the graph's loss buffer is overwritten by the next replay
         ctx.saved = model._step_fwd(*batch, capacity=capacity)
         return ctx.saved.loss.reshape(())
@@ -423,7 +423,7 @@ class _StepFn(torch.autograd.Function):
     def backward(ctx, dloss):
         # the fused step assumes loss.backward() with unit upstream gradient (multimodal_train.py:360)
         if ctx.entry is not None:
-            ctx.model._step_graphs.backward(ctx.entry, _begin_backward, _end_backward)
+            ctx.model._step_graphs.backward(ctx.entry, _begin_backward, _end_backward, ctx.serial)
         else:
             ctx.model._step_bwd(ctx.saved)
         return None, None, None

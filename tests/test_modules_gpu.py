@@ -477,3 +477,21 @@ def test_step_graph_sets_are_evicted_and_recaptured():
         states = [en.state for en in model._step_graphs.entries.values()]
         assert -1 not in states and states.count(1) == max_live, states
         model.enable_step_graphs(False)
+
+
+def test_step_graph_backward_after_a_later_forward_is_refused():
+    """A captured set's activations belong to its latest forward: a stale backward must fail loudly, not return wrong gradients."""
+    from multimodalsum_amd.modules import TextSupervised
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40, dropout=0.0)
+    model = TextSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    model.train()
+    model.enable_step_graphs()
+    b = to_dev(syn.yelp_batch(2, 3, 32, 1, cfg.vocab_size, seed=5, img_hw=8))
+    for _ in range(2):                                    # eager warm-up, then capture
+        model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0].backward()
+    first = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+    second = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+    with pytest.raises(RuntimeError, match="overwritten"):
+        first.backward()
+    second.backward()
+    torch.cuda.synchronize()
