@@ -107,6 +107,22 @@ def test_gemm_epilogues(dtype):
     o2 = acc.clone()
     kn.gemm(a, b, o2, accumulate=True, splitk=2)
     close(o2, ref, dtype, what="splitk")
+    # accumulate into an output of the operand dtype; ragged N (unaligned rows: scalar stores) with bias
+    o6 = rnd(M, N, dtype=dtype, seed=11)
+    ref6 = o6.float() + a.float() @ b.float().t()
+    kn.gemm(a, b, o6, accumulate=True)
+    close(o6, ref6, dtype, what="accum same dtype")
+    for Nr in (203, 264):
+        br, biasr = rnd(Nr, Kd, dtype=dtype, seed=12, std=0.3), rnd(Nr, seed=13)
+        o7 = rnd(300, Nr, dtype=dtype, seed=14)
+        ar = rnd(300, Kd, dtype=dtype, seed=15, std=0.3)
+        ref7 = o7.float() + ar.float() @ br.float().t() + biasr
+        kn.gemm(ar, br, o7, bias=biasr, accumulate=True)
+        close(o7, ref7, dtype, what="accum + bias, N=%d" % Nr)
+        o8 = rnd(300, Nr, seed=16)
+        ref8 = o8 + ar.float() @ br.float().t() + biasr
+        kn.gemm(ar, br, o8, bias=biasr, accumulate=True)
+        close(o8, ref8, dtype, what="f32 accum + bias, N=%d" % Nr)
     # split-K into partial slabs + deterministic reduce (no atomics)
     ws = torch.full((3 * M, N), float("nan"), device=DEV)
     kn.gemm(a, b, ws, splitk=3, slabs=True)
