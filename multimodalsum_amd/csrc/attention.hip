@@ -26,14 +26,24 @@ template <typename T> struct AttnTraits {
     static constexpr int kSlabsPer32 = 32 * sizeof(T) / SLAB_BYTES;   // slabs covering 32 reduction elements (1 / 2)
 };
 
-__device__ __forceinline__ int count_valid(const mmsum_attn_desc& d, int b, int excl) {
-    int cnt = 0;
-    for (int n = 0; n < d.N; ++n) {
-        if (n == excl) continue;
-        if (d.null_entity && d.null_entity[b * d.N + n]) continue;
-        ++cnt;
-    }
-    return cnt;
+// Bit n = entity n of business b takes part (not the excluded one, not all-padding).  Lane n reads entity n's flag and
+// the wave ballots: ONE global round trip (the per-entity loop it replaces was N dependent load -> wait steps, and the
+// dK/dV kernel ran it in every query-chunk iteration).  N <= 32.
+__device__ __forceinline__ uint32_t valid_entities(const mmsum_attn_desc& d, int b, int excl) {
+    const int n = threadIdx.x & 63;
+    bool ok = n < d.N && n != excl;
+    if (ok && d.null_entity) ok = d.null_entity[b * d.N + n] == 0;
+    return (uint32_t)__ballot(ok);
+}
+__device__ __forceinline__ int count_valid(const mmsum_attn_desc& d, int b, int excl) { return __popc(valid_entities(d, b, excl)); }
+
+// Retire loads into fragment registers HERE.  Without it the compiler places the wait at the first use inside the
+// entity loop, where the only loads still in flight are the next entity's prefetch -- and vmcnt retires in order, so the
+// prefetch would be waited for before the MFMAs it is supposed to hide under.
+template <int N>
+__device__ __forceinline__ void pin_frags(Frag (&f)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i].c[0]), "+v"(f[i].c[1]));
 }
 
 // Stage the key mask of one entity into LDS: 1 = masked (padded key, or key index >= S).
@@ -338,17 +348,25 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(mmsum_attn_des
             }
         }
     }
+    // the accumulate operand is requested for all 32 elements first: a load inside the store loop would wait for the
+    // previous store's acknowledgement every time (vmcnt retires in order)
+    float prev[2][16];
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
         const int col = h * HD + db * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = wave * 32 + acc_row(r, lane);
-            if (qq < d.T) {
-                T* o = dQ + ((long)qb * d.T + qq) * lddq + col;
-                const float v = dqacc[db][r] + (accumulate_dq ? to_f32(*o) : 0.f);
-                *o = from_f32<T>(v);
-            }
+            prev[db][r] = (accumulate_dq && qq < d.T) ? to_f32(dQ[((long)qb * d.T + qq) * lddq + col]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + acc_row(r, lane);
+            if (qq < d.T) dQ[((long)qb * d.T + qq) * lddq + col] = from_f32<T>(dqacc[db][r] + prev[db][r]);
         }
     }
 }
@@ -482,16 +500,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(mmsum_attn_de
 // workgroup pays one global round trip per kernel instead of two or three per entity.  K and V
 // (forward), K, V and K^T (dQ), Q, dO, Q^T and dO^T (dK/dV) live in separate LDS regions.
 // =============================================================================================
-__device__ __forceinline__ uint32_t valid_entities(const mmsum_attn_desc& d, int b, int excl) {
-    uint32_t m = 0;
-    for (int n = 0; n < d.N; ++n) {
-        if (n == excl) continue;
-        if (d.null_entity && d.null_entity[b * d.N + n]) continue;
-        m |= 1u << n;
-    }
-    return m;
-}
-
 template <typename T, int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) void attn_fwd_pipe_kernel(mmsum_attn_desc d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -525,6 +533,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) qf[sl] = global_frag<T>(qrow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
     }
+    pin_frags(qf);
     f32x16_t oacc[2] = {zero_acc(), zero_acc()};
 
     NatTile<T, SPAD, NS, ATT_THREADS> kreg;
@@ -616,6 +625,8 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
             dof[sl] = global_frag<T>(drow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
         }
     }
+    pin_frags(qf);
+    pin_frags(dof);
     f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
 
     NatTile<T, SPAD, NS, ATT_THREADS> kreg, vreg;
@@ -702,17 +713,25 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
             }
         }
     }
+    // the accumulate operand is requested for all 32 elements first: a load inside the store loop would wait for the
+    // previous store's acknowledgement every time (vmcnt retires in order)
+    float prev[2][16];
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
         const int col = h * HD + db * 32 + (lane & 31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = wave * 32 + acc_row(r, lane);
-            if (qq < d.T) {
-                T* o = dQ + ((long)qb * d.T + qq) * lddq + col;
-                const float v = dqacc[db][r] + (accumulate_dq ? to_f32(*o) : 0.f);
-                *o = from_f32<T>(v);
-            }
+            prev[db][r] = (accumulate_dq && qq < d.T) ? to_f32(dQ[((long)qb * d.T + qq) * lddq + col]) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = wave * 32 + acc_row(r, lane);
+            if (qq < d.T) dQ[((long)qb * d.T + qq) * lddq + col] = from_f32<T>(dqacc[db][r] + prev[db][r]);
         }
     }
 }
@@ -772,6 +791,8 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
             dof[sl] = global_frag<T>(drow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
         }
     }
+    pin_frags(qf);
+    pin_frags(dof);
     f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
 
     NatTile<T, SPAD, NS, KS_THREADS> kreg, vreg;
@@ -917,17 +938,24 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
     }
     __syncthreads();
     if (kg == 0) {
+        // accumulate operand first, for all 32 elements (see the 4-wave kernel)
+        float prev[2][16];
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
             const int col = h * HD + db * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int qq = qw * 32 + acc_row(r, lane);
-                if (qq < d.T) {
-                    T* o = dQ + ((long)qb * d.T + qq) * lddq + col;
-                    const float v = dqacc[db][r] + red[(db * 16 + r) * 64 + lane] + (accumulate_dq ? to_f32(*o) : 0.f);
-                    *o = from_f32<T>(v);
-                }
+                prev[db][r] = (accumulate_dq && qq < d.T) ? to_f32(dQ[((long)qb * d.T + qq) * lddq + col]) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int col = h * HD + db * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = qw * 32 + acc_row(r, lane);
+                if (qq < d.T) dQ[((long)qb * d.T + qq) * lddq + col] = from_f32<T>(dqacc[db][r] + red[(db * 16 + r) * 64 + lane] + prev[db][r]);
             }
         }
     }
@@ -982,6 +1010,9 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
         dkacc[o][0] = dkacc[o][1] = dvacc[o][0] = dvacc[o][1] = zero_acc();
     }
 
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) { pin_frags(kf[o]); pin_frags(vf[o]); }
+    const uint32_t live = valid_entities(d, b, -1);
     const int nchunks = (d.T + TQ - 1) / TQ;
     const int nqb = is_null ? 0 : (d.qpb - ((d.exclude_self && n < d.qpb) ? 1 : 0));
     const int n_it = nqb * nchunks;
@@ -1010,7 +1041,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
     for (int it = 0; it < n_it; ++it) {
         int qb, qc, i;
         coords(it, qb, qc, i);
-        const int cnt = __popc(valid_entities(d, b, d.exclude_self ? i : -1));
+        const int cnt = __popc(d.exclude_self ? (live & ~(1u << i)) : live);
         const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
         __syncthreads();
         qreg.commit(qn, tid);

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the entity-attention kernels at the training-step shapes (B=8)."""
+"""Micro-benchmark of the entity-attention kernels at the training-step shapes (B=8; ATTN_BENCH_B=28 for the bench batch).
+bwd+ = backward that accumulates into dQ (second and third modality of the decoder's cross-attention)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from multimodalsum_amd import kernels as kn
 
-CASES = [("cross_text", 8, 9, 9, 128, 128, True, False), ("self_causal", 72, 1, 1, 128, 128, False, True),
-         ("cross_img", 8, 9, 4, 196, 128, False, False), ("cross_table", 8, 9, 1, 47, 128, False, False)]
+NB = int(os.environ.get("ATTN_BENCH_B", "8"))
+CASES = [("cross_text", NB, 9, 9, 128, 128, True, False), ("self_causal", 9 * NB, 1, 1, 128, 128, False, True),
+         ("cross_img", NB, 9, 4, 196, 128, False, False), ("cross_table", NB, 9, 1, 47, 128, False, False)]
 
 
 def timeit(fn, iters=5):
@@ -46,7 +48,8 @@ def main():
         fl = 4.0 * nq * T * S * 64 * H * ents
         tf = timeit(lambda: kn.attn_fwd(desc, q))
         tb = timeit(lambda: kn.attn_bwd(desc, dout, dq, False, dkv[:, :D], dkv[:, D:], stats))
-        print("%-12s fwd %7.0f us (%6.1f TF/s)   bwd %7.0f us (%6.1f TF/s)" % (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6), flush=True)
+        ta = timeit(lambda: kn.attn_bwd(desc, dout, dq, True, dkv[:, :D], dkv[:, D:], stats))
+        print("%-12s fwd %7.0f us (%6.1f TF/s)   bwd %7.0f us (%6.1f TF/s)   bwd+ %7.0f us" % (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6, ta), flush=True)
 
 
 if __name__ == "__main__":
