@@ -46,6 +46,73 @@ __device__ __forceinline__ void pin_frags(Frag (&f)[N]) {
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i].c[0]), "+v"(f[i].c[1]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Writing a wave's 32 x 64 result tile (two 32x32 accumulators side by side).  In the accumulator layout a lane owns one
+// column and 16 scattered rows: a direct store is 32 two-byte stores per lane (and 32 two-byte loads when the result
+// accumulates into memory).  Staged through LDS as f32 [32][64] instead, a lane owns half a row: four 16-byte
+// stores (bf16), the accumulate operand fetched by four 16-byte loads issued before the staging.
+// `stg` is this wave's OUT_STAGE_BYTES of LDS (the operand tiles are dead by then).  ADD: the staging area already holds a
+// partial sum in the same layout (key-split dQ kernel).
+// ---------------------------------------------------------------------------------------------
+constexpr int OUT_STAGE_LD = 68;                               // floats per staged row
+constexpr int OUT_STAGE_BYTES = 32 * OUT_STAGE_LD * 4;
+
+template <typename T, bool ADD = false>
+__device__ __forceinline__ void flush_tile(float* stg, const f32x16_t (&acc)[2], T* g, long ld, int nrows, bool accumulate, int lane) {
+    if (nrows <= 0) return;                                    // wave-uniform
+    constexpr int EPV = 16 / sizeof(T), NV = 32 / EPV;         // elements per 16-byte vector, vectors per half row
+    const bool vec = ((((uintptr_t)g) | (uintptr_t)(ld * (long)sizeof(T))) & 15) == 0;
+    const int row = lane >> 1, half = lane & 1;
+    const bool mine = row < nrows;
+    T* o = g + (long)row * ld + half * 32;
+    u32x4_t prev[NV];
+    if (vec && accumulate && mine) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) prev[v] = *reinterpret_cast<const u32x4_t*>(o + v * EPV);
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float* p = stg + acc_row(r, lane) * OUT_STAGE_LD + db * 32 + (lane & 31);
+            *p = ADD ? *p + acc[db][r] : acc[db][r];
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+        const float* srow = stg + row * OUT_STAGE_LD + half * 32;
+        if (vec) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float x[EPV];
+#pragma unroll
+                for (int q4 = 0; q4 < EPV / 4; ++q4) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(srow + v * EPV + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[4 * q4 + e] = t[e];
+                }
+                T w[EPV];
+                if (accumulate) {
+                    __builtin_memcpy(w, &prev[v], 16);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) x[e] += to_f32(w[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) w[e] = from_f32<T>(x[e]);
+                u32x4_t pk;
+                __builtin_memcpy(&pk, w, 16);
+                *reinterpret_cast<u32x4_t*>(o + v * EPV) = pk;
+            }
+        } else {
+            float pv[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) pv[e] = accumulate ? to_f32(o[e]) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) o[e] = from_f32<T>(srow[e] + pv[e]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Stage the key mask of one entity into LDS: 1 = masked (padded key, or key index >= S).
 __device__ __forceinline__ void stage_mask(uint8_t* m, const uint8_t* pad, long ent, int S, int spad, int tid) {
     for (int s = tid; s < spad; s += ATT_THREADS) m[s] = (s >= S) ? 1 : (pad ? pad[ent * S + s] : 0);
@@ -575,15 +642,9 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
             }
         }
     }
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        const int col = h * HD + db * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = wave * 32 + acc_row(r, lane);
-            if (qq < d.T) O[((long)qb * d.T + qq) * d.ldo + col] = from_f32<T>(oacc[db][r]);
-        }
-    }
+    __syncthreads();                                           // the tiles are dead: their LDS stages the output rows
+    flush_tile<T>(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), oacc, O + ((long)qb * d.T + wave * 32) * d.ldo + h * HD, d.ldo,
+                  d.T - wave * 32, false, lane);
 }
 
 template <typename T, int NKB, bool CAUSAL>
@@ -713,27 +774,9 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
             }
         }
     }
-    // the accumulate operand is requested for all 32 elements first: a load inside the store loop would wait for the
-    // previous store's acknowledgement every time (vmcnt retires in order)
-    float prev[2][16];
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        const int col = h * HD + db * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = wave * 32 + acc_row(r, lane);
-            prev[db][r] = (accumulate_dq && qq < d.T) ? to_f32(dQ[((long)qb * d.T + qq) * lddq + col]) : 0.f;
-        }
-    }
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        const int col = h * HD + db * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qq = wave * 32 + acc_row(r, lane);
-            if (qq < d.T) dQ[((long)qb * d.T + qq) * lddq + col] = from_f32<T>(dqacc[db][r] + prev[db][r]);
-        }
-    }
+    __syncthreads();                                           // the tiles are dead: their LDS stages the output rows
+    flush_tile<T>(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), dqacc, dQ + ((long)qb * d.T + wave * 32) * lddq + h * HD, lddq,
+                  d.T - wave * 32, accumulate_dq != 0, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -927,38 +970,18 @@ __global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_d
             }
         }
     }
-    // ---- the two key groups' dQ partials meet in LDS (the tiles are dead now)
+    // ---- the two key groups' dQ partials meet in the output staging area (the tiles are dead now)
     __syncthreads();
-    float* red = reinterpret_cast<float*>(smem) + (size_t)qw * (2 * 16 * 64);
+    float* stg = reinterpret_cast<float*>(smem + qw * OUT_STAGE_BYTES);
     if (kg == 1) {
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[(db * 16 + r) * 64 + lane] = dqacc[db][r];
+            for (int r = 0; r < 16; ++r) stg[acc_row(r, lane) * OUT_STAGE_LD + db * 32 + (lane & 31)] = dqacc[db][r];
     }
     __syncthreads();
-    if (kg == 0) {
-        // accumulate operand first, for all 32 elements (see the 4-wave kernel)
-        float prev[2][16];
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const int col = h * HD + db * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = qw * 32 + acc_row(r, lane);
-                prev[db][r] = (accumulate_dq && qq < d.T) ? to_f32(dQ[((long)qb * d.T + qq) * lddq + col]) : 0.f;
-            }
-        }
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const int col = h * HD + db * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = qw * 32 + acc_row(r, lane);
-                if (qq < d.T) dQ[((long)qb * d.T + qq) * lddq + col] = from_f32<T>(dqacc[db][r] + red[(db * 16 + r) * 64 + lane] + prev[db][r]);
-            }
-        }
-    }
+    if (kg == 0)
+        flush_tile<T, true>(stg, dqacc, dQ + ((long)qb * d.T + qw * 32) * lddq + h * HD, lddq, d.T - qw * 32, accumulate_dq != 0, lane);
 }
 
 template <typename T> size_t ks_lds(int nkb) { return (size_t)3 * nkb * 32 * HD * sizeof(T) + 8 * ImageTraits<T>::kBytes + nkb * 32 * sizeof(float) + 2 * 3 * 2 * 128 * sizeof(float) + 48; }
@@ -1096,22 +1119,14 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
             }
         }
     }
+    __syncthreads();                                           // the query tiles are dead: their LDS stages the output rows
+    float* stg = reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES);
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
         const int kb = wave + 4 * o;
         if (kb >= NKB) continue;
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const int col = h * HD + db * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kb * 32 + acc_row(r, lane);
-                if (key < d.S) {
-                    dK[(row0 + key) * lddk + col] = from_f32<T>(dkacc[o][db][r]);
-                    dV[(row0 + key) * lddv + col] = from_f32<T>(dvacc[o][db][r]);
-                }
-            }
-        }
+        flush_tile<T>(stg, dkacc[o], dK + (row0 + kb * 32) * lddk + h * HD, lddk, d.S - kb * 32, false, lane);
+        flush_tile<T>(stg, dvacc[o], dV + (row0 + kb * 32) * lddv + h * HD, lddv, d.S - kb * 32, false, lane);
     }
 }
 
@@ -1144,7 +1159,10 @@ inline void allow_lds(KernelT kernel, size_t bytes) {
 inline int nkb_for(int S) { return S <= 64 ? 2 : (S <= 128 ? 4 : 7); }
 
 constexpr size_t LDS_MAX = 160 * 1024;
-template <typename T> size_t pipe_lds(int nkb, int ntiles) { return (size_t)ntiles * nkb * 32 * HD * sizeof(T) + 4 * ImageTraits<T>::kBytes + nkb * 32 * sizeof(float) + 16; }
+template <typename T> size_t pipe_lds(int nkb, int ntiles) {
+    const size_t need = (size_t)ntiles * nkb * 32 * HD * sizeof(T) + 4 * ImageTraits<T>::kBytes + nkb * 32 * sizeof(float) + 16;
+    return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
+}
 
 template <typename T>
 int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
