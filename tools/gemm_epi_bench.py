@@ -11,7 +11,7 @@ from multimodalsum_amd import _lib
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 20480
 CASES = [("proj+bias", 1024, 1024, "bias"), ("qkv+bias", 3072, 1024, "bias"), ("fc1+bias+gelu", 4096, 1024, "gelu"),
          ("fc2+bias", 1024, 4096, "bias"), ("dgrad plain", 1024, 1024, "none"), ("dgrad fc2 gelu'", 4096, 1024, "gelu_bwd"),
-         ("dgrad fc1", 1024, 4096, "none")]
+         ("dgrad fc1", 1024, 4096, "none"), ("dgrad accumulate", 1024, 1024, "acc"), ("dgrad fc1 accum", 1024, 4096, "acc")]
 
 
 def main():
@@ -34,6 +34,8 @@ def main():
                 kn.gemm(a[j], b[j], out[j], bias=bias, epi=_lib.EPI_GELU, aux=aux[j])
             elif kind == "gelu_bwd":
                 kn.gemm(a[j], b[j], out[j], epi=_lib.EPI_GELU_BWD, aux=aux[j], colsum=cs)
+            elif kind == "acc":
+                kn.gemm(a[j], b[j], out[j], accumulate=True)
             else:
                 kn.gemm(a[j], b[j], out[j])
         for i in range(3):
