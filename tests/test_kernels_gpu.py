@@ -377,6 +377,21 @@ def test_attention(dtype, case):
     close(dk, kf.grad, dtype, what=name + " dk")
     close(dv, vf.grad, dtype, what=name + " dv")
 
+    # accumulation into dQ (second and third modality of the decoder's cross-attention), and outputs whose row pitch is not
+    # a multiple of 16 bytes (the kernels then leave the 16-byte row path): same values
+    base = rnd(nq * T, D, dtype=dtype, seed=4)
+    dq2 = base.clone()
+    kn.attn_bwd(desc, dout, dq2, True, dk, dv, stats)
+    close(dq2, base.float() + qf.grad, dtype, what=name + " dq accumulate")
+    odd = lambda rows: torch.full((rows, D + 2), float("nan"), device=DEV, dtype=dtype)[:, :D]      # noqa: E731
+    out_o, dq_o, dk_o, dv_o = odd(nq * T), odd(nq * T), odd(B * N * S), odd(B * N * S)
+    desc_o = kn.make_attn_desc(q, k, v, out_o, pad_u8, null, nq, T, qpb, N, S, H, exclude, causal, scale)
+    kn.attn_fwd(desc_o, q)
+    assert torch.equal(out_o, out)
+    dq_o.copy_(base)
+    kn.attn_bwd(desc_o, dout, dq_o, True, dk_o, dv_o, stats)
+    assert torch.equal(dq_o, dq2) and torch.equal(dk_o, dk) and torch.equal(dv_o, dv)
+
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gate(dtype):
