@@ -53,10 +53,10 @@ def _unflatten(flat, spec):
 
 
 class _Entry:
-    __slots__ = ("state", "static", "fwd", "bwd", "saved", "serial")
+    __slots__ = ("state", "static", "fwd", "bwd", "saved", "serial", "nbytes")
 
     def __init__(self):
-        self.state, self.static, self.fwd, self.bwd, self.saved, self.serial = 0, None, None, [], None, 0
+        self.state, self.static, self.fwd, self.bwd, self.saved, self.serial, self.nbytes = 0, None, None, [], None, 0, 0
 
 
 class StepGraphs:
@@ -91,9 +91,15 @@ class StepGraphs:
             return None                          # capture failed for these shapes before: stay eager
         if ent.state == 0:
             live = [k for k, en in self.entries.items() if en.state == 1]
-            while len(live) >= self.max_live:     # least recently used set goes (dicts keep insertion order; replays re-insert)
+            # least recently used sets go (dicts keep insertion order; replays re-insert): when max_live are captured already, or
+            # when the device no longer has room for another set the size of the largest one captured so far
+            need = max([self.entries[k].nbytes for k in live], default=0)
+            while live and (len(live) >= self.max_live or self._free_bytes() < 1.15 * need):
                 old = self.entries[live.pop(0)]
                 old.state, old.fwd, old.bwd, old.saved, old.static = 0, None, [], None, None
+                if self._free_bytes() < 1.15 * need:
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()      # hand the evicted set's pool back before the new one is sized
             if not live:
                 self.pool = None                  # the allocator drops a graph pool with its last graph: start a new one
             try:
@@ -116,8 +122,13 @@ class StepGraphs:
         ent.serial += 1
         return ent
 
+    def _free_bytes(self):
+        """Device memory the allocator could still obtain (blocks cached inside graph pools are not counted: conservative)."""
+        return torch.cuda.mem_get_info(self.engine.device)[0]
+
     def _capture(self, ent, flat, spec, extra):
         e, m = self.engine, self.model
+        before = torch.cuda.memory_reserved(e.device)
         ent.static = [t.clone() for t in flat]
         torch.cuda.synchronize()
         check(lib.mmsum_set_dropout_salt(self.salt.data_ptr()), "mmsum_set_dropout_salt")
@@ -140,6 +151,7 @@ class StepGraphs:
             e.touched = keep_touched
         finally:
             check(lib.mmsum_set_dropout_salt(None), "mmsum_set_dropout_salt")
+        ent.nbytes = max(0, torch.cuda.memory_reserved(e.device) - before)      # what this set added to the graph pool
         ent.state = 1
 
     def backward(self, ent, begin_backward, end_backward, serial=None):
