@@ -407,33 +407,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zero_acc();
 
-    // one slab piece: 16 rows x 64 B; lane -> (row = lane>>2, physical chunk = lane&3)
+    // one slab piece: 16 rows x 64 B; lane -> (row = lane>>2, physical chunk = lane&3).  The row part of every piece's
+    // source address is fixed for the tile: computed once, the slab loop only adds the k offset.
     const int prow = lane >> 2;
+    long offA[Cfg::PPW], offA2[Cfg::PPW];          // element offsets (B pieces use offA's slots past PA)
+#pragma unroll
+    for (int i = 0; i < Cfg::PPW; ++i) {
+        const bool isA = i * Cfg::NW < Cfg::PA;
+        const int rb = isA ? i * Cfg::NW + wave : i * Cfg::NW - Cfg::PA + wave;
+        const int row = rb * 16 + prow;
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        int grow = (isA ? m0 : n0) + row;
+        const int lim = isA ? p.M : p.N;
+        grow = grow < lim ? grow : lim - 1;
+        offA[i] = (long)grow * (isA ? p.lda : p.ldb) + c * 8;
+        offA2[i] = isA ? (long)grow * p.lda2 + c * 8 : 0;
+    }
     auto issue = [&](int si) {          // si: slab index relative to s_beg
         char* As = smem + (si % NSTAGE) * Cfg::STAGE;
         char* Bs = As + Cfg::A_BYTES;
         int k0 = (s_beg + si) * 32;
         const int kb = k0;
-        const bf16_t* Ab = A;
-        long lda = p.lda;
-        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+        const bool second = A2 != nullptr && k0 >= p.ksplit;
+        const bf16_t* Ab = second ? A2 : A;
+        if (second) k0 -= p.ksplit;
 #pragma unroll
         for (int i = 0; i < Cfg::PPW; ++i) {
-            if (i * Cfg::NW < Cfg::PA) {
-                const int rb = i * Cfg::NW + wave;
-                const int row = rb * 16 + prow;
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                int grow = m0 + row;
-                grow = grow < p.M ? grow : p.M - 1;
-                dma16(Ab + (long)grow * lda + k0 + c * 8, As + rb * 1024);
-            } else {
-                const int rb = i * Cfg::NW - Cfg::PA + wave;
-                const int row = rb * 16 + prow;
-                const int c = (lane & 3) ^ ((row >> 2) & 3);
-                int grow = n0 + row;
-                grow = grow < p.N ? grow : p.N - 1;
-                dma16(B + (long)grow * p.ldb + kb + c * 8, Bs + rb * 1024);
-            }
+            if (i * Cfg::NW < Cfg::PA) dma16(Ab + (second ? offA2[i] : offA[i]) + k0, As + (i * Cfg::NW + wave) * 1024);
+            else dma16(B + offA[i] + kb, Bs + (i * Cfg::NW - Cfg::PA + wave) * 1024);
         }
     };
 
