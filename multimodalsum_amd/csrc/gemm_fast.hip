@@ -448,16 +448,19 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
             else if (ahead == 1) wait_vmcnt<Cfg::PPW>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (si + 3 < ns && ABLATE != 1) issue(si + 3);                          // ablation 1: only the first ring fill
             const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
             const char* Bs = As + Cfg::A_BYTES;
+            // this slab's first fragments are requested BEFORE the DMA of slab si+3 is issued (different ring slots): the
+            // address arithmetic and the four DMA instructions then run under the LDS latency instead of in front of it
             Frag b[Cfg::TN];
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+            Frag a0 = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32), lane);
+            if (si + 3 < ns && ABLATE != 1) issue(si + 3);                          // ablation 1: only the first ring fill
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
-                const Frag a = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
+                const Frag a = i == 0 ? a0 : lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
                 if (ABLATE == 2) {                                                  // ablation 2: operands read, no MFMA
                     acc[i][0][0] += __builtin_bit_cast(float, a.c[0][0] ^ b[0].c[0][0] ^ b[1].c[1][1] ^ a.c[1][2]);
                     continue;
