@@ -103,7 +103,7 @@ int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, 
  * encoder self-attention, causal decoder self-attention and the per-entity cross-attention with
  * entity mean:
  *   query block qb (T rows, row = qb*T + t, T <= 128) belongs to business b = qb / qpb; it attends,
- *   entity by entity, to entities n = 0..N-1 of b (rows mem_row0 + ((b*N+n)*S + s), S <= 224),
+ *   entity by entity, to entities n = 0..N-1 of b (rows mem_row0 + ((b*N+n)*S + s), S <= 224, N <= 32),
  *   skipping n == qb % qpb when `exclude_self` (leave-one-out) and entities with null[b*N+n] != 0;
  *   out = mean over the attended entities of softmax_s(scale * q.k + mask) v   (0 if none).
  *   pad [B*N*S] uint8 (1 = masked key) or NULL; causal: key s > query t masked (self-attention).

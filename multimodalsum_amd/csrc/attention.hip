@@ -1219,7 +1219,7 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
 }
 
 int check_desc(const mmsum_attn_desc* d, int dtype) {
-    if (!d || d->T <= 0 || d->T > 128 || d->S <= 0 || d->S > 224 || d->N <= 0 || d->H <= 0 || d->qpb <= 0 || d->n_qblocks <= 0 ||
+    if (!d || d->T <= 0 || d->T > 128 || d->S <= 0 || d->S > 224 || d->N <= 0 || d->N > 32 || d->H <= 0 || d->qpb <= 0 || d->n_qblocks <= 0 ||      // N <= 32: entity sets are 32-bit masks
         d->n_qblocks % d->qpb)
         return MMSUM_ERR_BAD_SHAPE;
     if (dtype != MMSUM_F32 && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;

@@ -646,3 +646,15 @@ def test_rows_gather(dtype):
     back = torch.full((R, C), 7.0, device=DEV, dtype=dtype)
     kn.rows_gather(comp, back, p2c)
     assert torch.equal(back[mask.to(DEV)], src[mask.to(DEV)]) and (back[~mask.to(DEV)] == 0).all()
+
+
+def test_attention_rejects_more_than_32_entities():
+    """Entity sets are 32-bit masks inside the kernels: N > 32 is a shape error, not a silent truncation."""
+    D = 64
+    q = torch.zeros(4, D, device=DEV, dtype=torch.bfloat16)
+    kv = torch.zeros(33 * 4, D, device=DEV, dtype=torch.bfloat16)
+    pad = torch.zeros(33 * 4, dtype=torch.uint8, device=DEV)
+    null = torch.zeros(33, dtype=torch.uint8, device=DEV)
+    desc = kn.make_attn_desc(q, kv, kv, torch.empty_like(q), pad, null, 1, 4, 1, 33, 4, 1, False, False, 0.125)
+    with pytest.raises(RuntimeError, match="mmsum_attn_fwd"):
+        kn.attn_fwd(desc, q)
