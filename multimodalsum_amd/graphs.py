@@ -86,22 +86,12 @@ class StepGraphs:
             if len(self.entries) >= self.max_shapes:
                 return None                      # too many distinct shapes: stay eager rather than hoard graph memory
             self.entries[key] = _Entry()
+            self._make_room(for_capture=False)   # the eager warm-up needs as much memory as a captured set pins
             return None                          # first sight of these shapes: eager warm-up
         if ent.state == -1:
             return None                          # capture failed for these shapes before: stay eager
         if ent.state == 0:
-            live = [k for k, en in self.entries.items() if en.state == 1]
-            # least recently used sets go (dicts keep insertion order; replays re-insert): when max_live are captured already, or
-            # when the device no longer has room for another set the size of the largest one captured so far
-            need = max([self.entries[k].nbytes for k in live], default=0)
-            while live and (len(live) >= self.max_live or self._free_bytes() < 1.15 * need):
-                old = self.entries[live.pop(0)]
-                old.state, old.fwd, old.bwd, old.saved, old.static = 0, None, [], None, None
-                if self._free_bytes() < 1.15 * need:
-                    torch.cuda.synchronize()
-                    torch.cuda.empty_cache()      # hand the evicted set's pool back before the new one is sized
-            if not live:
-                self.pool = None                  # the allocator drops a graph pool with its last graph: start a new one
+            self._make_room(for_capture=True)
             try:
                 self._capture(ent, flat, spec, extra)
             except Exception as exc:             # a failed capture must not take the training run down: fall back to eager launches
@@ -122,13 +112,41 @@ class StepGraphs:
         ent.serial += 1
         return ent
 
+    def _make_room(self, for_capture):
+        """Evict least recently used graph sets (dicts keep insertion order; replays re-insert): before a capture when max_live
+        are captured already, and -- capture or eager warm-up of new shapes -- while the device lacks room for another set the
+        size of the largest one captured so far."""
+        live = [k for k, en in self.entries.items() if en.state == 1]
+        # a captured set needs what the largest one so far took from the pool; an eager step of the same shapes holds more
+        # (every activation until its backward kernel ran, plus the allocator's rounding): measured ~1.5x
+        need = max([self.entries[k].nbytes for k in self.entries], default=0) * (1.0 if for_capture else 1.4)
+        if live and self._free_bytes() < 1.15 * need:
+            torch.cuda.empty_cache()              # blocks the allocator merely caches count as free: return them, then measure again
+        while live and ((for_capture and len(live) >= self.max_live) or self._free_bytes() < 1.15 * need):
+            old = self.entries[live.pop(0)]
+            old.state, old.fwd, old.bwd, old.saved, old.static = 0, None, [], None, None
+            if self._free_bytes() < 1.15 * need:
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()          # hand the evicted set's pool back before the new one is sized
+        if not live:
+            self.pool = None                      # the allocator drops a graph pool with its last graph: start a new one
+
+    def _pool_bytes(self):
+        """Bytes the allocator holds in this object's graph pool (segments tagged with the pool id)."""
+        if self.pool is None:
+            return 0
+        try:
+            return sum(seg["total_size"] for seg in torch.cuda.memory_snapshot() if tuple(seg.get("segment_pool_id", (0, 0))) == tuple(self.pool))
+        except Exception:
+            return 0
+
     def _free_bytes(self):
         """Device memory the allocator could still obtain (blocks cached inside graph pools are not counted: conservative)."""
         return torch.cuda.mem_get_info(self.engine.device)[0]
 
     def _capture(self, ent, flat, spec, extra):
         e, m = self.engine, self.model
-        before = torch.cuda.memory_reserved(e.device)
+        before = self._pool_bytes()
         ent.static = [t.clone() for t in flat]
         torch.cuda.synchronize()
         check(lib.mmsum_set_dropout_salt(self.salt.data_ptr()), "mmsum_set_dropout_salt")
@@ -151,7 +169,7 @@ class StepGraphs:
             e.touched = keep_touched
         finally:
             check(lib.mmsum_set_dropout_salt(None), "mmsum_set_dropout_salt")
-        ent.nbytes = max(0, torch.cuda.memory_reserved(e.device) - before)      # what this set added to the graph pool
+        ent.nbytes = max(0, self._pool_bytes() - before)                         # what this set added to the graph pool
         ent.state = 1
 
     def backward(self, ent, begin_backward, end_backward, serial=None):
