@@ -455,3 +455,45 @@ def test_padding_free_encoder_matches_oracle(monkeypatch, golden_dir, multimodal
             assert p.grad is None, name
         elif "img_encoder.resnet" not in name:
             _close(p.grad, ref, 5e-4, 5e-6, name)
+
+
+def test_graph_cache_eviction_policy(monkeypatch):
+    """graphs.StepGraphs._make_room: least recently used sets go at the count limit (captures only) and while the device lacks
+    room for another set -- 1.15x the largest set for a capture, 1.4x that for the eager warm-up of new shapes."""
+    import types
+    from multimodalsum_amd import graphs
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "empty_cache", lambda *a, **k: None)
+    model = types.SimpleNamespace(_engine=types.SimpleNamespace(device=torch.device("cpu")))
+    sg = graphs.StepGraphs(model, max_shapes=8, max_live=3)
+    GB = 1 << 30
+
+    def fill(n, nbytes):
+        sg.entries.clear()
+        sg.pool = (0, 1)
+        for i in range(n):
+            en = graphs._Entry()
+            en.state, en.nbytes = 1, nbytes
+            sg.entries["k%d" % i] = en
+
+    def live():
+        return [k for k, en in sg.entries.items() if en.state == 1]
+
+    free = {"v": 200 * GB}
+    monkeypatch.setattr(sg, "_free_bytes", lambda: free["v"])
+    fill(3, 40 * GB)                                     # count limit: a capture evicts the oldest, an eager warm-up does not
+    sg._make_room(for_capture=False)
+    assert live() == ["k0", "k1", "k2"]
+    sg._make_room(for_capture=True)
+    assert live() == ["k1", "k2"] and sg.entries["k0"].state == 0 and sg.entries["k0"].nbytes == 40 * GB
+    fill(2, 90 * GB)                                     # memory: 110 GB free holds a set (103.5 needed) but not an eager step (144.9)
+    free["v"] = 110 * GB
+    sg._make_room(for_capture=True)
+    assert live() == ["k0", "k1"]
+    monkeypatch.setattr(sg, "_free_bytes", lambda: 110 * GB + 90 * GB * (2 - len(live())))     # every eviction hands 90 GB back
+    sg._make_room(for_capture=False)
+    assert live() == ["k1"]                              # one eviction makes 200 GB: enough
+    fill(1, 180 * GB)                                    # a single huge set: evicted too when even that is not enough, pool restarted
+    monkeypatch.setattr(sg, "_free_bytes", lambda: 100 * GB)
+    sg._make_room(for_capture=False)
+    assert live() == [] and sg.pool is None
