@@ -9,7 +9,14 @@
  * leading dimensions in ELEMENTS, `dtype` = MMSUM_F32 | MMSUM_BF16 for activations/weights
  * (statistics, gradients of parameters and optimiser state are always f32), `stream` = a
  * hipStream_t.  Every function only enqueues work: it never allocates, synchronises or throws,
- * keeps no mutable global state, and returns MMSUM_OK or a negative error code.
+ * keeps no mutable global state (the only statics are once-initialised kernel attributes and the
+ * CU count of the device), and returns MMSUM_OK or a negative error code.
+ *
+ * `live_rows` (device int32, may be NULL) on the row-streaming entry points: the number of rows that
+ * are live in this call; rows at and past it are neither read nor written.  The value is read on the
+ * DEVICE when the kernel runs, so a HIP graph captured once for the row capacity (the host-side `M` /
+ * `R` / `nrows` argument) serves batches with any number of valid tokens: the padding-free text encoder
+ * and the cross-attention K/V projections work on compacted rows whose count changes every step.
  */
 #ifndef MMSUM_HIP_H
 #define MMSUM_HIP_H
@@ -18,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MMSUM_ABI_VERSION 1
+#define MMSUM_ABI_VERSION 2
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -41,6 +48,9 @@ enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_E
                                     (the bias gradient of the layer that produced the GEMM's input gradient) */
 
 int mmsum_abi_version(void);
+/* First 16 hex digits of the SHA-256 over the library's sources (csrc/Makefile: HASH_SRCS): lets the host tell a stale
+ * build from a fresh one. */
+const char* mmsum_build_id(void);
 
 /* C[m][n] = epi(alpha * sum_k A(m,k) B(n,k) + bias[n]) (+C).  Replaces every nn.Linear / F.linear
  * on the path and their autograd (modeling_multimodalsum.py:302,304,783-792,885,738-739,2281;
@@ -48,10 +58,23 @@ int mmsum_abi_version(void);
  * A2/ksplit: for k >= ksplit the A operand continues in A2 (K split over two tensors: the
  * torch.cat([text, table]) of :738-739 without the concat).  splitk > 1 needs OUT_F32 and either ACCUM
  * (f32 atomics into C) or SLABS (C = workspace of splitk partial slabs, summed by mmsum_slab_reduce:
- * deterministic, and cheaper than atomics). */
+ * deterministic, and cheaper than atomics).
+ * live_rows: natural A (no A_T): live rows of A and C (M); weight-gradient layout (A_T | B_T): live reduction length K.
+ * alpha_dev (device f32, may be NULL): alpha is multiplied by *alpha_dev when the kernel runs -- the upstream gradient of
+ * the loss (loss.backward(g), loss / accumulation_steps) enters the LM-head backward products this way, with no host read. */
 int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
-               int flags, int splitk, void* stream);
+               const float* alpha_dev, int flags, int splitk, const int* live_rows, void* stream);
+
+/* What mmsum_gemm would launch for these arguments (pure: no device work, pointers are only checked for alignment / NULL):
+ * plan[0] = kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (fewer than tiles * splitk:
+ * persistent workgroups walk the tile list).  Tests use it to assert that a shape reaches the kernel they mean to cover. */
+enum { MMSUM_PLAN_GENERIC = 0,   /* gemm_kernel: register-staged 128x128, f32 or bf16, any layout */
+       MMSUM_PLAN_NT_RING = 1,   /* gemm_nt_ring_kernel: bf16, K-contiguous operands, 4-stage LDS-DMA ring */
+       MMSUM_PLAN_TN_RING = 2,   /* gemm_tn_ring_kernel: bf16, reduction-major operands (weight gradients) */
+       MMSUM_PLAN_SKINNY = 3 };  /* gemm_skinny_kernel: M <= 128 weight-streaming (decode steps) */
+int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
+                    const float* bias, const void* aux, int M, int N, int K, int flags, int splitk, int* plan);
 
 /* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
 int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
@@ -60,18 +83,27 @@ int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* ou
  * mmsum_colsum_workspace(C) bytes. */
 long mmsum_colsum_workspace(int C);
 int mmsum_colsum(int dtype, const void* X, long ld, int R, int C, float* out, int accumulate, void* workspace,
-                 void* stream);
+                 const int* live_rows, void* stream);
+
+/* Dropout (F.dropout, modeling_multimodalsum.py:294,305,371,458,474,486,596): masks are a hash of (seed, element index);
+ * the reference draws them from the torch generator, so bit parity of masks is not defined and parity runs use p = 0.
+ * `salt` (device uint64, may be NULL) on every dropout entry point: the kernel uses seed + *salt * golden-ratio constant.
+ * A captured HIP graph replays the seed ARGUMENTS it was captured with; bumping the salt with mmsum_bump_u64 (a one-thread
+ * kernel, itself capturable) as the first node of the forward graph gives every replay fresh masks while the backward
+ * graphs of the same step regenerate the same ones. */
+int mmsum_bump_u64(void* dev_u64, unsigned long long inc, void* stream);
 
 /* K1/K7: y = dropout(LN(E[ids] + P[t+pos_offset] + rating_diff[seq]*rvec))
  * (modeling_multimodalsum.py:368-372, 581-597).  ids [nseq*T] int64; rating_diff/rvec may be NULL. */
 int mmsum_embed_ln_fwd(int dtype, const int64_t* ids, const void* E, const void* P, const float* rating_diff,
                        const void* rvec, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
-                       int nseq, int T, int D, int pos_offset, float eps, float p_drop, uint64_t seed, void* stream);
+                       int nseq, int T, int D, int pos_offset, float eps, float p_drop, uint64_t seed, const void* salt,
+                       void* stream);
 /* backward of the above: scatter-adds into dE (skipping pad_id rows), dP, drvec, dgamma, dbeta (all f32). */
 int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids, const void* E, const void* P,
                        const float* rating_diff, const void* rvec, const void* gamma, const float* mean,
                        const float* rstd, float* dE, float* dP, float* drvec, float* dgamma, float* dbeta, int nseq,
-                       int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, void* stream);
+                       int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, const void* salt, void* stream);
 
 /* Padding-free text encoder (MI355X-side restructuring, results identical): encoder rows that are padding never reach a
  * result (their keys are masked, :836-837; their outputs are masked again in the decoder's cross-attention, :858-866), so
@@ -79,25 +111,18 @@ int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids, const void
  * layout the attention kernel reads and the compact one with this gather:
  *   dst[i, :] = map[i] >= 0 ? src[map[i], :] : 0   (i < nrows; row_bytes multiple of 16; pitches in bytes). */
 int mmsum_rows_gather(const void* src, long src_pitch, int src_rows, void* dst, long dst_pitch, const int64_t* map, int nrows,
-                      int row_bytes, void* stream);
-
-/* Dropout salt for captured HIP graphs.  The reference draws fresh dropout masks every step from the torch
- * generator (F.dropout, modeling_multimodalsum.py:294,305,371,458,474,486,596); here masks are a hash of
- * (seed argument, element index).  A captured graph replays the same seed arguments, so a device-resident 64-bit
- * salt can be registered: every dropout kernel then uses seed + salt * golden-ratio constant, and
- * mmsum_bump_u64 (a one-thread kernel, capturable) advances it once per step.  NULL unregisters. */
-int mmsum_set_dropout_salt(const void* dev_u64);
-int mmsum_bump_u64(void* dev_u64, unsigned long long inc, void* stream);
+                      int row_bytes, const int* live_rows, void* stream);
 
 /* K4/K6/K21: y = LN(res + dropout(x))  (modeling_multimodalsum.py:294-297,305-308,458-461,474-477,486-489;
  * apex FusedLayerNorm :972-980). */
 int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,
-                     float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, void* stream);
+                     float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, const void* salt,
+                     const int* live_rows, void* stream);
 /* dres <- dz (or += if accumulate_dres), dx <- dz * dropmask/(1-p); dgamma/dbeta += (f32);
  * dxsum (f32 [D], may be NULL) += column sums of dx = the bias gradient of the Linear that produced x (:302,304,885). */
 int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, const void* gamma, const float* mean,
                      const float* rstd, void* dx, void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R,
-                     int D, float p_drop, uint64_t seed, float* dxsum, void* stream);
+                     int D, float p_drop, uint64_t seed, const void* salt, float* dxsum, const int* live_rows, void* stream);
 
 /* Entity attention (K3, K8, K11; modeling_multimodalsum.py:752-875).  One description covers
  * encoder self-attention, causal decoder self-attention and the per-entity cross-attention with

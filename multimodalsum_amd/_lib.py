@@ -18,6 +18,8 @@ ERRORS = {-1: "bad shape", -2: "bad dtype", -3: "bad alignment", -4: "workspace 
 GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
 GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM = 0x40, 0x80, 0x100, 0x200
+PLAN_GENERIC, PLAN_NT_RING, PLAN_TN_RING, PLAN_SKINNY = 0, 1, 2, 3
+ABI_VERSION = 2
 
 
 def gemm_epi(e):
@@ -35,20 +37,23 @@ class AttnDesc(ctypes.Structure):
 # name -> (restype, argtypes); mirrors include/mmsum_hip.h one to one
 SIGNATURES = {
     "mmsum_abi_version": (c_int, []),
+    "mmsum_build_id": (ctypes.c_char_p, []),
     "mmsum_gemm": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
-                           c_void_p, c_long, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+                           c_void_p, c_long, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "mmsum_gemm_plan": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p,
+                                c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     "mmsum_slab_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_void_p]),
     "mmsum_colsum_workspace": (c_long, [c_int]),
-    "mmsum_colsum": (c_int, [c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "mmsum_colsum": (c_int, [c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "mmsum_embed_ln_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_uint64, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_uint64, c_void_p, c_void_p]),
     "mmsum_embed_ln_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                   c_int, c_float, c_uint64, c_void_p]),
+                                   c_int, c_float, c_uint64, c_void_p, c_void_p]),
     "mmsum_add_ln_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                 c_float, c_float, c_uint64, c_void_p]),
+                                 c_float, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
     "mmsum_add_ln_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                 c_void_p, c_void_p, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmsum_entity_null": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmsum_attn_fwd": (c_int, [c_int, ctypes.POINTER(AttnDesc), c_void_p]),
     "mmsum_attn_bwd_workspace": (c_long, [ctypes.POINTER(AttnDesc)]),
@@ -66,8 +71,7 @@ SIGNATURES = {
                             c_float, c_void_p]),
     "mmsum_cast": (c_int, [c_int, c_void_p, c_int, c_void_p, c_long, c_void_p]),
     "mmsum_scale_by_clip": (c_int, [c_void_p, c_long, c_void_p, c_float, c_void_p]),
-    "mmsum_rows_gather": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p]),
-    "mmsum_set_dropout_salt": (c_int, [c_void_p]),
+    "mmsum_rows_gather": (c_int, [c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mmsum_bump_u64": (c_int, [c_void_p, ctypes.c_ulonglong, c_void_p]),
     "mmsum_transpose_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmsum_transpose_bf16_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -91,6 +95,9 @@ SIGNATURES = {
 }
 
 
+from ._build_id import source_build_id  # noqa: E402,F401
+
+
 def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libmmsum_hip.so not found at %s -- the HIP extension is mandatory (no CPU/torch fallback). "
@@ -100,6 +107,9 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args
+    if lib.mmsum_abi_version() != ABI_VERSION:
+        raise RuntimeError("libmmsum_hip.so at %s has ABI version %d, this package binds version %d: rebuild it (make -C multimodalsum_amd/csrc)"
+                           % (LIB_PATH, lib.mmsum_abi_version(), ABI_VERSION))
     return lib
 
 

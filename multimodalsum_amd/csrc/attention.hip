@@ -1144,15 +1144,17 @@ __global__ void entity_null_kernel(const uint8_t* __restrict__ pad, uint8_t* __r
 template <typename T> size_t fwd_lds(int nkb) { return (size_t)nkb * 32 * HD * sizeof(T) + 4 * ImageTraits<T>::kBytes + nkb * 32 + 16; }
 template <typename T> size_t dkv_lds() { return 4 * (size_t)64 * HD * sizeof(T) + 8 * ImageTraits<T>::kBytes + 64 * 2 * sizeof(float); }
 
-// Dynamic LDS above 64 KiB must be opted into per kernel (once; read-only afterwards).
+// Dynamic LDS above 64 KiB must be opted into per kernel: once per launch site, in a function-local static (initialised
+// exactly once and thread-safe by the language rules; read-only afterwards).  The bound is the device's 160 KiB, so the
+// attribute does not depend on the first caller's sizes.
 template <typename KernelT>
-inline void allow_lds(KernelT kernel, size_t bytes) {
-    if (bytes > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+inline bool allow_lds(KernelT kernel) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
 }
 #define LAUNCH_LDS(kern, grid, block, lds, s, ...)            \
     do {                                                      \
-        static bool once = false;                             \
-        if (!once) { allow_lds(kern, lds); once = true; }     \
+        static const bool allowed = allow_lds(kern);          \
+        (void)allowed;                                        \
         kern<<<grid, block, lds, s>>>(__VA_ARGS__);           \
     } while (0)
 
@@ -1186,8 +1188,7 @@ template <typename T>
 int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, long lddq, int accumulate_dq, void* dk, long lddk,
                void* dv, long lddv, void* stats, hipStream_t s) {
     const int nkb = nkb_for(d.S);
-    static const bool use_ks = !(getenv("MMSUM_ATTN_KS") && atoi(getenv("MMSUM_ATTN_KS")) == 0);
-    if (sizeof(T) == 2 && nkb == 4 && use_ks && ks_lds<T>(nkb) <= LDS_MAX) {   // 7 key blocks (images) spill at 256 registers: old kernel
+    if (sizeof(T) == 2 && nkb == 4 && ks_lds<T>(nkb) <= LDS_MAX) {   // 7 key blocks (images) spill at 256 registers: old kernel
         const dim3 grid(d.H, d.n_qblocks), block(KS_THREADS);
         const size_t lds = ks_lds<T>(nkb);
         if constexpr (sizeof(T) == 2) {

@@ -49,19 +49,22 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_kernel(GemmArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
+    int m_cap;                                  // the M the host sized the grid (and the split-K slabs) for
+    apply_live_rows(p, m_cap);
     // ---- tile assignment (bijective XCD remap: blocks b and b+8 share an XCD) -------------
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (m_cap + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int nwg = gridDim.x;
     const int bid = blockIdx.x;
     const int q = nwg >> 3, rr = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     const int tiles = tiles_m * tiles_n;
     const int ks = wg / tiles;                 // split-K slice
-    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
+    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * m_cap * p.ldc;
     const int t = wg % tiles;
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
+    if (m0 >= p.M) return;                      // tile of rows past the live count
 
     // ---- K range of this slice ---------------------------------------------------------------
     const int ktiles = (p.K + BK - 1) / BK;
@@ -159,9 +162,8 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
-                          void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
-                          int flags, int splitk, void* stream) {
+static int gemm_check(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb, const float* bias,
+                      int M, int N, int K, int flags, int splitk, const int* live_rows) {
     if (M <= 0 || N <= 0 || K <= 0 || splitk < 1) return MMSUM_ERR_BAD_SHAPE;
     if (dtype != MMSUM_F32 && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
     const int kc = (dtype == MMSUM_BF16) ? 8 : 4;
@@ -181,16 +183,43 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     if (!bt && ((ldb * es) & 15)) return MMSUM_ERR_BAD_ALIGN;
     if (at && ((lda * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
     if (bt && ((ldb * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
-    GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk};
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (live_rows && at && !bt) return MMSUM_ERR_BAD_SHAPE;     // a live row count needs a row-streamed operand
     if (flags & MMSUM_GEMM_COLSUM) {      // epilogue column sums exist on the LDS-DMA NT path with a bf16 result only
+        GemmArgs a{A, A2, B, nullptr, bias, nullptr, M, N, K, lda, lda2, ldb, 0, 0, ksplit, 1.f, flags, splitk, live_rows, nullptr};
         if (!gemm_glds_eligible(dtype, a) || (flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS)) || splitk != 1 || !bias)
             return MMSUM_ERR_BAD_SHAPE;
     }
+    return MMSUM_OK;
+}
+
+extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
+                          void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
+                          const float* alpha_dev, int flags, int splitk, const int* live_rows, void* stream) {
+    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, M, N, K, flags, splitk, live_rows);
+    if (rc != MMSUM_OK) return rc;
+    GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk, live_rows, alpha_dev};
+    hipStream_t s = static_cast<hipStream_t>(stream);
     if (gemm_skinny_eligible(dtype, a)) return launch_gemm_skinny(a, s);
     if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
     if (gemm_tn_eligible(dtype, a)) return launch_gemm_tn(a, s);
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
+}
+
+// Which kernel, tile and grid mmsum_gemm would launch for these arguments (no device work, no pointers dereferenced):
+// plan[0] = MMSUM_PLAN_* kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (< tiles * splitk
+// means persistent workgroups walking the tile list).  Lets tests assert that a shape reaches the kernel they mean to cover.
+extern "C" int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
+                               const float* bias, const void* aux, int M, int N, int K, int flags, int splitk, int* plan) {
+    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, M, N, K, flags, splitk, nullptr);
+    if (rc != MMSUM_OK) return rc;
+    GemmArgs a{A, A2, B, nullptr, bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, 0, 0, ksplit, 1.f, flags, splitk, nullptr, nullptr};
+    GemmPlan g;
+    if (gemm_skinny_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 32, (a.N + 31) / 32};
+    else if (gemm_glds_eligible(dtype, a)) g = plan_gemm_glds(a);
+    else if (gemm_tn_eligible(dtype, a)) g = plan_gemm_tn(a);
+    else g = GemmPlan{MMSUM_PLAN_GENERIC, BM, BN, ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.splitk};
+    plan[0] = g.kernel; plan[1] = g.bm; plan[2] = g.bn; plan[3] = g.grid;
+    return MMSUM_OK;
 }
 
 namespace {

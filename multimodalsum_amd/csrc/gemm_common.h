@@ -6,7 +6,21 @@
 struct GemmArgs {
     const void* A; const void* A2; const void* B; void* C; const float* bias; void* aux;
     int M, N, K; long lda, lda2, ldb, ldc, ldaux; int ksplit; float alpha; int flags; int splitk;
+    const int* live;     // device int32 or NULL: live rows of the row-streamed operand (M for natural A, K for the A_T|B_T product)
+    const float* alpha_dev;   // device f32 or NULL: alpha is multiplied by it when the kernel runs (an upstream gradient scale)
 };
+
+// Live row count (device-resident, so one captured HIP graph serves every batch): rows at and past it are neither read
+// nor written.  Natural A: limits M.  Reduction-major product (A_T | B_T, the weight gradient): limits K.
+__device__ __forceinline__ void apply_live_rows(GemmArgs& p, int& m_cap) {
+    m_cap = p.M;
+    if (p.alpha_dev != nullptr) p.alpha *= *p.alpha_dev;
+    if (p.live != nullptr) {
+        const int lv = max(0, __builtin_amdgcn_readfirstlane(*p.live));
+        if ((p.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) == (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) p.K = min(p.K, lv);
+        else p.M = min(p.M, lv);
+    }
+}
 
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
@@ -104,6 +118,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
 }
 
+struct GemmPlan { int kernel, bm, bn, grid; };                  // kernel: MMSUM_PLAN_* of include/mmsum_hip.h
+GemmPlan plan_gemm_glds(const GemmArgs& a);
+GemmPlan plan_gemm_tn(const GemmArgs& a);
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream);   // gemm_fast.hip
 bool gemm_glds_eligible(int dtype, const GemmArgs& a);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);   // gemm_skinny.hip: M <= 64 (decode step)

@@ -1,32 +1,18 @@
-// bf16 "NT" GEMM with direct global->LDS DMA (global_load_lds_dwordx4) for gfx950.
+// bf16 GEMMs with direct global->LDS DMA (global_load_lds_dwordx4) for gfx950.
 //
-//   C[m][n] = epi(alpha * sum_k A[m][k] * B[n][k] + bias[n]) (+C),   A [M,K], B [N,K] both K-contiguous.
+//   NT:  C[m][n] = epi(alpha * sum_k A[m][k] * B[n][k] + bias[n]) (+C),   A [M,K], B [N,K] both K-contiguous
+//        (forward x W^T; input gradients dy (W^T)^T through the transposed weight shadow)
+//   TN:  C[m][n] = sum_k A[k][m] * B[k][n],   A [K,M], B [K,N] both reduction-major
+//        (weight gradients dy^T x straight from the activations)
 //
-// Every product of the training step is routed here in bf16 mode: forward (x, W), dgrad (dy, W^T
-// from the transposed weight shadow) and wgrad (dy^T, x^T from the activation transposer).
-//
-// Tile BM x BN x 64, WAVES_M x WAVES_N waves, each wave (BM/WAVES_M) x (BN/WAVES_N) as MFMA 32x32x16
-// tiles.  Operands live in LDS in the k-slab format of mmsum_device.h; the DMA writes LDS linearly
-// (wave-uniform base + lane*16 B), so the XOR swizzle is applied to the per-lane SOURCE address and
-// again on the fragment read (guide rule 21: linear destination + swizzled source + swizzled read).
-// Two LDS stages: the DMA of K-tile t+1 is in flight while the MFMAs of tile t run; one
-// vmcnt(0)+barrier per K-tile.  Rows past M/N are clamped (their results are never stored).
+// Tile BM x BN, WAVES_M x WAVES_N waves, each wave (BM/WAVES_M) x (BN/WAVES_N) as MFMA 32x32x16 tiles.  Operands live in
+// LDS in the k-slab format of mmsum_device.h; the DMA writes LDS linearly (wave-uniform base + lane*16 B), so the XOR
+// swizzle is applied to the per-lane SOURCE address and again on the fragment read (guide rule 21: linear destination +
+// swizzled source + swizzled read).  Rows past M/N are clamped (their results are never stored).
 #include "gemm_common.h"
 #include <stdlib.h>
 
 namespace {
-
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-struct FastCfg {
-    static constexpr int NW = WAVES_M * WAVES_N;
-    static constexpr int THREADS = NW * 64;
-    static constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-    static constexpr int A_BYTES = BM * 2 * SLAB_BYTES, B_BYTES = BN * 2 * SLAB_BYTES;
-    static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int PA = BM / 16 * 2, PB = BN / 16 * 2;            // 1-KiB DMA pieces per operand tile
-    static constexpr int PPW = (PA + PB) / NW;                          // pieces per wave per K-tile
-    static_assert(PA % NW == 0 && PB % NW == 0, "pieces must split evenly over the waves");
-};
 
 // ---------------------------------------------------------------------------------------------
 // Epilogue through LDS.  In the accumulator layout a lane owns ONE column and 16 scattered rows, so a
@@ -241,102 +227,10 @@ __device__ __forceinline__ void dma16(const bf16_t* gsrc, char* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// One 1-KiB piece = 16 rows x 64 B of one slab.  `pidx` (wave-uniform) indexes pieces of a ROWS-row
-// tile: slab = pidx / (ROWS/16), row block = pidx % (ROWS/16).
-template <int ROWS>
-__device__ __forceinline__ void dma_piece(char* tile, const bf16_t* __restrict__ g, long ld, int row0, int R, int k0, int pidx, int lane) {
-    const int slab = pidx / (ROWS / 16), rb = pidx % (ROWS / 16);
-    const int row = rb * 16 + (lane >> 2);
-    const int c = (lane & 3) ^ ((row >> 2) & 3);               // logical chunk that belongs at this physical slot
-    int grow = row0 + row;
-    grow = grow < R ? grow : R - 1;
-    dma16(g + (long)grow * ld + k0 + slab * 32 + c * 8, tile + slab * (ROWS * SLAB_BYTES) + rb * 1024);
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_glds_kernel(GemmArgs p) {
-    using Cfg = FastCfg<BM, BN, WAVES_M, WAVES_N>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-
-    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles = tiles_m * tiles_n;
-    const int ks = wg / tiles;
-    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
-    const int t = wg % tiles;
-    int tm, tn;
-    tile_coords(t, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int ktiles = p.K / 64;
-    const int per = (ktiles + p.splitk - 1) / p.splitk;
-    const int kt_beg = ks * per, kt_end = min(ktiles, kt_beg + per);
-
-    const bf16_t* A = static_cast<const bf16_t*>(p.A);
-    const bf16_t* A2 = static_cast<const bf16_t*>(p.A2);
-    const bf16_t* B = static_cast<const bf16_t*>(p.B);
-
-    f32x16_t acc[Cfg::TM][Cfg::TN];
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j) acc[i][j] = zero_acc();
-
-    auto stage = [&](int buf, int kt) {
-        char* As = smem + buf * Cfg::STAGE;
-        char* Bs = As + Cfg::A_BYTES;
-        int k0 = kt * 64;
-        const bf16_t* Ab = A;
-        long lda = p.lda;
-        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
-        const int kb = kt * 64;
-#pragma unroll
-        for (int i = 0; i < Cfg::PPW; ++i) {
-            if (i * Cfg::NW < Cfg::PA) dma_piece<BM>(As, Ab, lda, m0, p.M, k0, i * Cfg::NW + wave, lane);
-            else dma_piece<BN>(Bs, B, p.ldb, n0, p.N, kb, i * Cfg::NW - Cfg::PA + wave, lane);
-        }
-    };
-
-    if (kt_beg < kt_end) {
-        stage(0, kt_beg);
-        __syncthreads();
-        int cur = 0;
-        for (int kt = kt_beg; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) stage(cur ^ 1, kt + 1);
-            const char* As = smem + cur * Cfg::STAGE;
-            const char* Bs = As + Cfg::A_BYTES;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                Frag b[Cfg::TN];
-#pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs + s * (BN * SLAB_BYTES), wn * (Cfg::TN * 32) + j * 32, lane);
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i) {
-                    const Frag a = lds_frag<bf16_t>(As + s * (BM * SLAB_BYTES), wm * (Cfg::TM * 32) + i * 32, lane);
-#pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a, b[j]);
-                }
-            }
-            __syncthreads();      // drains the DMA of tile kt+1 (vmcnt(0)) and fences the LDS reads of tile kt
-            cur ^= 1;
-        }
-    }
-    if constexpr (OUT == OUT_F32_ATOMIC) {
-        // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
-        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
-    } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// Ring variant: 4 LDS stages of ONE 32-deep k-slab each; the DMA runs three slabs ahead and is
+// NT ring kernel: 4 LDS stages of ONE 32-deep k-slab each; the DMA runs three slabs ahead and is
 // retired with counted s_waitcnt vmcnt(N) (never 0 in steady state) + a raw s_barrier, so a slab's
-// load latency is covered by three slabs of MFMA work instead of one (PMC on the 2-stage kernel:
-// 47 % of wave cycles parked at the vmcnt(0)+barrier, L2 hit rate 62 %).
+// load latency is covered by three slabs of MFMA work instead of one.
 //   iteration s:  wait(own DMA of slab s landed) ; barrier ; issue DMA of slab s+3 into slot (s+3)&3
 //                 (that slot was last read in iteration s-1, which every wave finished before this
 //                 barrier) ; MFMAs of slab s.
@@ -366,9 +260,7 @@ inline int cu_count() {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// ABLATE (tools/gemm_ablate.py only; results are wrong by construction): 1 = no DMA after the first ring fill, 2 = no MFMA,
-// 3 = no epilogue; the timing differences attribute the launch time to DMA wait, matrix pipe and epilogue.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1, int ABLATE = 0>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_ring_kernel(GemmArgs p) {
     static_assert(NSTAGE == 4, "the wait counts below are written for a 4-stage ring");
     using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
@@ -377,6 +269,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+    int m_cap;
+    apply_live_rows(p, m_cap);                    // the tile list shrinks with the live row count
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
     const int total = tiles * p.splitk;
@@ -386,7 +280,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
     for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
     const int wg = xcd_remap(vid, total);
     const int ks = wg / tiles;
-    p.C = (p.flags & MMSUM_GEMM_SLABS) ? static_cast<void*>(static_cast<float*>(C0) + (long)ks * p.M * p.ldc) : C0;
+    p.C = (p.flags & MMSUM_GEMM_SLABS) ? static_cast<void*>(static_cast<float*>(C0) + (long)ks * m_cap * p.ldc) : C0;
     const int t = wg % tiles;
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);
@@ -456,15 +350,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
             Frag a0 = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32), lane);
-            if (si + 3 < ns && ABLATE != 1) issue(si + 3);                          // ablation 1: only the first ring fill
+            if (si + 3 < ns) issue(si + 3);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
                 const Frag a = i == 0 ? a0 : lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
-                if (ABLATE == 2) {                                                  // ablation 2: operands read, no MFMA
-                    acc[i][0][0] += __builtin_bit_cast(float, a.c[0][0] ^ b[0].c[0][0] ^ b[1].c[1][1] ^ a.c[1][2]);
-                    continue;
-                }
 #pragma unroll
                 for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a, b[j]);
             }
@@ -475,8 +365,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
         // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
         gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
-        if (ABLATE != 3) epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
-        else if (acc[0][0][0] == 12345.678f) static_cast<float*>(p.C)[0] = acc[1][1][3] + acc[3][0][7] + acc[2][1][9];      // keep the accumulators alive
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
     }
     __syncthreads();          // the staging reads are done before the next tile's DMA lands in the same LDS
     }
@@ -533,6 +422,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_ring_kernel(Gem
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
+    int m_cap;
+    apply_live_rows(p, m_cap);                    // reduction-major product: the live count limits K
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = tiles_m * tiles_n;
@@ -629,12 +520,10 @@ int launch_tn_one(const GemmArgs& a, hipStream_t stream) {
     using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const size_t lds = R::NSTAGE * R::STAGE;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<BM, BN, WAVES_M, WAVES_N, MMSUM_EPI_NONE, OUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
-    }
+    // function-local static: initialised once, thread-safe (C++11), for the one device this process drives
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_ring_kernel<BM, BN, WAVES_M, WAVES_N, MMSUM_EPI_NONE, OUT>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MMSUM_ERR_HIP;
     gemm_tn_ring_kernel<BM, BN, WAVES_M, WAVES_N, MMSUM_EPI_NONE, OUT><<<dim3(tiles * a.splitk), dim3(R::THREADS), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
@@ -650,61 +539,29 @@ int launch_tn_cfg(const GemmArgs& a, hipStream_t stream) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
+// persistent workgroups: at most one per CU walks the tile list (measured +0..8 % on multi-round shapes: no relaunch
+// between a CU's tiles)
+inline int ring_grid(const GemmArgs& a, int bm, int bn) {
+    const int tiles = ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * a.splitk;
+    const int cus = cu_count();
+    return tiles > cus ? cus : tiles;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
-    static const bool use_ring = !(getenv("MMSUM_GEMM_RING") && atoi(getenv("MMSUM_GEMM_RING")) == 0);
-    if (use_ring || NSTAGE != 4) {
-        using R = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
-        const int tiles_r = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-        const size_t lds_r = R::NSTAGE * R::STAGE;
-        static bool once_r = false;
-        if (!once_r) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
-            once_r = true;
-        }
-        // persistent workgroups: one per CU walks the tile list (measured +0..8 % on multi-round shapes: no relaunch
-        // between a CU's tiles); MMSUM_GEMM_PERSIST=0 restores one workgroup per tile
-        static const int persist = getenv("MMSUM_GEMM_PERSIST") ? atoi(getenv("MMSUM_GEMM_PERSIST")) : cu_count();
-        int grid = tiles_r * a.splitk;
-        if (persist > 0 && grid > persist) grid = persist;
-        if constexpr (BM == 256 && BN == 256 && EPI == MMSUM_EPI_NONE && OUT == OUT_T && NSTAGE == 4) {
-            static const int ablate = getenv("MMSUM_GEMM_ABLATE") ? atoi(getenv("MMSUM_GEMM_ABLATE")) : 0;
-            if (ablate) {
-                static bool once_a = false;
-                auto set = [&](const void* f) { (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r); };
-                if (!once_a) {
-                    set(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 1>));
-                    set(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 2>));
-                    set(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 3>));
-                    once_a = true;
-                }
-                if (ablate == 1) gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 1><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
-                else if (ablate == 2) gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 2><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
-                else gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU, 3><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
-                return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
-            }
-        }
-        gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NSTAGE, MIN_WAVES_EU><<<dim3(grid), dim3(R::THREADS), lds_r, stream>>>(a);
-        return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
-    }
-    using Cfg = FastCfg<BM, BN, WAVES_M, WAVES_N>;
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    const size_t lds = 2 * Cfg::STAGE;
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_glds_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        once = true;
-    }
-    gemm_nt_glds_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT><<<dim3(tiles * a.splitk), dim3(Cfg::THREADS), lds, stream>>>(a);
+    using R = RingCfg<BM, BN, WAVES_M, WAVES_N, 4>;
+    const size_t lds = R::NSTAGE * R::STAGE;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MMSUM_ERR_HIP;
+    gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT><<<dim3(ring_grid(a, BM, BN)), dim3(R::THREADS), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NSTAGE = 4, int MIN_WAVES_EU = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
-#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O, NSTAGE, MIN_WAVES_EU>(a, stream);
+#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O>(a, stream);
     FAST_CASE(MMSUM_EPI_NONE, OUT_T) FAST_CASE(MMSUM_EPI_NONE, OUT_T_ACC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
     FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32)
     FAST_CASE(MMSUM_EPI_GELU, OUT_T) FAST_CASE(MMSUM_EPI_GELU_BWD, OUT_T) FAST_CASE(MMSUM_EPI_RELU, OUT_T) FAST_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
@@ -712,12 +569,23 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return MMSUM_ERR_BAD_SHAPE;
 }
 
+// Tile shape that keeps the 256 CUs busiest for a problem: fraction of the last round of workgroups that is filled x
+// fraction of the padded tile area that is real x relative main-loop efficiency of the shape (operand bytes per FLOP halve
+// from 128^2 to 256^2 and the L2 -> LDS DMA rate, not the MFMA rate, bounds the small tiles: measured 0.50 and 0.72).
 inline double tile_score(int M, int N, int splitk, int bm, int bn, double eff) {
     const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * splitk;
     const long rounds = (tiles + 255) / 256;
     const double fill = (double)tiles / (double)(rounds * 256);
     const double waste = ((double)M * N) / ((double)((M + bm - 1) / bm * bm) * ((N + bn - 1) / bn * bn));
     return fill * waste * eff;
+}
+enum { TILE_256x256 = 0, TILE_256x128 = 1, TILE_128x128 = 2 };
+inline int choose_tile(const GemmArgs& a) {
+    const double s256 = tile_score(a.M, a.N, a.splitk, 256, 256, 1.00);
+    const double s128 = tile_score(a.M, a.N, a.splitk, 128, 128, 0.50);
+    const double s2x1 = tile_score(a.M, a.N, a.splitk, 256, 128, 0.72);
+    if (s256 >= s128 && s256 >= s2x1) return TILE_256x256;
+    return s2x1 >= s128 ? TILE_256x128 : TILE_128x128;
 }
 
 }  // namespace
@@ -740,31 +608,31 @@ bool gemm_tn_eligible(int dtype, const GemmArgs& a) {
     // 16-byte column chunks: a ragged last chunk must still lie inside the row (leading dimension padded)
     if ((a.lda & 7) || (a.ldb & 7) || a.lda < ((a.M + 7) & ~7) || a.ldb < ((a.N + 7) & ~7)) return false;
     if ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15) return false;
-    static const bool off = getenv("MMSUM_GEMM_TN") && atoi(getenv("MMSUM_GEMM_TN")) == 0;
-    return !off;
+    return true;
 }
 
 int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
-    static const double e128 = getenv("MMSUM_E128") ? atof(getenv("MMSUM_E128")) : 0.50;
-    static const double e2x1 = getenv("MMSUM_E2X1") ? atof(getenv("MMSUM_E2X1")) : 0.72;
-    const double s256 = tile_score(a.M, a.N, a.splitk, 256, 256, 1.00);
-    const double s128 = tile_score(a.M, a.N, a.splitk, 128, 128, e128);
-    const double s2x1 = tile_score(a.M, a.N, a.splitk, 256, 128, e2x1);
-    if (s256 >= s128 && s256 >= s2x1) return launch_tn_cfg<256, 256, 2, 4>(a, stream);
-    if (s2x1 >= s128) return launch_tn_cfg<256, 128, 4, 2>(a, stream);
-    return launch_tn_cfg<128, 128, 2, 2>(a, stream);
+    switch (choose_tile(a)) {
+        case TILE_256x256: return launch_tn_cfg<256, 256, 2, 4>(a, stream);
+        case TILE_256x128: return launch_tn_cfg<256, 128, 4, 2>(a, stream);
+        default: return launch_tn_cfg<128, 128, 2, 2>(a, stream);
+    }
 }
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
-    // pick the tile shape that keeps the 256 CUs busiest for this problem
-    // relative main-loop efficiency of the tile shapes: operand bytes per FLOP halve from 128^2 to
-    // 256^2 and the L2 -> LDS DMA rate, not the MFMA rate, bounds the small tiles
-    static const double e128 = getenv("MMSUM_E128") ? atof(getenv("MMSUM_E128")) : 0.50;
-    static const double e2x1 = getenv("MMSUM_E2X1") ? atof(getenv("MMSUM_E2X1")) : 0.72;
-    const double s256 = tile_score(a.M, a.N, a.splitk, 256, 256, 1.00);
-    const double s128 = tile_score(a.M, a.N, a.splitk, 128, 128, e128);
-    const double s2x1 = tile_score(a.M, a.N, a.splitk, 256, 128, e2x1);
-    if (s256 >= s128 && s256 >= s2x1) return launch_cfg<256, 256, 2, 4>(a, stream);
-    if (s2x1 >= s128) return launch_cfg<256, 128, 4, 2>(a, stream);
-    return launch_cfg<128, 128, 2, 2>(a, stream);
+    switch (choose_tile(a)) {
+        case TILE_256x256: return launch_cfg<256, 256, 2, 4>(a, stream);
+        case TILE_256x128: return launch_cfg<256, 128, 4, 2>(a, stream);
+        default: return launch_cfg<128, 128, 2, 2>(a, stream);
+    }
+}
+
+static const int kTileDims[3][2] = {{256, 256}, {256, 128}, {128, 128}};
+GemmPlan plan_gemm_glds(const GemmArgs& a) {
+    const int* d = kTileDims[choose_tile(a)];
+    return GemmPlan{MMSUM_PLAN_NT_RING, d[0], d[1], ring_grid(a, d[0], d[1])};
+}
+GemmPlan plan_gemm_tn(const GemmArgs& a) {
+    const int* d = kTileDims[choose_tile(a)];
+    return GemmPlan{MMSUM_PLAN_TN_RING, d[0], d[1], ((a.M + d[0] - 1) / d[0]) * ((a.N + d[1] - 1) / d[1]) * a.splitk};
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 }  // namespace
 
 bool gemm_skinny_eligible(int dtype, const GemmArgs& a) {
-    if (dtype != MMSUM_BF16 || a.M > 128 || a.splitk != 1) return false;
+    if (dtype != MMSUM_BF16 || a.M > 128 || a.splitk != 1 || a.live != nullptr || a.alpha_dev != nullptr) return false;
     if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_ACCUM | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS | MMSUM_GEMM_COLSUM)) return false;
     const int epi = (a.flags >> 3) & 7;
     if (!(epi == MMSUM_EPI_NONE || (epi == MMSUM_EPI_GELU && a.aux == nullptr))) return false;

@@ -21,12 +21,17 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4_t v)
 
 // Dropout salt: an optional device-resident step counter mixed into every dropout seed.  A captured HIP graph bakes
 // the seed ARGUMENT into its kernel nodes; bumping the salt (mmsum_bump_u64, itself a graph node) gives every replay
-// fresh masks while forward and backward of one step still agree.  NULL (default) = seeds used as passed.
-const uint64_t* g_dropout_salt = nullptr;
+// fresh masks while forward and backward of one step still agree.  NULL = seeds used as passed.  The salt is an
+// ARGUMENT of every dropout entry point (the library keeps no state of its own).
 __device__ __forceinline__ uint64_t salted_seed(uint64_t seed, const uint64_t* salt) {
     return salt != nullptr ? seed + *salt * 0x9E3779B97F4A7C15ull : seed;
 }
 __global__ void bump_u64_kernel(uint64_t* p, uint64_t inc) { *p += inc; }
+// Device-resident live row count (NULL = all R rows): rows at and past it are neither read nor written, so one captured
+// HIP graph sized for the row capacity serves every batch.
+__device__ __forceinline__ int live_rows_of(int R, const int* __restrict__ live) {
+    return live != nullptr ? min(R, max(0, *live)) : R;
+}
 
 __device__ __forceinline__ uint32_t keep_threshold(float p_drop) {
     if (p_drop <= 0.f) return 0xFFFFFFFFu;
@@ -56,8 +61,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          T* __restrict__ y, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, int R, int D, float eps,
-                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ salt) {
+                                                         float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
+                                                         const int* __restrict__ live) {
     seed = salted_seed(seed, salt);
+    R = live_rows_of(R, live);
     const int lane = threadIdx.x & 63;
     const int wpb = blockDim.x >> 6;
     const uint32_t thr = keep_threshold(p_drop);
@@ -100,8 +107,9 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          T* __restrict__ dx, T* __restrict__ dres, int accumulate_dres,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int D,
                                                          float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
-                                                         float* __restrict__ dxsum) {
+                                                         float* __restrict__ dxsum, const int* __restrict__ live) {
     seed = salted_seed(seed, salt);
+    R = live_rows_of(R, live);
     __shared__ float red[4][VPL * 256 * 3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wpb = blockDim.x >> 6;
@@ -481,7 +489,9 @@ __global__ void segment_sum_kernel(const float* __restrict__ x, float* __restric
 constexpr int CS_SPLITS = 64;
 // block = 16 column groups (4 columns each, one 8/16-byte load) x 16 row lanes; grid (C/64, splits)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ part,
+                                                             const int* __restrict__ live) {
+    R = live_rows_of(R, live);
     __shared__ float red[16][64];
     const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int col = blockIdx.x * 64 + cg * 4;
@@ -630,48 +640,49 @@ int dispatch_vpl(int D, F&& f) {
 
 template <typename T>
 int add_ln_fwd_t(const void* x, const void* res, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int R,
-                 int D, float eps, float p_drop, uint64_t seed, hipStream_t s) {
+                 int D, float eps, float p_drop, uint64_t seed, const uint64_t* salt, const int* live, hipStream_t s) {
     const int grid = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
         add_ln_fwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)x, (const T*)res, (const float*)gamma, (const float*)beta,
-                                                                  (T*)y, mean, rstd, R, D, eps, p_drop, seed, g_dropout_salt);
+                                                                  (T*)y, mean, rstd, R, D, eps, p_drop, seed, salt, live);
     });
 }
 template <typename T>
 int add_ln_bwd_t(const void* dy, const void* x, const void* res, const void* gamma, const float* mean, const float* rstd, void* dx,
                  void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R, int D, float p_drop, uint64_t seed,
-                 float* dxsum, hipStream_t s) {
+                 const uint64_t* salt, float* dxsum, const int* live, hipStream_t s) {
     int grid = (R + 15) / 16;
     grid = grid > 1024 ? 1024 : grid;
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
         add_ln_bwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)dy, (const T*)x, (const T*)res, (const float*)gamma, mean,
                                                                   rstd, (T*)dx, (T*)dres, accumulate_dres, dgamma, dbeta, R, D, p_drop,
-                                                                  seed, g_dropout_salt, dxsum);
+                                                                  seed, salt, dxsum, live);
     });
 }
 template <typename T>
 int embed_ln_fwd_t(const int64_t* ids, const void* E, const void* P, const float* rd, const void* rvec, const void* gamma,
                    const void* beta, void* y, float* mean, float* rstd, int R, int T_len, int D, int pos_offset, float eps,
-                   float p_drop, uint64_t seed, hipStream_t s) {
+                   float p_drop, uint64_t seed, const uint64_t* salt, hipStream_t s) {
     const int grid = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
         embed_ln_fwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>(ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
                                                                     (const float*)gamma, (const float*)beta, (T*)y, mean, rstd, R,
-                                                                    T_len, D, pos_offset, eps, p_drop, seed, g_dropout_salt);
+                                                                    T_len, D, pos_offset, eps, p_drop, seed, salt);
     });
 }
 template <typename T>
 int embed_ln_bwd_t(const void* dy, const int64_t* ids, const void* E, const void* P, const float* rd, const void* rvec,
                    const void* gamma, const float* mean, const float* rstd, float* dE, float* dP, float* drvec, float* dgamma,
-                   float* dbeta, int nseq, int T_len, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, hipStream_t s) {
+                   float* dbeta, int nseq, int T_len, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, const uint64_t* salt,
+                   hipStream_t s) {
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
         embed_ln_bwd_kernel<T, VPL><<<dim3(T_len), dim3(256), 0, s>>>((const T*)dy, ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
                                                                      (const float*)gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta,
-                                                                     nseq, T_len, D, pos_offset, pad_id, p_drop, seed, g_dropout_salt);
+                                                                     nseq, T_len, D, pos_offset, pad_id, p_drop, seed, salt);
     });
 }
 
@@ -680,43 +691,49 @@ int embed_ln_bwd_t(const void* dy, const int64_t* ids, const void* E, const void
 extern "C" int mmsum_abi_version(void) { return MMSUM_ABI_VERSION; }
 
 extern "C" int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,
-                                float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, void* stream) {
+                                float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, const void* salt,
+                                const int* live_rows, void* stream) {
     if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MMSUM_BF16) return add_ln_fwd_t<bf16_t>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, s);
-    if (dtype == MMSUM_F32) return add_ln_fwd_t<float>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, s);
+    const uint64_t* sp = static_cast<const uint64_t*>(salt);
+    if (dtype == MMSUM_BF16) return add_ln_fwd_t<bf16_t>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, sp, live_rows, s);
+    if (dtype == MMSUM_F32) return add_ln_fwd_t<float>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, sp, live_rows, s);
     return MMSUM_ERR_BAD_DTYPE;
 }
 
 extern "C" int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, const void* gamma, const float* mean,
                                 const float* rstd, void* dx, void* dres, int accumulate_dres, float* dgamma, float* dbeta, int R,
-                                int D, float p_drop, uint64_t seed, float* dxsum, void* stream) {
+                                int D, float p_drop, uint64_t seed, const void* salt, float* dxsum, const int* live_rows, void* stream) {
     if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MMSUM_BF16) return add_ln_bwd_t<bf16_t>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, dxsum, s);
-    if (dtype == MMSUM_F32) return add_ln_bwd_t<float>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, dxsum, s);
+    const uint64_t* sp = static_cast<const uint64_t*>(salt);
+    if (dtype == MMSUM_BF16) return add_ln_bwd_t<bf16_t>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, sp, dxsum, live_rows, s);
+    if (dtype == MMSUM_F32) return add_ln_bwd_t<float>(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, R, D, p_drop, seed, sp, dxsum, live_rows, s);
     return MMSUM_ERR_BAD_DTYPE;
 }
 
 extern "C" int mmsum_embed_ln_fwd(int dtype, const int64_t* ids, const void* E, const void* P, const float* rating_diff,
                                   const void* rvec, const void* gamma, const void* beta, void* y, float* mean, float* rstd,
-                                  int nseq, int T, int D, int pos_offset, float eps, float p_drop, uint64_t seed, void* stream) {
+                                  int nseq, int T, int D, int pos_offset, float eps, float p_drop, uint64_t seed, const void* salt,
+                                  void* stream) {
     const int R = nseq * T;
     if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MMSUM_BF16) return embed_ln_fwd_t<bf16_t>(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, R, T, D, pos_offset, eps, p_drop, seed, s);
-    if (dtype == MMSUM_F32) return embed_ln_fwd_t<float>(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, R, T, D, pos_offset, eps, p_drop, seed, s);
+    const uint64_t* sp = static_cast<const uint64_t*>(salt);
+    if (dtype == MMSUM_BF16) return embed_ln_fwd_t<bf16_t>(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, R, T, D, pos_offset, eps, p_drop, seed, sp, s);
+    if (dtype == MMSUM_F32) return embed_ln_fwd_t<float>(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, R, T, D, pos_offset, eps, p_drop, seed, sp, s);
     return MMSUM_ERR_BAD_DTYPE;
 }
 
 extern "C" int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids, const void* E, const void* P,
                                   const float* rating_diff, const void* rvec, const void* gamma, const float* mean,
                                   const float* rstd, float* dE, float* dP, float* drvec, float* dgamma, float* dbeta, int nseq,
-                                  int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, void* stream) {
+                                  int T, int D, int pos_offset, int pad_id, float p_drop, uint64_t seed, const void* salt, void* stream) {
     if (nseq <= 0 || T <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == MMSUM_BF16) return embed_ln_bwd_t<bf16_t>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, s);
-    if (dtype == MMSUM_F32) return embed_ln_bwd_t<float>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, s);
+    const uint64_t* sp = static_cast<const uint64_t*>(salt);
+    if (dtype == MMSUM_BF16) return embed_ln_bwd_t<bf16_t>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, sp, s);
+    if (dtype == MMSUM_F32) return embed_ln_bwd_t<float>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, sp, s);
     return MMSUM_ERR_BAD_DTYPE;
 }
 
@@ -769,14 +786,15 @@ extern "C" int mmsum_segment_sum(const float* x, float* out, int nseg, int seg, 
 }
 
 extern "C" long mmsum_colsum_workspace(int C) { return (long)CS_SPLITS * C * sizeof(float); }
-extern "C" int mmsum_colsum(int dtype, const void* X, long ld, int R, int C, float* out, int accumulate, void* workspace, void* stream) {
+extern "C" int mmsum_colsum(int dtype, const void* X, long ld, int R, int C, float* out, int accumulate, void* workspace,
+                            const int* live_rows, void* stream) {
     if (R <= 0 || C <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int splits = R < CS_SPLITS * 16 ? max(1, R / 16) : CS_SPLITS;
     const dim3 grid((C + 63) / 64, splits);
     float* part = (float*)workspace;
-    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ld, R, C, part);
-    else if (dtype == MMSUM_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ld, R, C, part);
+    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ld, R, C, part, live_rows);
+    else if (dtype == MMSUM_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ld, R, C, part, live_rows);
     else return MMSUM_ERR_BAD_DTYPE;
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, splits, C, out, accumulate);
     return ok();
@@ -823,7 +841,9 @@ extern "C" int mmsum_cast(int dtype_dst, void* dst, int dtype_src, const void* s
 namespace {
 // Row compaction / expansion for the padding-free text encoder: dst[i] = src[map[i]] (zeros where map[i] < 0), 16-byte pieces.
 __global__ __launch_bounds__(256) void rows_gather_kernel(const char* __restrict__ src, long src_pitch, char* __restrict__ dst, long dst_pitch,
-                                                          const int64_t* __restrict__ map, int nrows, int row_bytes, int src_rows) {
+                                                          const int64_t* __restrict__ map, int nrows, int row_bytes, int src_rows,
+                                                          const int* __restrict__ live) {
+    nrows = live_rows_of(nrows, live);
     const int chunks = row_bytes >> 4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)nrows * chunks; i += (long)gridDim.x * 256) {
         const int r = (int)(i / chunks), c = (int)(i % chunks);
@@ -838,20 +858,15 @@ __global__ __launch_bounds__(256) void rows_gather_kernel(const char* __restrict
 /* dst[i, :] = map[i] >= 0 ? src[map[i], :] : 0 for i < nrows; rows are row_bytes long (multiple of 16), pitches in bytes.
  * One kernel serves both directions: compact (map = compact -> padded row) and expand (map = padded -> compact row). */
 extern "C" int mmsum_rows_gather(const void* src, long src_pitch, int src_rows, void* dst, long dst_pitch, const int64_t* map, int nrows,
-                                 int row_bytes, void* stream) {
+                                 int row_bytes, const int* live_rows, void* stream) {
     if (nrows <= 0 || row_bytes <= 0 || (row_bytes & 15) || (src_pitch & 15) || (dst_pitch & 15)) return MMSUM_ERR_BAD_SHAPE;
     if ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) return MMSUM_ERR_BAD_ALIGN;
     const long items = (long)nrows * (row_bytes >> 4);
     long blocks = (items + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     rows_gather_kernel<<<dim3((int)blocks), dim3(256), 0, (hipStream_t)stream>>>((const char*)src, src_pitch, (char*)dst, dst_pitch, map, nrows,
-                                                                              row_bytes, src_rows);
+                                                                              row_bytes, src_rows, live_rows);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
-}
-
-extern "C" int mmsum_set_dropout_salt(const void* dev_u64) {
-    g_dropout_salt = static_cast<const uint64_t*>(dev_u64);
-    return MMSUM_OK;
 }
 
 extern "C" int mmsum_bump_u64(void* dev_u64, unsigned long long inc, void* stream) {

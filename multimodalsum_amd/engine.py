@@ -151,6 +151,7 @@ class Engine:
         self.wt, self.wt_desc, self.conv_mats_t = {}, None, {}
         if compute_dtype == torch.bfloat16:
             self._build_wt_table()
+        self.salt = None                   # device uint64 mixed into every dropout seed (set by graphs.StepGraphs; None = seeds as passed)
         self.post_backward_hooks = []      # run once when a whole backward pass has finished (DDP finalisation)
         self.segment_hooks = []            # run when a parameter segment's gradients are final (DDP overlap)
         for name, p in self.arena.params.items():   # lets optim.py / parallel.py find the arena from a parameter
@@ -233,20 +234,22 @@ class Engine:
         for k, (o, cols, ld, rows) in list(self.wt.items()):
             self.wt[k] = self.wt_buf[o:o + cols * ld].view(cols, ld)
 
-    def dgrad(self, dy, key, w_natural, out, accumulate=False, epi=0, aux=None, rows=None, colsum=None):
+    def dgrad(self, dy, key, w_natural, out, accumulate=False, epi=0, aux=None, rows=None, colsum=None, live=None, alpha_dev=None):
         """out (+)= dy @ W  (W natural = [N_out, K_in]); uses the transposed shadow when present.
         colsum (f32 [K_in], optional) += column sums of out: the bias gradient of the layer below, taken in the GEMM
-        epilogue when the fast path allows it and by the column-sum kernel otherwise."""
+        epilogue when the fast path allows it and by the column-sum kernel otherwise.
+        live: device row count of dy / out (compacted rows); alpha_dev: device scalar multiplied into the product."""
         wt = self.wt.get(key)
         if wt is not None:
             fuse = colsum is not None and not accumulate and not self.deterministic and kn.gemm_colsum_fusable(dy)
-            kn.gemm(dy, wt if rows is None else wt[rows], out, accumulate=accumulate, epi=epi, aux=aux, colsum=colsum if fuse else None)
+            kn.gemm(dy, wt if rows is None else wt[rows], out, accumulate=accumulate, epi=epi, aux=aux, colsum=colsum if fuse else None,
+                    live=live, alpha_dev=alpha_dev)
             if colsum is not None and not fuse:
-                kn.colsum(out, colsum, accumulate=True)
+                kn.colsum(out, colsum, accumulate=True, live=live)
         else:
-            kn.gemm(dy, w_natural, out, b_t=True, accumulate=accumulate, epi=epi, aux=aux)
+            kn.gemm(dy, w_natural, out, b_t=True, accumulate=accumulate, epi=epi, aux=aux, live=live, alpha_dev=alpha_dev)
             if colsum is not None:
-                kn.colsum(out, colsum, accumulate=True)
+                kn.colsum(out, colsum, accumulate=True, live=live)
 
     def sync_weights(self):
         """Called at the start of every forward.  Parameters are ordinary f32 tensors that any
@@ -279,24 +282,24 @@ class Engine:
         sk = max(1, min(8, -(-768 // max(tiles, 1)), ktiles // 4))     # measured optimum: ~768/tiles slices (tools/wgrad_bench.py)
         return sk
 
-    def wgrad(self, dy, x, gname=None, gview=None, bias_g=None):
-        """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena."""
+    def wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
+        """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena (live: device count of the rows R)."""
         out = gview if gview is not None else self.arena.g(gname)
         if bias_g is not None:
-            kn.colsum(dy, bias_g, accumulate=True)
+            kn.colsum(dy, bias_g, accumulate=True, live=live)
         R = dy.shape[0]
         sk = self.splitk(dy.shape[1], x.shape[1], R)
         if self.dtype == torch.bfloat16 and sk > 1 and x.shape[1] % 4 == 0:
             # reduction-major product straight from the activations (gemm_tn_ring_kernel: transposing LDS reads);
             # split-K partial slabs + a deterministic reduce: cheaper than f32 atomics (1.3 TB/s chip-wide)
             ws = self.empty(sk * dy.shape[1], x.shape[1], dtype=torch.float32)
-            kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+            kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True, live=live, alpha_dev=alpha_dev)
             kn.slab_reduce(ws, sk, out, accumulate=True)
             return
-        kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=sk)
+        kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=sk, live=live, alpha_dev=alpha_dev)
 
-    def bgrad(self, dy, gname=None, gview=None):
-        kn.colsum(dy, gview if gview is not None else self.arena.g(gname), accumulate=True)
+    def bgrad(self, dy, gname=None, gview=None, live=None):
+        kn.colsum(dy, gview if gview is not None else self.arena.g(gname), accumulate=True, live=live)
 
     def touch(self, *names):
         self.touched.update(names)
@@ -307,25 +310,26 @@ class Engine:
     def _attn_names(self, lb, a):
         return [lb + a + "." + p for p in ("q_proj", "k_proj", "v_proj")]
 
-    def row_maps(self, attention_mask, capacity):
-        """Index maps of the padding-free encoder: c2p [capacity] = padded row of compact row i (-1 for the filler rows up
-        to the capacity), p2c [rows] = compact row of padded row r (-1 for padding).  Device-side, static shapes."""
-        flat = attention_mask.reshape(-1).ne(0)
+    def row_maps(self, keep):
+        """Index maps of the padding-free parts: keep = any tensor whose non-zero entries mark the live rows (row-major).
+        c2p [R] = padded row of compact row i (-1 past the live count), p2c [R] = compact row of padded row r (-1 for
+        padding), count = the live count as a device int32 scalar.  Everything stays on the device and has static shapes:
+        the kernels read `count` when they run (their `live_rows` argument), so neither a host read nor a per-count graph
+        is needed; the compact buffers are simply sized for all R rows."""
+        flat = keep.reshape(-1).ne(0)
         R = flat.numel()
         pos = torch.cumsum(flat.to(torch.int64), 0) - 1
         p2c = torch.where(flat, pos, torch.full_like(pos, -1))
         ar = torch.arange(R, dtype=torch.int64, device=flat.device)
-        # one spare slot swallows every padding row (all write -1 there) and any row beyond the capacity
-        c2p = torch.full((capacity + 1,), -1, dtype=torch.int64, device=flat.device)
-        c2p.index_put_((torch.where(flat, pos, torch.full_like(pos, capacity)).clamp_(max=capacity),),
-                       torch.where(flat, ar, torch.full_like(ar, -1)))
-        p2c = torch.where(p2c < capacity, p2c, torch.full_like(p2c, -1))
-        return NS(c2p=c2p[:capacity].contiguous(), p2c=p2c.contiguous(), capacity=capacity)
+        c2p = torch.full((R + 1,), -1, dtype=torch.int64, device=flat.device)       # slot R swallows the padding rows' writes
+        c2p.index_put_((torch.where(flat, pos, torch.full_like(pos, R)),), torch.where(flat, ar, torch.full_like(ar, -1)))
+        count = flat.sum().to(torch.int32).reshape(1)
+        return NS(c2p=c2p[:R].contiguous(), p2c=p2c.contiguous(), count=count, rows=R)
 
-    def encoder_fwd(self, ids, attention_mask, out=None, capacity=None):
+    def encoder_fwd(self, ids, attention_mask, out=None, compact=False):
         """ids [Bn,S] int64, attention_mask [Bn,S] (1 = keep).  -> hidden [Bn*S, D] (batch-major rows).
-        capacity (fused step only): run the layers on the valid rows only, `capacity` >= their number (rows that are
-        padding come out as zeros; nothing downstream reads them: they are masked keys of the cross-attention)."""
+        compact (fused step only): run the layers' GEMM / LayerNorm work on the valid rows only (rows that are padding
+        come out as zeros; nothing downstream reads them: they are masked keys of the cross-attention)."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
         Bn, S = ids.shape
@@ -338,16 +342,16 @@ class Engine:
         c.mean0, c.rstd0 = self.empty(R, dtype=torch.float32), self.empty(R, dtype=torch.float32)
         kn.embed_ln_fwd(c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), None, None,
                         a.f32(b + "layernorm_embedding.weight"), a.f32(b + "layernorm_embedding.bias"), x, c.mean0, c.rstd0,
-                        Bn, S, cfg.extra_pos_embeddings, 1e-5, c.p, c.seed0)
+                        Bn, S, cfg.extra_pos_embeddings, 1e-5, c.p, c.seed0, salt=self.salt)
         c.x0 = x
         c.maps = None
-        if capacity is not None and capacity < R:
-            c.maps = self.row_maps(attention_mask, capacity)
-            x = kn.rows_gather(x, self.empty(capacity, D), c.maps.c2p)
+        if compact:
+            c.maps = self.row_maps(attention_mask)
+            x = kn.rows_gather(x, self.empty(R, D), c.maps.c2p, live=c.maps.count)
         for i in range(cfg.encoder_layers):
             last = i == cfg.encoder_layers - 1
             x, lc = self._self_block_fwd(b + "layers.%d." % i, x, c.pad, Bn, S, causal=False, maps=c.maps)
-            x, fc = self._ffn_block_fwd(b + "layers.%d." % i, x, out if (last and c.maps is None) else None)
+            x, fc = self._ffn_block_fwd(b + "layers.%d." % i, x, out if (last and c.maps is None) else None, maps=c.maps)
             c.layers.append((lc, fc))
         if c.maps is not None:
             x = kn.rows_gather(x, out if out is not None else self.empty(R, D), c.maps.p2c)
@@ -365,7 +369,7 @@ class Engine:
         if carry is None:
             dx = dout
             if c.maps is not None:
-                dx = kn.rows_gather(dout, self.empty(c.maps.capacity, cfg.d_model), c.maps.c2p)
+                dx = kn.rows_gather(dout, self.empty(c.maps.rows, cfg.d_model), c.maps.c2p, live=c.maps.count)
         else:
             dx = carry
         for i in reversed(range(lo, hi)):
@@ -379,7 +383,8 @@ class Engine:
         kn.embed_ln_bwd(dx, c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), None, None,
                         a.f32(b + "layernorm_embedding.weight"), c.mean0, c.rstd0, a.g(self.bp + "model.shared.weight"),
                         a.g(b + "embed_positions.weight"), None, a.g(b + "layernorm_embedding.weight"),
-                        a.g(b + "layernorm_embedding.bias"), c.Bn, c.S, cfg.extra_pos_embeddings, cfg.pad_token_id, c.p, c.seed0)
+                        a.g(b + "layernorm_embedding.bias"), c.Bn, c.S, cfg.extra_pos_embeddings, cfg.pad_token_id, c.p, c.seed0,
+                        salt=self.salt)
         self.touch(self.bp + "model.shared.weight", b + "embed_positions.weight", b + "layernorm_embedding.weight",
                    b + "layernorm_embedding.bias")
         return None
@@ -387,42 +392,46 @@ class Engine:
     # ---- shared blocks ----------------------------------------------------------------------------
     def _self_block_fwd(self, lb, x, pad, Bn, T, causal, maps=None):
         """x -> LN(x + drop(out_proj(self_attention(x))))   (:288-297 / :442-461).
-        maps (padding-free encoder): x holds the valid rows only ([capacity, D]); q/k/v are expanded to the padded
-        [Bn*T, 3D] layout the attention kernel reads (zeros at padding) and its output is compacted again."""
+        maps (padding-free encoder): x holds the valid rows first (compact layout, live count on the device); q/k/v are
+        expanded to the padded [Bn*T, 3D] layout the attention kernel reads (zeros at padding) and its output is
+        compacted again."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
         R = x.shape[0]
+        live = maps.count if maps is not None else None
         q, k, v = self._attn_names(lb, "self_attn")
         c = NS(x=x, pad=pad, Bn=Bn, T=T, causal=causal, p=self.p_drop(), seed=self.next_seed(), maps=maps)
         c.qkv = self.empty(R, 3 * D)
-        kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), c.qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)))
+        kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), c.qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)),
+                live=live)
         if maps is not None:
             c.qkv = kn.rows_gather(c.qkv, self.empty(Bn * T, 3 * D), maps.p2c)
         attn = self.empty(Bn * T, D)
         c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn, pad, None, Bn, T, 1, 1, T, H,
                                    False, causal, 64 ** -0.5)
         kn.attn_fwd(c.desc, x)
-        c.attn = attn if maps is None else kn.rows_gather(attn, self.empty(R, D), maps.c2p)
+        c.attn = attn if maps is None else kn.rows_gather(attn, self.empty(R, D), maps.c2p, live=live)
         c.o = self.empty(R, D)
-        kn.gemm(c.attn, a.w(lb + "self_attn.out_proj.weight"), c.o, bias=a.f32(lb + "self_attn.out_proj.bias"))
+        kn.gemm(c.attn, a.w(lb + "self_attn.out_proj.weight"), c.o, bias=a.f32(lb + "self_attn.out_proj.bias"), live=live)
         y = self.empty(R, D)
         c.mean, c.rstd = self.empty(R, dtype=torch.float32), self.empty(R, dtype=torch.float32)
         kn.add_ln_fwd(c.o, x, a.f32(lb + "self_attn_layer_norm.weight"), a.f32(lb + "self_attn_layer_norm.bias"), y, c.mean,
-                      c.rstd, 1e-5, c.p, c.seed)
+                      c.rstd, 1e-5, c.p, c.seed, salt=self.salt, live=live)
         return y, c
 
     def _self_block_bwd(self, lb, c, dy):
         cfg, a = self.cfg, self.arena
         D = cfg.d_model
         R = dy.shape[0]
+        live = c.maps.count if c.maps is not None else None
         q, k, v = self._attn_names(lb, "self_attn")
         do, dx = self.empty(R, D), self.empty(R, D)
         kn.add_ln_bwd(dy, c.o, c.x, a.f32(lb + "self_attn_layer_norm.weight"), c.mean, c.rstd, do, dx, False,
                       a.g(lb + "self_attn_layer_norm.weight"), a.g(lb + "self_attn_layer_norm.bias"), c.p, c.seed,
-                      dxsum=a.g(lb + "self_attn.out_proj.bias"))         # out_proj's bias gradient = column sums of do
-        self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight")
+                      dxsum=a.g(lb + "self_attn.out_proj.bias"), salt=self.salt, live=live)   # out_proj's bias gradient = column sums of do
+        self.wgrad(do, c.attn, lb + "self_attn.out_proj.weight", live=live)
         dattn = self.empty(R, D)
-        self.dgrad(do, lb + "self_attn.out_proj.weight", a.w(lb + "self_attn.out_proj.weight"), dattn)
+        self.dgrad(do, lb + "self_attn.out_proj.weight", a.w(lb + "self_attn.out_proj.weight"), dattn, live=live)
         Rp = c.Bn * c.T
         if c.maps is not None:
             dattn = kn.rows_gather(dattn, self.empty(Rp, D), c.maps.p2c)
@@ -430,42 +439,45 @@ class Engine:
         stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
         kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
         if c.maps is not None:
-            dqkv = kn.rows_gather(dqkv, self.empty(R, 3 * D), c.maps.c2p)
-        self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)), bias_g=a.gspan(q + ".bias", v + ".bias", (3 * D,)))
-        self.dgrad(dqkv, q + ".weight", a.wspan(q + ".weight", v + ".weight", (3 * D, D)), dx, accumulate=True)
+            dqkv = kn.rows_gather(dqkv, self.empty(R, 3 * D), c.maps.c2p, live=live)
+        self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)), bias_g=a.gspan(q + ".bias", v + ".bias", (3 * D,)),
+                   live=live)
+        self.dgrad(dqkv, q + ".weight", a.wspan(q + ".weight", v + ".weight", (3 * D, D)), dx, accumulate=True, live=live)
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias",
                    lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.bias", lb + "self_attn_layer_norm.weight",
                    lb + "self_attn_layer_norm.bias")
         return dx
 
-    def _ffn_block_fwd(self, lb, x, out=None):
+    def _ffn_block_fwd(self, lb, x, out=None, maps=None):
         """x -> LN(x + drop(fc2(gelu(fc1(x)))))   (:299-308 / :479-489)."""
         cfg, a = self.cfg, self.arena
         R, D = x.shape
+        live = maps.count if maps is not None else None
         Fd = a.shapes[lb + "fc1.weight"][0]
-        c = NS(x=x, p=self.p_drop(), seed=self.next_seed())
+        c = NS(x=x, p=self.p_drop(), seed=self.next_seed(), live=live)
         c.u, c.h = self.empty(R, Fd), self.empty(R, Fd)
-        kn.gemm(x, a.w(lb + "fc1.weight"), c.h, bias=a.f32(lb + "fc1.bias"), epi=kn.EPI_GELU, aux=c.u)
+        kn.gemm(x, a.w(lb + "fc1.weight"), c.h, bias=a.f32(lb + "fc1.bias"), epi=kn.EPI_GELU, aux=c.u, live=live)
         c.f = self.empty(R, D)
-        kn.gemm(c.h, a.w(lb + "fc2.weight"), c.f, bias=a.f32(lb + "fc2.bias"))
+        kn.gemm(c.h, a.w(lb + "fc2.weight"), c.f, bias=a.f32(lb + "fc2.bias"), live=live)
         y = out if out is not None else self.empty(R, D)
         c.mean, c.rstd = self.empty(R, dtype=torch.float32), self.empty(R, dtype=torch.float32)
         kn.add_ln_fwd(c.f, x, a.f32(lb + "final_layer_norm.weight"), a.f32(lb + "final_layer_norm.bias"), y, c.mean, c.rstd,
-                      1e-5, c.p, c.seed)
+                      1e-5, c.p, c.seed, salt=self.salt, live=live)
         return y, c
 
     def _ffn_block_bwd(self, lb, c, dy):
         a = self.arena
         R, D = dy.shape
+        live = c.live
         df, dx = self.empty(R, D), self.empty(R, D)
         kn.add_ln_bwd(dy, c.f, c.x, a.f32(lb + "final_layer_norm.weight"), c.mean, c.rstd, df, dx, False,
                       a.g(lb + "final_layer_norm.weight"), a.g(lb + "final_layer_norm.bias"), c.p, c.seed,
-                      dxsum=a.g(lb + "fc2.bias"))                       # fc2's bias gradient = column sums of df
-        self.wgrad(df, c.h, lb + "fc2.weight")
+                      dxsum=a.g(lb + "fc2.bias"), salt=self.salt, live=live)                 # fc2's bias gradient = column sums of df
+        self.wgrad(df, c.h, lb + "fc2.weight", live=live)
         du = self.empty(R, c.u.shape[1])
-        self.dgrad(df, lb + "fc2.weight", a.w(lb + "fc2.weight"), du, epi=kn.EPI_GELU_BWD, aux=c.u, colsum=a.g(lb + "fc1.bias"))
-        self.wgrad(du, c.x, lb + "fc1.weight")
-        self.dgrad(du, lb + "fc1.weight", a.w(lb + "fc1.weight"), dx, accumulate=True)
+        self.dgrad(df, lb + "fc2.weight", a.w(lb + "fc2.weight"), du, epi=kn.EPI_GELU_BWD, aux=c.u, colsum=a.g(lb + "fc1.bias"), live=live)
+        self.wgrad(du, c.x, lb + "fc1.weight", live=live)
+        self.dgrad(du, lb + "fc1.weight", a.w(lb + "fc1.weight"), dx, accumulate=True, live=live)
         self.touch(lb + "fc1.weight", lb + "fc1.bias", lb + "fc2.weight", lb + "fc2.bias", lb + "final_layer_norm.weight",
                    lb + "final_layer_norm.bias")
         return dx
@@ -482,12 +494,12 @@ class Engine:
             off += B * N * S
         return NS(B=B, mods=list(mods), offs=offs, rows=off)
 
-    def decoder_fwd(self, dec_ids, dec_pad, rating_diff, mem, layout, pads, qpb, exclude_self, mem_capacity=None):
+    def decoder_fwd(self, dec_ids, dec_pad, rating_diff, mem, layout, pads, qpb, exclude_self, compact_mem=False):
         """dec_ids [Bd,T]; dec_pad [Bd,T] uint8 or None; rating_diff [Bd] f32 or None; mem [Rmem,D];
         pads: per-modality uint8 [B,N,S] (1 = padded key).  Bd = B*qpb.
-        mem_capacity (fused step): the cross-attention K/V projections (and their gradients) run on the memory rows that
-        are not masked keys only, at most `mem_capacity` of them; K/V are expanded to the padded layout the attention
-        kernel reads (masked rows zero) once per layer."""
+        compact_mem (fused step): the cross-attention K/V projections (and their gradients) run on the memory rows that
+        are not masked keys only (live count on the device); K/V are expanded to the padded layout the attention kernel
+        reads (masked rows zero) once per layer."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
         Bd, T = dec_ids.shape
@@ -496,10 +508,10 @@ class Engine:
         nm = len(layout.mods)
         c = NS(Bd=Bd, T=T, ids=dec_ids.contiguous(), rd=rating_diff, mem=mem, layout=layout, pads=pads, qpb=qpb,
                exclude_self=exclude_self, layers=[], p=self.p_drop(), seed0=self.next_seed(), dec_pad=dec_pad, mem_maps=None, mem_c=mem)
-        if mem_capacity is not None and mem_capacity < layout.rows:
+        if compact_mem:
             keep = torch.cat([pd.reshape(-1) for pd in pads]).eq(0)            # rows that are real keys, memory-row order
-            c.mem_maps = self.row_maps(keep, mem_capacity)
-            c.mem_c = kn.rows_gather(mem, self.empty(mem_capacity, D), c.mem_maps.c2p)
+            c.mem_maps = self.row_maps(keep)
+            c.mem_c = kn.rows_gather(mem, self.empty(layout.rows, D), c.mem_maps.c2p, live=c.mem_maps.count)
         # null-entity flags per modality (:858) and the per-business no-table / no-image flags (:732-736)
         c.nulls = []
         for (N, S), pad in zip(layout.mods, pads):
@@ -516,7 +528,7 @@ class Engine:
         kn.embed_ln_fwd(c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), rating_diff,
                         a.w(b + "rating_embeddings") if rating_diff is not None else None, a.f32(b + "layernorm_embedding.weight"),
                         a.f32(b + "layernorm_embedding.bias"), x, c.mean0, c.rstd0, Bd, T, cfg.extra_pos_embeddings, 1e-5, c.p,
-                        c.seed0)
+                        c.seed0, salt=self.salt)
         for i in range(cfg.decoder_layers):
             lb = b + "layers.%d." % i
             x, sc = self._self_block_fwd(lb, x, dec_pad, Bd, T, causal=True)
@@ -543,7 +555,8 @@ class Engine:
                         a.w(b + "rating_embeddings") if has_r else None, a.f32(b + "layernorm_embedding.weight"), c.mean0, c.rstd0,
                         a.g(self.bp + "model.shared.weight"), a.g(b + "embed_positions.weight"),
                         a.g(b + "rating_embeddings") if has_r else None, a.g(b + "layernorm_embedding.weight"),
-                        a.g(b + "layernorm_embedding.bias"), c.Bd, c.T, cfg.extra_pos_embeddings, cfg.pad_token_id, c.p, c.seed0)
+                        a.g(b + "layernorm_embedding.bias"), c.Bd, c.T, cfg.extra_pos_embeddings, cfg.pad_token_id, c.p, c.seed0,
+                        salt=self.salt)
         self.touch(self.bp + "model.shared.weight", b + "embed_positions.weight", b + "layernorm_embedding.weight",
                    b + "layernorm_embedding.bias")
         if has_r:
@@ -563,9 +576,10 @@ class Engine:
         c = NS(x=x, p=self.p_drop(), seed=self.next_seed())
         c.q = self.empty(Rq, D)
         kn.gemm(x, a.w(q + ".weight"), c.q, bias=a.f32(q + ".bias"))                                     # :783 (scale folded into the kernel)
+        mlive = dc.mem_maps.count if dc.mem_maps is not None else None
         c.kv = self.empty(dc.mem_c.shape[0], 2 * D)
         kn.gemm(dc.mem_c, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), c.kv,
-                bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)))                                  # :788-789, hoisted
+                bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)), live=mlive)                      # :788-789, hoisted
         if dc.mem_maps is not None:
             c.kv = kn.rows_gather(c.kv, self.empty(L.rows, 2 * D), dc.mem_maps.p2c)
         c.heads = self.empty(nm * Rq, D)
@@ -590,7 +604,7 @@ class Engine:
         y = self.empty(Rq, D)
         c.mean, c.rstd = self.empty(Rq, dtype=torch.float32), self.empty(Rq, dtype=torch.float32)
         kn.add_ln_fwd(c.c, x, a.f32(lb + "encoder_attn_layer_norm.weight"), a.f32(lb + "encoder_attn_layer_norm.bias"), y, c.mean,
-                      c.rstd, 1e-5, c.p, c.seed)
+                      c.rstd, 1e-5, c.p, c.seed, salt=self.salt)
         return y, c
 
     def _cross_block_bwd(self, lb, c, dc, dy, dmem, first):
@@ -603,7 +617,7 @@ class Engine:
         pre = lb + "encoder_attn."
         dcv, dx = self.empty(Rq, D), self.empty(Rq, D)
         kn.add_ln_bwd(dy, c.c, c.x, a.f32(lb + "encoder_attn_layer_norm.weight"), c.mean, c.rstd, dcv, dx, False,
-                      a.g(lb + "encoder_attn_layer_norm.weight"), a.g(lb + "encoder_attn_layer_norm.bias"), c.p, c.seed)
+                      a.g(lb + "encoder_attn_layer_norm.weight"), a.g(lb + "encoder_attn_layer_norm.bias"), c.p, c.seed, salt=self.salt)
         if self.multimodal:
             yt, ytab, yimg = c.y[:Rq], c.y[Rq:2 * Rq], c.y[2 * Rq:]
             dyy = self.empty(3 * Rq, D)
@@ -629,10 +643,13 @@ class Engine:
             rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
             stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
             kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
+        mlive = None
         if dc.mem_maps is not None:
-            dkv = kn.rows_gather(dkv, self.empty(dc.mem_maps.capacity, 2 * D), dc.mem_maps.c2p)
-        self.wgrad(dkv, dc.mem_c, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)))
-        self.dgrad(dkv, k + ".weight", a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, accumulate=not first)
+            mlive = dc.mem_maps.count
+            dkv = kn.rows_gather(dkv, self.empty(dc.mem_maps.rows, 2 * D), dc.mem_maps.c2p, live=mlive)
+        self.wgrad(dkv, dc.mem_c, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)),
+                   live=mlive)
+        self.dgrad(dkv, k + ".weight", a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, accumulate=not first, live=mlive)
         self.wgrad(dq, c.x, q + ".weight", bias_g=a.g(q + ".bias"))
         self.dgrad(dq, q + ".weight", a.w(q + ".weight"), dx, accumulate=True)
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias", pre + "out_proj.weight",
@@ -648,15 +665,17 @@ class Engine:
         kn.gemm(h, self.arena.w(self.bp + "model.shared.weight"), logits[:, :self.cfg.vocab_size])
         return logits
 
-    def lm_head_bwd(self, h, dlogits):
-        """dlogits [Rq, Vpad] with zero padding columns.  -> dh; accumulates the tied-embedding gradient."""
+    def lm_head_bwd(self, h, dlogits, upstream=None):
+        """dlogits [Rq, Vpad] with zero padding columns.  -> dh; accumulates the tied-embedding gradient.
+        upstream: device f32 scalar, the gradient arriving at the loss (loss.backward(g), loss / accumulation_steps):
+        every gradient of the step is linear in dlogits, so scaling the two products that read it scales them all."""
         V, name = self.cfg.vocab_size, self.bp + "model.shared.weight"
         dh = self.empty(h.shape[0], h.shape[1])
         if name in self.wt:
-            kn.gemm(dlogits, self.wt[name], dh)          # K = Vpad: padding columns of both operands are zero
+            kn.gemm(dlogits, self.wt[name], dh, alpha_dev=upstream)          # K = Vpad: padding columns of both operands are zero
         else:
-            kn.gemm(dlogits[:, :V], self.arena.w(name), dh, b_t=True)
-        self.wgrad(dlogits[:, :V], h, name)
+            kn.gemm(dlogits[:, :V], self.arena.w(name), dh, b_t=True, alpha_dev=upstream)
+        self.wgrad(dlogits[:, :V], h, name, alpha_dev=upstream)
         self.touch(name)
         return dh
 

@@ -15,12 +15,23 @@ over hipGraph) and replayed:
 What stays eager: weight shadow refresh (engine.sync_weights), gradient-buffer preparation, clipping and the
 optimiser (a handful of launches whose scalars -- lr, bias corrections -- change every step).
 
-Dropout: a captured graph replays the seed arguments it was captured with; the kernels mix in a device-resident
-salt that the forward graph bumps first (include/mmsum_hip.h: mmsum_set_dropout_salt), so every replay draws
-fresh masks and the backward graphs of the same step see the same ones.
+ONE set of graphs serves every batch of a given SHAPE.  What varies from batch to batch inside a shape -- how many
+review tokens are real, how many image slots are filled -- only changes how many rows the padding-free parts of the
+step work on, and those counts are device-side scalars (engine.row_maps -> the kernels' `live_rows` argument): the
+graph is captured for the row capacity (all rows) and every kernel reads the live count when it runs.  So a real
+loader with varying token counts never triggers a re-capture, and graph memory is one set of activations.  A second
+shape (e.g. the last, smaller batch of an epoch when drop_last is off) gets its own set; at most `max_live` sets are
+kept, the least recently used one is dropped first.
 
-Shapes: one set of graphs per distinct (input shapes, dtypes, training flag, row capacity of the padding-free encoder); the first call with new shapes runs
-eagerly (warm-up), the second captures, later ones replay.
+Dropout: a captured graph replays the seed arguments it was captured with; the kernels mix in a device-resident
+salt (their `salt` argument, engine.salt) that the forward graph bumps first, so every replay draws fresh masks and
+the backward graphs of the same step see the same ones.
+
+The upstream gradient of the loss (modules._StepFn.backward) is a device scalar the captured LM-head backward
+products multiply by; it is copied into a static buffer before the backward graphs replay.
+
+The first call with new shapes runs eagerly (warm-up: allocator, kernel attributes), the second captures, later ones
+replay.
 """
 import torch
 
@@ -53,47 +64,47 @@ def _unflatten(flat, spec):
 
 
 class _Entry:
-    __slots__ = ("state", "static", "fwd", "bwd", "saved", "serial", "nbytes")
+    __slots__ = ("state", "static", "fwd", "bwd", "saved", "serial", "upstream")
 
     def __init__(self):
-        self.state, self.static, self.fwd, self.bwd, self.saved, self.serial, self.nbytes = 0, None, None, [], None, 0, 0
+        self.state, self.static, self.fwd, self.bwd, self.saved, self.serial, self.upstream = 0, None, None, [], None, 0, None
 
 
 class StepGraphs:
     """Owned by a step module (MultimodalSum / TextSupervised); used by modules._StepFn."""
 
-    def __init__(self, model, max_shapes=8, max_live=4):
-        self.max_live = max_live                  # captured graph sets kept at once: each pins its own activations in HBM
+    def __init__(self, model, max_live=2):
+        self.max_live = max(1, int(max_live))     # captured graph sets kept at once: each pins its own activations in HBM
         self.model = model
         self.engine = model._engine
-        self.entries = {}
+        self.entries = {}                         # insertion order = least recently used first
         self.pool = None
-        self.max_shapes = max_shapes
+        self.captures = 0                         # how many times a set was captured (bench.py reports it)
         self.salt = torch.zeros(1, dtype=torch.int64, device=self.engine.device)
 
-    def _key(self, flat, extra):
+    def _key(self, flat):
         e = self.engine
-        return tuple((tuple(t.shape), t.dtype) for t in flat) + (e.training, e.p_drop(), extra)
+        from .modules import _compact
+        return tuple((tuple(t.shape), t.dtype) for t in flat) + (e.training, e.p_drop(), _compact(self.model))
 
-    def forward(self, batch, extra=None):
+    def forward(self, batch):
         """Returns the entry whose .saved holds this step's forward state, or None (caller runs eagerly)."""
         flat, spec = _flatten(batch)
         if not all(isinstance(t, torch.Tensor) and t.is_cuda for t in flat):
             return None
-        key = self._key(flat, extra)
+        key = self._key(flat)
         ent = self.entries.get(key)
         if ent is None:
-            if len(self.entries) >= self.max_shapes:
-                return None                      # too many distinct shapes: stay eager rather than hoard graph memory
             self.entries[key] = _Entry()
-            self._make_room(for_capture=False)   # the eager warm-up needs as much memory as a captured set pins
+            self._evict(keep=key)
             return None                          # first sight of these shapes: eager warm-up
         if ent.state == -1:
             return None                          # capture failed for these shapes before: stay eager
+        self.entries[key] = self.entries.pop(key)          # most recently used last
         if ent.state == 0:
-            self._make_room(for_capture=True)
+            self._evict(keep=key)
             try:
-                self._capture(ent, flat, spec, extra)
+                self._capture(ent, flat, spec)
             except Exception as exc:             # a failed capture must not take the training run down: fall back to eager launches
                 import warnings
                 warnings.warn("multimodalsum_amd: HIP-graph capture of the step failed (%r); continuing with eager launches" % (exc,))
@@ -106,61 +117,43 @@ class StepGraphs:
         else:
             for dst, src in zip(ent.static, flat):
                 if dst.data_ptr() != src.data_ptr():
-                    dst.copy_(src)
-        self.entries[key] = self.entries.pop(key)          # most recently used last
+                    dst.copy_(src, non_blocking=True)
         ent.fwd.replay()
         ent.serial += 1
         return ent
 
-    def _make_room(self, for_capture):
-        """Evict least recently used graph sets (dicts keep insertion order; replays re-insert): before a capture when max_live
-        are captured already, and -- capture or eager warm-up of new shapes -- while the device lacks room for another set the
-        size of the largest one captured so far."""
-        live = [k for k, en in self.entries.items() if en.state == 1]
-        # a captured set needs what the largest one so far took from the pool; an eager step of the same shapes holds more
-        # (every activation until its backward kernel ran, plus the allocator's rounding): measured ~1.5x
-        need = max([self.entries[k].nbytes for k in self.entries], default=0) * (1.0 if for_capture else 1.4)
-        if live and self._free_bytes() < 1.15 * need:
-            torch.cuda.empty_cache()              # blocks the allocator merely caches count as free: return them, then measure again
-        while live and ((for_capture and len(live) >= self.max_live) or self._free_bytes() < 1.15 * need):
-            old = self.entries[live.pop(0)]
+    def _evict(self, keep):
+        """Drop least recently used entries until at most max_live remain (the one being served included)."""
+        victims = [k for k in self.entries if k != keep]
+        dropped = False
+        while len(self.entries) > self.max_live and victims:
+            old = self.entries.pop(victims.pop(0))
+            dropped = dropped or old.state == 1
             old.state, old.fwd, old.bwd, old.saved, old.static = 0, None, [], None, None
-            if self._free_bytes() < 1.15 * need:
-                torch.cuda.synchronize()
-                torch.cuda.empty_cache()          # hand the evicted set's pool back before the new one is sized
-        if not live:
+        if dropped:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()              # hand the dropped set's pool blocks back before the next capture sizes its own
+        if not any(en.state == 1 for en in self.entries.values()):
             self.pool = None                      # the allocator drops a graph pool with its last graph: start a new one
 
-    def _pool_bytes(self):
-        """Bytes the allocator holds in this object's graph pool (segments tagged with the pool id)."""
-        if self.pool is None:
-            return 0
-        try:
-            return sum(seg["total_size"] for seg in torch.cuda.memory_snapshot() if tuple(seg.get("segment_pool_id", (0, 0))) == tuple(self.pool))
-        except Exception:
-            return 0
-
-    def _free_bytes(self):
-        """Device memory the allocator could still obtain (blocks cached inside graph pools are not counted: conservative)."""
-        return torch.cuda.mem_get_info(self.engine.device)[0]
-
-    def _capture(self, ent, flat, spec, extra):
+    def _capture(self, ent, flat, spec):
         e, m = self.engine, self.model
-        before = self._pool_bytes()
+        from .modules import _compact
         ent.static = [t.clone() for t in flat]
+        ent.upstream = torch.ones(1, dtype=torch.float32, device=e.device)
         torch.cuda.synchronize()
-        check(lib.mmsum_set_dropout_salt(self.salt.data_ptr()), "mmsum_set_dropout_salt")
+        e.salt = self.salt                       # the dropout kernels captured below mix this device counter into their seeds
         try:
             ent.fwd = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ent.fwd, pool=self.pool):
                 check(lib.mmsum_bump_u64(self.salt.data_ptr(), 1, kn._stream()), "mmsum_bump_u64")
-                ent.saved = m._step_fwd(*_unflatten(ent.static, spec), capacity=extra)
+                ent.saved = m._step_fwd(*_unflatten(ent.static, spec), compact=_compact(m))
             if self.pool is None:
                 self.pool = ent.fwd.pool()
             # the backward graphs are captured here too (capture records, it does not execute): autograd would
             # otherwise run the capture on its worker thread
             keep_touched = e.touched
-            for fn, prefixes in m._step_bwd_segments(ent.saved, release=False):
+            for fn, prefixes in m._step_bwd_segments(ent.saved, release=False, upstream=ent.upstream):
                 e.touched = set()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self.pool):
@@ -168,17 +161,21 @@ class StepGraphs:
                 ent.bwd.append((g, frozenset(e.touched), prefixes))
             e.touched = keep_touched
         finally:
-            check(lib.mmsum_set_dropout_salt(None), "mmsum_set_dropout_salt")
-        ent.nbytes = max(0, self._pool_bytes() - before)                         # what this set added to the graph pool
+            e.salt = None
+        self.captures += 1
         ent.state = 1
 
-    def backward(self, ent, begin_backward, end_backward, serial=None):
+    def backward(self, ent, begin_backward, end_backward, serial=None, upstream=None):
         e = self.engine
         if ent.state != 1 or (serial is not None and serial != ent.serial):
             # the set's activation buffers belong to its latest forward replay; the training loop this path serves
             # (multimodal_train.py:355-373) always runs backward before the next forward
             raise RuntimeError("multimodalsum_amd: backward of a step whose captured forward state was overwritten by a later "
                                "forward (or evicted); call backward before the next forward, or enable_step_graphs(False)")
+        if upstream is not None:
+            ent.upstream.copy_(upstream, non_blocking=True)
+        else:
+            ent.upstream.fill_(1.0)
         begin_backward(e)
         for g, touched, prefixes in ent.bwd:
             g.replay()

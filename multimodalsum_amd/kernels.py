@@ -43,10 +43,15 @@ def gemm_colsum_fusable(a, a_t=False, b_t=False, a2=None):
     return a.dtype == torch.bfloat16 and not a_t and not b_t and a2 is None and a.shape[1] % 64 == 0
 
 
-def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None,
-         splitk=1, slabs=False, colsum=None):
-    """out[M,N] = epi(alpha * A.B^T + bias) (+ out).  a: [M,K] (or [K,M] when a_t); b: [N,K] (or [K,N] when b_t);
-    a2: optional second half of the K range ([M,K2], natural layout).  out may be f32 while a/b are bf16."""
+def _live(t):
+    """Device int32 scalar holding a live row count (or None)."""
+    if t is None:
+        return None
+    assert t.dtype == torch.int32 and t.numel() == 1
+    return _p(t)
+
+
+def _gemm_args(a, b, out_rows, out_cols, a_t, b_t, bias, epi, aux, accumulate, a2, splitk, slabs, colsum, out_f32):
     dt = _dt(a)
     assert _dt(b) == dt
     M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
@@ -56,23 +61,44 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
         ksplit = K
         K = K + a2.shape[1]
     assert K == Kb, (K, Kb)
-    assert out.shape[0] == (M * splitk if slabs else M) and out.shape[1] == N, (out.shape, M, N)
+    assert out_rows == (M * splitk if slabs else M) and out_cols == N, (out_rows, out_cols, M, N)
     flags = (_lib.GEMM_A_T if a_t else 0) | (_lib.GEMM_B_T if b_t else 0) | (_lib.GEMM_BIAS if bias is not None else 0)
     flags |= _lib.gemm_epi(epi) | (_lib.GEMM_ACCUM if accumulate else 0) | (_lib.GEMM_SLABS if slabs else 0)
     if colsum is not None:            # f32 [N] += column sums of the stored result (bias slot becomes an output)
         assert bias is None and colsum.dtype == torch.float32 and gemm_colsum_fusable(a, a_t, b_t, a2)
         flags |= _lib.GEMM_COLSUM
         bias = colsum
-    if out.dtype == torch.float32 and dt == BF16:
+    if out_f32:
         flags |= _lib.GEMM_OUT_F32
-    elif out.dtype == torch.float32:
-        flags |= _lib.GEMM_OUT_F32
-    else:
-        assert _dt(out) == dt
     if bias is not None:
         assert bias.dtype == torch.float32
+    return dt, M, N, K, ksplit, flags, bias
+
+
+def gemm_plan(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, a2=None, splitk=1,
+              slabs=False, colsum=None):
+    """What gemm(...) with the same arguments would launch: (kernel family, BM, BN, workgroups) -- see mmsum_gemm_plan."""
+    dt, M, N, K, ksplit, flags, bias = _gemm_args(a, b, out.shape[0], out.shape[1], a_t, b_t, bias, epi, aux, accumulate, a2, splitk,
+                                                   slabs, colsum, out.dtype == torch.float32)
+    plan = (ctypes.c_int * 4)()
+    check(lib.mmsum_gemm_plan(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(bias), _p(aux),
+                              M, N, K, flags, splitk, plan), "mmsum_gemm_plan")
+    return tuple(plan)
+
+
+def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None,
+         splitk=1, slabs=False, colsum=None, live=None, alpha_dev=None):
+    """out[M,N] = epi(alpha * A.B^T + bias) (+ out).  a: [M,K] (or [K,M] when a_t); b: [N,K] (or [K,N] when b_t);
+    a2: optional second half of the K range ([M,K2], natural layout).  out may be f32 while a/b are bf16.
+    live: device int32 scalar, the live rows of the row-streamed operand (M, or K of the a_t & b_t product);
+    alpha_dev: device f32 scalar multiplied into alpha on the device."""
+    if out.dtype != torch.float32:
+        assert _dt(out) == _dt(a)
+    dt, M, N, K, ksplit, flags, bias = _gemm_args(a, b, out.shape[0], out.shape[1], a_t, b_t, bias, epi, aux, accumulate, a2, splitk,
+                                                   slabs, colsum, out.dtype == torch.float32)
     check(lib.mmsum_gemm(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(out), _ld(out),
-                         _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, float(alpha), flags, splitk, _stream()),
+                         _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, float(alpha), _p(alpha_dev), flags, splitk, _live(live),
+                         _stream()),
           "mmsum_gemm")
     return out
 
@@ -95,38 +121,39 @@ def _workspace(nbytes, device, key):
     return w
 
 
-def colsum(x, out, accumulate=False):
+def colsum(x, out, accumulate=False, live=None):
     R, C = x.shape
     ws = _workspace(lib.mmsum_colsum_workspace(C), x.device, "colsum")
-    check(lib.mmsum_colsum(_dt(x), _p(x), _ld(x), R, C, _p(out), int(accumulate), _p(ws), _stream()), "mmsum_colsum")
+    check(lib.mmsum_colsum(_dt(x), _p(x), _ld(x), R, C, _p(out), int(accumulate), _p(ws), _live(live), _stream()), "mmsum_colsum")
     return out
 
 
-def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq, T, pos_offset, eps, p_drop, seed):
+def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq, T, pos_offset, eps, p_drop, seed, salt=None):
     D = E.shape[1]
     check(lib.mmsum_embed_ln_fwd(_dt(E), _p(ids), _p(E), _p(P), _p(rating_diff), _p(rvec), _p(gamma), _p(beta), _p(y),
-                                 _p(mean), _p(rstd), nseq, T, D, pos_offset, eps, p_drop, seed, _stream()), "mmsum_embed_ln_fwd")
+                                 _p(mean), _p(rstd), nseq, T, D, pos_offset, eps, p_drop, seed, _p(salt), _stream()), "mmsum_embed_ln_fwd")
 
 
 def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, pos_offset,
-                 pad_id, p_drop, seed):
+                 pad_id, p_drop, seed, salt=None):
     D = E.shape[1]
     check(lib.mmsum_embed_ln_bwd(_dt(E), _p(dy), _p(ids), _p(E), _p(P), _p(rating_diff), _p(rvec), _p(gamma), _p(mean),
                                  _p(rstd), _p(dE), _p(dP), _p(drvec), _p(dgamma), _p(dbeta), nseq, T, D, pos_offset, pad_id,
-                                 p_drop, seed, _stream()), "mmsum_embed_ln_bwd")
+                                 p_drop, seed, _p(salt), _stream()), "mmsum_embed_ln_bwd")
 
 
-def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed):
+def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None, live=None):
     R, D = x.shape
     check(lib.mmsum_add_ln_fwd(_dt(x), _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), R, D, eps, p_drop, seed,
-                               _stream()), "mmsum_add_ln_fwd")
+                               _p(salt), _live(live), _stream()), "mmsum_add_ln_fwd")
 
 
-def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None):
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None, salt=None, live=None):
     """dxsum (f32 [D], optional) += column sums of dx: the bias gradient of the Linear that produced x."""
     R, D = x.shape
     check(lib.mmsum_add_ln_bwd(_dt(x), _p(dy), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres),
-                               int(accumulate_dres), _p(dgamma), _p(dbeta), R, D, p_drop, seed, _p(dxsum), _stream()), "mmsum_add_ln_bwd")
+                               int(accumulate_dres), _p(dgamma), _p(dbeta), R, D, p_drop, seed, _p(salt), _p(dxsum), _live(live),
+                               _stream()), "mmsum_add_ln_bwd")
 
 
 def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale):
@@ -287,10 +314,11 @@ def amazon_table_gather_bwd(dall, price, rating, dw_price, dw_rating, B, D):
           "mmsum_amazon_table_gather_bwd")
 
 
-def rows_gather(src, dst, row_map):
-    """dst[i] = src[row_map[i]] (zeros where row_map[i] < 0).  src [Rs, C], dst [Rd, C] (unit inner stride), row_map int64 [Rd]."""
+def rows_gather(src, dst, row_map, live=None):
+    """dst[i] = src[row_map[i]] (zeros where row_map[i] < 0).  src [Rs, C], dst [Rd, C] (unit inner stride), row_map int64 [Rd];
+    live: device int32 scalar, only rows i < live of dst are written."""
     assert src.dtype == dst.dtype and src.shape[1] == dst.shape[1] and row_map.dtype == torch.int64 and row_map.numel() == dst.shape[0]
     es = src.element_size()
     check(lib.mmsum_rows_gather(_p(src), _ld(src) * es, src.shape[0], _p(dst), _ld(dst) * es, _p(row_map), dst.shape[0], src.shape[1] * es,
-                                _stream()), "mmsum_rows_gather")
+                                _live(live), _stream()), "mmsum_rows_gather")
     return dst

@@ -411,65 +411,29 @@ class _StepFn(torch.autograd.Function):
     def forward(ctx, anchor, model, batch):
         ctx.model = model
         graphs = getattr(model, "_step_graphs", None)
-        capacity = _encoder_capacity(model, batch)
-        ctx.entry = graphs.forward(batch, capacity) if (graphs is not None and model._engine.training) else None
+        ctx.entry = graphs.forward(batch) if (graphs is not None and model._engine.training) else None
         if ctx.entry is not None:
             ctx.saved, ctx.serial = None, ctx.entry.serial
             return ctx.entry.saved.loss.reshape(()).clone()      # the graph's loss buffer is overwritten by the next replay
-        ctx.saved = model._step_fwd(*batch, capacity=capacity)
+        ctx.saved = model._step_fwd(*batch, compact=_compact(model))
         return ctx.saved.loss.reshape(())
 
     @staticmethod
     def backward(ctx, dloss):
-        # the fused step assumes loss.backward() with unit upstream gradient (multimodal_train.py:360)
+        # The upstream gradient (1 for loss.backward() as multimodal_train.py:360 calls it; anything else for loss / k,
+        # weighted sums of losses, loss scaling) stays on the device: the LM-head backward products multiply by it.
+        up = dloss.detach().reshape(1).to(torch.float32)
         if ctx.entry is not None:
-            ctx.model._step_graphs.backward(ctx.entry, _begin_backward, _end_backward, ctx.serial)
+            ctx.model._step_graphs.backward(ctx.entry, _begin_backward, _end_backward, ctx.serial, upstream=up)
         else:
-            ctx.model._step_bwd(ctx.saved)
+            ctx.model._step_bwd(ctx.saved, upstream=up)
         return None, None, None
 
 
-def _valid_count(mask):
-    """Non-zero entries of a mask: the loader side attaches it (`_mmsum_valid_rows`, counted on the host copy by prefetch.py /
-    bench.py); otherwise one device->host read."""
-    n = getattr(mask, "_mmsum_valid_rows", None)
-    return int(mask.ne(0).sum().item()) if n is None else int(n)
-
-
-def _bucket(n, total, granule):
-    cap = (n + granule - 1) // granule * granule
-    return cap if cap + granule <= total else None          # nothing to gain when (almost) no row is padding
-
-
-def _encoder_capacity(model, batch):
-    """Row capacities of the padding-free parts of the fused step for this batch: (text-encoder rows, memory rows of the
-    cross-attention K/V projections), each None = run padded.  Counts are rounded up to a bucket so that HIP graphs
-    (keyed by them) are reused across batches."""
-    e = model._engine
-    reviews_mask = batch[1]
-    if not getattr(model, "compact_encoder", True) or not e.training:
-        return None
-    n_text = _valid_count(reviews_mask)
-    R = reviews_mask.numel()
-    g = getattr(model, "encoder_row_granule", None) or (2048 if R >= 16384 else 256)     # coarse buckets: few graph sets
-    enc_cap = _bucket(n_text, R, g)
-    mem_cap = None
-    if len(batch) >= 7 and enc_cap is not None:               # multimodal step: + table rows (all counted) + rows of valid images
-        img, img_mask = batch[5], batch[6]
-        B, I = img.shape[0], img.shape[1]
-        hw = ((img.shape[-2] + 6 - 7) // 2 + 1, (img.shape[-1] + 6 - 7) // 2 + 1)
-        for _ in range(3):
-            hw = ((hw[0] + 2 - 3) // 2 + 1, (hw[1] + 2 - 3) // 2 + 1)
-        P = hw[0] * hw[1]
-        n_img = getattr(img_mask, "_mmsum_valid_rows", None)
-        n_img = B * I if n_img is None else int(n_img)       # no count at hand: every image slot counts (no device read for it)
-        total = R + B * e.table_positions + B * I * P
-        mem_cap = _bucket(n_text + B * e.table_positions + n_img * P, total, 4 * g)     # image counts vary more: coarser bucket
-    elif enc_cap is not None:
-        mem_cap = enc_cap                                      # text-only step: the memory is the text rows
-    if os.environ.get("MMSUM_COMPACT_MEM") == "0":
-        mem_cap = None
-    return (enc_cap, mem_cap)
+def _compact(model):
+    """Whether the fused step runs its text-encoder layers and cross-attention K/V projections on the valid rows only
+    (training steps; `model.compact_encoder = False` switches it off)."""
+    return bool(getattr(model, "compact_encoder", True)) and model._engine.training
 
 
 def _run_segments(engine, segments):
@@ -483,9 +447,11 @@ def _run_segments(engine, segments):
 class _StepGraphMixin:
     """enable_step_graphs(): replay the fused step from captured HIP graphs (graphs.StepGraphs)."""
 
-    def enable_step_graphs(self, enabled=True, max_shapes=8):
+    def enable_step_graphs(self, enabled=True, max_live=2):
+        """max_live: captured graph sets kept at once (one per distinct input SHAPE; token and image counts do not matter:
+        they are device-side row counts the kernels read when they run)."""
         from .graphs import StepGraphs
-        object.__setattr__(self, "_step_graphs", StepGraphs(self, max_shapes) if enabled else None)
+        object.__setattr__(self, "_step_graphs", StepGraphs(self, max_live) if enabled else None)
         return self
 
 
@@ -540,7 +506,7 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
         return NR, text_h, reviews_mask, table_h.unsqueeze(1), table_m.unsqueeze(1), img_h, img_m
 
     # ---- fused step -------------------------------------------------------------------------------
-    def _step_fwd(self, reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask, capacity=None):
+    def _step_fwd(self, reviews, reviews_mask, reviews_rating, field, field_value, img, img_mask, compact=False):
         e, cfg = self._engine, self._engine.cfg
         B, NR, S = reviews.shape
         I = img.shape[1]
@@ -565,8 +531,7 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
             with torch.cuda.stream(side):
                 _, s.tab = e.table_fwd(field, field_value, out=s.mem[o1:o2])
                 _, s.img = e.img_fwd(imgs, out=s.mem[o2:])
-        enc_cap, mem_cap = capacity if capacity is not None else (None, None)
-        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1], capacity=enc_cap)
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1], compact=compact)
         if side is not None:
             main.wait_stream(side)
         else:
@@ -579,19 +544,20 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
         dec_pad = dec_in.eq(cfg.pad_token_id).to(torch.uint8).contiguous()
         r = reviews_rating.float()
         rating_diff = (r - (r.sum(dim=1, keepdim=True) - r) / (NR - 1)).reshape(-1).contiguous()     # multimodal_train.py:153-156
-        hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True, mem_capacity=mem_cap)
+        hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True, compact_mem=compact)
         s.hL = hL
         s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
         return s
 
-    def _step_bwd_segments(self, s, release=True):
-        """The backward schedule as (callable, finished-parameter prefixes) segments, in execution order."""
+    def _step_bwd_segments(self, s, release=True, upstream=None):
+        """The backward schedule as (callable, finished-parameter prefixes) segments, in execution order.
+        upstream: device f32 scalar multiplied into every gradient (the gradient arriving at the loss)."""
         e = self._engine
         o1, o2 = s.layout.offs[1], s.layout.offs[2]
         st = {}
 
         def decoder():
-            dh = e.lm_head_bwd(s.hL, s.dlogits)
+            dh = e.lm_head_bwd(s.hL, s.dlogits, upstream=upstream)
             if release:
                 s.dlogits = None
             st["dmem"] = e.decoder_bwd(s.dec, dh)
@@ -625,8 +591,8 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
             return [(decoder, [e.bp + "model.decoder."]), (encoders_upper, upper + lower)]
         return [(decoder, [e.bp + "model.decoder."]), (encoders_upper, upper), (encoder_lower, lower)]
 
-    def _step_bwd(self, s):
-        _run_segments(self._engine, self._step_bwd_segments(s))
+    def _step_bwd(self, s, upstream=None):
+        _run_segments(self._engine, self._step_bwd_segments(s, upstream=upstream))
 
 
 class TextSupervised(_StepGraphMixin, nn.Module):
@@ -655,29 +621,28 @@ class TextSupervised(_StepGraphMixin, nn.Module):
         _new_forward(e)
         return (_StepFn.apply(_anchor(e), self, (reviews, reviews_mask, reviews_rating)),)
 
-    def _step_fwd(self, reviews, reviews_mask, reviews_rating, capacity=None):
+    def _step_fwd(self, reviews, reviews_mask, reviews_rating, compact=False):
         e, cfg = self._engine, self._engine.cfg
         B, NR, S = reviews.shape
         s = type("Saved", (), {})()
         s.layout = e.make_memory(B, [(NR, S)])
         s.mem = e.empty(s.layout.rows, cfg.d_model)
-        enc_cap, mem_cap = capacity if capacity is not None else (None, None)
-        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem, capacity=enc_cap)
+        _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem, compact=compact)
         pads = [reviews_mask.eq(0).to(torch.uint8).contiguous()]
         dec_in = shift_tokens_right_batched(reviews, reviews[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id).reshape(B * NR, S)
         dec_pad = dec_in.eq(cfg.pad_token_id).to(torch.uint8).contiguous()
         r = reviews_rating.float()
         rating_diff = (r - (r.sum(dim=1, keepdim=True) - r) / (NR - 1)).reshape(-1).contiguous()
-        s.hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True, mem_capacity=mem_cap)
+        s.hL, s.dec = e.decoder_fwd(dec_in, dec_pad, rating_diff, s.mem, s.layout, pads, NR, True, compact_mem=compact)
         s.loss, s.seq_loss, s.dlogits = e.lm_loss_fwd(s.hL, reviews.reshape(B * NR, S), self.label_smoothing, B * NR)
         return s
 
-    def _step_bwd_segments(self, s, release=True):
+    def _step_bwd_segments(self, s, release=True, upstream=None):
         e = self._engine
         st = {}
 
         def decoder():
-            dh = e.lm_head_bwd(s.hL, s.dlogits)
+            dh = e.lm_head_bwd(s.hL, s.dlogits, upstream=upstream)
             if release:
                 s.dlogits = None
             st["dmem"] = e.decoder_bwd(s.dec, dh)
@@ -687,8 +652,8 @@ class TextSupervised(_StepGraphMixin, nn.Module):
 
         return [(decoder, [e.bp + "model.decoder."]), (text_encoder, [e.bp + "model.encoder.", e.bp + "model.shared."])]
 
-    def _step_bwd(self, s):
-        _run_segments(self._engine, self._step_bwd_segments(s))
+    def _step_bwd(self, s, upstream=None):
+        _run_segments(self._engine, self._step_bwd_segments(s, upstream=upstream))
 
 
 class _LossFn(torch.autograd.Function):

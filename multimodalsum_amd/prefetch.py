@@ -38,11 +38,6 @@ class _Prefetcher:
         assert len(host) == self.n_fields, "loader batch has %d tensors, expected %d" % (len(host), self.n_fields)
         with torch.cuda.stream(self.stream):
             self.batch = [self._to_device(t) for t in host]
-        # the padding-free text encoder sizes its row buffers by the number of real tokens: count on the host copy so that
-        # the step does not have to read it back from the device (modules._encoder_capacity)
-        self.batch[1]._mmsum_valid_rows = int(host[1].ne(0).sum())
-        if self.n_fields == 11:
-            self.batch[10]._mmsum_valid_rows = int(host[10].ne(0).sum())       # valid images (rows of the cross-attention memory)
 
     def _regroup(self, b):
         raise NotImplementedError

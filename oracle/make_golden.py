@@ -104,12 +104,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--full", action="store_true", help="also run the full-size BART-large spot check (minutes)")
+    ap.add_argument("--only-full", action="store_true", help="run only the full-size fixtures F8 / F8b")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
     torch.set_grad_enabled(True)
     mt, tp, mm, BartConfig, te, ru, RefAdamW = import_reference()
     G = lambda n: os.path.join(args.out, n)  # noqa: E731
+    if args.only_full:
+        full_size_spot_check(mm, BartConfig, ru, G)
+        full_size_step(mt, mm, te, BartConfig, G)
+        return
 
     # ---- F7: shift_tokens_right / padding mask helpers ------------------------------------
     cases = torch.tensor([
@@ -334,6 +339,7 @@ def main():
 
     if args.full:
         full_size_spot_check(mm, BartConfig, ru, G)
+        full_size_step(mt, mm, te, BartConfig, G)
 
 
 def full_size_spot_check(mm, BartConfig, ru, G):
@@ -359,6 +365,76 @@ def full_size_spot_check(mm, BartConfig, ru, G):
         loss = ru.LabelSmoothingLoss(cfg.vocab_size, 0.1)(logits.view(-1, cfg.vocab_size), b["reviews"][:, 0].view(-1))
     npz(G("f8_fullsize.npz"), seed=np.int64(1234), enc_sample=enc[:, :4, :32], enc_abs_sum=enc.double().abs().sum(),
         logits_sample=logits[0, :8, :64], logits_abs_sum=logits.double().abs().sum(), loss=loss, rating_diff=rd)
+
+
+F8_GRADS = [
+    "bart_model.model.shared.weight",
+    "bart_model.model.decoder.rating_embeddings",
+    "bart_model.model.encoder.embed_positions.weight",
+    "bart_model.model.encoder.layers.0.self_attn.q_proj.weight",
+    "bart_model.model.encoder.layers.5.fc1.weight",
+    "bart_model.model.encoder.layers.11.fc2.weight",
+    "bart_model.model.encoder.layers.11.final_layer_norm.weight",
+    "bart_model.model.decoder.layers.0.self_attn.v_proj.weight",
+    "bart_model.model.decoder.layers.0.encoder_attn.k_proj.weight",
+    "bart_model.model.decoder.layers.3.encoder_attn.alpha_proj.weight",
+    "bart_model.model.decoder.layers.6.encoder_attn.beta_proj.bias",
+    "bart_model.model.decoder.layers.6.encoder_attn.out_proj.weight",
+    "bart_model.model.decoder.layers.11.fc1.weight",
+    "bart_model.model.decoder.layers.11.fc2.bias",
+    "bart_model.model.decoder.layers.11.encoder_attn_layer_norm.weight",
+    "table_encoder.fc.weight",
+    "table_encoder.rating_embedding.weight",
+]
+
+
+def full_size_step(mt, mm, te, BartConfig, G):
+    """F8b: the reference's MultimodalSum.forward + backward (multimodal_train.py:124-163) at cfg/bart-large.json,
+    B=1, 9 reviews x 128 tokens, 4 images of 224x224 (backbone = the oracle restatement, as in F3), formula weights,
+    dropout 0, train mode.  Stores the loss, and for a spread of parameters a gradient slice + the gradient's L1 norm."""
+    cfg = BartConfig.from_json_file("/root/reference/cfg/bart-large.json")
+    cfg.dropout = 0.0
+    ms = mt.MultimodalSum.__new__(mt.MultimodalSum)
+    torch.nn.Module.__init__(ms)
+    ms.bart_model = mm.BartForMultiEncConditionalGeneration(cfg)
+    load_formula(ms.bart_model, prefix="bart_model.", std=0.02)
+    ms.table_encoder = te.YelpTableEncoder(ms.bart_model.model.shared)
+    for n, p in ms.table_encoder.named_parameters():
+        if not n.startswith("bart_embedding"):
+            p.data.copy_(formula_tensor("table_encoder." + n, p.shape, 0.02))
+    rs_sd = formula_state_dict(eo.resnet_param_shapes(1024), std=0.05)
+
+    class StandInImg(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Parameter(rs_sd["img_encoder.linear.weight"].clone())
+
+        def forward(self, x):
+            sd = dict(rs_sd)
+            sd["img_encoder.linear.weight"] = self.lin
+            return eo.resnet101_features(sd, x, training=True)
+
+    ms.img_encoder = StandInImg()
+    mt.args = argparse.Namespace(label_smoothing=0.1)
+    ms.train()
+    b = syn.yelp_batch(1, 9, 128, 4, cfg.vocab_size, seed=1234, img_hw=224)
+    if not bool(b["img_mask"].any()):
+        b["img_mask"][0, 0] = True            # keep the image branch live in this fixture
+    import time
+    t0 = time.time()
+    loss = ms(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+    loss.backward()
+    print("full-size reference step: %.1f s, loss %.6f" % (time.time() - t0, float(loss)))
+    named = dict(ms.named_parameters())
+    named["img_encoder.linear.weight"] = named["img_encoder.lin"]
+    out = {"seed": np.int64(1234), "loss": loss, "img_mask": b["img_mask"]}
+    for n in F8_GRADS + ["img_encoder.linear.weight"]:
+        g = named[n].grad
+        key = n.replace(".", "_")
+        flat = g.reshape(-1) if g.dim() < 2 else g.reshape(g.shape[0], -1)
+        out["g_" + key] = flat[:256] if g.dim() < 2 else flat[:8, :256]
+        out["l1_" + key] = g.double().abs().sum()
+    npz(G("f8_fullstep.npz"), **out)
 
 
 if __name__ == "__main__":

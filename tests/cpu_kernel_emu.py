@@ -26,8 +26,25 @@ def gemm_colsum_fusable(a, a_t=False, b_t=False, a2=None):
     return a.dtype == torch.bfloat16 and not a_t and not b_t and a2 is None and a.shape[1] % 64 == 0
 
 
+def _n(live, rows):
+    """Live row count of a kernel call: the device scalar when given (clamped to the capacity), else every row."""
+    return rows if live is None else max(0, min(rows, int(live.reshape(-1)[0])))
+
+
 def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None, splitk=1, slabs=False,
-         colsum=None):
+         colsum=None, live=None, alpha_dev=None):
+    """`live` as in include/mmsum_hip.h: natural A -> only the first `live` rows of A / aux / out take part; a_t & b_t ->
+    only the first `live` reduction rows; rows past it are neither read nor written."""
+    if alpha_dev is not None:
+        alpha = alpha * float(alpha_dev.reshape(-1)[0])
+    if live is not None and a_t and b_t:
+        n = _n(live, a.shape[0])
+        a, b, live = a[:n], b[:n], None
+    if live is not None:
+        assert not a_t and not slabs
+        n = _n(live, a.shape[0])
+        return gemm(a[:n], b, out[:n], False, b_t, bias, epi, None if aux is None else aux[:n], accumulate, alpha,
+                    None if a2 is None else a2[:n], splitk, False, colsum)
     A = a.float().t() if a_t else a.float()
     if a2 is not None:
         A = torch.cat([A, a2.float()], dim=1)
@@ -68,13 +85,13 @@ def slab_reduce(ws, nslabs, out, accumulate=True):
         out.copy_(s)
 
 
-def colsum(x, out, accumulate=False):
-    s = x.float().sum(0)
+def colsum(x, out, accumulate=False, live=None):
+    s = x[:_n(live, x.shape[0])].float().sum(0)
     out.copy_(out + s if accumulate else s)
     return out
 
 
-def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq, T, pos_offset, eps, p_drop, seed):
+def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq, T, pos_offset, eps, p_drop, seed, salt=None):
     D = E.shape[1]
     z = E.float()[ids.reshape(nseq, T)] + P.float()[torch.arange(T) + pos_offset]
     if rating_diff is not None:
@@ -89,7 +106,7 @@ def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq,
 
 
 def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, pos_offset, pad_id,
-                 p_drop, seed):
+                 p_drop, seed, salt=None):
     D = E.shape[1]
     z = E.float()[ids.reshape(nseq, T)] + P.float()[torch.arange(T) + pos_offset]
     if rating_diff is not None:
@@ -109,7 +126,11 @@ def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, dr
         drvec.add_((dz.view(nseq, T, D) * rating_diff.view(nseq, 1, 1)).sum((0, 1)))
 
 
-def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed):
+def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None, live=None):
+    if live is not None:
+        n = _n(live, x.shape[0])
+        assert p_drop == 0, "the emulator's dropout mask is keyed by the full shape"
+        return add_ln_fwd(x[:n], res[:n], gamma, beta, y[:n], mean[:n], rstd[:n], eps, p_drop, seed)
     z = x.float() * _keep_mask(x.shape, p_drop, seed) + res.float()
     mu = z.mean(-1)
     rs = (z.var(-1, unbiased=False) + eps).rsqrt()
@@ -118,7 +139,12 @@ def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed):
     y.copy_((z - mu[:, None]) * rs[:, None] * gamma + beta)
 
 
-def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None):
+def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None, salt=None, live=None):
+    if live is not None:
+        n = _n(live, x.shape[0])
+        assert p_drop == 0, "the emulator's dropout mask is keyed by the full shape"
+        return add_ln_bwd(dy[:n], x[:n], res[:n], gamma, mean[:n], rstd[:n], dx[:n], dres[:n], accumulate_dres, dgamma, dbeta, p_drop,
+                          seed, dxsum)
     km = _keep_mask(x.shape, p_drop, seed)
     z = x.float() * km + res.float()
     xh = (z - mean[:, None]) * rstd[:, None]
@@ -416,10 +442,12 @@ def amazon_table_gather_bwd(dall, price, rating, dw_price, dw_rating, B, D):
     dw_rating.add_(torch.einsum("bk,bd->dk", rating.float(), dv[:, 1]))
 
 
-def rows_gather(src, dst, row_map):
-    ok = row_map >= 0
-    dst.zero_()
-    dst[ok] = src[row_map[ok]]
+def rows_gather(src, dst, row_map, live=None):
+    n = _n(live, dst.shape[0])              # rows of dst past the live count are left as they are
+    ok = row_map[:n] >= 0
+    d = dst[:n]
+    d.zero_()
+    d[ok] = src[row_map[:n][ok]]
     return dst
 
 
@@ -433,3 +461,14 @@ def install(monkeypatch):
     me = sys.modules[__name__]
     for m in (eng, mods, opt, gen):
         monkeypatch.setattr(m, "kn", me)
+    # scratch tensors come back poisoned: a schedule that reads a row no kernel wrote (e.g. a compact row past the live
+    # count) turns its results into NaN instead of passing on whatever the allocator happened to hand out
+    real_empty = eng.Engine.empty
+
+    def poisoned_empty(self, *shape, dtype=None):
+        t = real_empty(self, *shape, dtype=dtype)
+        if t.is_floating_point():
+            t.fill_(float("nan"))
+        return t
+
+    monkeypatch.setattr(eng.Engine, "empty", poisoned_empty)

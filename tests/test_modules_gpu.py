@@ -227,7 +227,6 @@ def test_step_graph_replay_matches_eager(dtype):
         torch.cuda.synchronize()
         return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
 
-    model.encoder_row_granule = 8          # tiny shapes: let the padding-free encoder / K-V projections engage
     eager = [step(b) for b in batches]
     model.enable_step_graphs()
     for _ in range(2):                     # per (shapes, row-capacity bucket): first sight = eager warm-up, second = capture + replay
@@ -427,7 +426,6 @@ def test_padding_free_encoder_equals_padded(dtype):
         model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=dtype, deterministic=True)
         model.train()
         model.compact_encoder = compact
-        model.encoder_row_granule = 8
         loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
         loss.backward()
         torch.cuda.synchronize()
@@ -453,7 +451,6 @@ def test_step_graph_sets_are_evicted_and_recaptured():
     cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40, dropout=0.0)
     model = TextSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
     model.train()
-    model.encoder_row_granule = 8
     batches = [to_dev(syn.yelp_batch(2, 3, 32, 1, cfg.vocab_size, seed=s, img_hw=8)) for s in (5, 6, 7)]
 
     def step(b):
