@@ -47,6 +47,116 @@ def _get(root, dotted):
     return node
 
 
+# ------------------------------------------------------------------------------------------------
+# checkpoint contract: strict loads with an explicit alias map
+# ------------------------------------------------------------------------------------------------
+_STAGE_ALIASES = (("stage1.0.", "resnet.conv1."), ("stage1.1.", "resnet.bn1."), ("stage1.4.", "resnet.layer1."),
+                  ("stage2.0.", "resnet.layer2."), ("stage3.0.", "resnet.layer3."))
+
+
+def canonical_key(key):
+    """The key of the tensor an aliased state_dict entry shares storage with (None if `key` is not an alias).  The reference
+    registers the same Parameter under several names: encoder/decoder.embed_tokens and table_encoder.bart_embedding alias
+    model.shared (modeling_multimodalsum.py:1001-1006, multimodal_train.py:117), img_encoder.stage{1,2,3} alias
+    img_encoder.resnet.* (img_encoder.py:21-24)."""
+    for tail in ("model.encoder.embed_tokens.weight", "model.decoder.embed_tokens.weight"):
+        if key.endswith(tail):
+            return key[:-len(tail)] + "model.shared.weight"
+    if key.endswith("table_encoder.bart_embedding.weight"):
+        return key[:-len("table_encoder.bart_embedding.weight")] + "bart_model.model.shared.weight"
+    for alias, real in _STAGE_ALIASES:
+        i = key.find(alias)
+        if i >= 0 and (i == 0 or key[i - 1] == "."):
+            return key[:i] + real + key[i + len(alias):]
+    return None
+
+
+def complete_aliases(module, state_dict):
+    """A copy of `state_dict` in which every aliased key the module expects, and the dict lacks, is filled from its canonical
+    tensor (checkpoints written by code that de-duplicates shared tensors, oracle-side dicts keyed by canonical names);
+    `final_logits_bias` -- a constant zero buffer (:2189) -- is filled with zeros when absent."""
+    sd = dict(state_dict)
+    for k, v in module.state_dict().items():
+        if k in sd:
+            continue
+        c = canonical_key(k)
+        if c is not None and c in sd:
+            sd[k] = sd[c]
+        elif k.endswith("final_logits_bias"):
+            sd[k] = torch.zeros_like(v)
+    return sd
+
+
+def load_pretrained(module, path, allowed_missing=()):
+    """`module.load_state_dict(torch.load(<path>/pytorch_model.bin))` as the reference does it for its stage hand-offs
+    (multimodal_train.py:116-122): the file must exist, no key may be unexpected, and the only keys that may be missing are
+    those matching `allowed_missing` (for BART the reference's `authorized_missing_keys`, :2183, plus the parameters its
+    fine-tuning adds to facebook/bart-large)."""
+    import re
+    ckpt = os.path.join(str(path), "pytorch_model.bin")
+    if not os.path.isfile(ckpt):
+        raise FileNotFoundError("pretrained weights %r not found (%s is missing; hub names cannot be fetched: no network)" % (str(path), ckpt))
+    sd = complete_aliases(module, torch.load(ckpt, map_location="cpu"))
+    res = nn.Module.load_state_dict(module, sd, strict=False)
+    bad_missing = [k for k in res.missing_keys if not any(re.search(p, k) for p in allowed_missing)]
+    if res.unexpected_keys or bad_missing:
+        raise RuntimeError("checkpoint %s does not match %s: unexpected keys %s, missing keys %s"
+                           % (ckpt, type(module).__name__, sorted(res.unexpected_keys)[:8], sorted(bad_missing)[:8]))
+    module._engine.mark_weights_changed()
+    return res
+
+
+def bart_reference_names(cfg, multimodal):
+    """Parameter names of the reference's BART in ITS registration order (BartModel.__init__ :1001-1006, BartEncoder :330-344,
+    EncoderLayer :262-274, BartDecoder :510-528, DecoderLayer :409-430, SelfAttention :695-704): named_parameters() order
+    decides the parameter indices inside optimizer.state_dict(), so it is part of the checkpoint contract.  The arena keeps
+    its own order (decay group first, q/k/v adjacent); only the module tree follows this one."""
+    names = ["model.shared.weight"]
+    for side, nl in (("encoder", cfg.encoder_layers), ("decoder", cfg.decoder_layers)):
+        b = "model.%s." % side
+        if side == "decoder":
+            names.append(b + "rating_embeddings")
+        names.append(b + "embed_positions.weight")
+        for i in range(nl):
+            lb = b + "layers.%d." % i
+            for att in (("self_attn",) if side == "encoder" else ("self_attn", "encoder_attn")):
+                projs = ("k_proj", "v_proj", "q_proj", "out_proj")
+                if att == "encoder_attn" and multimodal:
+                    projs += ("alpha_proj", "beta_proj")
+                for pr in projs:
+                    names += [lb + att + "." + pr + ".weight", lb + att + "." + pr + ".bias"]
+                names += [lb + att + "_layer_norm.weight", lb + att + "_layer_norm.bias"]
+            names += [lb + "fc1.weight", lb + "fc1.bias", lb + "fc2.weight", lb + "fc2.bias",
+                      lb + "final_layer_norm.weight", lb + "final_layer_norm.bias"]
+        names += [b + "layernorm_embedding.weight", b + "layernorm_embedding.bias"]
+    return names
+
+
+def resnet_reference_names():
+    """torchvision resnet101 parameter names in its registration order (conv1, bn1, layer1..4, fc), then the projection."""
+    names = ["resnet.conv1.weight", "resnet.bn1.weight", "resnet.bn1.bias"]
+    for li, bi, inp, pl, stride, down in resnet_blocks():
+        b = "resnet.layer%d.%d." % (li, bi)
+        for j in (1, 2, 3):
+            names += [b + "conv%d.weight" % j, b + "bn%d.weight" % j, b + "bn%d.bias" % j]
+        if down:
+            names += [b + "downsample.0.weight", b + "downsample.1.weight", b + "downsample.1.bias"]
+    return names + ["resnet.fc.weight", "resnet.fc.bias", "linear.weight"]
+
+
+def _attach_ordered(root, engine, prefix, ordered):
+    """Register the arena parameters named prefix + n, n in `ordered`, on `root` in that order (all of them: the two name
+    lists must agree)."""
+    have = {n for n in engine.arena.params if n.startswith(prefix)}
+    want = [prefix + n for n in ordered]
+    assert have == set(want), sorted(have ^ set(want))[:6]
+    for n in want:
+        _attach(root, n[len(prefix):], engine.arena.params[n])
+
+
+BART_ALLOWED_MISSING = (r"alpha_proj", r"beta_proj", r"rating_embeddings$", r"final_logits_bias$")
+
+
 def _anchor(engine):
     if not hasattr(engine, "_anchor"):
         engine._anchor = torch.zeros(1, device=engine.device, requires_grad=True)
@@ -206,41 +316,40 @@ class _BartBase(nn.Module):
         model = _Node()
         self.add_module("model", model)
         _attach(self, "model.shared.weight", e.arena.params[pre + "model.shared.weight"])   # registered first, as in BartModel.__init__ (:1001)
+        shared = model.shared.weight
         enc = BartEncoder()
         object.__setattr__(enc, "_engine", e)
         model.add_module("encoder", enc)
-        for name, p in e.arena.params.items():
-            if name.startswith(pre + "model."):
-                _attach(self, name[len(pre):], p)
-        self.register_buffer("final_logits_bias", e.buffers[pre + "final_logits_bias"])
-        shared = model.shared.weight
+        model.add_module("decoder", _Node())
         for side in ("encoder", "decoder"):
             tok = _Node()
-            tok.register_parameter("weight", shared)     # aliases of `shared` (state_dict keys encoder/decoder.embed_tokens.weight)
-            getattr(model, side).add_module("embed_tokens", tok)
+            tok.register_parameter("weight", shared)     # aliases of `shared` (state_dict keys encoder/decoder.embed_tokens.weight),
+            getattr(model, side).add_module("embed_tokens", tok)       # the first child of either side (:330, :510)
+        have = {n[len(pre):] for n in e.arena.params if n.startswith(pre + "model.")}
+        want = bart_reference_names(self.config, self.multimodal)
+        assert have == set(want), sorted(have ^ set(want))[:6]
+        for n in want:
+            _attach(self, n, e.arena.params[pre + n])
+        self.register_buffer("final_logits_bias", e.buffers[pre + "final_logits_bias"])
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, config=None, **kw):
         """Construction contract of multimodal_train.py:116.  `config` is a BartConfig or a JSON path.
-        A directory holding pytorch_model.bin is loaded; anything else (e.g. 'facebook/bart-large':
-        no network) yields the reference's random init `_init_weights` equivalent via formula init."""
+        The directory must hold pytorch_model.bin (there is no network to fetch hub names such as
+        'facebook/bart-large': that raises); for a random-init model construct the class directly."""
         if isinstance(config, str):
             config = BartConfig.from_json_file(config)
         elif config is None:
             cfgp = os.path.join(str(pretrained_model_name_or_path), "config.json")
             config = BartConfig.from_json_file(cfgp)
         m = cls(config, **kw)
-        ckpt = os.path.join(str(pretrained_model_name_or_path), "pytorch_model.bin")
-        if os.path.exists(ckpt):
-            sd = torch.load(ckpt, map_location="cpu")
-            m.load_state_dict(sd, strict=False)
-        else:
-            init_formula(m)
+        init_formula(m)                     # parameters a bart-large checkpoint lacks (alpha/beta, rating) keep this init
+        load_pretrained(m, pretrained_model_name_or_path, BART_ALLOWED_MISSING)
         m.eval()
         return m
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        r = super().load_state_dict(complete_aliases(self, state_dict), strict=strict, **kw)
         self._engine.mark_weights_changed()
         return r
 
@@ -353,9 +462,13 @@ class YelpTableEncoder(nn.Module):
         emb = _Node()
         emb.register_parameter("weight", bart_embedding.weight if hasattr(bart_embedding, "weight") else bart_embedding)
         self.add_module("bart_embedding", emb)
-        for name, p in engine.arena.params.items():
-            if name.startswith("table_encoder."):
-                _attach(self, name[len("table_encoder."):], p)
+        from .engine import table_specs
+        _attach_ordered(self, engine, "table_encoder.", [n[len("table_encoder."):] for n, _ in table_specs(kind=self.kind)])
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._engine.mark_weights_changed()
+        return r
 
     def forward(self, field, field_value):
         e = self._engine
@@ -379,9 +492,7 @@ class Resnet(nn.Module):
             raise RuntimeError("Resnet needs an engine (build it through MultimodalSum)")
         object.__setattr__(self, "_engine", engine)
         pre = "img_encoder."
-        for name, p in engine.arena.params.items():
-            if name.startswith(pre):
-                _attach(self, name[len(pre):], p)
+        _attach_ordered(self, engine, pre, resnet_reference_names())
         for name, b in engine.buffers.items():
             if name.startswith(pre):
                 _attach(self, name[len(pre):], b, is_buffer=True)
@@ -396,6 +507,11 @@ class Resnet(nn.Module):
         self.stage1 = nn.Sequential(r.conv1, r.bn1, r.relu, r.maxpool, r.layer1)
         self.stage2 = nn.Sequential(r.layer2)
         self.stage3 = nn.Sequential(r.layer3)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(complete_aliases(self, state_dict), strict=strict, **kw)
+        self._engine.mark_weights_changed()
+        return r
 
     def forward(self, x):
         e = self._engine
@@ -473,9 +589,14 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
         self.table_encoder = TableEncoder(self.bart_model.model.shared, engine=e)
         self.img_encoder = Resnet(cfg.d_model, engine=e)
         init_formula(self)
-        for sub, path in ((self.bart_model, bart_pretrained), (self.table_encoder, table_pretrained), (self.img_encoder, img_pretrained)):
-            if path is not None and os.path.exists(os.path.join(str(path), "pytorch_model.bin")):
-                sub.load_state_dict(torch.load(os.path.join(str(path), "pytorch_model.bin"), map_location="cpu"), strict=False)
+        # stage hand-off files (multimodal_train.py:116-122): BART through from_pretrained's lenient key check, the table and
+        # image encoders strictly, exactly as the reference loads them; None = keep the formula init (tests, bench)
+        if bart_pretrained is not None:
+            load_pretrained(self.bart_model, bart_pretrained, BART_ALLOWED_MISSING)
+        if table_pretrained is not None:
+            load_pretrained(self.table_encoder, table_pretrained)
+        if img_pretrained is not None:
+            load_pretrained(self.img_encoder, img_pretrained)
         e.mark_weights_changed()
 
     def train(self, mode=True):
@@ -484,7 +605,7 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
         return self
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        r = super().load_state_dict(complete_aliases(self, state_dict), strict=strict, **kw)
         self._engine.mark_weights_changed()
         return r
 
@@ -607,14 +728,19 @@ class TextSupervised(_StepGraphMixin, nn.Module):
         self.label_smoothing = label_smoothing
         self.bart_model = BartForEncConditionalGeneration(cfg, engine=e, prefix="bart_model.")
         init_formula(self)
-        if bart_pretrained is not None and os.path.exists(os.path.join(str(bart_pretrained), "pytorch_model.bin")):
-            self.bart_model.load_state_dict(torch.load(os.path.join(str(bart_pretrained), "pytorch_model.bin"), map_location="cpu"), strict=False)
+        if bart_pretrained is not None:
+            load_pretrained(self.bart_model, bart_pretrained, BART_ALLOWED_MISSING)
         e.mark_weights_changed()
 
     def train(self, mode=True):
         super().train(mode)
         self._engine.training = mode
         return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(complete_aliases(self, state_dict), strict=strict, **kw)
+        self._engine.mark_weights_changed()
+        return r
 
     def forward(self, reviews, reviews_mask, reviews_rating, **unused):
         e = self._engine
@@ -705,8 +831,8 @@ class _SingleModality(nn.Module):
         if with_table:
             self.table_encoder = (AmazonTableEncoder if with_table == "amazon" else YelpTableEncoder)(self.bart_model.model.shared, engine=e)
         init_formula(self)
-        if bart_pretrained is not None and os.path.exists(os.path.join(str(bart_pretrained), "pytorch_model.bin")):
-            self.bart_model.load_state_dict(torch.load(os.path.join(str(bart_pretrained), "pytorch_model.bin"), map_location="cpu"), strict=False)
+        if bart_pretrained is not None:
+            load_pretrained(self.bart_model, bart_pretrained, BART_ALLOWED_MISSING)
         e.mark_weights_changed()
 
     def train(self, mode=True):
@@ -715,7 +841,7 @@ class _SingleModality(nn.Module):
         return self
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        r = super().load_state_dict(complete_aliases(self, state_dict), strict=strict, **kw)
         self._engine.mark_weights_changed()
         return r
 

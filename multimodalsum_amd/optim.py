@@ -98,13 +98,23 @@ def _subtract(span, owned):
 class FusedAdamW(torch.optim.Optimizer):
     """HF AdamW semantics (eps outside the sqrt, bias correction folded into the step size, decoupled
     decay applied after the Adam update with the updated weight) as one kernel per contiguous
-    arena range; also writes the bf16 weight shadow and applies a pending gradient clip on the fly."""
+    arena range; also writes the bf16 weight shadow and applies a pending gradient clip on the fly.
+
+    The moments live in two flat f32 buffers laid out like the parameter arena; `self.state[p]` holds
+    per-parameter VIEWS of them in the HF layout ({"step", "exp_avg", "exp_avg_sq"}, optimization.py:225-232),
+    so `optimizer.state_dict()` -- what train_utils.py:97 writes to training_state.bin -- carries the full
+    optimiser state and `load_state_dict()` restores it (moments copied back into the flat buffers).
+    All parameters of a group that carry a gradient step together (one counter per group, exported per
+    parameter): that is what happens in the reference's loop, where every optimised parameter receives a
+    gradient in every step."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
         super().__init__(params, defaults)
         self._state_bufs = None
+        self._hyper = {}
         self._steps = {}
+        self._state_members = {}        # group index -> ids of the parameters whose state views exist
 
     def _arena(self):
         for g in self.param_groups:
@@ -112,6 +122,60 @@ class FusedAdamW(torch.optim.Optimizer):
             if a is not None:
                 return a
         return None
+
+    def _buffers(self, arena):
+        if self._state_bufs is None:
+            self._state_bufs = (torch.zeros_like(arena.data), torch.zeros_like(arena.data))
+        return self._state_bufs
+
+    def _attach_state(self, arena, gi, group):
+        """state[p] = views of the flat moment buffers for every parameter of the group that has a gradient."""
+        m, v = self._buffers(arena)
+        seen = self._state_members.setdefault(gi, set())
+        for p in group["params"]:
+            if p.grad is None or id(p) in seen:
+                continue
+            name = p._mmsum_name
+            self.state[p] = {"step": 0, "exp_avg": arena.view(m, name), "exp_avg_sq": arena.view(v, name)}
+            seen.add(id(p))
+
+    def _sync_steps(self):
+        for gi, group in enumerate(self.param_groups):
+            step = self._steps.get((gi,), 0)
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] = step
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)           # torch casts / copies the saved tensors next to their parameters
+        arena = self._arena()
+        if arena is None:
+            return
+        m, v = self._buffers(arena)
+        self._state_members = {}
+        for gi, group in enumerate(self.param_groups):
+            steps = []
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                name = p._mmsum_name
+                mv, vv = arena.view(m, name), arena.view(v, name)
+                mv.copy_(st["exp_avg"].reshape(mv.shape))
+                vv.copy_(st["exp_avg_sq"].reshape(vv.shape))
+                st["exp_avg"], st["exp_avg_sq"] = mv, vv
+                steps.append(int(st["step"]))
+                self._state_members.setdefault(gi, set()).add(id(p))
+            if steps:
+                if min(steps) != max(steps):
+                    raise ValueError("FusedAdamW: parameters of group %d were saved at different step counts (%d..%d); the fused "
+                                     "update steps a group together" % (gi, min(steps), max(steps)))
+                self._steps[(gi,)] = steps[0]
 
     def zero_grad(self, set_to_none=True):
         super().zero_grad(set_to_none=set_to_none)
@@ -122,10 +186,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if arena is None:
             raise RuntimeError("FusedAdamW only drives parameters that live in a multimodalsum_amd arena")
         eng = next(p for g in self.param_groups for p in g["params"])._mmsum_engine
-        if self._state_bufs is None:
-            self._state_bufs = (torch.zeros_like(arena.data), torch.zeros_like(arena.data))
-            self._hyper = {}
-        m, v = self._state_bufs
+        m, v = self._buffers(arena)
         pending = getattr(eng, "pending_clip", None)
         all_ranges = []
         for gi, group in enumerate(self.param_groups):
@@ -133,6 +194,9 @@ class FusedAdamW(torch.optim.Optimizer):
             if not rs:
                 continue
             key = (gi,)
+            n_grad = sum(1 for p in group["params"] if p.grad is not None)
+            if len(self._state_members.get(gi, ())) != n_grad:
+                self._attach_state(arena, gi, group)
             step = self._steps.get(key, 0) + 1
             self._steps[key] = step
             b1, b2 = group["betas"]

@@ -17,7 +17,7 @@ def run_step(state_dict=None, dtype=torch.float32, seed=31, B=2, NR=3, S=16, I=2
     cfg = tiny_config()
     model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cuda:0", dtype=dtype, deterministic=True)
     if state_dict is not None:
-        model.load_state_dict(state_dict, strict=False)
+        model.load_state_dict(state_dict)
     model.train()
     bc = syn.yelp_batch(B, NR, S, I, cfg.vocab_size, seed=seed, img_hw=img_hw)
     b = syn.batch_to(bc, "cuda:0")

@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--full", action="store_true", help="also run the full-size BART-large spot check (minutes)")
     ap.add_argument("--only-full", action="store_true", help="run only the full-size fixtures F8 / F8b")
+    ap.add_argument("--only-contract", action="store_true", help="run only the state_dict key/shape contract fixture")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.manual_seed(0)
@@ -114,6 +115,9 @@ def main():
     if args.only_full:
         full_size_spot_check(mm, BartConfig, ru, G)
         full_size_step(mt, mm, te, BartConfig, G)
+        return
+    state_dict_contract(mt, tp, mm, te, BartConfig, RefAdamW, G)
+    if args.only_contract:
         return
 
     # ---- F7: shift_tokens_right / padding mask helpers ------------------------------------
@@ -365,6 +369,40 @@ def full_size_spot_check(mm, BartConfig, ru, G):
         loss = ru.LabelSmoothingLoss(cfg.vocab_size, 0.1)(logits.view(-1, cfg.vocab_size), b["reviews"][:, 0].view(-1))
     npz(G("f8_fullsize.npz"), seed=np.int64(1234), enc_sample=enc[:, :4, :32], enc_abs_sum=enc.double().abs().sum(),
         logits_sample=logits[0, :8, :64], logits_abs_sum=logits.double().abs().sum(), loss=loss, rating_diff=rd)
+
+
+def state_dict_contract(mt, tp, mm, te, BartConfig, RefAdamW, G):
+    """The checkpoint contract: state_dict keys and shapes of the reference's own modules at a small
+    config (key names do not depend on the sizes), and the layout of optimizer.state_dict() that train_utils.py:97 saves.
+    img_encoder.* is absent: torchvision cannot be imported here (its keys are pinned by the published resnet101 layout
+    only, like the backbone's arithmetic)."""
+    import json
+    cfg = tiny_cfg(BartConfig, vocab=200, d=1024, ffn=64, layers=2, heads=16, maxpos=32)
+    out = {}
+    ms = mt.MultimodalSum.__new__(mt.MultimodalSum)
+    torch.nn.Module.__init__(ms)
+    ms.bart_model = mm.BartForMultiEncConditionalGeneration(cfg)
+    ms.table_encoder = te.YelpTableEncoder(ms.bart_model.model.shared)
+    out["multimodal_yelp"] = [[k, list(v.shape)] for k, v in ms.state_dict().items()]
+    ms.table_encoder = te.AmazonTableEncoder(ms.bart_model.model.shared)
+    out["multimodal_amazon"] = [[k, list(v.shape)] for k, v in ms.state_dict().items()]
+    ts = tp.TextSupervised.__new__(tp.TextSupervised)
+    torch.nn.Module.__init__(ts)
+    ts.bart_model = mm.BartForEncConditionalGeneration(cfg)
+    out["text"] = [[k, list(v.shape)] for k, v in ts.state_dict().items()]
+    ms.table_encoder = te.YelpTableEncoder(ms.bart_model.model.shared)
+    out["named_parameters_multimodal_yelp"] = [n for n, _ in ms.named_parameters()]
+    # optimizer.state_dict() layout after one step (HF AdamW, optimization.py:225-232)
+    lin = torch.nn.Linear(3, 2)
+    opt = RefAdamW([{"params": [lin.weight], "weight_decay": 0.01}, {"params": [lin.bias], "weight_decay": 0.0}], lr=1e-3)
+    lin(torch.ones(1, 3)).sum().backward()
+    opt.step()
+    osd = opt.state_dict()
+    out["optimizer"] = {"top": sorted(osd), "state_entry": sorted(osd["state"][0]), "group_keys": sorted(osd["param_groups"][0]),
+                        "step_after_one": int(osd["state"][0]["step"]), "exp_avg_shape": list(osd["state"][0]["exp_avg"].shape)}
+    with open(G("state_dict_contract.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote", G("state_dict_contract.json"))
 
 
 F8_GRADS = [

@@ -35,7 +35,7 @@ def _build(dtype=torch.float32):
     cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40)
     sd = formula_state_dict(bo.bart_param_shapes(oracle_cfg(cfg), False, prefix="bart_model."), std=0.08)
     model = TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=dtype)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     return cfg, model
 

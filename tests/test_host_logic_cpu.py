@@ -52,7 +52,7 @@ def test_multimodal_step_matches_oracle_and_golden(monkeypatch, golden_dir):
     ocfg = oracle_cfg(cfg)
     sd = f3_state(ocfg)
     model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
-    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing, unexpected = model.load_state_dict(sd)
     assert not unexpected, unexpected
     assert all(("embed_tokens" in k or "bart_embedding" in k or "stage" in k or k.endswith("final_logits_bias")) for k in missing), missing
     model.train()
@@ -107,7 +107,7 @@ def test_text_step_c1(monkeypatch, golden_dir):
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.08)
     model = TextSupervised(config=cfg, label_smoothing=None, device="cpu", dtype=torch.float32)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     b = syn.yelp_batch(2, 2, 64, 1, cfg.vocab_size, seed=int(g["seed"]), img_hw=8)
     loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
@@ -130,7 +130,7 @@ def test_coarse_modules_match_oracle(monkeypatch):
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
     model = BartForMultiEncConditionalGeneration(cfg, device="cpu", dtype=torch.float32)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     Bz, N, S, T = 2, 3, 8, 10
     ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
@@ -173,7 +173,7 @@ def test_optimizer_q1_and_clip(monkeypatch):
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.08)
     model = TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     opt = optim.get_optimizer(1e-3, so.NO_DECAY, model.named_parameters(), None)
     assert len(opt.param_groups[1]["params"]) == 0
@@ -209,6 +209,64 @@ def test_optimizer_q1_and_clip(monkeypatch):
             _close(p.grad, ref[name].grad, 1e-3, 1e-6, name + " accumulated grad (Q1b)")
 
 
+def test_optimizer_state_dict_roundtrip(monkeypatch, tmp_path):
+    """training_state.bin of the reference = {epoch, optimizer.state_dict(), scheduler.state_dict()} (train_utils.py:97).
+    FusedAdamW exports its flat moment buffers per parameter in the HF AdamW layout (optimization.py:225-232: step, exp_avg,
+    exp_avg_sq), and a fresh model + optimiser that loads the checkpoint continues bit for bit."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import TextSupervised
+    from multimodalsum_amd import optim
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40)
+    sd = formula_state_dict(bo.bart_param_shapes(oracle_cfg(cfg), False, prefix="bart_model."), std=0.08)
+
+    def make():
+        model = TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
+        model.load_state_dict(sd)
+        model.train()
+        opt = optim.get_optimizer(1e-3, so.NO_DECAY, model.named_parameters(), None)
+        return model, opt, optim.get_linear_schedule_with_warmup(opt, 1, 6)
+
+    def step(model, opt, sch, i):
+        b = syn.yelp_batch(2, 3, 16, 1, cfg.vocab_size, seed=70 + i, img_hw=8)
+        loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+        opt.zero_grad()
+        loss.backward()
+        optim.clip_grad_norm_(model.parameters(), 1.0, fused=True)
+        opt.step()
+        sch.step()
+
+    model, opt, sch = make()
+    for i in range(2):
+        step(model, opt, sch, i)
+    osd = opt.state_dict()
+    n_opt = len(opt.param_groups[0]["params"])
+    assert sorted(osd) == ["param_groups", "state"] and len(osd["state"]) == n_opt > 0
+    for idx, st in osd["state"].items():
+        assert sorted(st) == ["exp_avg", "exp_avg_sq", "step"] and st["step"] == 2
+        p = opt.param_groups[0]["params"][idx]
+        assert st["exp_avg"].shape == p.shape and st["exp_avg_sq"].shape == p.shape
+        assert float(st["exp_avg_sq"].abs().sum()) > 0
+    path = str(tmp_path / "training_state.bin")
+    torch.save({"epoch": 1, "optimizer": osd, "scheduler": sch.state_dict(), "model": model.state_dict()}, path)
+    # Q1b: gradients of the never-optimised parameters keep accumulating; they are not checkpointed by the reference either,
+    # so a resumed run restarts them from zero -- compare the optimised parameters only
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    model2, opt2, sch2 = make()
+    model2.load_state_dict(ck["model"])
+    opt2.load_state_dict(ck["optimizer"])
+    sch2.load_state_dict(ck["scheduler"])
+    for p in model.parameters():
+        p.grad = None
+    step(model, opt, sch, 2)
+    step(model2, opt2, sch2, 2)
+    for (n, a), (_, b) in zip(model.named_parameters(), model2.named_parameters()):
+        assert torch.equal(a, b), n
+    assert opt2.state_dict()["state"][0]["step"] == 3
+    # the moments the loaded optimiser steps are views of its flat buffers again (one kernel per arena range)
+    st = opt2.state[opt2.param_groups[0]["params"][0]]
+    assert st["exp_avg"].untyped_storage().data_ptr() == opt2._state_bufs[0].untyped_storage().data_ptr()
+
+
 def test_bf16_mode_schedules(monkeypatch, golden_dir):
     """bf16 compute mode takes different host paths (bf16 weight shadow, transposed-weight table for dgrad,
     activation transposes for wgrad).  Run them through the emulator and check against the f32 oracle at
@@ -220,7 +278,7 @@ def test_bf16_mode_schedules(monkeypatch, golden_dir):
     ocfg = oracle_cfg(cfg)
     sd = f3_state(ocfg)
     model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.bfloat16)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     b = syn.yelp_batch(int(g["B"]), int(g["NR"]), int(g["S"]), int(g["I"]), cfg.vocab_size, seed=int(g["seed"]), img_hw=int(g["img_hw"]))
     loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
@@ -259,7 +317,7 @@ def test_single_modality_wrappers(monkeypatch):
     shapes.update(eo.table_param_shapes())
     sd = formula_state_dict(shapes, std=0.02)
     tm = TableSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
-    tm.load_state_dict(sd, strict=False)
+    tm.load_state_dict(sd)
     tm.train()
     field, fv = syn.table_batch(2, cfg.vocab_size, seed=9)
     loss = tm(field, fv, labels=labels)[0]
@@ -281,7 +339,7 @@ def test_single_modality_wrappers(monkeypatch):
     sd = formula_state_dict(shapes, std=0.02)
     sd.update(formula_state_dict(eo.resnet_param_shapes(1024), std=0.05))
     im = ImgSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
-    im.load_state_dict(sd, strict=False)
+    im.load_state_dict(sd)
     im.train()
     g = torch.Generator().manual_seed(3)
     imgs = torch.randn(2, 2, 3, 64, 64, generator=g)
@@ -334,7 +392,7 @@ def test_beam_search_host_logic(monkeypatch, case):
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, multimodal, prefix=""), std=0.08)
     cls = BartForMultiEncConditionalGeneration if multimodal else BartForEncConditionalGeneration
     model = cls(cfg, device="cpu", dtype=torch.float32)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.eval()
     Bz, N, S = 3, 3, 8
     ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
@@ -379,7 +437,7 @@ def test_amazon_table_encoder_module(monkeypatch):
     shapes.update(eo.amazon_table_param_shapes())
     sd = formula_state_dict(shapes, std=0.02)
     tm = TableSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32, TableEncoder=AmazonTableEncoder)
-    tm.load_state_dict(sd, strict=False)
+    tm.load_state_dict(sd)
     tm.train()
     field, fv = syn.amazon_table_batch(2, cfg.vocab_size, seed=9)
     h, m = tm.table_encoder(field, fv)
@@ -422,7 +480,7 @@ def test_padding_free_encoder_matches_oracle(monkeypatch, golden_dir, multimodal
     else:
         sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.02)
         model = TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     seen = {}
     orig = model._engine.encoder_fwd
@@ -485,3 +543,59 @@ def test_graph_cache_keeps_one_set_per_shape(monkeypatch):
     sg.entries["k3"] = graphs._Entry()
     sg._evict(keep="k3")
     assert list(sg.entries) == ["k2", "k3"] and k1.state == 0 and sg.pool is None
+
+
+def test_state_dict_contract_matches_reference(golden_dir):
+    """Keys, shapes and ORDER of state_dict() / named_parameters() equal the reference's own modules' (fixture written by
+    oracle/make_golden.py from the imported reference): checkpoints and optimizer.state_dict() parameter indices interchange.
+    img_encoder.* keys are not in the fixture (torchvision cannot be imported to generate them)."""
+    import json
+    from multimodalsum_amd.modules import AmazonTableEncoder, MultimodalSum, TextSupervised
+    with open(os.path.join(golden_dir, "state_dict_contract.json")) as f:
+        ref = json.load(f)
+    cfg = tiny_cfg(vocab=200, d=1024, ffn=64, layers=2, heads=16, maxpos=32)
+
+    def ours(model):
+        return [[k, list(v.shape)] for k, v in model.state_dict().items() if not k.startswith("img_encoder.")]
+
+    ms = MultimodalSum(config=cfg, device="cpu", dtype=torch.float32)
+    assert ours(ms) == ref["multimodal_yelp"]
+    assert [n for n, _ in ms.named_parameters() if not n.startswith("img_encoder.")] == ref["named_parameters_multimodal_yelp"]
+    # a checkpoint with exactly the reference's keys (+ ours for the image encoder) loads strictly
+    sd = {k: torch.zeros(shape) for k, shape in ref["multimodal_yelp"]}
+    sd.update({k: v for k, v in ms.state_dict().items() if k.startswith("img_encoder.")})
+    ms.load_state_dict(sd, strict=True)
+    with pytest.raises(RuntimeError):
+        ms.load_state_dict({**sd, "bart_model.model.decoder.layers.0.gamma_proj.weight": torch.zeros(1)}, strict=True)
+    ma = MultimodalSum(config=cfg, device="cpu", dtype=torch.float32, TableEncoder=AmazonTableEncoder)
+    assert ours(ma) == ref["multimodal_amazon"]
+    assert ours(TextSupervised(config=cfg, device="cpu", dtype=torch.float32)) == ref["text"]
+    assert ref["optimizer"]["state_entry"] == ["exp_avg", "exp_avg_sq", "step"] and ref["optimizer"]["top"] == ["param_groups", "state"]
+
+
+def test_pretrained_paths_are_checked(tmp_path):
+    """multimodal_train.py:116-122: a stage hand-off directory must exist and match; nothing is loaded leniently."""
+    from multimodalsum_amd.modules import MultimodalSum
+    cfg = tiny_cfg()
+    with pytest.raises(FileNotFoundError):
+        MultimodalSum(bart_pretrained=str(tmp_path / "nowhere"), config=cfg, device="cpu", dtype=torch.float32)
+    ms = MultimodalSum(config=cfg, device="cpu", dtype=torch.float32)
+    d = tmp_path / "table"
+    d.mkdir()
+    sd = ms.table_encoder.state_dict()
+    torch.save(sd, str(d / "pytorch_model.bin"))
+    MultimodalSum(table_pretrained=str(d), config=cfg, device="cpu", dtype=torch.float32)           # loads strictly
+    sd.pop("fc.bias")
+    torch.save(sd, str(d / "pytorch_model.bin"))
+    with pytest.raises(RuntimeError):
+        MultimodalSum(table_pretrained=str(d), config=cfg, device="cpu", dtype=torch.float32)
+    # BART: what a facebook/bart-large checkpoint lacks (alpha/beta projections, rating embedding) may be missing, nothing else
+    b = tmp_path / "bart"
+    b.mkdir()
+    bsd = {k: v for k, v in ms.bart_model.state_dict().items() if "alpha_proj" not in k and "beta_proj" not in k and "rating_emb" not in k}
+    torch.save(bsd, str(b / "pytorch_model.bin"))
+    MultimodalSum(bart_pretrained=str(b), config=cfg, device="cpu", dtype=torch.float32)
+    bsd.pop("model.decoder.layers.0.fc1.weight")
+    torch.save(bsd, str(b / "pytorch_model.bin"))
+    with pytest.raises(RuntimeError):
+        MultimodalSum(bart_pretrained=str(b), config=cfg, device="cpu", dtype=torch.float32)

@@ -44,7 +44,7 @@ def test_multimodal_step_f3(dtype, golden_dir):
     ocfg = oracle_cfg(cfg)
     sd = f3_state(ocfg)
     model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=dtype, deterministic=True)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     bc = syn.yelp_batch(int(g["B"]), int(g["NR"]), int(g["S"]), int(g["I"]), cfg.vocab_size, seed=int(g["seed"]), img_hw=int(g["img_hw"]))
     b = to_dev(bc)
@@ -89,7 +89,7 @@ def test_text_step_c1(dtype):
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.08)
     model = TextSupervised(config=cfg, label_smoothing=None, device=DEV, dtype=dtype, deterministic=True)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     bc = syn.yelp_batch(2, 2, 64, 1, cfg.vocab_size, seed=41, img_hw=8)
     b = to_dev(bc)
@@ -117,7 +117,7 @@ def test_coarse_modules_logits_f32():
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
     model = BartForMultiEncConditionalGeneration(cfg, device=DEV, dtype=torch.float32, deterministic=True)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     Bz, N, S, T = 2, 3, 8, 10
     ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
@@ -160,7 +160,7 @@ def test_training_loop_optimizer_f32():
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.08)
     model = TextSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     opt = optim.get_optimizer(1e-3, so.NO_DECAY, model.named_parameters(), None)
     sch = optim.get_linear_schedule_with_warmup(opt, 1, 6)
@@ -278,7 +278,7 @@ def test_beam_search_generation_token_ids(case):
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, multimodal, prefix=""), std=0.08)
     cls = BartForMultiEncConditionalGeneration if multimodal else BartForEncConditionalGeneration
     model = cls(cfg, device=DEV, dtype=torch.float32, deterministic=True)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.eval()
     Bz, N, S = 3, 3, 8
     ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
@@ -345,7 +345,7 @@ def test_amazon_table_encoder_f32():
     shapes.update(eo.amazon_table_param_shapes())
     sd = formula_state_dict(shapes, std=0.02)
     tm = TableSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, TableEncoder=AmazonTableEncoder, deterministic=True)
-    tm.load_state_dict(sd, strict=False)
+    tm.load_state_dict(sd)
     tm.train()
     field, fv = syn.amazon_table_batch(2, cfg.vocab_size, seed=9)
     loss = tm(field.to(DEV), [t.to(DEV) for t in fv], labels=labels.to(DEV))[0]
@@ -385,7 +385,7 @@ def test_multimodal_step_ragged_shapes_f32(B, NR, S, I, img_hw, images):
     ocfg = oracle_cfg(cfg)
     sd = f3_state(ocfg)
     model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
-    model.load_state_dict(sd, strict=False)
+    model.load_state_dict(sd)
     model.train()
     bc = syn.yelp_batch(B, NR, S, I, cfg.vocab_size, seed=90 + B, img_hw=img_hw)
     if not images:
