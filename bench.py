@@ -2,34 +2,45 @@
 """Benchmark of the hot path: training samples/sec (businesses/sec) of the full multimodal
 leave-one-out training step (forward + backward + grad clip + AdamW) on synthetic Yelp-shaped data.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `value` is whole-job businesses/s with inputs resident in HBM;
-`roofline` prices the step against the dense bf16 MFMA peak using the canonical algorithmic FLOP
-count of SURVEY.md section 8d (K/V projections counted once per step), plus a live HIP-event
-measurement of the dominant kernel (the bf16 MFMA GEMM); `cpu_baseline` times the CPU oracle (the
-restated reference algorithm) on the host cores over a bounded sample of the same workload.
+N > 1: bench.py starts the N ranks itself (`python -m torch.distributed.run ... bench.py`, one process per GPU,
+RCCL) before it touches a GPU, relays rank 0's JSON line and exits with the child's code; when it is ALREADY
+running under torch.distributed.run (WORLD_SIZE set, the driver's form of the launch) it is one of the ranks.
+
+Prints ONE JSON line (rank 0).  `value` is whole-job businesses/s with inputs resident in HBM -- a fresh batch with
+fresh review lengths and image counts is generated ON THE DEVICE inside every timed step.
+`roofline` describes the step's dominant kernel as it runs IN the step: after the timed region one more step is
+issued eagerly with HIP events around every launch of that kernel (on its launch stream), so `achieved` is its
+algorithmic FLOPs / its in-step duration; `roofline.step` prices the whole step against the dense bf16 MFMA peak with
+the canonical algorithmic FLOP count of SURVEY.md section 8d (padded rows, K/V projections once per step) and, beside
+it, with the FLOPs actually executed (valid rows only).  `cpu_baseline` times the CPU oracle (the restated reference
+algorithm, literal) on the host cores: whole B=1 steps of the same configuration, no extrapolation.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+NO_DECAY = ('bias', 'bn1.weight', 'bn2.weight', 'bn3.weight', 'layer_norm.weight', 'layernorm_embedding.weight')
 
 
-def flops_per_business(D, F, V, L_enc, L_dec, NR, S, T, I, P=196, Ft=47, multimodal=True, with_resnet=True):
+def flops_per_business(D, F, V, L_enc, L_dec, NR, S, T, I, P=196, Ft=47, multimodal=True, with_resnet=True, enc_rows=None,
+                       mem_rows=None):
     """Algorithmic FLOPs (2*MAC) of ONE training step for ONE business, de-duplicated count of
-    SURVEY.md section 8d: forward x3 for everything with weights + input grads, ResNet stage 1-2 forward only."""
+    SURVEY.md section 8d: forward x3 for everything with weights + input grads, ResNet stage 1-2 forward only.
+    enc_rows / mem_rows (per business): rows the padding-free encoder layers / K-V projections really work on -- the
+    'executed' count; None = all padded rows, the canonical count."""
     R = NR * S
-    enc = L_enc * (8 * R * D * D + 4 * R * D * F + 4 * S * D * R)
+    Re = R if enc_rows is None else enc_rows
+    enc = L_enc * (8 * Re * D * D + 4 * Re * D * F + 4 * S * D * R)
     nproj_out = 3 if multimodal else 1
     per_pass_layer = (8 * T * D * D + 4 * T * T * D) + 2 * T * D * D + nproj_out * 2 * T * D * D + 4 * T * D * F
     per_pass_layer += (NR - 1) * 4 * T * S * D
@@ -37,6 +48,8 @@ def flops_per_business(D, F, V, L_enc, L_dec, NR, S, T, I, P=196, Ft=47, multimo
     if multimodal:
         per_pass_layer += 8 * T * D * D + 4 * T * Ft * D + I * 4 * T * P * D
         rmem += Ft + I * P
+    if mem_rows is not None:
+        rmem = mem_rows
     dec = L_dec * NR * per_pass_layer + L_dec * 4 * rmem * D * D + NR * 2 * T * D * V
     total = 3.0 * (enc + dec)
     if multimodal:
@@ -46,23 +59,47 @@ def flops_per_business(D, F, V, L_enc, L_dec, NR, S, T, I, P=196, Ft=47, multimo
     return total
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=56,
-                    help="businesses per GPU per step (56: 9*56*128 decoder rows = 252 x 256-row GEMM tiles, four full rounds of 256 CUs per "
-                         "N=1024 product; ~96 GB of the 288 GB.  28 is 4 %% slower per business, 8 is BASELINE C4's reference-style batch)")
+                    help="businesses per GPU per step (56: 9*56*128 decoder rows = 252 x 256-row GEMM tiles; ~105 GB of the 288 GB.  "
+                         "28 is 4 %% slower per business, 8 is BASELINE C4's reference-style batch)")
     ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="issue every kernel from Python instead of replaying captured HIP graphs")
-    return ap.parse_args()
+    ap.add_argument("--fixed-batches", action="store_true", help="alternate two pre-generated batches instead of generating one per step")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the wire")
+    ap.add_argument("--master-port", type=int, default=29517)
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 from a plain `python bench.py --gpus N`: start the ranks as children BEFORE any GPU call
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(args.master_port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env)
+    last_json = None
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            last_json = line.strip()
+        else:
+            sys.stderr.write(line)                # RCCL banners etc.: keep stdout to the one JSON line
+    rc = proc.wait()
+    if last_json is not None:
+        print(last_json, flush=True)
+    sys.exit(rc if rc != 0 or last_json is not None else 1)
 
 
 def build(args, device):
+    import torch
     import multimodalsum_amd as mm
     cfg = mm.BartConfig.from_json_file(os.path.join(ROOT, "cfg", "bart-large.json"))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -74,18 +111,22 @@ def build(args, device):
     return cfg, model
 
 
-def make_batches(args, cfg, device, rank, n=2):
+def batch_source(args, cfg, device, rank):
+    """A callable returning the next step's inputs (device tensors)."""
     from multimodalsum_amd import synthetic as syn
-    out = []
-    for i in range(n):
-        b = syn.yelp_batch(args.batch, 9, 128, 4 if args.workload == "multimodal" else 1, cfg.vocab_size,
-                           seed=1234 + 1000 * rank + i, img_hw=224 if args.workload == "multimodal" else 8)
-        dev = syn.batch_to(b, device)
-        # what a loader-side prefetcher does on the host copy (multimodalsum_amd/prefetch.py): the number of non-padding review tokens
-        dev["reviews_mask"]._mmsum_valid_rows = int(b["reviews_mask"].ne(0).sum())
-        dev["img_mask"]._mmsum_valid_rows = int(b["img_mask"].ne(0).sum())
-        out.append(dev)
-    return out
+    multimodal = args.workload == "multimodal"
+    I, hw = (4, 224) if multimodal else (1, 8)
+    if args.fixed_batches:
+        fixed = [syn.batch_to(syn.yelp_batch(args.batch, 9, 128, I, cfg.vocab_size, seed=1234 + 1000 * rank + i, img_hw=hw), device)
+                 for i in range(2)]
+        state = {"i": 0}
+
+        def nxt():
+            state["i"] += 1
+            return fixed[state["i"] % 2]
+        return nxt
+    gen = syn.DeviceBatches(args.batch, 9, 128, I, cfg.vocab_size, device, seed=1234 + rank, img_hw=hw)
+    return gen.next
 
 
 def run_step(args, model, opt, sch, b):
@@ -102,66 +143,89 @@ def run_step(args, model, opt, sch, b):
     return loss
 
 
-def kernel_probe(dtype, batch=14):
-    """Live HIP-event timing of the dominant kernel: the MFMA GEMM on the decoder FFN shape at the
-    bench batch (M = 9*B*128 rows, fc1: N=4096, K=1024).  Events are recorded on the launch stream."""
-    from multimodalsum_amd import kernels as kn
-    M, N, K = 9 * batch * 128, 4096, 1024
-    a = torch.randn(M, K, device="cuda").to(dtype)
-    w = torch.randn(N, K, device="cuda").to(dtype)
-    out = torch.empty(M, N, device="cuda", dtype=dtype)
-    for _ in range(3):
-        kn.gemm(a, w, out)
-    iters = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        kn.gemm(a, w, out)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    fl = 2.0 * M * N * K
-    return {"kernel": "gemm_nt_ring_kernel<256,256,2,4> (bf16 NT GEMM, 4-stage LDS-DMA ring, 256x256x32 slabs)" if dtype == torch.bfloat16
-            else "gemm_kernel<f32,NT>",
-            "shape": [M, N, K], "avg_launch_ms": ms, "flops_per_launch": fl, "achieved": fl / ms / 1e9, "unit": "TFLOP/s"}
+# ------------------------------------------------------------------------------------------------
+# the dominant kernel, timed where it runs: inside a step
+# ------------------------------------------------------------------------------------------------
+def probe_dominant_kernel(args, model, runner, opt, sch, b, cfg):
+    """One more training step, issued eagerly (no graph replay), with a HIP event pair around every launch of the step's
+    dominant kernel: the FFN up-projection + bias + GELU (+ saved pre-activation) NT GEMM, `gemm_nt_ring_kernel<256,256,2,4,
+    EPI_GELU,OUT_T>` -- 24 launches per step (12 decoder layers on all 9*B*128 rows, 12 encoder layers on the valid rows).
+    Events are recorded on the stream the kernel is launched on (torch's current stream at the call)."""
+    import torch
+    from multimodalsum_amd import engine as eng_mod, kernels as kn
+    e = model._engine
+    Fd, D = cfg.decoder_ffn_dim, cfg.d_model
+    real = kn.gemm
+    rec = []
 
+    def timed_gemm(a, w, out, *pos, **kw):
+        hit = (kw.get("epi") == kn.EPI_GELU and not kw.get("a_t") and not kw.get("b_t") and w.shape == (Fd, D) and a.shape[0] >= 4096)
+        if not hit:
+            return real(a, w, out, *pos, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = real(a, w, out, *pos, **kw)
+        e1.record()
+        rec.append((e0, e1, a.shape[0], kw.get("live")))
+        return r
 
-def padding_note(args, model, b):
-    """What the padding-free encoder / K-V projections skip in this run (results identical; the FLOP count used for the
-    roofline fraction stays the reference's padded one)."""
-    from multimodalsum_amd.modules import _encoder_capacity
-    batch = ((b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])
-             if args.workload == "multimodal" else (b["reviews"], b["reviews_mask"], b["reviews_rating"]))
-    cap = _encoder_capacity(model, batch)
-    if cap is None or cap[0] is None:
+    graphs = getattr(model, "_step_graphs", None)
+    object.__setattr__(model, "_step_graphs", None)
+    eng_mod.kn.gemm = timed_gemm
+    try:
+        run_step(args, runner, opt, sch, b)
+        torch.cuda.synchronize()
+    finally:
+        eng_mod.kn.gemm = real
+        object.__setattr__(model, "_step_graphs", graphs)
+    dec, enc = [], []
+    for e0, e1, rows, live in rec:
+        ms = e0.elapsed_time(e1)
+        if live is None:
+            dec.append((ms, rows))
+        else:
+            enc.append((ms, int(live.item())))
+    if not dec:
         return None
-    R = b["reviews_mask"].numel()
-    return {"encoder_rows_computed": cap[0], "encoder_rows_padded": R, "memory_rows_projected": cap[1],
-            "note": "rows that are padding never reach a result; roofline.step keeps the padded FLOP count of SURVEY 8d"}
+    plan = kn.gemm_plan(torch.empty(dec[0][1], D, device=e.device, dtype=e.dtype), torch.empty(Fd, D, device=e.device, dtype=e.dtype),
+                        torch.empty(dec[0][1], Fd, device=e.device, dtype=e.dtype), epi=kn.EPI_GELU,
+                        bias=torch.empty(Fd, device=e.device), aux=torch.empty(dec[0][1], Fd, device=e.device, dtype=e.dtype))
+    M = dec[0][1]
+    avg = sum(ms for ms, _ in dec) / len(dec)
+    fl = 2.0 * M * Fd * D
+    out = {"kernel": "gemm_nt_ring_kernel<%d,%d,2,4,EPI_GELU,OUT_T> (bf16 NT GEMM x W^T + bias, GELU, pre-activation saved; 4-stage LDS-DMA ring; "
+                     "%d persistent workgroups)" % (plan[1], plan[2], plan[3]) if args.dtype == "bf16" else "gemm_kernel<f32,NT,EPI_GELU>",
+           "shape": [M, Fd, D], "launches_timed": len(dec), "avg_launch_ms": avg, "min_launch_ms": min(ms for ms, _ in dec),
+           "max_launch_ms": max(ms for ms, _ in dec), "flops_per_launch": fl, "achieved": fl / avg / 1e9,
+           "algorithmic_bytes_per_launch": 2.0 * (M * D + Fd * D + 2 * M * Fd) + 4.0 * Fd,
+           "measured": "HIP events around each in-step launch (one eager step after the timed region)"}
+    if enc:
+        eavg = sum(ms for ms, _ in enc) / len(enc)
+        erows = sum(r for _, r in enc) / len(enc)
+        out["encoder_calls"] = {"launches_timed": len(enc), "live_rows": erows, "avg_launch_ms": eavg,
+                                "achieved": 2.0 * erows * Fd * D / eavg / 1e9}
+    return out
 
 
 def pmc_traffic(shape):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary (FETCH_SIZE doubled per
-    the gfx950 correction + WRITE_SIZE); None when no profile of this exact shape is committed."""
+    """HBM-side bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary of this exact shape
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, profiles/*dominant_gemm_pmc*.json, newest round first)."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_dominant_gemm_pmc*.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dominant_gemm_pmc*.json")), reverse=True):
         try:
             with open(path) as f:
                 prof = json.load(f)
             if list(prof["shape"]) == list(shape):
-                return prof["hbm_bytes_per_launch"]
+                return prof["hbm_bytes_per_launch"], os.path.basename(path)
         except Exception:
             continue
-    return None
+    return None, None
 
 
-def cpu_baseline(args, cfg):
-    """The reference algorithm (CPU oracle, literal: 9 sequential passes, K/V re-projected per pass)
-    on the host cores.  Bounded sample: B=1, BART-large width/vocab, 1 encoder + 1 decoder layer,
-    1 image; businesses/s for the full model is extrapolated by the literal FLOP ratio."""
-    from multimodalsum_amd import synthetic as syn
-    from multimodalsum_amd.formula_init import formula_state_dict
-    from oracle import bart_oracle as bo, encoders_oracle as eo, step_oracle as so
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: whole steps of the restated reference algorithm on the host cores
+# ------------------------------------------------------------------------------------------------
+def host_cores():
     try:
         cores = len(os.sched_getaffinity(0))       # cores this process may actually run on (cgroup/affinity aware)
     except AttributeError:
@@ -172,25 +236,51 @@ def cpu_baseline(args, cfg):
             cores = min(cores, max(1, int(int(quota) / int(period))))
     except Exception:
         pass
-    cores = max(1, min(cores, 32))
+    return max(1, cores)
+
+
+def cpu_baseline(workload, budget_s=75.0, max_steps=3):
+    """the reference algorithm (CPU oracle, literal: 9 sequential decoder passes, K/V re-projected per
+    pass, unfused loss, PyTorch fp32) on the host cores -- one B=1 step of the SAME configuration as the GPU run (BART-large
+    12+12 layers, 9 reviews x 128 tokens, 4 images of 224x224, table), forward + backward, no optimiser (the reference's
+    optimiser step is a few per cent of its step).  1 warm-up + up to `max_steps` timed steps within `budget_s`.
+    Weights are random (uniform, the formula init's spread): the closed-form init costs ~50 s at this size and the timing
+    does not depend on the values."""
+    import torch
+    from multimodalsum_amd import synthetic as syn
+    from multimodalsum_amd.config import BartConfig
+    from oracle import bart_oracle as bo, encoders_oracle as eo, step_oracle as so
+    cfg = BartConfig.from_json_file(os.path.join(ROOT, "cfg", "bart-large.json"))
+    cores = min(host_cores(), 64)
     torch.set_num_threads(cores)
-    L = 1
+    multimodal = workload == "multimodal"
+    L = cfg.encoder_layers
     ocfg = bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim, encoder_layers=L,
-                      decoder_layers=L, heads=cfg.heads, max_position_embeddings=cfg.max_position_embeddings, dropout=0.1)
-    multimodal = args.workload == "multimodal"
+                      decoder_layers=cfg.decoder_layers, heads=cfg.heads, max_position_embeddings=cfg.max_position_embeddings, dropout=0.1)
     shapes = bo.bart_param_shapes(ocfg, multimodal, prefix="bart_model.")
     if multimodal:
         shapes.update(eo.table_param_shapes())
-    sd = formula_state_dict(shapes, std=0.02)
-    if multimodal:
-        sd.update(formula_state_dict(eo.resnet_param_shapes(cfg.d_model), std=0.05))
+        shapes.update(eo.resnet_param_shapes(cfg.d_model))
+    g = torch.Generator().manual_seed(7)
+    sd = {}
+    for k, shp in shapes.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.int64)
+        elif k.endswith("running_var") or ((".bn" in k or "layer_norm" in k or "layernorm_embedding" in k or "downsample.1" in k) and k.endswith(".weight")):
+            sd[k] = torch.ones(shp)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.zeros(shp)
+        else:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * (0.05 if "img_encoder" in k else 0.035)
     for k, v in sd.items():
         if v.is_floating_point() and v.dim() > 0 and "running" not in k:
             v.requires_grad_(True)
-    I = 1
+    I = 4 if multimodal else 1
     b = syn.yelp_batch(1, 9, 128, I, cfg.vocab_size, seed=1234, img_hw=224 if multimodal else 8)
 
     def step():
+        for v in sd.values():
+            v.grad = None
         if multimodal:
             loss = so.multimodal_step_loss(sd, ocfg, b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"],
                                            b["field_value"], b["img"], b["img_mask"], 0.1, training=True)
@@ -198,39 +288,35 @@ def cpu_baseline(args, cfg):
             loss = so.text_step_loss(sd, ocfg, b["reviews"], b["reviews_mask"], b["reviews_rating"], None, training=True)
         loss.backward()
 
+    t_w = time.time()
     step()                       # warm-up (allocator, thread pool)
+    t_w = time.time() - t_w
+    times = []
     t0 = time.time()
-    nstep = 0
-    while nstep < 12 and (nstep == 0 or time.time() - t0 < 12.0):      # ~10-30 s of CPU work
+    while len(times) < max_steps and (not times or (time.time() - t0) + times[-1] < budget_s):
+        t1 = time.time()
         step()
-        nstep += 1
-    total = time.time() - t0
-    dt = total / nstep
+        times.append(time.time() - t1)
+    dt = sum(times) / len(times)
     D, F, V = cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size
-
-    def literal(Lx, Ix):         # reference-literal FLOPs: K/V re-projected in all 9 passes, q x3
-        f = flops_per_business(D, F, V, Lx, Lx, 9, 128, 128, Ix, multimodal=multimodal)
-        kv = Lx * 4 * (9 * 128 + (47 + Ix * 196 if multimodal else 0)) * D * D
-        kv_lit = Lx * 9 * 4 * (8 * 128 + (47 + Ix * 196 if multimodal else 0)) * D * D
-        q_extra = Lx * 9 * (2 if multimodal else 0) * 2 * 128 * D * D
-        return f + 3.0 * (kv_lit - kv + q_extra)
-
-    sample_flops = literal(L, I)
-    full_flops = literal(cfg.encoder_layers, 4 if multimodal else 1)
-    return {"value": (sample_flops / dt) / full_flops, "unit": "businesses/s", "cores": cores, "kind": "port",
-            "sample": "CPU oracle (PyTorch fp32, literal reference algorithm) fwd+bwd of one B=1 step with 1+1 layers, "
-                      "BART-large width/vocab, %d image: %d steps in %.1f s (%.0f GFLOP/s); extrapolated to the 12+12-layer, "
-                      "%d-image step by the reference-literal FLOP count" % (I, nstep, total, sample_flops / dt / 1e9, 4 if multimodal else 1),
-            "sample_seconds": total}
+    f = flops_per_business(D, F, V, L, L, 9, 128, 128, I, multimodal=multimodal)
+    kv = L * 4 * (9 * 128 + (47 + I * 196 if multimodal else 0)) * D * D
+    kv_lit = L * 9 * 4 * (8 * 128 + (47 + I * 196 if multimodal else 0)) * D * D
+    q_extra = L * 9 * (2 if multimodal else 0) * 2 * 128 * D * D
+    literal = f + 3.0 * (kv_lit - kv + q_extra)
+    return {"value": 1.0 / dt, "unit": "businesses/s", "cores": cores, "kind": "port",
+            "sample": "CPU oracle (PyTorch fp32, the reference algorithm restated literally) on %d host cores: whole forward+backward steps of "
+                      "the bench configuration at B=1 (BART-large 12+12 layers, 9 reviews x 128 tokens%s): 1 warm-up (%.1f s) + %d timed steps, "
+                      "%.1f s each (%.0f GFLOP/s on the reference-literal %.2f TFLOP/step); measured, not extrapolated"
+                      % (cores, ", 4 images 224x224 through ResNet101, 47-field table" if multimodal else "", t_w, len(times), dt,
+                         literal / dt / 1e9, literal / 1e12),
+            "step_seconds": times, "warmup_seconds": t_w}
 
 
-def cpu_baseline_bounded(args, budget_s=240):
+def cpu_baseline_bounded(args, budget_s=420):
     """Runs cpu_baseline() in a child process (no GPU touched there) under a hard wall-clock budget."""
-    import subprocess
-    code = ("import sys, json, types; sys.path.insert(0, %r); import bench; from multimodalsum_amd.config import BartConfig; "
-            "cfg = BartConfig.from_json_file(%r); "
-            "print('CPUBASE ' + json.dumps(bench.cpu_baseline(types.SimpleNamespace(workload=%r), cfg)))"
-            % (ROOT, os.path.join(ROOT, "cfg", "bart-large.json"), args.workload))
+    code = ("import sys, json; sys.path.insert(0, %r); import bench; print('CPUBASE ' + json.dumps(bench.cpu_baseline(%r)))"
+            % (ROOT, args.workload))
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     try:
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=budget_s, env=env)
@@ -245,29 +331,39 @@ def cpu_baseline_bounded(args, budget_s=240):
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)                       # does not return
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_ddp = os.environ.get("MMSUM_FORCE_DDP") == "1"          # debugging aid: run the RCCL gradient path at world size 1
+    dist = None
     if world > 1 or force_ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
     import multimodalsum_amd as mm
     from multimodalsum_amd import optim
     cfg, model = build(args, device)
-    runner = mm.DistributedDataParallel(model, delay_allreduce=True, always_reduce=force_ddp) if (world > 1 or force_ddp) else model
-    opt = optim.get_optimizer(1e-5, ('bias', 'bn1.weight', 'bn2.weight', 'bn3.weight', 'layer_norm.weight', 'layernorm_embedding.weight'),
-                              model.named_parameters(), None)
+    ddp = None
+    if world > 1 or force_ddp:
+        ddp = mm.DistributedDataParallel(model, delay_allreduce=True, always_reduce=force_ddp, collect_stats=True,
+                                         grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
+    runner = ddp if ddp is not None else model
+    opt = optim.get_optimizer(1e-5, NO_DECAY, model.named_parameters(), None)
     sch = optim.get_linear_schedule_with_warmup(opt, 100, 100000)
-    batches = make_batches(args, cfg, device, rank)
+    next_batch = batch_source(args, cfg, device, rank)
 
     def sync():
         torch.cuda.synchronize()
@@ -280,13 +376,17 @@ def main():
         model.enable_step_graphs()
         priming = 2                         # un-timed: one eager step, one that captures the HIP graphs
         for i in range(priming):
-            run_step(args, runner, opt, sch, batches[i % len(batches)])
+            run_step(args, runner, opt, sch, next_batch())
     for i in range(args.warmup):
-        run_step(args, runner, opt, sch, batches[i % len(batches)])
+        run_step(args, runner, opt, sch, next_batch())
+    stats_skip = len(ddp.stats) if ddp is not None else 0
+    live_rows = []
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        loss = run_step(args, runner, opt, sch, batches[i % len(batches)])
+        b = next_batch()                   # generated on the device inside the timed step
+        loss = run_step(args, runner, opt, sch, b)
+        live_rows.append((b["reviews_mask"].sum(), b["img_mask"].sum() if args.workload == "multimodal" else None))   # device scalars, read after the region
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -294,40 +394,57 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.item())
+    comm = ddp.comm_stats(skip=stats_skip) if ddp is not None else None
+    graphs = getattr(model, "_step_graphs", None)
+    captures = graphs.captures if graphs is not None else 0
+    peak_gb = round(torch.cuda.max_memory_reserved() / 2**30, 1)
+    probe = None
+    if rank == 0 and not args.no_kernel_probe and world == 1:
+        probe = probe_dominant_kernel(args, model, runner, opt, sch, b, cfg)
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
         multimodal = args.workload == "multimodal"
-        fpb = flops_per_business(cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128,
-                                 4 if multimodal else 1, multimodal=multimodal)
+        I = 4 if multimodal else 1
+        dims = (cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, I)
+        fpb = flops_per_business(*dims, multimodal=multimodal)
+        text_rows = sum(float(t) for t, _ in live_rows) / len(live_rows) / args.batch
+        mem_rows = text_rows + ((47 + 196 * sum(float(im) for _, im in live_rows) / len(live_rows) / args.batch) if multimodal else 0)
+        fpb_exec = flops_per_business(*dims, multimodal=multimodal, enc_rows=text_rows, mem_rows=mem_rows)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = value / world * fpb / 1e12
         step_roof = {"achieved": achieved, "frac": achieved / peak, "flops_per_business": fpb,
-                     "scope": "whole training step per GPU (algorithmic FLOPs of SURVEY.md 8d / step time)"}
-        if args.no_kernel_probe:
+                     "executed": {"achieved": value / world * fpb_exec / 1e12, "frac": value / world * fpb_exec / 1e12 / peak,
+                                  "flops_per_business": fpb_exec, "encoder_rows_per_business": text_rows, "memory_rows_per_business": mem_rows,
+                                  "note": "FLOPs of the rows the padding-free encoder layers / K-V projections really process (results identical)"},
+                     "scope": "whole training step per GPU (canonical algorithmic FLOPs of SURVEY.md 8d, padded rows) / step time"}
+        if probe is None:
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                    "scope": step_roof["scope"], "flops_per_business": fpb}
+                    "scope": step_roof["scope"], "flops_per_business": fpb, "executed": step_roof["executed"]}
         else:
-            # the dominant kernel, timed live with HIP events on its launch stream; traffic from the committed PMC profile
-            dk = kernel_probe(torch.bfloat16 if args.dtype == "bf16" else torch.float32, args.batch)
-            roof = {"bound": "mfma", "achieved": dk["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": dk["achieved"] / peak,
-                    "traffic": pmc_traffic(dk["shape"]), "kernel": dk["kernel"], "shape": dk["shape"], "avg_launch_ms": dk["avg_launch_ms"],
-                    "flops_per_launch": dk["flops_per_launch"], "step": step_roof}
+            traffic, src = pmc_traffic(probe["shape"])
+            roof = {"bound": "mfma", "achieved": probe["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": probe["achieved"] / peak,
+                    "traffic": traffic, "traffic_source": src, "step": step_roof}
+            roof.update({k: v for k, v in probe.items() if k != "achieved"})
         out = {"metric": "training samples/sec (businesses/sec) BART-large multimodal" if multimodal else
                "training samples/sec (businesses/sec) BART-large text-only",
                "value": value, "unit": "businesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
-               "data": "synthetic Yelp-shaped batches (seeded), formula-initialised BART-large/ResNet101 weights",
+               "data": "synthetic Yelp-shaped batches generated on the device inside every timed step (fresh review lengths and image counts "
+                       "per step), formula-initialised BART-large/ResNet101 weights" if not args.fixed_batches else
+                       "two fixed synthetic Yelp-shaped batches (seeded), formula-initialised BART-large/ResNet101 weights",
                "config": {"workload": "multimodal_train.py full text+img(4x224^2)+table step (fwd+bwd+clip+AdamW), 9 reviews x 128 tok"
                           if multimodal else "text_pretrain.py BART-large text-only step, 9 reviews x 128 tok",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "dropout": cfg.dropout},
-               "padding_free": padding_note(args, model, batches[0]),
-               "launch": "eager" if args.no_graphs else "hip-graph replay (1 forward graph + 1 graph per backward gradient segment), %d priming steps before warmup" % priming,
-               "final_loss": loss_val, "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1), "roofline": roof}
+               "launch": "eager" if args.no_graphs else "hip-graph replay (1 forward graph + 1 graph per backward gradient segment, ONE set for all "
+                         "batches: row counts are device-side), %d priming steps before warmup, %d capture(s) in the whole run" % (priming, captures),
+               "graph_captures": captures, "final_loss": loss_val, "peak_hbm_gb": peak_gb, "roofline": roof}
+        if comm is not None:
+            out["comm"] = comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_bounded(args)
-    if world > 1 or force_ddp:
+    if dist is not None:
         dist.destroy_process_group()          # RCCL prints its library banner on teardown: keep the JSON line last
     if rank == 0:
         sys.stdout.flush()

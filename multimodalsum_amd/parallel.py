@@ -6,10 +6,16 @@ Replaces apex.parallel.DistributedDataParallel(model, delay_allreduce=True)
 
 The reference flattens every gradient into one buffer AFTER backward and all-reduces it with no
 overlap.  Here the gradients already live in one arena, so there is nothing to flatten, and the
-fused step tells us when a whole parameter segment (decoder / image+table encoders / encoder +
-tied embedding) is final: its arena ranges are all-reduced on a side stream in large buckets while
-the rest of the backward keeps the compute stream busy.  Parameters that never receive a gradient
-(ResNet stem/layer1/layer2/layer4/fc) are simply absent from the ranges.
+fused step tells us when a whole parameter segment (decoder / image+table encoders + upper text
+encoder layers / lower layers + tied embedding) is final: its arena ranges are all-reduced on a
+side stream in large buckets while the rest of the backward keeps the compute stream busy.
+Parameters that never receive a gradient (ResNet stem/layer1/layer2/layer4/fc) are simply absent
+from the ranges.
+
+The mean is taken by the collective itself (ReduceOp.AVG on RCCL: no extra pass over the 1.95 GB of
+gradients); backends without AVG (gloo) get SUM followed by one scaling pass.  `grad_dtype=torch.bfloat16`
+sends bf16 buckets (half the bytes on the xGMI links; the f32 arena stays the accumulator) -- off by
+default because the reference reduces in f32.
 """
 import torch
 import torch.distributed as dist
@@ -27,7 +33,7 @@ def reduce_tensor(tensor, world_size):
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, delay_allreduce=True, bucket_elems=64 * 1024 * 1024, overlap=True, process_group=None,
-                 always_reduce=False):
+                 always_reduce=False, grad_dtype=None, collect_stats=False):
         super().__init__()
         self.module = module
         self.group = process_group
@@ -37,8 +43,12 @@ class DistributedDataParallel(nn.Module):
         self.arena = self.engine.arena
         self.overlap = overlap and self.arena.grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
+        self.grad_dtype = grad_dtype
+        self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.collect_stats = bool(collect_stats) and self.arena.grad.is_cuda
+        self.stats = []                          # per step: (events of every bucket, bytes), read by comm_stats()
+        self._events, self._bytes = [], 0
         self._done = set()
-        self._pending = []
         if self.world_size > 1 or (always_reduce and dist.is_initialized()):      # always_reduce: exercise the path at world size 1
             dist.broadcast(self.arena.data, 0, group=self.group)          # C2: parameters from rank 0
             for b in self.engine.buffers.values():
@@ -50,17 +60,36 @@ class DistributedDataParallel(nn.Module):
 
     def forward(self, *args, **kwargs):
         self._done = set()
+        self._events, self._bytes = [], 0
         return self.module(*args, **kwargs)
 
     # ---- gradient all-reduce ----------------------------------------------------------------------
+    def _all_reduce_mean(self, chunk):
+        buf = chunk
+        if self.grad_dtype is not None and self.grad_dtype != chunk.dtype:
+            buf = chunk.to(self.grad_dtype)
+        if self.native_avg:
+            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf.mul_(1.0 / self.world_size)
+        if buf is not chunk:
+            chunk.copy_(buf)
+        return buf.numel() * buf.element_size()
+
     def _reduce_ranges(self, ranges):
         g = self.arena.grad
-        inv = 1.0 / self.world_size
         for s, e in ranges:
             for b0 in range(s, e, self.bucket_elems):
                 chunk = g[b0:min(e, b0 + self.bucket_elems)]
-                chunk.mul_(inv)                      # pre-divide: SUM of g/world == mean (apex divides after)
-                dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                if self.collect_stats:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    self._bytes += self._all_reduce_mean(chunk)
+                    e1.record()
+                    self._events.append((e0, e1))
+                else:
+                    self._all_reduce_mean(chunk)
 
     def _segment_ready(self, prefixes):
         params = [p for n, p in self.arena.params.items() if p.grad is not None and n not in self._done
@@ -84,4 +113,29 @@ class DistributedDataParallel(nn.Module):
             self._done.update(p._mmsum_name for p in rest)
             self._reduce_ranges(_ranges(self.arena, rest))
         if self.overlap:
+            if self.collect_stats:
+                bwd_done = torch.cuda.Event(enable_timing=True)
+                bwd_done.record()                                  # compute stream: the backward kernels end here
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            if self.collect_stats:
+                all_done = torch.cuda.Event(enable_timing=True)
+                all_done.record()                                  # ... and here the last collective has landed too
+                self.stats.append((self._events, self._bytes, bwd_done, all_done))
+        elif self.collect_stats:
+            self.stats.append((self._events, self._bytes, None, None))
+
+    def comm_stats(self, skip=0):
+        """Averages over the recorded steps (after a device synchronise): milliseconds inside the collectives per step,
+        milliseconds of them left exposed after the backward's last kernel, bytes reduced per step, and the bus bandwidth
+        2 (N-1)/N * bytes / time that a ring all-reduce's links saw."""
+        steps = self.stats[skip:]
+        if not steps:
+            return None
+        comm = sum(sum(a.elapsed_time(b) for a, b in ev) for ev, _, _, _ in steps) / len(steps)
+        exposed = sum((bd.elapsed_time(ad) if bd is not None else 0.0) for _, _, bd, ad in steps) / len(steps)
+        nbytes = sum(nb for _, nb, _, _ in steps) / len(steps)
+        n = self.world_size
+        bus = (2.0 * (n - 1) / n * nbytes / (comm * 1e-3) / 1e9) if (comm > 0 and n > 1) else 0.0
+        return {"allreduce_ms": comm, "exposed_ms": exposed, "overlap_frac": (1.0 - exposed / comm) if comm > 0 else None,
+                "bytes_per_step": nbytes, "bus_gb_s": bus, "buckets_per_step": sum(len(ev) for ev, _, _, _ in steps) / len(steps),
+                "grad_dtype": str(self.grad_dtype or torch.float32)}

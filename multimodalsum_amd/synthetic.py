@@ -108,3 +108,57 @@ def batch_to(batch, device):
     for k, v in batch.items():
         out[k] = [t.to(device) for t in v] if isinstance(v, list) else v.to(device)
     return out
+
+
+class DeviceBatches:
+    """Yelp-shaped training batches generated ON THE DEVICE, a new one per call (inputs are regenerated
+    every step so that the loader is not measured, and every step sees fresh review lengths / image counts -- which is what
+    exercises the device-side live row counts of the fused step).  Same distributions as `yelp_batch`; the values differ
+    (device generator), which is irrelevant for a throughput run.  The constant `field` tensor is made once."""
+
+    def __init__(self, B, NR, S, I, vocab, device, seed, img_hw=224):
+        self.B, self.NR, self.S, self.I, self.vocab, self.img_hw = B, NR, S, I, vocab, img_hw
+        self.device = torch.device(device)
+        self.g = torch.Generator(device=self.device)
+        self.g.manual_seed(int(seed))
+        self.field = table_batch(1, vocab, seed)[0].to(self.device)
+        self.pos = torch.arange(S, device=self.device).unsqueeze(0)
+
+    def _rand(self, *shape):
+        return torch.rand(*shape, generator=self.g, device=self.device)
+
+    def _ids(self, *shape):
+        return torch.randint(3, self.vocab, shape, generator=self.g, device=self.device)
+
+    def _trailing(self, shape, min_real=0):
+        L = shape[-1]
+        n_real = torch.randint(min_real, L + 1, shape[:-1] + (1,), generator=self.g, device=self.device)
+        ids = self._ids(*shape)
+        return torch.where(torch.arange(L, device=self.device).expand(shape) < n_real, ids, torch.full_like(ids, PAD))
+
+    def next(self):
+        B, NR, S, I, dev = self.B, self.NR, self.S, self.I, self.device
+        mean_len, std_len, min_len = (75.0, 20.0, 32) if S == 128 else (0.6 * S, 0.16 * S, max(2, S // 4))
+        lens = torch.clamp(torch.round(torch.randn(B * NR, generator=self.g, device=dev) * std_len + mean_len), min_len, S).long().unsqueeze(1)
+        ids = self._ids(B * NR, S)
+        ids = torch.where((self.pos == lens - 1) & (lens < S), torch.full_like(ids, EOS), ids)
+        reviews = torch.where(self.pos >= lens, torch.full_like(ids, PAD), ids).view(B, NR, S)
+        rating = torch.randint(1, 6, (B, NR), generator=self.g, device=dev).float()
+        name = self._trailing((B, 24), 1)
+        category = self._trailing((B, 6, 12), 1)
+        drop = self._rand(B, 6) < 0.5
+        drop[:, :3] = False
+        category = torch.where(drop.unsqueeze(-1), torch.full_like(category, PAD), category)
+        str_cat = self._trailing((B, 5, 3), 0)
+        str_bool = self._ids(B, 32, 1)
+        str_bool = torch.where(self._rand(B, 32, 1) < 0.3, torch.full_like(str_bool, PAD), str_bool)
+        rbits = (self._rand(B, 4) < 0.5).long()
+        day = torch.randint(0, 4, (B, 7), generator=self.g, device=dev)
+        hours = torch.nn.functional.one_hot(day, 4).long()
+        hours = torch.where((self._rand(B, 7) < 0.2).unsqueeze(-1), torch.zeros_like(hours), hours)
+        img = torch.randn(B, I, 3, self.img_hw, self.img_hw, generator=self.g, device=dev)
+        n_valid = torch.randint(0, I + 1, (B,), generator=self.g, device=dev)
+        img_mask = torch.arange(I, device=dev).unsqueeze(0) < n_valid.unsqueeze(1)
+        img = img * img_mask[:, :, None, None, None].float()
+        return {"reviews": reviews, "reviews_mask": reviews.ne(PAD).long(), "reviews_rating": rating, "field": self.field,
+                "field_value": [name, category, str_cat, str_bool, rbits, hours], "img": img, "img_mask": img_mask}

@@ -78,8 +78,44 @@ def bart_param_shapes(cfg, multimodal=True, prefix=""):
     return s
 
 
+# bf16 emulation (tests only): with EMULATE_BF16 on, every Linear of the path rounds its operands and its result to bf16
+# (f32 accumulation), forward and backward, the way ANY bf16 implementation of the same algorithm must.  The difference
+# between the emulated and the plain f32 run is the yardstick the bf16 HIP path is held to (tests/test_bench_shapes_gpu.py):
+# its error against the f32 oracle may be a small multiple of this one, per tensor.  Off (None) = the reference's arithmetic.
+EMULATE_BF16 = False
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _QuantLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xq, wq = _q(x), _q(w)
+        ctx.save_for_backward(xq, wq)
+        ctx.has_bias = b is not None
+        y = F.linear(xq, wq, b)
+        return _q(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq, wq = ctx.saved_tensors
+        dyq = _q(dy)
+        dx = _q(dyq @ wq)
+        dw = dyq.reshape(-1, dyq.shape[-1]).t() @ xq.reshape(-1, xq.shape[-1])
+        db = dyq.reshape(-1, dyq.shape[-1]).sum(0) if ctx.has_bias else None
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    if EMULATE_BF16:
+        return _QuantLinear.apply(x, w, b)
+    return F.linear(x, w, b)
+
+
 def _lin(sd, name, x):
-    return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+    return linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
 
 
 def _ln(sd, name, x):
@@ -252,14 +288,14 @@ def multienc_forward(sd, cfg, text_h, text_m, table_h, table_m, img_h, img_m, ra
     dec_in, dec_pad, causal = decoder_inputs_from_labels(cfg, labels)
     h = bart_decoder(sd, cfg, dec_in, [text_h, table_h, img_h], [text_m, table_m, img_m], dec_pad, causal,
                      rating_diff, True, training, prefix)
-    return F.linear(h, sd[prefix + "model.shared.weight"])  # final_logits_bias is a zero buffer (:2189)
+    return linear(h, sd[prefix + "model.shared.weight"])  # final_logits_bias is a zero buffer (:2189)
 
 
 def enc_forward(sd, cfg, enc_h, rating_diff, enc_m, labels, training=False, prefix=""):
     """BartForEncConditionalGeneration.forward (:1317-1396): text-only variant, single key tensor."""
     dec_in, dec_pad, causal = decoder_inputs_from_labels(cfg, labels)
     h = bart_decoder(sd, cfg, dec_in, enc_h, enc_m, dec_pad, causal, rating_diff, False, training, prefix)
-    return F.linear(h, sd[prefix + "model.shared.weight"])
+    return linear(h, sd[prefix + "model.shared.weight"])
 
 
 # --------------------------------------------------------------------------------------------

@@ -1,0 +1,410 @@
+"""GPU: parity AT THE SIZES AND ON THE KERNELS THE BENCHMARK RUNS.
+
+The tile chooser sends small test shapes to the 128x128 kernels; the bench (B=56 per GPU: 64,512 decoder rows, ~38,900
+valid encoder rows, F=4096, V=50265) runs the persistent 256x256 ring kernels.  This file holds those kernels and sizes to
+element-wise bounds against fp32 / fp64 matmuls (a wrong epilogue on a few tiles cannot hide behind a norm), asserts through
+mmsum_gemm_plan that each case really reaches the kernel it means to cover, checks the device-side live row counts at
+those sizes, and compares the HIP path with the reference's own outputs at the real cfg/bart-large.json (fixtures F8, F8b
+written by oracle/make_golden.py --only-full) and with the oracle at BART-large width in both compute modes.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from multimodalsum_amd import kernels as kn
+    from multimodalsum_amd import _lib
+
+from multimodalsum_amd import synthetic as syn
+from multimodalsum_amd.config import BartConfig
+from multimodalsum_amd.formula_init import formula_state_dict, formula_tensor
+
+DEV = "cuda"
+BF = torch.bfloat16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rnd(*shape, dtype=BF, seed=0, std=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=DEV) * std).to(dtype)
+
+
+def check(out, ref, what, rel=2.0 ** -7, atol=2e-2):
+    """Element-wise: |out - ref| <= rel*|ref| + atol everywhere (bf16 keeps 8 bits: one rounding is 2^-9 relative, an
+    accumulate epilogue two roundings; the f32-accumulated dot product itself is far tighter).  All on the device."""
+    out, ref = out.float(), ref.float()
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    bad = ~((out - ref).abs() <= rel * ref.abs() + atol)          # NaN compares false -> counted as bad
+    n = int(bad.sum())
+    if n:
+        idx = bad.nonzero()[0].tolist()
+        raise AssertionError("%s: %d of %d elements out of bounds, first at %s: got %r want %r"
+                             % (what, n, out.numel(), idx, float(out[tuple(idx)]), float(ref[tuple(idx)])))
+
+
+def assert_plan(plan, family, bm=256, bn=256, persistent=None):
+    assert plan[0] == family and (plan[1], plan[2]) == (bm, bn), plan
+    if persistent is not None:
+        assert (plan[3] <= 256) and persistent, plan
+
+
+# the step's NT products at the bench batch: (M rows) x (N, K) of qkv / out_proj / fc1 / fc2 / kv projections
+NT_SHAPES = [(64512, 4096, 1024), (64512, 1024, 4096), (64512, 3072, 1024), (64512, 1024, 1024), (38912, 4096, 1024),
+             (38912, 1024, 4096), (38912, 3072, 1024), (38912, 1024, 1024), (38912, 2048, 1024), (64512, 2048, 2048)]
+
+
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_nt_ring_256_persistent_all_epilogues(M, N, K):
+    """gemm_nt_ring_kernel<256,256,2,4,*> with more tiles than CUs (persistent tile walk): every epilogue / output form the
+    step uses, against an fp32 matmul of the same bf16 operands."""
+    a, w = rnd(M, K, seed=1, std=0.5), rnd(N, K, seed=2, std=0.5)
+    bias = rnd(N, dtype=torch.float32, seed=3)
+    ref = a.float() @ w.float().t()
+    sc = math.sqrt(K / 1024.0)
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    plan = kn.gemm_plan(a, w, out, bias=bias)
+    assert_plan(plan, _lib.PLAN_NT_RING)
+    assert plan[3] == 256 and (M // 256) * (N // 256) > 256          # persistent workgroups walking a longer tile list
+    kn.gemm(a, w, out, bias=bias)
+    check(out, ref + bias, "bias", atol=2e-2 * sc)
+    # GELU + saved pre-activation (fc1), then GELU' on a saved pre-activation (fc2's input gradient)
+    aux = torch.full((M, N), float("nan"), device=DEV, dtype=BF)
+    kn.gemm(a, w, out, bias=bias, alpha=0.25, epi=kn.EPI_GELU, aux=aux)
+    pre = ref * 0.25 + bias
+    check(aux, pre, "gelu aux", atol=2e-2 * sc)
+    check(out, F.gelu(pre), "gelu out", atol=2e-2 * sc)
+    u = rnd(M, N, seed=4)
+    uf = u.float()
+    gp = 0.5 * (1 + torch.erf(uf / math.sqrt(2))) + uf * torch.exp(-0.5 * uf * uf) / math.sqrt(2 * math.pi)
+    cs = torch.ones(N, device=DEV)
+    kn.gemm(a, w, out, epi=kn.EPI_GELU_BWD, aux=u, colsum=cs)                 # + bias-gradient column sums in the epilogue
+    check(out, ref * gp, "gelu' out", rel=2.0 ** -6, atol=4e-2 * sc)
+    want_cs = 1.0 + out.double().sum(0)
+    assert ((cs.double() - want_cs).abs() <= 1e-3 * out.double().abs().sum(0) + 1e-2).all(), "column sums"
+    del u, uf, gp
+    # ReLU' (table encoder), += into bf16 (dq / dx accumulation), += into f32, plain f32 output
+    r = rnd(M, N, seed=5)
+    kn.gemm(a, w, out, epi=kn.EPI_RELU_BWD, aux=r)
+    check(out, ref * (r.float() > 0), "relu'", atol=2e-2 * sc)
+    prev = rnd(M, N, seed=6)
+    acc = prev.clone()
+    kn.gemm(a, w, acc, accumulate=True)
+    check(acc, prev.float() + ref, "+= bf16", rel=2.0 ** -6, atol=3e-2 * sc)
+    del r, prev, acc, aux
+    accf = rnd(M, N, dtype=torch.float32, seed=7)
+    want = accf + ref
+    kn.gemm(a, w, accf, accumulate=True)
+    check(accf, want, "+= f32", rel=1e-4, atol=2e-3 * sc)
+    kn.gemm(a, w, accf)
+    check(accf, ref, "f32 out", rel=1e-4, atol=2e-3 * sc)
+
+
+def test_nt_ring_a2_split_and_lm_head():
+    """K split over two A operands (alpha/beta projections: cat([text, table]) without the concat) at the bench row count; the LM
+    head forward with the ragged vocabulary (50265 = 196 tiles + 89 columns) and its input gradient with K = 50304."""
+    M, D, V, Vp = 64512, 1024, 50265, 50304
+    yt, ytab, w = rnd(M, D, seed=11, std=0.5), rnd(M, D, seed=12, std=0.5), rnd(D, 2 * D, seed=13, std=0.5)
+    bias = rnd(D, dtype=torch.float32, seed=14)
+    out = torch.full((M, D), float("nan"), device=DEV, dtype=BF)
+    assert_plan(kn.gemm_plan(yt, w, out, a2=ytab, bias=bias), _lib.PLAN_NT_RING)
+    kn.gemm(yt, w, out, a2=ytab, bias=bias)
+    check(out, yt.float() @ w[:, :D].float().t() + ytab.float() @ w[:, D:].float().t() + bias, "a2 split", atol=3e-2)
+    del yt, ytab
+    # LM head forward: logits [M, Vpad] buffer, columns >= V untouched
+    M = 16128                                   # B=14: 126 x 197 tiles, still far more than 256
+    h, E = rnd(M, D, seed=15, std=0.5), rnd(V, D, seed=16, std=0.05)
+    logits = torch.full((M, Vp), 7.0, device=DEV, dtype=BF)
+    assert_plan(kn.gemm_plan(h, E, logits[:, :V]), _lib.PLAN_NT_RING)
+    kn.gemm(h, E, logits[:, :V])
+    check(logits[:, :V], h.float() @ E.float().t(), "lm head", atol=1e-2)
+    assert bool((logits[:, V:] == 7.0).all()), "columns past the vocabulary were written"
+    # input gradient through the transposed shadow: dh = dlogits [M, Vpad] @ (E^T)^T, K = 50304 (padding columns zero)
+    dl = rnd(M, Vp, seed=17, std=0.02)
+    dl[:, V:] = 0
+    Et = torch.zeros(D, Vp, device=DEV, dtype=BF)
+    Et[:, :V] = E.t()
+    dh = torch.full((M, D), float("nan"), device=DEV, dtype=BF)
+    assert_plan(kn.gemm_plan(dl, Et, dh), _lib.PLAN_NT_RING)
+    up = torch.full((1,), 0.5, device=DEV)
+    kn.gemm(dl, Et, dh, alpha_dev=up)                                        # with the device-side upstream gradient scale
+    check(dh, 0.5 * (dl.float() @ Et.float().t()), "lm head dgrad x upstream", atol=1e-2)
+    # tied-embedding weight gradient: dE[V, D] += dlogits^T h, reduction over M rows, split-K slabs
+    sk = 2
+    ws = torch.full((sk * V, D), float("nan"), device=DEV)
+    plan = kn.gemm_plan(dl[:, :V], h, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+    assert_plan(plan, _lib.PLAN_TN_RING)
+    kn.gemm(dl[:, :V], h, ws, a_t=True, b_t=True, splitk=sk, slabs=True, alpha_dev=up)
+    g = torch.ones(V, D, device=DEV)
+    kn.slab_reduce(ws, sk, g, accumulate=True)
+    want = 1.0 + 0.5 * (dl[:, :V].double().t() @ h.double())
+    check(g, want, "lm head wgrad", rel=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("R,No,Ki", [(64512, 4096, 1024), (64512, 1024, 4096), (38912, 3072, 1024), (64512, 1024, 1024), (111048, 2048, 1024)])
+def test_tn_ring_256_weight_gradients(R, No, Ki):
+    """gemm_tn_ring_kernel<256,256,2,4>: dW[No, Ki] = dy[R, No]^T x[R, Ki] straight from the reduction-major activations, with
+    the split-K the engine picks at these sizes, against an fp64 product."""
+    dy, x = rnd(R, No, seed=21, std=0.1), rnd(R, Ki, seed=22, std=0.5)
+    tiles = ((No + 127) // 128) * ((Ki + 127) // 128)
+    sk = max(1, min(8, -(-768 // tiles), (R // 64) // 4))                      # engine.Engine.splitk
+    assert sk > 1
+    ws = torch.full((sk * No, Ki), float("nan"), device=DEV)
+    assert_plan(kn.gemm_plan(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True), _lib.PLAN_TN_RING)
+    kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+    g = torch.zeros(No, Ki, device=DEV)
+    kn.slab_reduce(ws, sk, g, accumulate=True)
+    want = dy.double().t() @ x.double()
+    check(g, want, "wgrad", rel=1e-3, atol=1e-3 * math.sqrt(R / 1024.0))
+
+
+def test_live_row_counts_at_bench_sizes():
+    """The device-side live row count on the big kernels: rows past it are neither read (they hold NaN) nor written (they keep
+    their sentinel), rows below it match; one launch geometry (capacity 64,512) serves any count -- including 0 and ragged
+    ones that end inside a tile."""
+    cap, D, Fd = 64512, 1024, 4096
+    for live_n in (38907, 256, 0, cap):
+        live = torch.tensor([live_n], device=DEV, dtype=torch.int32)
+        a = rnd(cap, D, seed=31, std=0.5)
+        a[live_n:] = float("nan")
+        w = rnd(Fd, D, seed=32, std=0.5)
+        bias = rnd(Fd, dtype=torch.float32, seed=33)
+        out = torch.full((cap, Fd), 3.0, device=DEV, dtype=BF)
+        aux = torch.full((cap, Fd), 5.0, device=DEV, dtype=BF)
+        kn.gemm(a, w, out, bias=bias, epi=kn.EPI_GELU, aux=aux, live=live)
+        pre = a[:live_n].float() @ w.float().t() + bias
+        check(out[:live_n], F.gelu(pre), "live gelu out (%d)" % live_n)
+        check(aux[:live_n], pre, "live gelu aux (%d)" % live_n)
+        assert bool((out[live_n:] == 3.0).all()) and bool((aux[live_n:] == 5.0).all()), "rows past the live count were written"
+        # weight gradient: reduction over the live rows only (the rest is NaN and must not be read)
+        dy = rnd(cap, Fd, seed=34, std=0.1)
+        dy[live_n:] = float("nan")
+        sk = 3
+        ws = torch.full((sk * Fd, D), float("nan"), device=DEV)
+        kn.gemm(dy, a, ws, a_t=True, b_t=True, splitk=sk, slabs=True, live=live)
+        g = torch.zeros(Fd, D, device=DEV)
+        kn.slab_reduce(ws, sk, g, accumulate=True)
+        check(g, dy[:live_n].double().t() @ a[:live_n].double(), "live wgrad (%d)" % live_n, rel=1e-3, atol=1e-2)
+        cs = torch.zeros(Fd, device=DEV)
+        kn.colsum(dy, cs, live=live)
+        check(cs, dy[:live_n].double().sum(0), "live colsum (%d)" % live_n, rel=1e-3, atol=1e-2)
+        del out, aux, dy, ws
+        # LayerNorm forward / backward and the row gather
+        x, res = rnd(cap, D, seed=35), rnd(cap, D, seed=36)
+        x[live_n:] = float("nan")
+        gamma, beta = 1 + 0.1 * rnd(D, dtype=torch.float32, seed=37), rnd(D, dtype=torch.float32, seed=38)
+        y = torch.full((cap, D), 9.0, device=DEV, dtype=BF)
+        mean, rstd = torch.zeros(cap, device=DEV), torch.zeros(cap, device=DEV)
+        kn.add_ln_fwd(x, res, gamma, beta, y, mean, rstd, 1e-5, 0.0, 1, live=live)
+        check(y[:live_n], F.layer_norm(x[:live_n].float() + res[:live_n].float(), (D,), gamma, beta, 1e-5), "live ln (%d)" % live_n, atol=3e-2)
+        assert bool((y[live_n:] == 9.0).all())
+        dyl = rnd(cap, D, seed=39)
+        dyl[live_n:] = float("nan")
+        dx = torch.full((cap, D), 9.0, device=DEV, dtype=BF)
+        dres = torch.full((cap, D), 9.0, device=DEV, dtype=BF)
+        dg, db, dxs = torch.zeros(D, device=DEV), torch.zeros(D, device=DEV), torch.zeros(D, device=DEV)
+        kn.add_ln_bwd(dyl, x, res, gamma, mean, rstd, dx, dres, False, dg, db, 0.0, 1, dxsum=dxs, live=live)
+        assert bool(torch.isfinite(dg).all() and torch.isfinite(db).all() and torch.isfinite(dxs).all()), "a NaN row past the live count was read"
+        assert bool((dx[live_n:] == 9.0).all()) and bool((dres[live_n:] == 9.0).all())
+        check(db, dyl[:live_n].double().sum(0), "live ln dbeta (%d)" % live_n, rel=1e-3, atol=5e-2)
+        m = torch.randperm(cap, device=DEV)
+        dst = torch.full((cap, D), 9.0, device=DEV, dtype=BF)
+        kn.rows_gather(res, dst, m, live=live)
+        assert torch.equal(dst[:live_n], res[m[:live_n]]) and bool((dst[live_n:] == 9.0).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# cfg/bart-large.json against the reference's own outputs (F8, F8b)
+# ------------------------------------------------------------------------------------------------
+def _full_state(cfg, device):
+    from oracle import bart_oracle as bo, encoders_oracle as eo
+    ocfg = bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim, encoder_layers=cfg.encoder_layers,
+                      decoder_layers=cfg.decoder_layers, heads=cfg.heads, max_position_embeddings=cfg.max_position_embeddings, dropout=0.0)
+    shapes = bo.bart_param_shapes(ocfg, True, prefix="bart_model.")
+    shapes.update(eo.table_param_shapes())
+    sd = formula_state_dict(shapes, std=0.02, device=device)
+    sd.update(formula_state_dict(eo.resnet_param_shapes(cfg.d_model), std=0.05, device=device))
+    return sd, ocfg
+
+
+def _bart_large(dropout=0.0):
+    cfg = BartConfig.from_json_file(os.path.join(ROOT, "cfg", "bart-large.json"))
+    cfg.dropout = dropout
+    return cfg
+
+
+def test_f8_full_size_forward_vs_reference(golden_dir):
+    """F8: cfg/bart-large.json, formula weights, the reference's BartEncoder + one multi-encoder decoder pass +
+    LabelSmoothingLoss in eval mode.  HIP path in f32 mode: encoder sample, logits sample, their L1 sums and the loss within
+    the north-star 1e-3."""
+    from multimodalsum_amd.modules import LabelSmoothingLoss, MultimodalSum
+    g = np.load(os.path.join(golden_dir, "f8_fullsize.npz"))
+    cfg = _bart_large()
+    model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    sd, _ = _full_state(cfg, DEV)
+    model.load_state_dict(sd)
+    del sd
+    model.eval()
+    bc = syn.yelp_batch(1, 9, 128, 4, cfg.vocab_size, seed=int(g["seed"]), img_hw=8)
+    b = syn.batch_to(bc, DEV)
+    with torch.no_grad():
+        enc = model.bart_model.model.encoder(input_ids=b["reviews"].view(-1, 128), attention_mask=b["reviews_mask"].view(-1, 128))[0]
+        want = torch.from_numpy(g["enc_sample"]).to(DEV)
+        assert float((enc[:, :4, :32] - want).abs().max()) <= 1e-3 * float(want.abs().max()) + 1e-5
+        # padded positions are masked keys downstream: the reference's sum runs over all rows, so compare on the valid ones
+        text_h = enc.view(1, 9, 128, -1)
+        table_h = formula_tensor("f8.table_h", (1, 1, 47, 1024), 1.0, device=DEV)
+        img_h = formula_tensor("f8.img_h", (1, 4, 196, 1024), 1.0, device=DEV)
+        table_m = torch.ones(1, 1, 47, dtype=torch.bool, device=DEV)
+        img_m = torch.ones(1, 4, 196, dtype=torch.bool, device=DEV)
+        img_m[0, 3] = False
+        others = list(range(1, 9))
+        rd = torch.from_numpy(g["rating_diff"]).to(DEV)
+        logits = model.bart_model(text_h[:, others], b["reviews_mask"][:, others], table_h, table_m, img_h, img_m, rating_diff=rd,
+                                  labels=b["reviews"][:, 0])[0]
+        want = torch.from_numpy(g["logits_sample"]).to(DEV)
+        assert float((logits[0, :8, :64] - want).abs().max()) <= 1e-3 * float(want.abs().max()) + 1e-5
+        assert abs(float(logits.double().abs().sum()) - float(g["logits_abs_sum"])) <= 1e-3 * float(g["logits_abs_sum"])
+        loss = LabelSmoothingLoss(cfg.vocab_size, 0.1)(logits.view(-1, cfg.vocab_size), b["reviews"][:, 0].reshape(-1))
+        assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"]))
+
+
+def test_f8b_full_size_step_vs_reference(golden_dir):
+    """F8b: the reference's MultimodalSum.forward + backward at cfg/bart-large.json (B=1, 9 x 128 tokens, 4 images 224x224):
+    the fused HIP step in f32 mode reproduces its loss and, for 18 parameters spread over every sub-module, a gradient slice
+    and the gradient's L1 norm within 1e-3."""
+    from multimodalsum_amd.modules import MultimodalSum
+    g = np.load(os.path.join(golden_dir, "f8_fullstep.npz"))
+    cfg = _bart_large()
+    model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    sd, _ = _full_state(cfg, DEV)
+    model.load_state_dict(sd)
+    del sd
+    model.train()
+    bc = syn.yelp_batch(1, 9, 128, 4, cfg.vocab_size, seed=int(g["seed"]), img_hw=224)
+    bc["img_mask"] = torch.from_numpy(g["img_mask"])
+    b = syn.batch_to(bc, DEV)
+    loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    named = dict(model.named_parameters())
+    checked = 0
+    for key in g.files:
+        if not key.startswith("g_"):
+            continue
+        name = next(n for n in named if n.replace(".", "_") == key[2:])
+        grad = named[name].grad
+        flat = grad.reshape(-1) if grad.dim() < 2 else grad.reshape(grad.shape[0], -1)
+        got = flat[:256] if grad.dim() < 2 else flat[:8, :256]
+        want = torch.from_numpy(g[key]).to(DEV)
+        l1 = float(g["l1_" + key[2:]])
+        scale = max(float(want.abs().max()), l1 / grad.numel())           # a slice can be all-small: fall back to the mean magnitude
+        assert float((got - want).abs().max()) <= 1e-3 * scale + 1e-9, (name, float((got - want).abs().max()), scale)
+        assert abs(float(grad.double().abs().sum()) - l1) <= 1e-3 * l1 + 1e-9, (name, "L1")
+        checked += 1
+    assert checked >= 18
+
+
+# ------------------------------------------------------------------------------------------------
+# BART-large WIDTH, both compute modes, vs the oracle on this box
+# ------------------------------------------------------------------------------------------------
+def test_wide_step_f32_and_bf16_vs_oracle():
+    """D=1024, F=4096, V=50265, S=T=128, H=16, L=2+2, B=2, 9 reviews, 2 images: the widths (and so the kernels: 256x256 ring for
+    the LM head and FFN, 128-key attention, the compaction) of the bench model.  f32 mode: loss and every gradient within
+    1e-3 of the oracle.  bf16 mode -- the mode the bench times: per tensor, the error against the f32 oracle is at most 3x
+    the error of the oracle's own bf16 emulation (every Linear's operands and result rounded to bf16, forward and
+    backward) + 1e-3, in relative L2; train mode, dropout 0; the eval-mode loss (validate(), multimodal_train.py:381-408) too."""
+    from multimodalsum_amd.modules import MultimodalSum
+    from oracle import bart_oracle as bo, step_oracle as so
+    cfg = _bart_large()
+    cfg.encoder_layers = cfg.decoder_layers = 2
+    sd, ocfg = _full_state(cfg, "cpu")
+    bc = syn.yelp_batch(2, 9, 128, 2, cfg.vocab_size, seed=77, img_hw=64)
+    bc["img_mask"][0, 0] = True
+    b = syn.batch_to(bc, DEV)
+
+    def oracle(emulate, training=True):
+        bo.EMULATE_BF16 = emulate
+        try:
+            state = {k: (v.detach().clone().requires_grad_(v.is_floating_point() and v.dim() > 0) if "running" not in k and "num_batches" not in k
+                         else v.clone()) for k, v in sd.items()}
+            ol = so.multimodal_step_loss(state, ocfg, bc["reviews"], bc["reviews_mask"], bc["reviews_rating"], bc["field"], bc["field_value"],
+                                         bc["img"], bc["img_mask"], 0.1, training=training)
+            if training:
+                ol.backward()
+            return float(ol), {k: v.grad for k, v in state.items() if getattr(v, "grad", None) is not None}
+        finally:
+            bo.EMULATE_BF16 = False
+
+    l32, g32 = oracle(False)
+    lemu, gemu = oracle(True)
+    leval, _ = oracle(False, training=False)
+
+    def hip(dtype):
+        model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=dtype, deterministic=(dtype == torch.float32))
+        model.load_state_dict({k: v.detach() for k, v in sd.items()})
+        model.train()
+        loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+        loss.backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
+        model.eval()
+        with torch.no_grad():
+            ev = float(model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0])
+        return float(loss), grads, ev
+
+    lf, gf, evf = hip(torch.float32)
+    assert abs(lf - l32) <= 1e-3 * abs(l32), (lf, l32)
+    assert abs(evf - leval) <= 1e-3 * abs(leval), ("eval-mode loss", evf, leval)
+    assert set(gf) == set(g32)
+    for n, ref in g32.items():
+        err = float((gf[n] - ref).abs().max())
+        assert err <= 1e-3 * float(ref.abs().max()) + 2e-6, (n, err, float(ref.abs().max()))
+    lb, gb, evb = hip(torch.bfloat16)
+    assert abs(lb - l32) <= 3 * abs(lemu - l32) + 1e-3 * abs(l32), (lb, l32, lemu)
+    assert abs(evb - leval) <= 3 * abs(lemu - l32) + 2e-3 * abs(leval), ("eval-mode loss bf16", evb, leval)
+    worst = []
+    for n, ref in g32.items():
+        if "img_encoder.resnet" in n:
+            continue        # the emulation leaves the ResNet convolutions in f32: no yardstick (held by the f32 comparison above)
+        nrm = float(ref.norm()) + 1e-30
+        e_hip, e_emu = float((gb[n] - ref).norm()) / nrm, float((gemu[n] - ref).norm()) / nrm
+        worst.append((e_hip / (3 * e_emu + 1e-3), n, e_hip, e_emu))
+        assert torch.isfinite(gb[n]).all(), n
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 1.0, "bf16 gradients beyond 3x the bf16-emulation error + 1e-3 (relative L2): %r" % (worst[:5],)
+
+
+def test_upstream_gradient_scales_every_gradient():
+    """loss.backward(g): the fused step multiplies every gradient by the upstream gradient on the device (the coarse module
+    path does it through autograd); (loss * 0.25).backward() gives a quarter of loss.backward(), eager and graph replay alike."""
+    from multimodalsum_amd.modules import TextSupervised
+    from tests.test_host_logic_cpu import tiny_cfg
+    cfg = tiny_cfg(vocab=150, d=256, ffn=128, layers=1, heads=4, maxpos=80)
+    model = TextSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=BF)
+    model.train()
+    b = syn.batch_to(syn.yelp_batch(2, 3, 32, 1, cfg.vocab_size, seed=5, img_hw=8), DEV)
+
+    def grads(scale, graphs):
+        model.enable_step_graphs(graphs)
+        out = None
+        for _ in range(3 if graphs else 1):          # eager warm-up, capture, replay
+            for p in model.parameters():
+                p.grad = None
+            loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
+            (loss * scale).backward()
+            torch.cuda.synchronize()
+            out = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        return out
+
+    base = grads(1.0, False)
+    for graphs in (False, True):
+        q = grads(0.25, graphs)
+        for n, ref in base.items():
+            assert float((q[n] - 0.25 * ref).abs().max()) <= 2e-2 * float(ref.abs().max()) * 0.25 + 1e-7, (n, graphs)

@@ -229,11 +229,14 @@ def test_step_graph_replay_matches_eager(dtype):
 
     eager = [step(b) for b in batches]
     model.enable_step_graphs()
-    for _ in range(2):                     # per (shapes, row-capacity bucket): first sight = eager warm-up, second = capture + replay
+    for _ in range(2):                     # per input SHAPE: first sight = eager warm-up, second = capture + replay
         for b in batches:
             step(b)
+    # the two batches differ in token and image counts, not in shape: ONE captured set serves both (the row counts of the
+    # padding-free parts are device-side scalars the kernels read when they run)
+    assert int(batches[0]["reviews_mask"].sum()) != int(batches[1]["reviews_mask"].sum())
     ents = list(model._step_graphs.entries.values())
-    assert 1 <= len(ents) <= 2 and all(en.state == 1 for en in ents)
+    assert len(ents) == 1 and ents[0].state == 1 and model._step_graphs.captures == 1
     for rep in range(2):
         for b, (le, ge) in zip(batches, eager):
             lg, gg = step(b)
@@ -451,7 +454,7 @@ def test_step_graph_sets_are_evicted_and_recaptured():
     cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40, dropout=0.0)
     model = TextSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
     model.train()
-    batches = [to_dev(syn.yelp_batch(2, 3, 32, 1, cfg.vocab_size, seed=s, img_hw=8)) for s in (5, 6, 7)]
+    batches = [to_dev(syn.yelp_batch(B, 3, 32, 1, cfg.vocab_size, seed=5 + B, img_hw=8)) for B in (2, 3, 4)]      # three input SHAPES
 
     def step(b):
         for p in model.parameters():
@@ -463,16 +466,18 @@ def test_step_graph_sets_are_evicted_and_recaptured():
 
     eager = [step(b) for b in batches]
     import warnings
-    for max_live in (1, 2):
-        model.enable_step_graphs()
-        model._step_graphs.max_live = max_live
+    for max_live in (1, 2, 3):
+        model.enable_step_graphs(max_live=max_live)
         with warnings.catch_warnings():
             warnings.simplefilter("error")            # a failed capture only warns and falls back to eager launches
             for rep in range(3):
                 for b, le in zip(batches, eager):
-                    assert torch.equal(step(b), le), (max_live, rep)
+                    for _ in range(3):                # warm-up, capture, replay (when the shape's entry survives that long)
+                        assert torch.equal(step(b), le), (max_live, rep)
         states = [en.state for en in model._step_graphs.entries.values()]
-        assert -1 not in states and states.count(1) == max_live, states
+        assert -1 not in states and len(states) <= max_live and states.count(1) >= 1, states
+        if max_live == 3:
+            assert model._step_graphs.captures == 3 and states == [1, 1, 1]      # every shape captured exactly once, none evicted
         model.enable_step_graphs(False)
 
 
