@@ -48,6 +48,17 @@ __device__ __forceinline__ void epilogue_bias(const GemmArgs& p, int n0, int ks,
     for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(bv[e]));
 }
 
+// Workgroup barrier that orders LDS traffic only: the wave's LDS operations are retired (lgkmcnt) and then the raw s_barrier
+// is taken.  __syncthreads() must not be used in the epilogue: its fence also waits vmcnt(0), i.e. for the acknowledgement of
+// every global store issued so far -- with one barrier per staged band the tile then left in four bursts, each paying a full
+// store round trip (measured at M=64,512: the epilogue took 40-52 % of every K=1024 launch; the main loop alone runs at
+// 1.3-1.5 PFLOP/s).  With this barrier the stores of one band stay in flight under the staging of the next, and the last
+// band's stores under the next tile's ring fill.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                 char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane) {
@@ -64,6 +75,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     constexpr int NSETS = (LDS_BYTES >= 2 * WAVES_M * BAND * 4) ? 2 : 1;
     constexpr int NIT = (CHUNKS + THREADS - 1) / THREADS;
     constexpr bool kAuxIn = (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD);
+    constexpr bool kPre = kAuxIn || OUT == OUT_T_ACC || OUT == OUT_F32_ACC;       // the pass reads something from global memory
     static_assert(LDS_BYTES >= WAVES_M * BAND * 4, "epilogue staging does not fit the kernel's LDS");
     float* stage0 = reinterpret_cast<float*>(smem);
     const bool do_colsum = (p.flags & MMSUM_GEMM_COLSUM) != 0;     // bias slot = f32 output: += column sums of the stored tile
@@ -76,35 +88,36 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     const bool vec_ok = kF32Out ? ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 3) == 0)
                                 : ((((uintptr_t)p.C) & 15) == 0 && (p.ldc & 7) == 0);
     const bool aux_vec = aux != nullptr && ((((uintptr_t)p.aux) & 15) == 0) && ((p.ldaux & 7) == 0);
-    __syncthreads();                                  // every wave is done reading the operand stages
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        float* set = stage0 + (NSETS == 2 ? (i & 1) * (WAVES_M * BAND) : 0);
-        // what the pass reads from global memory (saved pre-activation of the *_BWD epilogues, C of an accumulating store)
-        // is requested for all of its chunks up front, under the LDS staging, instead of one load -> wait -> store at a time
-        u32x4_t aux_pre[NIT], c_pre[NIT];
-        f32x4_t cf_pre[NIT][2];
-        if constexpr (kAuxIn || OUT == OUT_T_ACC || OUT == OUT_F32_ACC) {
+    // What a pass reads from global memory (saved pre-activation of the *_BWD epilogues, C of an accumulating store) is
+    // requested one pass AHEAD, before the previous pass's stores are issued: vmcnt retires in issue order, so a load issued
+    // behind stores would make its consumer wait for their acknowledgement; issued in front of them it only waits for itself.
+    u32x4_t aux_pre[2][NIT], c_pre[2][NIT];
+    f32x4_t cf_pre[2][NIT][2];
+    auto prefetch = [&](int i, u32x4_t (&ap)[NIT], u32x4_t (&cp)[NIT], f32x4_t (&cfp)[NIT][2]) {
+        if constexpr (kPre) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int c = tid + it * THREADS;
                 const int wr = c / (32 * CPR), lr = (c / CPR) % 32, cc = (c % CPR) * 8;
                 const int row = m0 + wr * (TM * 32) + i * 32 + lr, col = n0 + cc;
-                aux_pre[it] = u32x4_t{0u, 0u, 0u, 0u};
-                c_pre[it] = u32x4_t{0u, 0u, 0u, 0u};
-                if (c < CHUNKS && row < p.M && col + 8 <= p.N) {
-                    if constexpr (kAuxIn) { if (aux_vec) aux_pre[it] = *reinterpret_cast<const u32x4_t*>(aux + (long)row * p.ldaux + col); }
-                    if constexpr (OUT == OUT_T_ACC) { if (vec_ok) c_pre[it] = *reinterpret_cast<const u32x4_t*>(Ct + (long)row * p.ldc + col); }
-                    if constexpr (OUT == OUT_F32_ACC) {
-                        if (vec_ok) {
-                            cf_pre[it][0] = *reinterpret_cast<const f32x4_t*>(Cf + (long)row * p.ldc + col);
-                            cf_pre[it][1] = *reinterpret_cast<const f32x4_t*>(Cf + (long)row * p.ldc + col + 4);
-                        }
-                    }
+                // unconditional loads from clamped (always valid) addresses: a load inside a divergent branch makes hipcc fall
+                // back to vmcnt(0) at its use; rows / columns past the edge are simply not stored
+                const long rc = row < p.M ? row : p.M - 1, cl = col < p.N ? col : p.N - 8;
+                if constexpr (kAuxIn) ap[it] = *reinterpret_cast<const u32x4_t*>(aux + rc * p.ldaux + cl);
+                if constexpr (OUT == OUT_T_ACC) cp[it] = *reinterpret_cast<const u32x4_t*>(Ct + rc * p.ldc + cl);
+                if constexpr (OUT == OUT_F32_ACC) {
+                    cfp[it][0] = *reinterpret_cast<const f32x4_t*>(Cf + rc * p.ldc + cl);
+                    cfp[it][1] = *reinterpret_cast<const f32x4_t*>(Cf + rc * p.ldc + cl + 4);
                 }
             }
         }
-        if (NSETS == 1 && i > 0) __syncthreads();
+    };
+    prefetch(0, aux_pre[0], c_pre[0], cf_pre[0]);
+    lds_barrier();                                    // every wave is done reading the operand stages
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float* set = stage0 + (NSETS == 2 ? (i & 1) * (WAVES_M * BAND) : 0);
+        if (NSETS == 1 && i > 0) lds_barrier();
         {
             float* stage = set + wm * BAND;
 #pragma unroll
@@ -114,7 +127,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
                 for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * BN + col] = acc[i][j][r];
             }
         }
-        __syncthreads();
+        lds_barrier();
+        if (i + 1 < TM) prefetch(i + 1, aux_pre[(i + 1) & 1], c_pre[(i + 1) & 1], cf_pre[(i + 1) & 1]);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = tid + it * THREADS;
@@ -152,14 +166,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
             } else if constexpr (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD) {
-                const long oa = (long)row * p.ldaux + col;
-                bf16_t t[8];
-                if (full && aux_vec) {
-                    __builtin_memcpy(t, &aux_pre[it], 16);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) t[e] = (e < nvalid) ? aux[oa + e] : (bf16_t)0.f;
-                }
+                bf16_t t[8];                          // always the prefetched vector: the host admits these epilogues for
+                __builtin_memcpy(t, &aux_pre[i & 1][it], 16);       // aligned operands and N % 8 == 0 only (no scalar path)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if constexpr (EPI == MMSUM_EPI_GELU_BWD) v[e] *= gelu_grad_fast_f((float)t[e]);
@@ -173,46 +181,49 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) csum[e] += (e < nvalid) ? (float)(bf16_t)v[e] : 0.f;     // what a separate pass over the bf16 result would add
             }
-            if constexpr (OUT == OUT_T || OUT == OUT_T_ACC) {
+            if constexpr (OUT == OUT_T_ACC) {
+                bf16_t t[8];
+                __builtin_memcpy(t, &c_pre[i & 1][it], 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (bf16_t)(v[e] + (float)t[e]);
+                u32x4_t w;
+                __builtin_memcpy(&w, t, 16);
+                *reinterpret_cast<u32x4_t*>(Ct + o) = w;
+            } else if constexpr (OUT == OUT_F32_ACC) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    *reinterpret_cast<f32x4_t*>(Cf + o + 4 * h) = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]} + cf_pre[i & 1][it][h];
+            } else if constexpr (OUT == OUT_T) {
                 if (full && vec_ok) {
                     bf16_t t[8];
-                    if constexpr (OUT == OUT_T_ACC) {
-                        __builtin_memcpy(t, &c_pre[it], 16);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
-                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
                     u32x4_t w;
                     __builtin_memcpy(&w, t, 16);
                     *reinterpret_cast<u32x4_t*>(Ct + o) = w;
                 } else {
-                    for (int e = 0; e < nvalid; ++e) Ct[o + e] = (bf16_t)(OUT == OUT_T_ACC ? (float)Ct[o + e] + v[e] : v[e]);
+                    for (int e = 0; e < nvalid; ++e) Ct[o + e] = (bf16_t)v[e];
                 }
             } else if constexpr (OUT == OUT_F32_ATOMIC) {
                 for (int e = 0; e < nvalid; ++e) atomicAdd(Cf + o + e, v[e]);
             } else {
                 if (full && vec_ok) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        f32x4_t w = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
-                        if constexpr (OUT == OUT_F32_ACC) w = w + cf_pre[it][h];
-                        *reinterpret_cast<f32x4_t*>(Cf + o + 4 * h) = w;
-                    }
+                    for (int h = 0; h < 2; ++h) *reinterpret_cast<f32x4_t*>(Cf + o + 4 * h) = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
                 } else {
-                    for (int e = 0; e < nvalid; ++e) Cf[o + e] = (OUT == OUT_F32_ACC ? Cf[o + e] : 0.f) + v[e];
+                    for (int e = 0; e < nvalid; ++e) Cf[o + e] = v[e];
                 }
             }
         }
     }
     if (do_colsum) {
         // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
-        __syncthreads();
+        lds_barrier();
         float* red = reinterpret_cast<float*>(smem);
         constexpr int NPART = THREADS / CPR;
 #pragma unroll
         for (int e = 0; e < 8; ++e) red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = csum[e];
-        __syncthreads();
+        lds_barrier();
         for (int c = tid; c < BN; c += THREADS) {
             float t = 0.f;
 #pragma unroll
@@ -262,7 +273,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_ring_kernel(GemmArgs p) {
-    static_assert(NSTAGE == 4, "the wait counts below are written for a 4-stage ring");
+    static_assert(NSTAGE == 4 || NSTAGE == 3, "the wait counts below are written for a 3- or 4-stage ring");
+    constexpr int AHEAD = NSTAGE - 1;               // slabs of DMA in flight beyond the one being consumed: 3 (one workgroup per CU) or 2
     using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -335,11 +347,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
     if (ns > 0) {
         issue(0);
         if (ns > 1) issue(1);
-        if (ns > 2) issue(2);
+        if (AHEAD > 2 && ns > 2) issue(2);
         for (int si = 0; si < ns; ++si) {
-            const int ahead = ns - 1 - si;                       // slabs issued after slab si (capped at 2)
-            if (ahead >= 2) wait_vmcnt<2 * Cfg::PPW>();
-            else if (ahead == 1) wait_vmcnt<Cfg::PPW>();
+            const int ahead = ns - 1 - si;                       // slabs issued after slab si (capped at AHEAD - 1)
+            if (AHEAD > 2 && ahead >= 2) wait_vmcnt<2 * Cfg::PPW>();
+            else if (ahead >= 1) wait_vmcnt<Cfg::PPW>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
@@ -350,7 +362,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
             Frag a0 = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32), lane);
-            if (si + 3 < ns) issue(si + 3);
+            if (si + AHEAD < ns) issue(si + AHEAD);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
@@ -365,9 +377,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
         // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
         gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
+#ifdef MMSUM_DIAG_NO_EPILOGUE     // tools/ builds only (never defined for the shipped library): main loop without the epilogue
+        if (acc[0][0][0] == 12345.678f) static_cast<float*>(p.C)[0] = acc[Cfg::TM - 1][Cfg::TN - 1][3] + acc[Cfg::TM - 1][0][7] + acc[0][Cfg::TN - 1][9];
+#else
         epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+#endif
     }
-    __syncthreads();          // the staging reads are done before the next tile's DMA lands in the same LDS
+    lds_barrier();            // the staging reads are done before the next tile's DMA lands in the same LDS (stores stay in flight)
     }
 }
 
@@ -547,21 +563,26 @@ inline int ring_grid(const GemmArgs& a, int bm, int bn) {
     return tiles > cus ? cus : tiles;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+// WG_PER_CU = 2: four-wave workgroups with a 3-stage ring (72 KB), two resident per CU.  They drift out of phase, so one's
+// epilogue (per-CU store rate ~10 B/clk: 6-12 us per tile with nothing else to do) runs under the other's MFMA main loop.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int WG_PER_CU = 1>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
-    using R = RingCfg<BM, BN, WAVES_M, WAVES_N, 4>;
+    constexpr int NST = WG_PER_CU == 2 ? 3 : 4;
+    using R = RingCfg<BM, BN, WAVES_M, WAVES_N, NST>;
     const size_t lds = R::NSTAGE * R::STAGE;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NST, WG_PER_CU>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT><<<dim3(ring_grid(a, BM, BN)), dim3(R::THREADS), lds, stream>>>(a);
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.splitk;
+    const int cap = cu_count() * WG_PER_CU;
+    gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NST, WG_PER_CU><<<dim3(tiles > cap ? cap : tiles), dim3(R::THREADS), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int WG_PER_CU = 1>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
-#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O>(a, stream);
+#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O, WG_PER_CU>(a, stream);
     FAST_CASE(MMSUM_EPI_NONE, OUT_T) FAST_CASE(MMSUM_EPI_NONE, OUT_T_ACC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
     FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32)
     FAST_CASE(MMSUM_EPI_GELU, OUT_T) FAST_CASE(MMSUM_EPI_GELU_BWD, OUT_T) FAST_CASE(MMSUM_EPI_RELU, OUT_T) FAST_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
@@ -590,6 +611,20 @@ inline int choose_tile(const GemmArgs& a) {
 
 }  // namespace
 
+// The staged epilogue reads its global operands (saved pre-activation of GELU' / ReLU', C of an accumulating store) as
+// 16-byte vectors only -- a scalar fallback inside the kernel makes hipcc wait vmcnt(0) at every join, i.e. for every store
+// issued before it.  Products whose operands do not allow that (ragged N, unaligned pitch) take the generic kernel.
+static bool epilogue_reads_vectorisable(const GemmArgs& a) {
+    const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
+    const bool aux_in = epi == MMSUM_EPI_GELU_BWD || epi == MMSUM_EPI_RELU_BWD;
+    if (!aux_in && out != OUT_T_ACC && out != OUT_F32_ACC) return true;           // nothing is read
+    if (a.N % 8) return false;
+    if (aux_in && (a.aux == nullptr || (((uintptr_t)a.aux) & 15) || (a.ldaux & 7))) return false;
+    if (out == OUT_T_ACC && ((((uintptr_t)a.C) & 15) || (a.ldc & 7))) return false;
+    if (out == OUT_F32_ACC && ((((uintptr_t)a.C) & 15) || (a.ldc & 3))) return false;
+    return true;
+}
+
 bool gemm_glds_eligible(int dtype, const GemmArgs& a) {
     if (dtype != MMSUM_BF16) return false;
     if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) return false;
@@ -597,7 +632,7 @@ bool gemm_glds_eligible(int dtype, const GemmArgs& a) {
     if (a.A2 && (a.ksplit % 64)) return false;
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
     if (epi != MMSUM_EPI_NONE && out != OUT_T) return false;     // rare combinations stay on the generic kernel
-    return true;
+    return epilogue_reads_vectorisable(a);
 }
 
 // A [K,M] and B [K,N] reduction-major bf16 (flags A_T | B_T): the weight-gradient layout
@@ -608,7 +643,7 @@ bool gemm_tn_eligible(int dtype, const GemmArgs& a) {
     // 16-byte column chunks: a ragged last chunk must still lie inside the row (leading dimension padded)
     if ((a.lda & 7) || (a.ldb & 7) || a.lda < ((a.M + 7) & ~7) || a.ldb < ((a.N + 7) & ~7)) return false;
     if ((((uintptr_t)a.A) | ((uintptr_t)a.B)) & 15) return false;
-    return true;
+    return epilogue_reads_vectorisable(a);
 }
 
 int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {

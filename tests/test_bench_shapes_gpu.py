@@ -146,16 +146,18 @@ def test_nt_ring_a2_split_and_lm_head():
     check(g, want, "lm head wgrad", rel=1e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("R,No,Ki", [(64512, 4096, 1024), (64512, 1024, 4096), (38912, 3072, 1024), (64512, 1024, 1024), (111048, 2048, 1024)])
-def test_tn_ring_256_weight_gradients(R, No, Ki):
-    """gemm_tn_ring_kernel<256,256,2,4>: dW[No, Ki] = dy[R, No]^T x[R, Ki] straight from the reduction-major activations, with
-    the split-K the engine picks at these sizes, against an fp64 product."""
+@pytest.mark.parametrize("R,No,Ki,tile", [(64512, 4096, 1024, (256, 256)), (64512, 1024, 4096, (256, 256)), (38912, 3072, 1024, (256, 256)),
+                                          (64512, 1024, 1024, (256, 128)), (111048, 2048, 1024, (256, 256))])
+def test_tn_ring_weight_gradients_at_bench_sizes(R, No, Ki, tile):
+    """gemm_tn_ring_kernel<256,256,2,4> / <256,128,4,2>: dW[No, Ki] = dy[R, No]^T x[R, Ki] straight from the reduction-major
+    activations, with the split-K the engine picks at these sizes (the chooser takes the 256x128 tile for the square D x D
+    products: 8 slices of 32 tiles fill the chip exactly), against an fp64 product."""
     dy, x = rnd(R, No, seed=21, std=0.1), rnd(R, Ki, seed=22, std=0.5)
     tiles = ((No + 127) // 128) * ((Ki + 127) // 128)
     sk = max(1, min(8, -(-768 // tiles), (R // 64) // 4))                      # engine.Engine.splitk
     assert sk > 1
     ws = torch.full((sk * No, Ki), float("nan"), device=DEV)
-    assert_plan(kn.gemm_plan(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True), _lib.PLAN_TN_RING)
+    assert_plan(kn.gemm_plan(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True), _lib.PLAN_TN_RING, *tile)
     kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
     g = torch.zeros(No, Ki, device=DEV)
     kn.slab_reduce(ws, sk, g, accumulate=True)
@@ -294,7 +296,7 @@ def test_f8b_full_size_step_vs_reference(golden_dir):
     torch.cuda.synchronize()
     assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
     named = dict(model.named_parameters())
-    checked = 0
+    rows = []
     for key in g.files:
         if not key.startswith("g_"):
             continue
@@ -304,11 +306,15 @@ def test_f8b_full_size_step_vs_reference(golden_dir):
         got = flat[:256] if grad.dim() < 2 else flat[:8, :256]
         want = torch.from_numpy(g[key]).to(DEV)
         l1 = float(g["l1_" + key[2:]])
-        scale = max(float(want.abs().max()), l1 / grad.numel())           # a slice can be all-small: fall back to the mean magnitude
-        assert float((got - want).abs().max()) <= 1e-3 * scale + 1e-9, (name, float((got - want).abs().max()), scale)
-        assert abs(float(grad.double().abs().sum()) - l1) <= 1e-3 * l1 + 1e-9, (name, "L1")
-        checked += 1
-    assert checked >= 18
+        # error of the slice against the gradient's typical magnitude (a slice can happen to hold small entries only)
+        scale = max(float(want.abs().max()), l1 / grad.numel())
+        rows.append((float((got - want).abs().max()) / scale, abs(float(grad.double().abs().sum()) - l1) / l1, name))
+    assert len(rows) >= 18
+    # rating_embeddings: d/dr = sum over rows of rating_diff[b] * dz, and the nine leave-one-out rating differences of a
+    # business sum to zero by construction (multimodal_train.py:153-156): the terms cancel to ~1 % of their size, so two f32
+    # evaluations with different summation orders (the reference's own included) agree to ~1e-2 of the result, not 1e-3
+    bad = [(e, l, n) for e, l, n in rows if max(e, l) > (2e-2 if n.endswith("rating_embeddings") else 1e-3)]
+    assert not bad, "gradients beyond tolerance (slice error / scale, L1 error, name): %r\nall: %r" % (bad, sorted(rows, reverse=True))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -349,14 +355,14 @@ def test_wide_step_f32_and_bf16_vs_oracle():
     def hip(dtype):
         model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=dtype, deterministic=(dtype == torch.float32))
         model.load_state_dict({k: v.detach() for k, v in sd.items()})
+        model.eval()            # first (a train-mode forward moves the BatchNorm running statistics the eval mode normalises with)
+        with torch.no_grad():
+            ev = float(model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0])
         model.train()
         loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
         loss.backward()
         torch.cuda.synchronize()
         grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
-        model.eval()
-        with torch.no_grad():
-            ev = float(model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0])
         return float(loss), grads, ev
 
     lf, gf, evf = hip(torch.float32)
