@@ -44,8 +44,9 @@ enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_E
 #define MMSUM_GEMM_ACCUM   0x040  /* C += */
 #define MMSUM_GEMM_OUT_F32 0x080  /* C is f32 regardless of dtype */
 #define MMSUM_GEMM_SLABS   0x100  /* split-K without atomics: slice s writes its partial to C + s*M*ldc (f32) */
-#define MMSUM_GEMM_COLSUM  0x200  /* bf16 NT fast path only: `bias` is an OUTPUT, bias[n] += sum_m C[m][n] of the stored result
-                                    (the bias gradient of the layer that produced the GEMM's input gradient) */
+#define MMSUM_GEMM_COLSUM  0x200  /* bf16 NT fast path, plain or GELU_BWD epilogue, bf16 store: `bias` is an OUTPUT,
+                                    bias[n] += sum_m C[m][n] of the stored result (the bias gradient of the layer that
+                                    produced the GEMM's input gradient) */
 
 int mmsum_abi_version(void);
 /* First 16 hex digits of the SHA-256 over the library's sources (csrc/Makefile: HASH_SRCS): lets the host tell a stale
@@ -74,7 +75,8 @@ enum { MMSUM_PLAN_GENERIC = 0,   /* gemm_kernel: register-staged 128x128, f32 or
        MMSUM_PLAN_TN_RING = 2,   /* gemm_tn_ring_kernel: bf16, reduction-major operands (weight gradients) */
        MMSUM_PLAN_SKINNY = 3 };  /* gemm_skinny_kernel: M <= 128 weight-streaming (decode steps) */
 int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
-                    const float* bias, const void* aux, int M, int N, int K, int flags, int splitk, int* plan);
+                    const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
+                    int splitk, int* plan);
 
 /* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
 int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
@@ -250,6 +252,23 @@ int mmsum_amazon_table_gather(int dtype, const void* E, const int64_t* field, co
 /* d w_price [D,11] += sum_b price[b,k] * dvalue[b,0,d]; d w_rating [D,4] += sum_b rating[b,k] * dvalue[b,1,d]. */
 int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* price, const int64_t* rating, float* dw_price,
                                   float* dw_rating, int B, int D, void* stream);
+
+/* ---- Beam-search decode step (modeling_multimodalsum.py:2857-3010; generation_utils.py:57-98,848-868) -----------------
+ * mmsum_beam_topk: the tail of one step on the [rows, V] logits (rows = businesses * num_beams, hypotheses of a business
+ * consecutive): forced token (adjust_logits_during_generation :3084-3089: BOS at cur_len 1, EOS at max_length - 1; -1 =
+ * none), log_softmax (:2874), then -- AFTER the normalisation, as the reference does -- ban_token (EOS while cur_len <
+ * min_length; -1 = none) and the no-repeat-n-gram bans (`banned` [rows, nban] int32, -1 padded, may be NULL), + beam_scores
+ * [rows], and the top 2*num_beams of each business's num_beams * V candidates (:2925): out_scores / out_ids
+ * [rows / num_beams, 2 * num_beams], best first, id = beam * V + token, ties by lower id.  The banned positions of `logits`
+ * are overwritten with -inf.  row_scores / row_tokens: workspaces of rows * 2 * num_beams elements.  num_beams <= 8.
+ * mmsum_decode_self_attn: single-query self-attention of every hypothesis over its K/V cache rows (:776-815), reached
+ * through an ancestor table: key s (< len) of row r is row ancestors[r * Tmax + s] * Tmax + s of k_cache / v_cache
+ * ([rows * Tmax, H*64]).  A beam reorder (_reorder_cache :3104-3115) is then a gather of the table, not of the caches. */
+int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const float* beam_scores, const int* banned, int nban, int force_token,
+                    int ban_token, int rows, int num_beams, float* row_scores, int* row_tokens, float* out_scores, long long* out_ids,
+                    void* stream);
+int mmsum_decode_self_attn(int dtype, const void* q, long ldq, const void* k_cache, const void* v_cache, long ld_cache, const int* ancestors,
+                           void* out, long ldo, int rows, int H, int len, int Tmax, float scale, void* stream);
 
 #ifdef __cplusplus
 }

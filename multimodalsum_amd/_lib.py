@@ -40,8 +40,8 @@ SIGNATURES = {
     "mmsum_build_id": (ctypes.c_char_p, []),
     "mmsum_gemm": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
                            c_void_p, c_long, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "mmsum_gemm_plan": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p,
-                                c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+    "mmsum_gemm_plan": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
+                                c_long, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
     "mmsum_slab_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_void_p]),
     "mmsum_colsum_workspace": (c_long, [c_int]),
     "mmsum_colsum": (c_int, [c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
@@ -92,6 +92,10 @@ SIGNATURES = {
     "mmsum_table_gather_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmsum_amazon_table_gather": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p]),
     "mmsum_amazon_table_gather_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "mmsum_beam_topk": (c_int, [c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
+    "mmsum_decode_self_attn": (c_int, [c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
+                                       c_int, c_float, c_void_p]),
 }
 
 

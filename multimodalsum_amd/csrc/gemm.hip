@@ -163,7 +163,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 static int gemm_check(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb, const float* bias,
-                      int M, int N, int K, int flags, int splitk, const int* live_rows) {
+                      const void* C, long ldc, const void* aux, long ldaux, int M, int N, int K, int flags, int splitk, const int* live_rows) {
     if (M <= 0 || N <= 0 || K <= 0 || splitk < 1) return MMSUM_ERR_BAD_SHAPE;
     if (dtype != MMSUM_F32 && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
     const int kc = (dtype == MMSUM_BF16) ? 8 : 4;
@@ -185,8 +185,10 @@ static int gemm_check(int dtype, const void* A, long lda, const void* A2, long l
     if (bt && ((ldb * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
     if (live_rows && at && !bt) return MMSUM_ERR_BAD_SHAPE;     // a live row count needs a row-streamed operand
     if (flags & MMSUM_GEMM_COLSUM) {      // epilogue column sums exist on the LDS-DMA NT path with a bf16 result only
-        GemmArgs a{A, A2, B, nullptr, bias, nullptr, M, N, K, lda, lda2, ldb, 0, 0, ksplit, 1.f, flags, splitk, live_rows, nullptr};
-        if (!gemm_glds_eligible(dtype, a) || (flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS)) || splitk != 1 || !bias)
+        GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, live_rows, nullptr};
+        const int epi = (flags >> 3) & 7;
+        if (!gemm_glds_eligible(dtype, a) || (flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS | MMSUM_GEMM_ACCUM)) || splitk != 1 ||
+            !bias || !(epi == MMSUM_EPI_NONE || epi == MMSUM_EPI_GELU_BWD))
             return MMSUM_ERR_BAD_SHAPE;
     }
     return MMSUM_OK;
@@ -195,7 +197,7 @@ static int gemm_check(int dtype, const void* A, long lda, const void* A2, long l
 extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                           void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
                           const float* alpha_dev, int flags, int splitk, const int* live_rows, void* stream) {
-    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, M, N, K, flags, splitk, live_rows);
+    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, C, ldc, aux, ldaux, M, N, K, flags, splitk, live_rows);
     if (rc != MMSUM_OK) return rc;
     GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk, live_rows, alpha_dev};
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -209,10 +211,11 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
 // plan[0] = MMSUM_PLAN_* kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (< tiles * splitk
 // means persistent workgroups walking the tile list).  Lets tests assert that a shape reaches the kernel they mean to cover.
 extern "C" int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
-                               const float* bias, const void* aux, int M, int N, int K, int flags, int splitk, int* plan) {
-    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, M, N, K, flags, splitk, nullptr);
+                               const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
+                               int splitk, int* plan) {
+    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, C, ldc, aux, ldaux, M, N, K, flags, splitk, nullptr);
     if (rc != MMSUM_OK) return rc;
-    GemmArgs a{A, A2, B, nullptr, bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, 0, 0, ksplit, 1.f, flags, splitk, nullptr, nullptr};
+    GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, nullptr, nullptr};
     GemmPlan g;
     if (gemm_skinny_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 32, (a.N + 31) / 32};
     else if (gemm_glds_eligible(dtype, a)) g = plan_gemm_glds(a);

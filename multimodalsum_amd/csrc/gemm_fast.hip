@@ -59,11 +59,10 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Edge tiles (rows past M / columns past N inside the tile, unaligned C): every access guarded, scalar fallbacks.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES>
-__device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
-                                                char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane) {
-    float bv[8];
-    epilogue_bias<BN, WAVES_M * WAVES_N * 64>(p, n0, ks, tid, bv);
+__device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                           char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, const float (&bv)[8]) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr int CPR = BN / 8;                       // 8-column chunks per row
@@ -91,28 +90,28 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     // What a pass reads from global memory (saved pre-activation of the *_BWD epilogues, C of an accumulating store) is
     // requested one pass AHEAD, before the previous pass's stores are issued: vmcnt retires in issue order, so a load issued
     // behind stores would make its consumer wait for their acknowledgement; issued in front of them it only waits for itself.
-    u32x4_t aux_pre[2][NIT], c_pre[2][NIT];
-    f32x4_t cf_pre[2][NIT][2];
-    auto prefetch = [&](int i, u32x4_t (&ap)[NIT], u32x4_t (&cp)[NIT], f32x4_t (&cfp)[NIT][2]) {
+    // ONE register set: an iteration consumes its operand and at once requests the same iteration's operand of the NEXT pass,
+    // before its own store is issued.
+    u32x4_t aux_pre[NIT], c_pre[NIT];
+    f32x4_t cf_pre[NIT][2];
+    auto prefetch1 = [&](int i, int it) {
         if constexpr (kPre) {
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int c = tid + it * THREADS;
-                const int wr = c / (32 * CPR), lr = (c / CPR) % 32, cc = (c % CPR) * 8;
-                const int row = m0 + wr * (TM * 32) + i * 32 + lr, col = n0 + cc;
-                // unconditional loads from clamped (always valid) addresses: a load inside a divergent branch makes hipcc fall
-                // back to vmcnt(0) at its use; rows / columns past the edge are simply not stored
-                const long rc = row < p.M ? row : p.M - 1, cl = col < p.N ? col : p.N - 8;
-                if constexpr (kAuxIn) ap[it] = *reinterpret_cast<const u32x4_t*>(aux + rc * p.ldaux + cl);
-                if constexpr (OUT == OUT_T_ACC) cp[it] = *reinterpret_cast<const u32x4_t*>(Ct + rc * p.ldc + cl);
-                if constexpr (OUT == OUT_F32_ACC) {
-                    cfp[it][0] = *reinterpret_cast<const f32x4_t*>(Cf + rc * p.ldc + cl);
-                    cfp[it][1] = *reinterpret_cast<const f32x4_t*>(Cf + rc * p.ldc + cl + 4);
-                }
+            const int c = tid + it * THREADS;
+            const int wr = c / (32 * CPR), lr = (c / CPR) % 32, cc = (c % CPR) * 8;
+            const int row = m0 + wr * (TM * 32) + i * 32 + lr, col = n0 + cc;
+            // unconditional loads from clamped (always valid) addresses: a load inside a divergent branch makes hipcc fall
+            // back to vmcnt(0) at its use; rows / columns past the edge are simply not stored
+            const long rc = row < p.M ? row : p.M - 1, cl = col < p.N ? col : p.N - 8;
+            if constexpr (kAuxIn) aux_pre[it] = *reinterpret_cast<const u32x4_t*>(aux + rc * p.ldaux + cl);
+            if constexpr (OUT == OUT_T_ACC) c_pre[it] = *reinterpret_cast<const u32x4_t*>(Ct + rc * p.ldc + cl);
+            if constexpr (OUT == OUT_F32_ACC) {
+                cf_pre[it][0] = *reinterpret_cast<const f32x4_t*>(Cf + rc * p.ldc + cl);
+                cf_pre[it][1] = *reinterpret_cast<const f32x4_t*>(Cf + rc * p.ldc + cl + 4);
             }
         }
     };
-    prefetch(0, aux_pre[0], c_pre[0], cf_pre[0]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) prefetch1(0, it);
     lds_barrier();                                    // every wave is done reading the operand stages
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -128,7 +127,6 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
             }
         }
         lds_barrier();
-        if (i + 1 < TM) prefetch(i + 1, aux_pre[(i + 1) & 1], c_pre[(i + 1) & 1], cf_pre[(i + 1) & 1]);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int c = tid + it * THREADS;
@@ -136,6 +134,13 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
             const int wr = c / (32 * CPR), lr = (c / CPR) % 32, cc = (c % CPR) * 8;
             const float* stage = set + wr * BAND;
             const int row = m0 + wr * (TM * 32) + i * 32 + lr, col = n0 + cc;
+            // take this iteration's prefetched operands and request the next pass's at once (unconditionally: see prefetch1)
+            u32x4_t aux_now, c_now;
+            f32x4_t cf_now[2];
+            if constexpr (kAuxIn) aux_now = aux_pre[it];
+            if constexpr (OUT == OUT_T_ACC) c_now = c_pre[it];
+            if constexpr (OUT == OUT_F32_ACC) { cf_now[0] = cf_pre[it][0]; cf_now[1] = cf_pre[it][1]; }
+            if (i + 1 < TM) prefetch1(i + 1, it);
             if (row >= p.M || col >= p.N) continue;
             float v[8];
             {
@@ -163,11 +168,13 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
                         for (int e = 0; e < nvalid; ++e) aux[oa + e] = (bf16_t)v[e];
                     }
                 }
+#if !defined(MMSUM_DIAG_EPI) || MMSUM_DIAG_EPI != 3        // tools/ builds only: 3 = no GELU arithmetic
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+#endif
             } else if constexpr (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD) {
                 bf16_t t[8];                          // always the prefetched vector: the host admits these epilogues for
-                __builtin_memcpy(t, &aux_pre[i & 1][it], 16);       // aligned operands and N % 8 == 0 only (no scalar path)
+                __builtin_memcpy(t, &aux_now, 16);                  // aligned operands and N % 8 == 0 only (no scalar path)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if constexpr (EPI == MMSUM_EPI_GELU_BWD) v[e] *= gelu_grad_fast_f((float)t[e]);
@@ -181,9 +188,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
 #pragma unroll
                 for (int e = 0; e < 8; ++e) csum[e] += (e < nvalid) ? (float)(bf16_t)v[e] : 0.f;     // what a separate pass over the bf16 result would add
             }
+#if defined(MMSUM_DIAG_EPI) && MMSUM_DIAG_EPI == 2           // tools/ builds only: 2 = everything but the stores of C
+#pragma unroll
+            for (int e = 0; e < 8; ++e) csum[e] += v[e];
+            if (csum[0] != 12345.678f) continue;
+#endif
             if constexpr (OUT == OUT_T_ACC) {
                 bf16_t t[8];
-                __builtin_memcpy(t, &c_pre[i & 1][it], 16);
+                __builtin_memcpy(t, &c_now, 16);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = (bf16_t)(v[e] + (float)t[e]);
                 u32x4_t w;
@@ -192,7 +204,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
             } else if constexpr (OUT == OUT_F32_ACC) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    *reinterpret_cast<f32x4_t*>(Cf + o + 4 * h) = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]} + cf_pre[i & 1][it][h];
+                    *reinterpret_cast<f32x4_t*>(Cf + o + 4 * h) = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]} + cf_now[h];
             } else if constexpr (OUT == OUT_T) {
                 if (full && vec_ok) {
                     bf16_t t[8];
@@ -216,6 +228,9 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
             }
         }
     }
+#if defined(MMSUM_DIAG_EPI) && MMSUM_DIAG_EPI == 2
+    if (csum[1] == 12345.678f) Cf[0] = csum[2] + csum[7];
+#endif
     if (do_colsum) {
         // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
         lds_barrier();
@@ -231,6 +246,167 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
             if (n0 + c < p.N) atomicAdd(const_cast<float*>(p.bias) + n0 + c, t);
         }
     }
+}
+
+// Interior tiles (the whole BM x BN tile inside the matrix, 16-byte aligned C / aux): the same staging, with everything that
+// does not depend on data taken out of the loop -- the staged epilogue above spends ~2,600 instructions per wave and tile on
+// guards, index arithmetic and run-time flags (measured at M = 64,512, N = 4096, K = 1024: 232 us of a 696 us launch with the
+// global stores REMOVED, against 386 us for the main loop alone).  Here a thread's rows are base + compile-time constants,
+// the LDS addresses are immediates, and bias / alpha / activation / accumulate / column sums are compile-time forms.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, bool CS, int LDS_BYTES>
+__device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                                  char* smem, int m0, int n0, int wm, int wn, int tid, int lane, const float (&bv)[8]) {
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int THREADS = WAVES_M * WAVES_N * 64;
+    constexpr int CPR = BN / 8, BAND = 32 * BN;
+    constexpr int RPI = THREADS / CPR;                 // rows one iteration of the write-back covers
+    constexpr int NIT = WAVES_M * 32 / RPI;
+    static_assert(THREADS % CPR == 0 && RPI <= 32 && 32 % RPI == 0 && NIT * RPI == WAVES_M * 32, "write-back geometry");
+    constexpr int NSETS = (LDS_BYTES >= 2 * WAVES_M * BAND * 4) ? 2 : 1;
+    constexpr bool kAuxIn = (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD);
+    constexpr bool kPre = kAuxIn || OUT == OUT_T_ACC || OUT == OUT_F32_ACC;
+    constexpr bool kF32Out = (OUT == OUT_F32_ACC || OUT == OUT_F32);
+    float* stage0 = reinterpret_cast<float*>(smem);
+    const int trow = tid / CPR, cc = (tid % CPR) * 8;
+    // row of iteration `it` of pass `i` = m0 + trow + ROW(i, it), ROW a compile-time constant
+    auto row_of = [](int i, int it) { return ((it * RPI) / 32) * (TM * 32) + i * 32 + (it * RPI) % 32; };
+    const long cbase = (long)(m0 + trow) * p.ldc + n0 + cc;
+    const long abase = (long)(m0 + trow) * p.ldaux + n0 + cc;
+    bf16_t* Ct = static_cast<bf16_t*>(p.C);
+    float* Cf = static_cast<float*>(p.C);
+    bf16_t* aux = static_cast<bf16_t*>(p.aux);
+    const float alpha = p.alpha;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // ONE register set: an iteration consumes its operand and at once requests the same iteration's operand of the NEXT pass,
+    // before its own store is issued (vmcnt retires in issue order: a load issued behind stores would wait for their
+    // acknowledgement; issued in front of them it only waits for the stores of a pass ago).
+    u32x4_t aux_pre[NIT], c_pre[NIT];
+    f32x4_t cf_pre[NIT][2];
+    auto prefetch1 = [&](int i, int it) {
+        if constexpr (kPre) {
+            const long r = row_of(i, it);
+            if constexpr (kAuxIn) aux_pre[it] = *reinterpret_cast<const u32x4_t*>(aux + abase + r * p.ldaux);
+            if constexpr (OUT == OUT_T_ACC) c_pre[it] = *reinterpret_cast<const u32x4_t*>(Ct + cbase + r * p.ldc);
+            if constexpr (OUT == OUT_F32_ACC) {
+                cf_pre[it][0] = *reinterpret_cast<const f32x4_t*>(Cf + cbase + r * p.ldc);
+                cf_pre[it][1] = *reinterpret_cast<const f32x4_t*>(Cf + cbase + r * p.ldc + 4);
+            }
+        }
+    };
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) prefetch1(0, it);
+    lds_barrier();                                    // every wave is done reading the operand stages
+    const float* rd0 = stage0 + trow * BN + cc;       // this thread's read position inside a band set (+ compile-time offsets)
+    float* wr0 = stage0 + wm * BAND + (4 * (lane >> 5)) * BN + wn * (TN * 32) + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        constexpr int SETF = WAVES_M * BAND;
+        const int seto = (NSETS == 2 ? (i & 1) * SETF : 0);
+        if (NSETS == 1 && i > 0) lds_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wr0[seto + ((r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r];
+        lds_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            u32x4_t aux_now, c_now;
+            f32x4_t cf_now[2];
+            if constexpr (kAuxIn) aux_now = aux_pre[it];
+            if constexpr (OUT == OUT_T_ACC) c_now = c_pre[it];
+            if constexpr (OUT == OUT_F32_ACC) { cf_now[0] = cf_pre[it][0]; cf_now[1] = cf_pre[it][1]; }
+            if (i + 1 < TM) prefetch1(i + 1, it);
+            const float* src = rd0 + seto + ((it * RPI) / 32) * BAND + ((it * RPI) % 32) * BN;
+            const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src);
+            const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + 4);
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = fmaf(a[e], alpha, bv[e]); v[4 + e] = fmaf(b[e], alpha, bv[4 + e]); }
+            const long r = row_of(i, it);
+            if constexpr (EPI == MMSUM_EPI_GELU) {
+                if (aux != nullptr) {
+                    bf16_t t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+                    u32x4_t w;
+                    __builtin_memcpy(&w, t, 16);
+                    *reinterpret_cast<u32x4_t*>(aux + abase + r * p.ldaux) = w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
+            } else if constexpr (kAuxIn) {
+                bf16_t t[8];
+                __builtin_memcpy(t, &aux_now, 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if constexpr (EPI == MMSUM_EPI_GELU_BWD) v[e] *= gelu_grad_fast_f((float)t[e]);
+                    else v[e] = ((float)t[e] > 0.f) ? v[e] : 0.f;
+                }
+            } else if constexpr (EPI == MMSUM_EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if constexpr (kF32Out) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4_t w = f32x4_t{v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};
+                    if constexpr (OUT == OUT_F32_ACC) w = w + cf_now[h];
+                    *reinterpret_cast<f32x4_t*>(Cf + cbase + r * p.ldc + 4 * h) = w;
+                }
+            } else {
+                bf16_t t[8];
+                if constexpr (OUT == OUT_T_ACC) {
+                    __builtin_memcpy(t, &c_now, 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+                if constexpr (CS) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) csum[e] += (float)t[e];                     // what a separate pass over the bf16 result would add
+                }
+                u32x4_t w;
+                __builtin_memcpy(&w, t, 16);
+                *reinterpret_cast<u32x4_t*>(Ct + cbase + r * p.ldc) = w;
+            }
+        }
+    }
+    if constexpr (CS) {
+        // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
+        lds_barrier();
+        float* red = reinterpret_cast<float*>(smem);
+        constexpr int NPART = THREADS / CPR;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = csum[e];
+        lds_barrier();
+        for (int c = tid; c < BN; c += THREADS) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPART; ++k) t += red[k * BN + c];
+            atomicAdd(const_cast<float*>(p.bias) + n0 + c, t);
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES>
+__device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                                char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane) {
+    float bv[8];
+    epilogue_bias<BN, WAVES_M * WAVES_N * 64>(p, n0, ks, tid, bv);
+    constexpr bool kF32 = (OUT == OUT_F32_ACC || OUT == OUT_F32_ATOMIC || OUT == OUT_F32);
+    const bool aligned = (((uintptr_t)p.C) & 15) == 0 && (p.ldc & (kF32 ? 3 : 7)) == 0 &&
+                         (p.aux == nullptr || ((((uintptr_t)p.aux) & 15) == 0 && (p.ldaux & 7) == 0));
+    const bool interior = m0 + BM <= p.M && n0 + BN <= p.N && aligned;        // workgroup-uniform
+    // the lean path serves the epilogues without a saved operand; GELU' / ReLU' (whose derivative arithmetic, unrolled over a
+    // pass, does not fit the 128 registers left beside the accumulators: 167 spilled) and column sums keep the guarded form
+    if constexpr (OUT != OUT_F32_ATOMIC && EPI != MMSUM_EPI_GELU_BWD && EPI != MMSUM_EPI_RELU_BWD) {
+        if (interior && !(p.flags & MMSUM_GEMM_COLSUM)) {
+            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, false, LDS_BYTES>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv);
+            return;
+        }
+    }
+    epilogue_edge<BM, BN, WAVES_M, WAVES_N, EPI, OUT, LDS_BYTES>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, bv);
 }
 
 __device__ __forceinline__ void dma16(const bf16_t* gsrc, char* lds_dst) {
@@ -378,7 +554,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
         gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
 #ifdef MMSUM_DIAG_NO_EPILOGUE     // tools/ builds only (never defined for the shipped library): main loop without the epilogue
-        if (acc[0][0][0] == 12345.678f) static_cast<float*>(p.C)[0] = acc[Cfg::TM - 1][Cfg::TN - 1][3] + acc[Cfg::TM - 1][0][7] + acc[0][Cfg::TN - 1][9];
+#pragma unroll                    // every accumulator stays live: a dead one would take its MFMAs with it
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
         epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
 #endif

@@ -15,9 +15,12 @@ MI355X-first differences from the reference (token ids identical):
 * one decode step = embed+LN (position = current length - 1), per layer fused qkv GEMM -> cache append -> entity
   attention over the cache (keys beyond the current length masked) -> out_proj -> add+LN, the per-entity
   cross-attention + gate, the FFN, then the tied LM head.
-The hypothesis bookkeeping stays on the host like the reference's (one device->host transfer of the 2*num_beams
-candidates per step); log-softmax / ban / top-k use torch ops on the [rows, V] logits (fusing them into one kernel is
-the remaining section-8f item).
+* the step's tail -- forced BOS/EOS, log-softmax, min-length and n-gram bans, + beam scores, top 2*num_beams of every
+  business -- is mmsum_beam_topk (two launches over the [rows, V] logits; the reference materialises four [rows, V] f32
+  tensors per step), and the beam reorder is a gather of a [rows, max_length] ancestor table that
+  mmsum_decode_self_attn reads the caches through (the reference index_selects every layer's K and V cache).
+The hypothesis bookkeeping stays on the host like the reference's: per step one small host->device block (tokens, parents,
+banned n-gram tokens, beam scores) and one device->host read of the 2*num_beams candidates per business.
 """
 import torch
 
@@ -63,20 +66,28 @@ def _banned_ngram_tokens(rows, n, cur_len):
 
 
 class DecodeSession:
-    """KV-cached single-token decoder over an engine's weights; rows = B * rows_per_business hypotheses.
+    """KV-cached single-token decoder over an engine's weights; rows = B * num_beams hypotheses.
 
-    Every buffer is static (memory matrix, masks, cross K/V of all layers, two ping-pong sets of self-attention
-    caches, token / beam-index inputs, logits), so a decode step at position t is the same launch sequence on the
-    same addresses in every generate() call: on the GPU it is captured once per position into a HIP graph
-    (first use) and replayed afterwards -- a step is ~250 launches of a few microseconds each, i.e. purely
-    launch-bound when issued from Python.  Sessions are cached on the engine per (memory layout, beams, max_length)."""
+    Every buffer is static (memory matrix, masks, cross K/V of all layers, self-attention caches + ancestor tables, the
+    step's host-filled inputs, logits, candidate outputs), so a decode step at position t is the same launch sequence on
+    the same addresses in every generate() call: on the GPU it is captured once per position into a HIP graph (first use)
+    and replayed afterwards -- a step is ~250 launches of a few microseconds each, i.e. purely launch-bound when issued
+    from Python.  Sessions are cached on the engine per (memory layout, beams, lengths, n-gram size).
 
-    def __init__(self, engine, layout, rows_per_business, max_length, has_rating):
+    Per step the host sends ONE int32 block (token and parent hypothesis of every row, the banned n-gram tokens) and the
+    beam scores, and reads back the 2*num_beams (score, index) candidates of every business: log-softmax, forced BOS/EOS,
+    bans and the top-k run in mmsum_beam_topk, and the beam reorder is a gather of the [rows, max_length] ancestor table
+    (mmsum_decode_self_attn reads the caches through it) instead of a gather of every layer's K/V cache."""
+
+    def __init__(self, engine, layout, num_beams, max_length, has_rating, min_length=0, ngram=0):
         e, cfg = engine, engine.cfg
         if max_length > 224:
             raise ValueError("max_length > 224 exceeds the attention kernel's key tile")
-        self.e, self.L, self.qpb, self.Tmax = e, layout, rows_per_business, max_length
-        D, R = cfg.d_model, layout.B * rows_per_business
+        if num_beams > 8:
+            raise ValueError("num_beams > 8: the candidate kernel keeps 2*num_beams <= 16 entries per thread")
+        self.e, self.L, self.qpb, self.Tmax = e, layout, num_beams, max_length
+        self.min_length, self.ngram = min_length, ngram
+        D, R = cfg.d_model, layout.B * num_beams
         self.rows = R
         dev = e.device
         self.mem = e.empty(layout.rows, D)
@@ -86,15 +97,29 @@ class DecodeSession:
         self.no_img = e.empty(layout.B, dtype=torch.uint8) if e.multimodal else None
         self.rd = e.empty(R, dtype=torch.float32) if has_rating else None
         self.kv = [e.empty(layout.rows, 2 * D) for _ in range(cfg.decoder_layers)]
-        # self-attention caches, two sets: step t reads/extends set t & 1 after gathering it from set (t-1) & 1 by beam index;
-        # zero-filled once (masked keys carry probability 0, so whatever they hold must stay finite)
-        self.kc = [[e.zeros(R * max_length, D) for _ in range(cfg.decoder_layers)] for _ in range(2)]
-        self.vc = [[e.zeros(R * max_length, D) for _ in range(cfg.decoder_layers)] for _ in range(2)]
-        self.self_pad = torch.ones(R, max_length, dtype=torch.uint8, device=dev)
+        # self-attention caches [rows * max_length, D]: position t of physical row r is written once, by the hypothesis that sits
+        # in row r at step t; later hypotheses that descend from it find it through the ancestor table (two tables, ping-pong)
+        self.kc = [e.zeros(R * max_length, D) for _ in range(cfg.decoder_layers)]
+        self.vc = [e.zeros(R * max_length, D) for _ in range(cfg.decoder_layers)]
+        self.anc = [torch.zeros(R, max_length, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.arange = torch.arange(R, dtype=torch.int32, device=dev)
         self.mean, self.rstd = e.empty(R, dtype=torch.float32), e.empty(R, dtype=torch.float32)
+        # host-filled inputs of a step: [tokens R | parent rows R | banned tokens R * nban] int32, beam scores f32
+        self.nban = max_length if ngram > 0 else 0
+        pin = dev.type == "cuda"
+        self.h_int = torch.zeros(R * (2 + self.nban), dtype=torch.int32, pin_memory=pin)
+        self.h_sc = torch.zeros(R, dtype=torch.float32, pin_memory=pin)
+        self.d_int = torch.zeros(R * (2 + self.nban), dtype=torch.int32, device=dev)
+        self.beam_scores = torch.zeros(R, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(R, 1, dtype=torch.long, device=dev)
-        self.beam_idx = torch.arange(R, dtype=torch.long, device=dev)
         self.logits = e.empty(R, e.Vpad)
+        K = 2 * num_beams
+        self.row_scores = torch.zeros(R * K, dtype=torch.float32, device=dev)
+        self.row_tokens = torch.zeros(R * K, dtype=torch.int32, device=dev)
+        self.out_scores = torch.zeros(layout.B, K, dtype=torch.float32, device=dev)
+        self.out_ids = torch.zeros(layout.B, K, dtype=torch.int64, device=dev)
+        self.h_out_scores = torch.zeros(layout.B, K, dtype=torch.float32, pin_memory=pin)
+        self.h_out_ids = torch.zeros(layout.B, K, dtype=torch.int64, pin_memory=pin)
         self.use_graphs = dev.type == "cuda" and __import__("os").environ.get("MMSUM_DECODE_GRAPHS") != "0"
         self.graphs, self.pool, self.warm = {}, None, False
 
@@ -119,14 +144,28 @@ class DecodeSession:
             _, k, v = e._attn_names(b + "layers.%d." % i, "encoder_attn")
             kn.gemm(self.mem, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), self.kv[i],
                     bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)))
-        self.self_pad.fill_(1)
 
-    def step(self, tokens, beam_idx, t):
-        """tokens [rows] int64 = token at position t of every hypothesis, which continues hypothesis beam_idx[row] of the
-        previous step (None at t = 0).  -> next-token logits [rows, V] f32."""
-        self.tokens.copy_(tokens.view(-1, 1))
-        if beam_idx is not None:
-            self.beam_idx.copy_(beam_idx)
+    def step(self, tokens, parents, scores, banned, t):
+        """One decode step at position t.  tokens / parents: host lists [rows] (token at position t of every hypothesis and the
+        row of the previous step it continues; parents None at t = 0), scores: host list of beam scores, banned: per-row host
+        lists of banned next tokens (or None).  -> (scores [B][2*beams], ids [B][2*beams]) host lists, best first,
+        id = beam * V + token."""
+        R, nb = self.rows, self.nban
+        hi = self.h_int
+        hi[:R] = torch.tensor(tokens, dtype=torch.int32)
+        hi[R:2 * R] = torch.arange(R, dtype=torch.int32) if parents is None else torch.tensor(parents, dtype=torch.int32)
+        if nb:
+            hb = hi[2 * R:].view(R, nb)
+            hb.fill_(-1)
+            if banned is not None:
+                for r, bt in enumerate(banned):
+                    if bt:
+                        if len(bt) > nb:
+                            raise RuntimeError("more banned n-gram continuations than positions: corrupt hypothesis bookkeeping")
+                        hb[r, :len(bt)] = torch.tensor(bt, dtype=torch.int32)
+        self.h_sc.copy_(torch.tensor(scores, dtype=torch.float32))
+        self.d_int.copy_(hi, non_blocking=True)
+        self.beam_scores.copy_(self.h_sc, non_blocking=True)
         if not self.use_graphs:
             self._step(t)
         else:
@@ -143,7 +182,11 @@ class DecodeSession:
                     self.pool = g.pool()
                 self.graphs[t] = g
             g.replay()
-        return self.logits[:, :self.e.cfg.vocab_size].float()
+        self.h_out_scores.copy_(self.out_scores, non_blocking=True)
+        self.h_out_ids.copy_(self.out_ids, non_blocking=True)
+        if self.out_ids.is_cuda:
+            torch.cuda.current_stream().synchronize()             # the step's one host<->device round trip
+        return self.h_out_scores.tolist(), self.h_out_ids.tolist()
 
     def _step(self, t):
         e, cfg, a = self.e, self.e.cfg, self.e.arena
@@ -151,16 +194,15 @@ class DecodeSession:
         b = e.bp + "model.decoder."
         scale = 64 ** -0.5
         cur, prev = t & 1, (t - 1) & 1
-        kc, vc = self.kc[cur], self.vc[cur]
-        if t > 0:                                                # beam reorder (:2996-3003, _reorder_cache) = gather into the other cache set
-            for i in range(cfg.decoder_layers):
-                torch.index_select(self.kc[prev][i].view(R, Tm, D), 0, self.beam_idx, out=kc[i].view(R, Tm, D))
-                torch.index_select(self.vc[prev][i].view(R, Tm, D), 0, self.beam_idx, out=vc[i].view(R, Tm, D))
+        self.tokens.copy_(self.d_int[:R].view(R, 1))
+        anc = self.anc[cur]
+        if t > 0:                                                # beam reorder (:2996-3003, _reorder_cache) = gather of the ancestor table
+            torch.index_select(self.anc[prev], 0, self.d_int[R:2 * R], out=anc)
+        anc[:, t] = self.arange
         x = e.empty(R, D)
         kn.embed_ln_fwd(self.tokens, a.w(e.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), self.rd,
                         a.w(b + "rating_embeddings") if self.rd is not None else None, a.f32(b + "layernorm_embedding.weight"),
                         a.f32(b + "layernorm_embedding.bias"), x, self.mean, self.rstd, R, 1, cfg.extra_pos_embeddings + t, 1e-5, 0.0, 0)
-        self.self_pad[:, t] = 0
         nm = len(self.L.mods)
         for i in range(cfg.decoder_layers):
             lb = b + "layers.%d." % i
@@ -168,11 +210,10 @@ class DecodeSession:
             q, k, v = e._attn_names(lb, "self_attn")
             qkv = e.empty(R, 3 * D)
             kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)))
-            kc[i].view(R, Tm, D)[:, t].copy_(qkv[:, D:2 * D])
-            vc[i].view(R, Tm, D)[:, t].copy_(qkv[:, 2 * D:])
+            self.kc[i].view(R, Tm, D)[:, t].copy_(qkv[:, D:2 * D])
+            self.vc[i].view(R, Tm, D)[:, t].copy_(qkv[:, 2 * D:])
             att = e.empty(R, D)
-            d = kn.make_attn_desc(qkv[:, :D], kc[i], vc[i], att, self.self_pad, None, R, 1, 1, 1, Tm, H, False, False, scale)
-            kn.attn_fwd(d, x)
+            kn.decode_self_attn(qkv[:, :D], self.kc[i], self.vc[i], anc, att, H, t + 1, Tm, scale)
             o = e.empty(R, D)
             kn.gemm(att, a.w(lb + "self_attn.out_proj.weight"), o, bias=a.f32(lb + "self_attn.out_proj.bias"))
             y = e.empty(R, D)
@@ -217,17 +258,26 @@ class DecodeSession:
             kn.add_ln_fwd(f, x, a.f32(lb + "final_layer_norm.weight"), a.f32(lb + "final_layer_norm.bias"), y, self.mean, self.rstd, 1e-5,
                           0.0, 0)
             x = y
-        kn.gemm(x, a.w(e.bp + "model.shared.weight"), self.logits[:, :cfg.vocab_size],
+        V = cfg.vocab_size
+        kn.gemm(x, a.w(e.bp + "model.shared.weight"), self.logits[:, :V],
                 bias=e.buffers[e.bp + "final_logits_bias"].reshape(-1))                                      # :2281
+        # ---- tail: forced BOS / EOS, log-softmax, min-length and n-gram bans, + beam scores, top 2*beams per business
+        cur_len = t + 1
+        eos = cfg.eos_token_id
+        force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)      # :3084-3089
+        ban = eos if (eos is not None and cur_len < self.min_length) else -1
+        banned = self.d_int[2 * R:].view(R, self.nban) if self.nban else None
+        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.row_scores, self.row_tokens, self.out_scores,
+                     self.out_ids)
 
 
-def _session(engine, layout, num_beams, max_length, has_rating):
-    key = (tuple(layout.mods), layout.B, num_beams, max_length, has_rating)
+def _session(engine, layout, num_beams, max_length, has_rating, min_length, ngram):
+    key = (tuple(layout.mods), layout.B, num_beams, max_length, has_rating, min_length, ngram)
     cache = engine.__dict__.setdefault("_decode_sessions", {})
     if key not in cache:
         if len(cache) >= 4:                          # static buffers + graphs per shape: keep only a few
             cache.pop(next(iter(cache)))
-        cache[key] = DecodeSession(engine, layout, num_beams, max_length, has_rating)
+        cache[key] = DecodeSession(engine, layout, num_beams, max_length, has_rating, min_length, ngram)
     return cache[key]
 
 
@@ -240,41 +290,20 @@ def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_lengt
     dev = engine.device
     B = layout.B
     R = B * num_beams
-    sess = _session(engine, layout, num_beams, max_length, rating_diff is not None)
+    sess = _session(engine, layout, num_beams, max_length, rating_diff is not None, min_length if eos is not None else 0, no_repeat_ngram_size)
     sess.begin(hiddens, pads, rating_diff)
-    beam_idx_dev = None
     rows = [[decoder_start_token_id] for _ in range(R)]                    # host copy of input_ids
-    last = torch.full((R,), decoder_start_token_id, dtype=torch.long, device=dev)
+    last = [decoder_start_token_id] * R
+    parents = None
     hyps = [_Hypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
-    beam_scores = torch.zeros(B, num_beams, device=dev)
-    beam_scores[:, 1:] = -1e9
-    beam_scores = beam_scores.view(-1)
-    host_scores = beam_scores.tolist()
+    host_scores = [0.0 if r % num_beams == 0 else -1e9 for r in range(R)]  # :2836-2840: only the first beam of a business is live
     done = [False] * B
     cur_len = 1
-    neg_inf = float("-inf")
     while cur_len < max_length:
-        logits = sess.step(last, beam_idx_dev, cur_len - 1)
-        if cur_len == 1:                                                   # force BOS (:3084-3086)
-            keep = logits[:, bos].clone()
-            logits.fill_(neg_inf)
-            logits[:, bos] = keep
-        if cur_len == max_length - 1 and eos is not None:                  # force EOS (:3087-3088)
-            keep = logits[:, eos].clone()
-            logits.fill_(neg_inf)
-            logits[:, eos] = keep
-        scores = torch.log_softmax(logits, dim=-1)
-        if eos is not None and cur_len < min_length:
-            scores[:, eos] = neg_inf
-        if no_repeat_ngram_size > 0:
-            banned = _banned_ngram_tokens(rows, no_repeat_ngram_size, cur_len)
-            ri = [i for i, bt in enumerate(banned) for _ in bt]
-            if ri:
-                ci = [tk for bt in banned for tk in bt]
-                scores[torch.tensor(ri, device=dev), torch.tensor(ci, device=dev)] = neg_inf
-        cand = (scores + beam_scores[:, None]).view(B, num_beams * V)
-        top_s, top_i = torch.topk(cand, 2 * num_beams, dim=1, largest=True, sorted=True)
-        top_s, top_i = top_s.tolist(), top_i.tolist()                      # the step's one device->host transfer
+        banned = _banned_ngram_tokens(rows, no_repeat_ngram_size, cur_len) if no_repeat_ngram_size > 0 else None
+        # one decode step + its tail on the device: forced BOS / EOS (:3084-3089), log_softmax (:2874), min-length and n-gram
+        # bans, + beam scores, top 2*num_beams of every business (:2925)
+        top_s, top_i = sess.step(last, parents, host_scores, banned, cur_len - 1)
         nxt = []
         for b in range(B):
             if done[b]:
@@ -298,11 +327,9 @@ def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_lengt
         if all(done):
             break
         host_scores = [x[0] for x in nxt]
-        beam_scores = torch.tensor(host_scores, dtype=torch.float32, device=dev)
-        beam_idx = [x[2] for x in nxt]
-        rows = [rows[j] + [x[1]] for j, x in zip(beam_idx, nxt)]
-        last = torch.tensor([x[1] for x in nxt], dtype=torch.long, device=dev)
-        beam_idx_dev = torch.tensor(beam_idx, dtype=torch.long, device=dev)
+        parents = [x[2] for x in nxt]
+        rows = [rows[j] + [x[1]] for j, x in zip(parents, nxt)]
+        last = [x[1] for x in nxt]
         cur_len += 1
     for b in range(B):
         if done[b]:

@@ -81,8 +81,8 @@ def gemm_plan(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None
     dt, M, N, K, ksplit, flags, bias = _gemm_args(a, b, out.shape[0], out.shape[1], a_t, b_t, bias, epi, aux, accumulate, a2, splitk,
                                                    slabs, colsum, out.dtype == torch.float32)
     plan = (ctypes.c_int * 4)()
-    check(lib.mmsum_gemm_plan(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(bias), _p(aux),
-                              M, N, K, flags, splitk, plan), "mmsum_gemm_plan")
+    check(lib.mmsum_gemm_plan(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(out), _ld(out),
+                              _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, flags, splitk, plan), "mmsum_gemm_plan")
     return tuple(plan)
 
 
@@ -322,3 +322,24 @@ def rows_gather(src, dst, row_map, live=None):
     check(lib.mmsum_rows_gather(_p(src), _ld(src) * es, src.shape[0], _p(dst), _ld(dst) * es, _p(row_map), dst.shape[0], src.shape[1] * es,
                                 _live(live), _stream()), "mmsum_rows_gather")
     return dst
+
+
+def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, row_scores, row_tokens, out_scores, out_ids):
+    """Tail of one beam-search step (see mmsum_beam_topk): logits [rows, >=V] (banned entries are overwritten with -inf),
+    beam_scores [rows] f32, banned [rows, nban] int32 (-1 padded) or None -> out_scores f32 / out_ids int64 [B, 2*num_beams]."""
+    rows = logits.shape[0]
+    assert beam_scores.dtype == torch.float32 and out_scores.dtype == torch.float32 and out_ids.dtype == torch.int64
+    assert row_scores.numel() >= rows * 2 * num_beams and row_tokens.dtype == torch.int32 and row_tokens.numel() >= rows * 2 * num_beams
+    nban = 0 if banned is None else banned.shape[1]
+    if banned is not None:
+        assert banned.dtype == torch.int32 and banned.is_contiguous() and banned.shape[0] == rows
+    check(lib.mmsum_beam_topk(_dt(logits), _p(logits), _ld(logits), V, _p(beam_scores), _p(banned), nban, int(force_token), int(ban_token), rows,
+                              num_beams, _p(row_scores), _p(row_tokens), _p(out_scores), _p(out_ids), _stream()), "mmsum_beam_topk")
+
+
+def decode_self_attn(q, k_cache, v_cache, ancestors, out, H, length, Tmax, scale):
+    """out[r] = softmax(scale * q[r] . K_r) V_r over the first `length` cache positions of hypothesis r, whose key s lives at
+    cache row ancestors[r, s] * Tmax + s (see mmsum_decode_self_attn)."""
+    assert ancestors.dtype == torch.int32 and ancestors.is_contiguous() and ancestors.shape == (q.shape[0], Tmax)
+    check(lib.mmsum_decode_self_attn(_dt(q), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _ld(k_cache), _p(ancestors), _p(out), out.stride(0),
+                                     q.shape[0], H, int(length), Tmax, float(scale), _stream()), "mmsum_decode_self_attn")

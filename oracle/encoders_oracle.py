@@ -40,18 +40,18 @@ def yelp_table_encoder(sd, emb_weight, field, field_value, prefix="table_encoder
     E = emb_weight.detach()  # every embedding read is under no_grad (table_encoder.py:28,35,41,50,56)
 
     def msum(ids, dim):
-        return (F.embedding(ids, E) * ids.ne(1).unsqueeze(-1).float()).sum(dim=dim)
+        return (F.embedding(ids, E) * ids.ne(1).unsqueeze(-1).to(E.dtype)).sum(dim=dim)
 
     field_name = msum(field, 1)                                           # [47,D]
     name_e = msum(name, 1).unsqueeze(1)                                   # [B,1,D]
     cat_tok = msum(category, 2)                                           # [B,6,D]
-    cat_valid = category.ne(1).any(dim=-1).unsqueeze(-1).float()          # [B,6,1]
+    cat_valid = category.ne(1).any(dim=-1).unsqueeze(-1).to(E.dtype)          # [B,6,1]
     cat_e = (cat_tok * cat_valid).sum(dim=1, keepdim=True) / (cat_valid.sum(dim=1, keepdim=True) + 1e-6)
     strcat_e = msum(str_cat, 2)                                           # [B,5,D]
     sb = str_bool.squeeze(-1)
-    strbool_e = F.embedding(sb, E) * str_bool.ne(1).float()               # [B,32,D]
-    rating_e = F.linear(rating.float(), sd[prefix + "rating_embedding.weight"]).unsqueeze(1)
-    hours_e = F.linear(hours.float(), sd[prefix + "hours_embedding.weight"])
+    strbool_e = F.embedding(sb, E) * str_bool.ne(1).to(E.dtype)               # [B,32,D]
+    rating_e = F.linear(rating.to(E.dtype), sd[prefix + "rating_embedding.weight"]).unsqueeze(1)
+    hours_e = F.linear(hours.to(E.dtype), sd[prefix + "hours_embedding.weight"])
     B = name.shape[0]
     names = field_name.unsqueeze(0).expand(B, -1, -1)
     values = torch.cat([name_e, cat_e, strcat_e, strbool_e, rating_e, hours_e], dim=1)   # [B,47,D]
@@ -82,19 +82,19 @@ def amazon_table_encoder(sd, emb_weight, field, field_value, prefix="table_encod
     E = emb_weight.detach()                                               # embedding reads are under no_grad (:108,119,125,131,147)
 
     def msum(ids, dim):
-        return (F.embedding(ids, E) * ids.ne(1).unsqueeze(-1).float()).sum(dim=dim)
+        return (F.embedding(ids, E) * ids.ne(1).unsqueeze(-1).to(E.dtype)).sum(dim=dim)
 
     fn = F.embedding(field, E).squeeze(1)                                 # [6,D]
     field_name = torch.cat([fn[:-1], fn[-1:].repeat(128, 1)])             # [133,D]  (:110)
-    price_e = F.linear(price.float(), sd[prefix + "price_embedding.weight"]).unsqueeze(1)
-    rating_e = F.linear(rating.float(), sd[prefix + "rating_embedding.weight"]).unsqueeze(1)
+    price_e = F.linear(price.to(E.dtype), sd[prefix + "price_embedding.weight"]).unsqueeze(1)
+    rating_e = F.linear(rating.to(E.dtype), sd[prefix + "rating_embedding.weight"]).unsqueeze(1)
     brand_e = msum(brand, 1).unsqueeze(1)
     name_e = msum(name, 1).unsqueeze(1)
     rows = msum(category, 3)                                              # [B,3,8,D]
     row_valid = category.ne(1).any(dim=-1)                                # [B,3,8]
-    rv = row_valid.unsqueeze(-1).float()
+    rv = row_valid.unsqueeze(-1).to(E.dtype)
     groups = (rows * rv).sum(dim=2) / (rv.sum(dim=2) + 1e-6)              # [B,3,D]
-    gv = row_valid.any(dim=-1).unsqueeze(-1).float()                      # [B,3,1]
+    gv = row_valid.any(dim=-1).unsqueeze(-1).to(E.dtype)                      # [B,3,1]
     cat_e = (groups * gv).sum(dim=1, keepdim=True) / (gv.sum(dim=1, keepdim=True) + 1e-6)
     desc_e = F.embedding(description, E)                                  # not masked (:148)
     B = price.shape[0]

@@ -49,7 +49,7 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
         at, bt = flags & _lib.GEMM_A_T, flags & _lib.GEMM_B_T
         lda = lda or (M if at else K)
         ldb = ldb or (N if bt else K)
-        rc = lib.mmsum_gemm_plan(_lib.BF16, fake, lda, None, 0, 0, fake, ldb, None, None, M, N, K, flags, splitk, plan)
+        rc = lib.mmsum_gemm_plan(_lib.BF16, fake, lda, None, 0, 0, fake, ldb, fake, N, None, None, 0, M, N, K, flags, splitk, plan)
         assert rc == 0, rc
         return tuple(plan)
 
@@ -64,7 +64,7 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
     assert p(4096, 1024, 64512, tn, 8)[:3] == (_lib.PLAN_TN_RING, 256, 256)     # fc1 weight gradient, split-K slabs
     assert p(1000, 520, 128)[0] == _lib.PLAN_NT_RING and p(1000, 520, 128)[1:3] == (128, 128)
     assert p(32, 4096, 1024)[0] == _lib.PLAN_SKINNY                              # decode-step rows
-    assert lib.mmsum_gemm_plan(_lib.F32, fake, 1024, None, 0, 0, fake, 1024, None, None, 512, 512, 1024, 0, 1, plan) == 0
+    assert lib.mmsum_gemm_plan(_lib.F32, fake, 1024, None, 0, 0, fake, 1024, fake, 512, None, None, 0, 512, 512, 1024, 0, 1, plan) == 0
     assert plan[0] == _lib.PLAN_GENERIC
 
 

@@ -294,7 +294,7 @@ def test_f8b_full_size_step_vs_reference(golden_dir):
     loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
     loss.backward()
     torch.cuda.synchronize()
-    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * abs(float(g["loss"])), (float(loss), float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss64"])) <= 1e-3 * abs(float(g["loss64"])), (float(loss.detach()), float(g["loss64"]))
     named = dict(model.named_parameters())
     rows = []
     for key in g.files:
@@ -303,18 +303,26 @@ def test_f8b_full_size_step_vs_reference(golden_dir):
         name = next(n for n in named if n.replace(".", "_") == key[2:])
         grad = named[name].grad
         flat = grad.reshape(-1) if grad.dim() < 2 else grad.reshape(grad.shape[0], -1)
-        got = flat[:256] if grad.dim() < 2 else flat[:8, :256]
-        want = torch.from_numpy(g[key]).to(DEV)
-        l1 = float(g["l1_" + key[2:]])
-        # error of the slice against the gradient's typical magnitude (a slice can happen to hold small entries only)
-        scale = max(float(want.abs().max()), l1 / grad.numel())
-        rows.append((float((got - want).abs().max()) / scale, abs(float(grad.double().abs().sum()) - l1) / l1, name))
+        got = (flat[:256] if grad.dim() < 2 else flat[:8, :256]).double()
+        ref32 = torch.from_numpy(g[key]).to(DEV).double()                 # the reference as it runs (fp32)
+        ref64 = torch.from_numpy(g["g64_" + key[2:]]).to(DEV)             # the same modules in fp64: the exact value
+        l1_32, l1_64 = float(g["l1_" + key[2:]]), float(g["l164_" + key[2:]])
+        if l1_64 == 0.0:               # an exactly zero gradient (this batch's four rating bits are all 0: rating_embedding sees a zero input)
+            assert float(grad.double().abs().sum()) == 0.0, name
+            rows.append((0.0, 0.0, name))
+            continue
+        # magnitude of the slice, or the gradient's typical magnitude when the slice happens to hold small entries only
+        scale = max(float(ref64.abs().max()), l1_64 / grad.numel())
+        ref_err = max(float((ref32 - ref64).abs().max()) / scale, abs(l1_32 - l1_64) / l1_64)       # the reference's own fp32 rounding
+        hip_err = max(float((got - ref64).abs().max()) / scale, abs(float(grad.double().abs().sum()) - l1_64) / l1_64)
+        rows.append((hip_err, ref_err, name))
     assert len(rows) >= 18
-    # rating_embeddings: d/dr = sum over rows of rating_diff[b] * dz, and the nine leave-one-out rating differences of a
-    # business sum to zero by construction (multimodal_train.py:153-156): the terms cancel to ~1 % of their size, so two f32
-    # evaluations with different summation orders (the reference's own included) agree to ~1e-2 of the result, not 1e-3
-    bad = [(e, l, n) for e, l, n in rows if max(e, l) > (2e-2 if n.endswith("rating_embeddings") else 1e-3)]
-    assert not bad, "gradients beyond tolerance (slice error / scale, L1 error, name): %r\nall: %r" % (bad, sorted(rows, reverse=True))
+    # north star: within fp32 1e-3 of the reference.  Where the reference's own fp32 evaluation is further than that from the
+    # exact (fp64) value -- sums of cancelling terms: rating_embeddings (the nine leave-one-out rating differences of a business
+    # sum to zero, multimodal_train.py:153-156), the LayerNorm backward of the near-constant embedding rows -- no fp32
+    # implementation can agree with it to 1e-3, and the bound is 3x the reference's own error instead
+    bad = [(h, r, n) for h, r, n in rows if h > max(1e-3, 3 * r)]
+    assert not bad, "gradients beyond tolerance (HIP error vs fp64, reference fp32 error vs fp64, name): %r\nall: %r" % (bad, sorted(rows, reverse=True))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -323,9 +331,10 @@ def test_f8b_full_size_step_vs_reference(golden_dir):
 def test_wide_step_f32_and_bf16_vs_oracle():
     """D=1024, F=4096, V=50265, S=T=128, H=16, L=2+2, B=2, 9 reviews, 2 images: the widths (and so the kernels: 256x256 ring for
     the LM head and FFN, 128-key attention, the compaction) of the bench model.  f32 mode: loss and every gradient within
-    1e-3 of the oracle.  bf16 mode -- the mode the bench times: per tensor, the error against the f32 oracle is at most 3x
-    the error of the oracle's own bf16 emulation (every Linear's operands and result rounded to bf16, forward and
-    backward) + 1e-3, in relative L2; train mode, dropout 0; the eval-mode loss (validate(), multimodal_train.py:381-408) too."""
+    1e-3 of the oracle evaluated in fp64 (3x the fp32 oracle's own error where that is larger).  bf16 mode -- the mode the
+    bench times: per tensor, the error against the exact gradient is at most 3x the error of the oracle's own bf16 emulation
+    (every Linear's operands and result rounded to bf16, forward and backward) + 1e-3, in relative L2; train mode, dropout
+    0; the eval-mode loss (validate(), multimodal_train.py:381-408) too."""
     from multimodalsum_amd.modules import MultimodalSum
     from oracle import bart_oracle as bo, step_oracle as so
     cfg = _bart_large()
@@ -335,22 +344,23 @@ def test_wide_step_f32_and_bf16_vs_oracle():
     bc["img_mask"][0, 0] = True
     b = syn.batch_to(bc, DEV)
 
-    def oracle(emulate, training=True):
+    def oracle(emulate, training=True, dt=torch.float32):
         bo.EMULATE_BF16 = emulate
         try:
-            state = {k: (v.detach().clone().requires_grad_(v.is_floating_point() and v.dim() > 0) if "running" not in k and "num_batches" not in k
-                         else v.clone()) for k, v in sd.items()}
-            ol = so.multimodal_step_loss(state, ocfg, bc["reviews"], bc["reviews_mask"], bc["reviews_rating"], bc["field"], bc["field_value"],
-                                         bc["img"], bc["img_mask"], 0.1, training=training)
+            state = {k: (v.detach().to(dt).clone().requires_grad_(v.dim() > 0 and "running" not in k) if v.is_floating_point() else v.clone())
+                     for k, v in sd.items()}
+            ol = so.multimodal_step_loss(state, ocfg, bc["reviews"], bc["reviews_mask"], bc["reviews_rating"].to(dt), bc["field"],
+                                         bc["field_value"], bc["img"].to(dt), bc["img_mask"], 0.1, training=training)
             if training:
                 ol.backward()
-            return float(ol), {k: v.grad for k, v in state.items() if getattr(v, "grad", None) is not None}
+            return float(ol.detach()), {k: v.grad.double() for k, v in state.items() if getattr(v, "grad", None) is not None}
         finally:
             bo.EMULATE_BF16 = False
 
-    l32, g32 = oracle(False)
-    lemu, gemu = oracle(True)
-    leval, _ = oracle(False, training=False)
+    l64, g64 = oracle(False, dt=torch.float64)          # the exact value
+    l32, g32 = oracle(False)                            # the reference's arithmetic (fp32): its distance from g64 is its own rounding
+    lemu, gemu = oracle(True)                           # ... and with every Linear rounded to bf16
+    leval, _ = oracle(False, training=False, dt=torch.float64)
 
     def hip(dtype):
         model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=dtype, deterministic=(dtype == torch.float32))
@@ -365,22 +375,27 @@ def test_wide_step_f32_and_bf16_vs_oracle():
         grads = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters() if p.grad is not None}
         return float(loss), grads, ev
 
+    def rel(a, ref):
+        return float((a.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-30)
+
     lf, gf, evf = hip(torch.float32)
-    assert abs(lf - l32) <= 1e-3 * abs(l32), (lf, l32)
+    assert abs(lf - l64) <= 1e-3 * abs(l64), (lf, l64)
     assert abs(evf - leval) <= 1e-3 * abs(leval), ("eval-mode loss", evf, leval)
-    assert set(gf) == set(g32)
-    for n, ref in g32.items():
-        err = float((gf[n] - ref).abs().max())
-        assert err <= 1e-3 * float(ref.abs().max()) + 2e-6, (n, err, float(ref.abs().max()))
+    assert set(gf) == set(g64)
+    # f32 mode: within 1e-3 of the exact gradient -- or within 3x the reference arithmetic's own fp32 error where that is
+    # larger (cancelling sums, the BatchNorm stack over a handful of small images: no fp32 evaluation is reproducible there)
+    bad = [(rel(gf[n], g64[n]), rel(g32[n], g64[n]), n) for n in g64 if float(g64[n].abs().max()) > 1e-7
+           and rel(gf[n], g64[n]) > max(1e-3, 3 * rel(g32[n], g64[n]))]
+    assert not bad, "f32 gradients beyond tolerance (HIP vs fp64, oracle fp32 vs fp64, name): %r" % (sorted(bad, reverse=True)[:8],)
     lb, gb, evb = hip(torch.bfloat16)
-    assert abs(lb - l32) <= 3 * abs(lemu - l32) + 1e-3 * abs(l32), (lb, l32, lemu)
-    assert abs(evb - leval) <= 3 * abs(lemu - l32) + 2e-3 * abs(leval), ("eval-mode loss bf16", evb, leval)
+    assert abs(lb - l64) <= 3 * abs(lemu - l64) + 1e-3 * abs(l64), (lb, l64, lemu)
+    assert abs(evb - leval) <= 3 * abs(lemu - l64) + 2e-3 * abs(leval), ("eval-mode loss bf16", evb, leval)
     worst = []
-    for n, ref in g32.items():
-        if "img_encoder.resnet" in n:
+    for n, ref in g64.items():
+        if "img_encoder.resnet" in n or float(ref.abs().max()) <= 1e-7:
             continue        # the emulation leaves the ResNet convolutions in f32: no yardstick (held by the f32 comparison above)
         nrm = float(ref.norm()) + 1e-30
-        e_hip, e_emu = float((gb[n] - ref).norm()) / nrm, float((gemu[n] - ref).norm()) / nrm
+        e_hip, e_emu = float((gb[n].double() - ref).norm()) / nrm, float((gemu[n] - ref).norm()) / nrm
         worst.append((e_hip / (3 * e_emu + 1e-3), n, e_hip, e_emu))
         assert torch.isfinite(gb[n]).all(), n
     worst.sort(reverse=True)

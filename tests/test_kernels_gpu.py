@@ -658,3 +658,80 @@ def test_attention_rejects_more_than_32_entities():
     desc = kn.make_attn_desc(q, kv, kv, torch.empty_like(q), pad, null, 1, 4, 1, 33, 4, 1, False, False, 0.125)
     with pytest.raises(RuntimeError, match="mmsum_attn_fwd"):
         kn.attn_fwd(desc, q)
+
+
+# ------------------------------------------------------------------------------------------------
+# beam-search decode step (csrc/decode.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("num_beams,V", [(4, 50265), (2, 200), (8, 1031)])
+def test_beam_topk(dtype, num_beams, V):
+    """mmsum_beam_topk against the reference's sequence of torch ops (adjust_logits -> log_softmax -> bans -> + beam scores ->
+    topk over [B, beams * V], modeling_multimodalsum.py:2874-2925): same candidate ids in the same order, scores to f32
+    rounding; forced token, min-length ban and n-gram bans included."""
+    B = 3
+    R, K = B * num_beams, 2 * num_beams
+    ld = (V + 127) // 128 * 128
+    g = torch.Generator().manual_seed(7)
+    for force, ban, with_bans in ((-1, -1, False), (-1, 2, True), (0, -1, False), (2, -1, True)):
+        logits = (torch.randn(R, ld, generator=g) * 3).to(DEV).to(dtype)
+        beam_scores = (torch.randn(R, generator=g) * 2).to(DEV)
+        beam_scores[1] = -1e9
+        banned = None
+        if with_bans:
+            banned = torch.full((R, 7), -1, dtype=torch.int32)
+            top_tok = logits[:, :V].float().argmax(-1).cpu()
+            for r in range(R):
+                banned[r, 0] = int(top_tok[r])                    # ban each row's best token: the winner must change
+                banned[r, 3] = (r * 13 + 5) % V
+            banned = banned.to(DEV)
+        ref = logits[:, :V].float().clone()
+        if force >= 0:
+            keep = ref[:, force].clone()
+            ref.fill_(float("-inf"))
+            ref[:, force] = keep
+        sc = torch.log_softmax(ref, dim=-1)
+        if ban >= 0:
+            sc[:, ban] = float("-inf")
+        if banned is not None:
+            for r in range(R):
+                for t in banned[r].tolist():
+                    if t >= 0:
+                        sc[r, t] = float("-inf")
+        cand = (sc + beam_scores[:, None]).view(B, num_beams * V)
+        want_s, want_i = torch.topk(cand, K, dim=1)
+        row_s = torch.zeros(R * K, device=DEV)
+        row_t = torch.zeros(R * K, dtype=torch.int32, device=DEV)
+        out_s = torch.zeros(B, K, device=DEV)
+        out_i = torch.zeros(B, K, dtype=torch.int64, device=DEV)
+        kn.beam_topk(logits, V, beam_scores, banned, force, ban, num_beams, row_s, row_t, out_s, out_i)
+        finite = torch.isfinite(want_s)
+        assert torch.equal(torch.isfinite(out_s), finite), (force, ban)
+        assert torch.equal(out_i[finite], want_i[finite]), (force, ban, out_i, want_i)         # -inf ties have no defined order
+        assert float((out_s[finite] - want_s[finite]).abs().max()) <= 2e-5 * (1 + float(want_s[finite].abs().max()) / 1e3 * 0 + 10)
+        if banned is not None and force < 0:
+            assert bool(torch.isinf(logits[0, int(banned[0, 0])].float()))                     # the ban is written into the logits
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_decode_self_attn_through_ancestor_table(dtype):
+    """mmsum_decode_self_attn: one query per hypothesis over cache rows reached through the ancestor table == softmax(q K^T) V
+    over the gathered rows (what the reference gets after index_select-ing its caches, modeling_multimodalsum.py:3104-3115)."""
+    R, H, Tmax, D = 12, 16, 40, 1024
+    g = torch.Generator().manual_seed(11)
+    for length in (1, 7, 40):
+        q = torch.randn(R, 3 * D, generator=g).to(DEV).to(dtype)               # a [R, 3D] qkv buffer: the query is a strided view
+        kc = torch.randn(R * Tmax, D, generator=g).to(DEV).to(dtype)
+        vc = torch.randn(R * Tmax, D, generator=g).to(DEV).to(dtype)
+        anc = torch.randint(0, R, (R, Tmax), generator=g, dtype=torch.int32).to(DEV)
+        out = torch.full((R, D), float("nan"), device=DEV, dtype=dtype)
+        kn.decode_self_attn(q[:, :D], kc, vc, anc, out, H, length, Tmax, 0.125)
+        s = torch.arange(length, device=DEV)
+        ref = torch.empty(R, D, device=DEV)
+        for r in range(R):
+            phys = anc[r, :length].long() * Tmax + s
+            k = kc.float()[phys].view(length, H, 64)
+            v = vc.float()[phys].view(length, H, 64)
+            p = torch.softmax(torch.einsum("hd,shd->hs", q[r, :D].float().view(H, 64) * 0.125, k), dim=-1)
+            ref[r] = torch.einsum("hs,shd->hd", p, v).reshape(D)
+        close(out, ref, dtype, what="decode self-attention, length %d" % length)

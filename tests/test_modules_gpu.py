@@ -497,3 +497,74 @@ def test_step_graph_backward_after_a_later_forward_is_refused():
         first.backward()
     second.backward()
     torch.cuda.synchronize()
+
+
+def test_img_supervised_step_with_encoder_only_clipping():
+    """Step-2 image pretraining (img_pretrain.py:85-141,184-196) on the HIP path: ImgSupervised forward + backward against the
+    oracle composition (ResNet101 restatement -> unimodal decoder branch -> label-smoothing loss; fp64 yardstick: the BatchNorm
+    stack over three small images is ill-conditioned in fp32), then the loop's `clip_grad_norm_` over the img_encoder parameters
+    ONLY (:190-194) and an optimiser built from `model.img_encoder.named_parameters()` (:284): the BART gradients keep their
+    values, the encoder's are scaled by min(1, max_norm / (norm + 1e-6)), and only the encoder's decay group moves (quirk Q1)."""
+    from multimodalsum_amd import optim
+    from multimodalsum_amd.modules import ImgSupervised
+    from oracle import encoders_oracle as eo
+    cfg = tiny_cfg(vocab=200, d=1024, ffn=64, layers=1, heads=16, maxpos=32)
+    ocfg = oracle_cfg(cfg)
+    labels = syn.token_batch(2, 12, cfg.vocab_size, seed=5, min_len=4)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.02)
+    sd.update(formula_state_dict(eo.resnet_param_shapes(1024), std=0.05))
+    im = ImgSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    im.load_state_dict(sd)
+    im.train()
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn(2, 2, 3, 64, 64, generator=g)
+    imask = torch.tensor([[True, True], [True, False]])
+    imgs = imgs * imask[:, :, None, None, None].float()
+    loss = im(imgs.to(DEV), imask.to(DEV), labels=labels.to(DEV))[0]
+    loss.backward()
+    torch.cuda.synchronize()
+
+    def oracle(dt):
+        sdx = {k: (v.clone().to(dt).requires_grad_(True) if (v.is_floating_point() and v.dim() > 0 and "running" not in k)
+                   else (v.to(dt) if v.is_floating_point() else v)) for k, v in sd.items()}
+        ih = eo.resnet101_features(sdx, imgs.reshape(-1, 3, 64, 64).to(dt), training=True).reshape(2, 2, -1, 1024)
+        lg = bo.enc_forward(sdx, ocfg, ih, torch.zeros(2, 1, dtype=dt), imask.unsqueeze(-1).repeat(1, 1, ih.shape[2]), labels,
+                            training=True, prefix="bart_model.")
+        ls = bo.label_smoothing_loss(lg.view(-1, cfg.vocab_size), labels.view(-1), cfg.vocab_size, 0.1)
+        ls.backward()
+        return ls, sdx
+    l32, o32 = oracle(torch.float32)
+    l64, o64 = oracle(torch.float64)
+    assert abs(loss.item() - l64.item()) <= 3 * abs(l32.item() - l64.item()) + 1e-5
+    named = dict(im.named_parameters())
+    for name, p in named.items():
+        r64 = o64[name].grad
+        if r64 is None:
+            assert p.grad is None, name
+            continue
+        scale = r64.abs().max().item() + 1e-30
+        e_hip = (p.grad.double().cpu() - r64).abs().max().item() / scale
+        e_o32 = (o32[name].grad.double() - r64).abs().max().item() / scale
+        assert e_hip <= max(1e-3, 3 * e_o32), (name, e_hip, e_o32)
+    # the loop's clipping and optimiser: image encoder only
+    enc = [p for n, p in im.named_parameters() if n.startswith("img_encoder")]
+    before = {n: p.grad.clone() for n, p in named.items() if p.grad is not None}
+    weights = {n: p.detach().clone() for n, p in named.items()}
+    max_norm = 0.05
+    opt = optim.get_optimizer(1e-3, ('bias', 'bn1.weight', 'bn2.weight', 'bn3.weight', 'layer_norm.weight', 'layernorm_embedding.weight'),
+                              im.img_encoder.named_parameters(), None)
+    assert len(opt.param_groups[1]["params"]) == 0                     # Q1: the generator was consumed by the first group
+    norm = optim.clip_grad_norm_(enc, max_norm)
+    want_norm = torch.sqrt(sum((before[n].double() ** 2).sum() for n in before if n.startswith("img_encoder")))
+    assert abs(float(norm) - float(want_norm)) <= 1e-4 * float(want_norm)
+    coef = min(1.0, max_norm / (float(want_norm) + 1e-6))
+    assert coef < 1.0
+    for n, gb in before.items():
+        want = gb * coef if n.startswith("img_encoder") else gb
+        close(named[n].grad, want, 1e-5, 1e-9, "clipped " + n)
+    opt.step()
+    torch.cuda.synchronize()
+    moved = {n for n, p in named.items() if not torch.equal(p.detach(), weights[n])}
+    assert moved and all(n.startswith("img_encoder") for n in moved), sorted(moved)[:5]
+    assert not any(nd in n for n in moved for nd in ("bias", "bn1.weight", "bn2.weight", "bn3.weight")), "a no-decay parameter moved (Q1)"
+    assert "img_encoder.linear.weight" in moved and "img_encoder.resnet.layer3.0.conv1.weight" in moved

@@ -9,7 +9,8 @@ from multimodalsum_amd import kernels as kn
 from multimodalsum_amd import _lib
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 20480
-CASES = [("proj+bias", 1024, 1024, "bias"), ("qkv+bias", 3072, 1024, "bias"), ("fc1+bias+gelu", 4096, 1024, "gelu"),
+ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+CASES = [("fc1+bias", 4096, 1024, "bias"), ("proj+bias", 1024, 1024, "bias"), ("qkv+bias", 3072, 1024, "bias"), ("fc1+bias+gelu", 4096, 1024, "gelu"),
          ("fc2+bias", 1024, 4096, "bias"), ("dgrad plain", 1024, 1024, "none"), ("dgrad fc2 gelu'", 4096, 1024, "gelu_bwd"),
          ("dgrad fc1", 1024, 4096, "none"), ("dgrad accumulate", 1024, 1024, "acc"), ("dgrad fc1 accum", 1024, 4096, "acc")]
 
@@ -19,6 +20,8 @@ def main():
     nbuf = 6
     tot = 0.0
     for name, N, K, kind in CASES:
+        if ONLY is not None and name not in ONLY:
+            continue
         a = [torch.randn(M, K, device="cuda").to(dt) for _ in range(nbuf)]
         b = [torch.randn(N, K, device="cuda").to(dt) * 0.03 for _ in range(nbuf)]
         out = [torch.empty(M, N, device="cuda", dtype=dt) for _ in range(nbuf)]
