@@ -67,7 +67,8 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=56,
                     help="businesses per GPU per step (56: 9*56*128 decoder rows = 252 x 256-row GEMM tiles; ~105 GB of the 288 GB.  "
                          "28 is 4 %% slower per business, 8 is BASELINE C4's reference-style batch)")
-    ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text"])
+    ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text", "generate"],
+                    help="multimodal / text: the training step (BASELINE configs 4 / 2); generate: test.py's beam search (BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true")
@@ -329,8 +330,51 @@ def cpu_baseline_bounded(args, budget_s=420):
                 "sample": "cpu baseline exceeded its %d s budget on this host" % budget_s}
 
 
+def bench_generate(args):
+    """BASELINE config 5 (test.py:137-164): B=8 businesses (test.py:176) x 8 reviews x 128 tokens + table + 4 images through the three
+    encoders, then 4-beam search, max_length 128, no_repeat_ngram_size 3, early_stopping; bf16, random-init weights (they never
+    emit EOS early, so every summary runs to max_length: the worst case).  One 'step' = one generate() call of the batch."""
+    import torch
+    import multimodalsum_amd as mm
+    from multimodalsum_amd import synthetic as syn
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    device = torch.device("cuda", 0)
+    cfg = mm.BartConfig.from_json_file(os.path.join(ROOT, "cfg", "bart-large.json"))
+    model = mm.MultimodalSum(config=cfg, label_smoothing=0.1, device=device, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.eval()
+    B = 8 if args.batch == 56 else args.batch
+    max_length, beams = 128, 4
+    b = syn.batch_to(syn.yelp_batch(B, 8, 128, 4, cfg.vocab_size, seed=7, img_hw=224), device)
+
+    def run():
+        with torch.no_grad():
+            _, th, tm, tabh, tabm, ih, im = model.get_multimodal_outputs(b["reviews"], b["reviews_mask"], b["field"], b["field_value"], b["img"], b["img_mask"])
+            rd = torch.zeros(B, 1, device=device)                                  # test.py:155
+            return model.bart_model.generate(th, tm, tabh, tabm, ih, im, rating_diff=rd, num_beams=beams, length_penalty=1.0, max_length=max_length,
+                                             no_repeat_ngram_size=3, early_stopping=True)
+    for _ in range(max(1, args.warmup)):       # the first call captures the per-position decode graphs
+        out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    steps = out.shape[1] - 1
+    print(json.dumps({"metric": "generated summaries/sec (4-beam search, max_length 128) BART-large multimodal", "value": B / dt, "unit": "summaries/s",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": args.dtype, "data": "synthetic Yelp-shaped test batch (seeded), formula-initialised weights",
+                      "config": {"workload": "test.py beam-search generation (beam=4, max_len=128, no_repeat_ngram_size=3, early_stopping) full multimodal: "
+                                             "8 reviews x 128 tok + table + 4 images per business", "per_gpu_batch": B, "num_beams": beams},
+                      "decode_steps": steps, "ms_per_decode_step": dt * 1e3 / max(steps, 1), "tokens_per_s": B * steps / dt,
+                      "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1)}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "generate":
+        return bench_generate(args)
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         spawn_ranks(args)                       # does not return

@@ -445,6 +445,9 @@ inline int cu_count() {
     return n;
 }
 
+#ifndef MMSUM_GEMM_STAGGER
+#define MMSUM_GEMM_STAGGER 1
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
@@ -524,29 +527,78 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
         issue(0);
         if (ns > 1) issue(1);
         if (AHEAD > 2 && ns > 2) issue(2);
-        for (int si = 0; si < ns; ++si) {
+        // STAGGER (8-wave tiles): the two waves of a SIMD (wave w and w + 4: wave rows 0 and 1) run the same program, so without
+        // help they read LDS together, issue their DMA together (an LDS-DMA instruction costs its wave 100-185 cycles of issue
+        // among MFMAs) and then compete for the matrix pipe together.  The second wave row therefore runs HALF A SLAB LATE:
+        // after the barrier it first issues the MFMAs of the previous slab's second half (operands kept in registers across
+        // the barrier) -- while the first row reads and issues DMA --, and reads / issues DMA while the first row computes.
+        constexpr bool STAGGER = MMSUM_GEMM_STAGGER && WAVES_M == 2 && Cfg::TM == 4;
+        constexpr int HALF = Cfg::TM / 2;
+        auto wait_slab = [&](int si) {
             const int ahead = ns - 1 - si;                       // slabs issued after slab si (capped at AHEAD - 1)
             if (AHEAD > 2 && ahead >= 2) wait_vmcnt<2 * Cfg::PPW>();
             else if (ahead >= 1) wait_vmcnt<Cfg::PPW>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
-            const char* Bs = As + Cfg::A_BYTES;
-            // this slab's first fragments are requested BEFORE the DMA of slab si+3 is issued (different ring slots): the
-            // address arithmetic and the four DMA instructions then run under the LDS latency instead of in front of it
-            Frag b[Cfg::TN];
+        };
+        if (!(STAGGER && wm == 1)) {
+            for (int si = 0; si < ns; ++si) {
+                wait_slab(si);
+                const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
+                const char* Bs = As + Cfg::A_BYTES;
+                // this slab's first fragments are requested BEFORE the DMA of slab si+3 is issued (different ring slots): the
+                // address arithmetic and the four DMA instructions then run under the LDS latency instead of in front of it
+                Frag b[Cfg::TN];
 #pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
-            Frag a0 = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32), lane);
-            if (si + AHEAD < ns) issue(si + AHEAD);
-            __builtin_amdgcn_s_setprio(1);
+                for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+                Frag a0 = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32), lane);
+                if (si + AHEAD < ns) issue(si + AHEAD);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < Cfg::TM; ++i) {
-                const Frag a = i == 0 ? a0 : lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
+                for (int i = 0; i < Cfg::TM; ++i) {
+                    const Frag a = i == 0 ? a0 : lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
 #pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a, b[j]);
+                    for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a, b[j]);
+                }
+                __builtin_amdgcn_s_setprio(0);
             }
-            __builtin_amdgcn_s_setprio(0);
+        } else {
+            // the late wave row: same barriers, its matrix work shifted by half a slab (separate loop: the two programs share
+            // no basic block, so neither constrains the other's registers)
+            Frag aH[HALF], bH[Cfg::TN];
+            for (int si = 0; si < ns; ++si) {
+                wait_slab(si);
+                const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
+                const char* Bs = As + Cfg::A_BYTES;
+                if (si > 0) {
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int i = 0; i < HALF; ++i)
+#pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[HALF + i][j], aH[i], bH[j]);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);                 // the reads below stay behind those MFMAs
+                Frag a[HALF];
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) bH[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) a[i] = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
+#pragma unroll
+                for (int i = 0; i < HALF; ++i) aH[i] = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + (HALF + i) * 32, lane);
+                if (si + AHEAD < ns) issue(si + AHEAD);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < HALF; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a[i], bH[j]);
+                __builtin_amdgcn_s_setprio(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of this ring slot has returned before the barrier that frees it
+            }
+#pragma unroll
+            for (int i = 0; i < HALF; ++i)
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[HALF + i][j], aH[i], bH[j]);
         }
     }
     if constexpr (OUT == OUT_F32_ATOMIC) {

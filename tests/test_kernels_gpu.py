@@ -707,8 +707,18 @@ def test_beam_topk(dtype, num_beams, V):
         kn.beam_topk(logits, V, beam_scores, banned, force, ban, num_beams, row_s, row_t, out_s, out_i)
         finite = torch.isfinite(want_s)
         assert torch.equal(torch.isfinite(out_s), finite), (force, ban)
-        assert torch.equal(out_i[finite], want_i[finite]), (force, ban, out_i, want_i)         # -inf ties have no defined order
-        assert float((out_s[finite] - want_s[finite]).abs().max()) <= 2e-5 * (1 + float(want_s[finite].abs().max()) / 1e3 * 0 + 10)
+        tol = 2e-4
+        # the K best scores, best first ...
+        assert float((out_s[finite] - want_s[finite]).abs().max()) <= tol, (force, ban)
+        # ... each belonging to the candidate it names, no candidate twice (bf16 logits tie often: among equal scores the
+        # kernel returns the lower index, torch.topk leaves the order open, so ids are compared only where f32 logits make
+        # ties impossible)
+        for b in range(B):
+            ids = out_i[b][finite[b]]
+            assert ids.unique().numel() == ids.numel()
+            assert float((cand[b][ids] - out_s[b][finite[b]]).abs().max()) <= tol
+        if dtype == torch.float32:
+            assert torch.equal(out_i[finite], want_i[finite]), (force, ban, out_i, want_i)     # -inf ties have no defined order
         if banned is not None and force < 0:
             assert bool(torch.isinf(logits[0, int(banned[0, 0])].float()))                     # the ban is written into the logits
 
