@@ -147,7 +147,24 @@ def resnet_param_shapes(embedding_dim=1024, prefix="img_encoder."):
     return s
 
 
+def _q(t):
+    """bf16 emulation (tests only, see bart_oracle.EMULATE_BF16): round a tensor to bf16 in the forward pass, identity gradient.
+    Off = the reference's arithmetic untouched."""
+    from oracle import bart_oracle as _bo
+    if not _bo.EMULATE_BF16:
+        return t
+    return t + (t.to(torch.bfloat16).to(t.dtype) - t).detach()
+
+
+def _conv(x, w, **kw):
+    return _q(F.conv2d(_q(x), _q(w), **kw))
+
+
 def _bn(sd, name, x, training, running):
+    return _q(_bn_exact(sd, name, x, training, running))
+
+
+def _bn_exact(sd, name, x, training, running):
     """BatchNorm2d, eps 1e-5, momentum 0.1.  `running` (dict) receives updated running stats in
     train mode, mirroring nn.BatchNorm2d's buffer side effect."""
     w, b = sd[name + ".weight"], sd[name + ".bias"]
@@ -164,11 +181,11 @@ def _bn(sd, name, x, training, running):
 
 def _bottleneck(sd, b, x, stride, has_down, training, running):
     idt = x
-    o = F.relu(_bn(sd, b + "bn1", F.conv2d(x, sd[b + "conv1.weight"]), training, running))
-    o = F.relu(_bn(sd, b + "bn2", F.conv2d(o, sd[b + "conv2.weight"], stride=stride, padding=1), training, running))
-    o = _bn(sd, b + "bn3", F.conv2d(o, sd[b + "conv3.weight"]), training, running)
+    o = F.relu(_bn(sd, b + "bn1", _conv(x, sd[b + "conv1.weight"]), training, running))
+    o = F.relu(_bn(sd, b + "bn2", _conv(o, sd[b + "conv2.weight"], stride=stride, padding=1), training, running))
+    o = _bn(sd, b + "bn3", _conv(o, sd[b + "conv3.weight"]), training, running)
     if has_down:
-        idt = _bn(sd, b + "downsample.1", F.conv2d(x, sd[b + "downsample.0.weight"], stride=stride), training, running)
+        idt = _bn(sd, b + "downsample.1", _conv(x, sd[b + "downsample.0.weight"], stride=stride), training, running)
     return F.relu(o + idt)
 
 
@@ -185,11 +202,12 @@ def resnet101_features(sd, x, training=True, running=None, prefix="img_encoder."
     detached (:33) so stem/layer1/layer2 get no gradient; BN runs in batch-statistics mode when
     `training` (zero-padded images included -- SURVEY.md section 7 hard parts)."""
     r = prefix + "resnet."
-    x = F.conv2d(x, sd[r + "conv1.weight"], stride=2, padding=3)
+    x = _conv(x, sd[r + "conv1.weight"], stride=2, padding=3)
     x = F.relu(_bn(sd, r + "bn1", x, training, running))
     x = F.max_pool2d(x, 3, 2, 1)
     x = _layer(sd, r, 1, x, training, running)
     x = _layer(sd, r, 2, x, training, running).detach()
     x = _layer(sd, r, 3, x, training, running)
     x = x.flatten(start_dim=-2).transpose(1, 2)             # [n, HW, 1024]
-    return F.linear(x, sd[prefix + "linear.weight"])
+    from oracle import bart_oracle as _bo
+    return _bo.linear(x, sd[prefix + "linear.weight"])
