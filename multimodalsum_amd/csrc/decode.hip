@@ -171,15 +171,18 @@ __global__ __launch_bounds__(64) void decode_self_attn_kernel(const T* __restric
     float qv[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) qv[d] = to_f32(qrow[d]) * scale;        // uniform loads: every lane holds the query (the :783 scaling)
-    // scores: lane owns keys lane, lane + 64, ... (Tmax <= 224: at most 4)
+    // scores: lane owns keys lane, lane + 64, ... (Tmax <= 256: at most 4); it keeps their cache rows for the second phase
     float sc[4];
+    long prow[4];
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int s = lane + 64 * j;
         sc[j] = -INFINITY;
+        prow[j] = 0;
         if (s < len) {
-            const T* krow = kc + ((long)anc[(long)r * Tmax + s] * Tmax + s) * ldc + h * HD;
+            prow[j] = ((long)anc[(long)r * Tmax + s] * Tmax + s) * ldc + h * HD;
+            const T* krow = kc + prow[j];
             float acc = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) acc = fmaf(qv[d], to_f32(krow[d]), acc);
@@ -193,14 +196,26 @@ __global__ __launch_bounds__(64) void decode_self_attn_kernel(const T* __restric
     for (int j = 0; j < 4; ++j) { sc[j] = (sc[j] == -INFINITY) ? 0.f : __expf(sc[j] - m); l += sc[j]; }
     l = warp_sum(l);
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    // output: lane owns dimension `lane`; probabilities are broadcast from their owner
+    // output: lane owns dimension `lane`; probability and cache row of key s are broadcast from their owner lane (no memory
+    // access on the address path), eight keys' V rows in flight at a time
     float o = 0.f;
-    for (int s = 0; s < len; ++s) {
-        float p = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if ((s >> 6) == j) p = __shfl(sc[j], s & 63);
-        const T* vrow = vc + ((long)anc[(long)r * Tmax + s] * Tmax + s) * ldc + h * HD;
-        o = fmaf(p, to_f32(vrow[lane]), o);
+    for (int j = 0; j < 4; ++j) {
+        const int base = 64 * j;
+        if (base >= len) break;
+        const int n = min(64, len - base);
+        for (int s0 = 0; s0 < n; s0 += 8) {
+            float p[8], v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int src = min(s0 + u, n - 1);
+                p[u] = (s0 + u < n) ? __shfl(sc[j], src) : 0.f;
+                const long row = __shfl(prow[j], src);
+                v[u] = to_f32(vc[row + lane]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o = fmaf(p[u], v[u], o);
+        }
     }
     out[(long)r * ldo + h * HD + lane] = from_f32<T>(o * inv);
 }

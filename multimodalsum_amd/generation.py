@@ -22,6 +22,7 @@ MI355X-first differences from the reference (token ids identical):
 The hypothesis bookkeeping stays on the host like the reference's: per step one small host->device block (tokens, parents,
 banned n-gram tokens, beam scores) and one device->host read of the 2*num_beams candidates per business.
 """
+import numpy as np
 import torch
 
 from . import kernels as kn
@@ -53,15 +54,24 @@ class _Hypotheses:
         return self.worst >= best_sum_logprobs / cur_len ** self.length_penalty
 
 
-def _banned_ngram_tokens(rows, n, cur_len):
+def _banned_ngram_table(tokens, n, cur_len, out):
+    """calc_banned_ngram_tokens (generation_utils.py:57-98) for every hypothesis at once: `tokens` [rows, >= cur_len] (numpy, the
+    first cur_len columns are the hypotheses so far); a next token t is banned for a row when the row's last n-1 tokens followed
+    by t already occur in it.  Fills `out` [rows, nban] (int32, -1 padded) and returns it."""
+    out.fill(-1)
     if cur_len + 1 < n:
-        return [[] for _ in rows]
-    out = []
-    for toks in rows:
-        seen = {}
-        for i in range(len(toks) - n + 1):
-            seen.setdefault(tuple(toks[i:i + n - 1]), []).append(toks[i + n - 1])
-        out.append(seen.get(tuple(toks[cur_len + 1 - n:cur_len]), []))
+        return out
+    seq = tokens[:, :cur_len]
+    npos = cur_len - n + 1                                   # start positions of complete n-grams
+    if npos <= 0:
+        return out
+    match = np.ones((seq.shape[0], npos), dtype=bool)
+    for k in range(n - 1):                                   # the (n-1)-gram starting at i equals the row's last n-1 tokens
+        match &= seq[:, k:k + npos] == seq[:, cur_len - (n - 1) + k][:, None]
+    r, c = np.nonzero(match)
+    if r.size:
+        rank = (np.cumsum(match, axis=1) - 1)[r, c]
+        out[r, rank] = seq[r, c + n - 1]
     return out
 
 
@@ -109,6 +119,7 @@ class DecodeSession:
         pin = dev.type == "cuda"
         self.h_int = torch.zeros(R * (2 + self.nban), dtype=torch.int32, pin_memory=pin)
         self.h_sc = torch.zeros(R, dtype=torch.float32, pin_memory=pin)
+        self.h_int_np, self.h_sc_np = self.h_int.numpy(), self.h_sc.numpy()       # host views the bookkeeping writes with numpy
         self.d_int = torch.zeros(R * (2 + self.nban), dtype=torch.int32, device=dev)
         self.beam_scores = torch.zeros(R, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(R, 1, dtype=torch.long, device=dev)
@@ -145,25 +156,18 @@ class DecodeSession:
             kn.gemm(self.mem, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), self.kv[i],
                     bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)))
 
-    def step(self, tokens, parents, scores, banned, t):
-        """One decode step at position t.  tokens / parents: host lists [rows] (token at position t of every hypothesis and the
-        row of the previous step it continues; parents None at t = 0), scores: host list of beam scores, banned: per-row host
-        lists of banned next tokens (or None).  -> (scores [B][2*beams], ids [B][2*beams]) host lists, best first,
-        id = beam * V + token."""
+    def step(self, tokens, parents, scores, history, t):
+        """One decode step at position t.  tokens / parents: numpy [rows] (token at position t of every hypothesis and the row of
+        the previous step it continues; parents None at t = 0), scores: numpy [rows] beam scores, history: numpy [rows, >= t+1]
+        tokens so far (for the n-gram bans).  -> (scores [B, 2*beams], ids [B, 2*beams]) numpy, best first, id = beam * V + token."""
         R, nb = self.rows, self.nban
-        hi = self.h_int
-        hi[:R] = torch.tensor(tokens, dtype=torch.int32)
-        hi[R:2 * R] = torch.arange(R, dtype=torch.int32) if parents is None else torch.tensor(parents, dtype=torch.int32)
+        hi = self.h_int_np
+        hi[:R] = tokens
+        hi[R:2 * R] = np.arange(R, dtype=np.int32) if parents is None else parents
         if nb:
-            hb = hi[2 * R:].view(R, nb)
-            hb.fill_(-1)
-            if banned is not None:
-                for r, bt in enumerate(banned):
-                    if bt:
-                        if len(bt) > nb:
-                            raise RuntimeError("more banned n-gram continuations than positions: corrupt hypothesis bookkeeping")
-                        hb[r, :len(bt)] = torch.tensor(bt, dtype=torch.int32)
-        self.h_sc.copy_(torch.tensor(scores, dtype=torch.float32))
+            _banned_ngram_table(history, self.ngram, t + 1, hi[2 * R:].reshape(R, nb))
+        self.h_sc_np[:] = scores
+        hi = self.h_int
         self.d_int.copy_(hi, non_blocking=True)
         self.beam_scores.copy_(self.h_sc, non_blocking=True)
         if not self.use_graphs:
@@ -186,7 +190,7 @@ class DecodeSession:
         self.h_out_ids.copy_(self.out_ids, non_blocking=True)
         if self.out_ids.is_cuda:
             torch.cuda.current_stream().synchronize()             # the step's one host<->device round trip
-        return self.h_out_scores.tolist(), self.h_out_ids.tolist()
+        return self.h_out_scores.numpy(), self.h_out_ids.numpy()
 
     def _step(self, t):
         e, cfg, a = self.e, self.e.cfg, self.e.arena
@@ -292,51 +296,53 @@ def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_lengt
     R = B * num_beams
     sess = _session(engine, layout, num_beams, max_length, rating_diff is not None, min_length if eos is not None else 0, no_repeat_ngram_size)
     sess.begin(hiddens, pads, rating_diff)
-    rows = [[decoder_start_token_id] for _ in range(R)]                    # host copy of input_ids
-    last = [decoder_start_token_id] * R
+    hist = np.full((R, max_length), pad, dtype=np.int64)                   # host copy of input_ids
+    hist[:, 0] = decoder_start_token_id
+    last = hist[:, 0].astype(np.int32)
     parents = None
     hyps = [_Hypotheses(num_beams, max_length, length_penalty, early_stopping) for _ in range(B)]
-    host_scores = [0.0 if r % num_beams == 0 else -1e9 for r in range(R)]  # :2836-2840: only the first beam of a business is live
+    host_scores = np.where(np.arange(R) % num_beams == 0, 0.0, -1e9).astype(np.float32)    # :2836-2840: only the first beam of a business is live
     done = [False] * B
     cur_len = 1
     while cur_len < max_length:
-        banned = _banned_ngram_tokens(rows, no_repeat_ngram_size, cur_len) if no_repeat_ngram_size > 0 else None
         # one decode step + its tail on the device: forced BOS / EOS (:3084-3089), log_softmax (:2874), min-length and n-gram
         # bans, + beam scores, top 2*num_beams of every business (:2925)
-        top_s, top_i = sess.step(last, parents, host_scores, banned, cur_len - 1)
-        nxt = []
+        top_s, top_i = sess.step(last, parents, host_scores, hist, cur_len - 1)
+        top_beam, top_tok = top_i // V, top_i % V
+        nxt_s = np.zeros(R, dtype=np.float32)
+        nxt_t = np.full(R, pad, dtype=np.int32)
+        nxt_p = np.zeros(R, dtype=np.int32)
         for b in range(B):
             if done[b]:
-                nxt.extend([(0.0, pad, 0)] * num_beams)
-                continue
-            sent = []
-            for rank, (tok_id, sc) in enumerate(zip(top_i[b], top_s[b])):
-                beam, tok = tok_id // V, tok_id % V
-                row = b * num_beams + beam
+                continue                                                   # padded out: score 0, pad token, parent row 0 (:2938-2941)
+            n_sent = 0
+            for rank in range(2 * num_beams):
+                tok, sc = int(top_tok[b, rank]), float(top_s[b, rank])
+                row = b * num_beams + int(top_beam[b, rank])
                 if eos is not None and tok == eos:
                     if rank >= num_beams:
                         continue
-                    hyps[b].add(list(rows[row]), sc)
+                    hyps[b].add(hist[row, :cur_len].tolist(), sc)
                 else:
-                    sent.append((sc, tok, row))
-                if len(sent) == num_beams:
+                    j = b * num_beams + n_sent
+                    nxt_s[j], nxt_t[j], nxt_p[j] = sc, tok, row
+                    n_sent += 1
+                if n_sent == num_beams:
                     break
-            done[b] = done[b] or hyps[b].is_done(max(top_s[b]), cur_len)
-            assert len(sent) == num_beams, "Beam should always be full"
-            nxt.extend(sent)
+            done[b] = done[b] or hyps[b].is_done(float(top_s[b].max()), cur_len)
+            assert n_sent == num_beams, "Beam should always be full"
         if all(done):
             break
-        host_scores = [x[0] for x in nxt]
-        parents = [x[2] for x in nxt]
-        rows = [rows[j] + [x[1]] for j, x in zip(parents, nxt)]
-        last = [x[1] for x in nxt]
+        host_scores, parents, last = nxt_s, nxt_p, nxt_t
+        hist = hist[parents]
+        hist[:, cur_len] = last
         cur_len += 1
     for b in range(B):
         if done[b]:
             continue
         for beam in range(num_beams):
             row = b * num_beams + beam
-            hyps[b].add(list(rows[row]), host_scores[row])
+            hyps[b].add(hist[row, :cur_len].tolist(), float(host_scores[row]))
     best = [sorted(h.items, key=lambda x: x[0])[-1][1] for h in hyps]
     lens = [len(t) for t in best]
     if min(lens) != max(lens):
