@@ -15,6 +15,7 @@
 #include "mmsum_device.h"
 #include "mmsum_kernels.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -1130,6 +1131,522 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
     }
 }
 
+// =============================================================================================
+// bf16 kernels on the gfx950 transposing LDS read and accumulator-as-operand products.
+//
+// K, V (forward, dQ) and Q, dO (dK/dV) are staged ONCE, in the natural k-slab layout.  Every product that needs a staged
+// tile transposed reads it with ds_read_b64_tr_b16 (a 16-lane group fetches 4 rows x 16 columns and lane i receives
+// column i; four consecutive rows of a slab are 256 contiguous bytes, so the read is bank-conflict free), and every product
+// whose operand is a freshly computed tile (P, dS) takes it straight from the accumulator registers: a 32x32 result has
+// its column on the lane and its rows in the registers, which is the B-operand layout of a product that sums over the
+// rows (guide: "an accumulator tile as the next MFMA's operand").  The k order inside such a 16-deep step is permuted
+// (element j of lane half h = row 16 s + 8 (j >> 2) + 4 h + (j & 3)); tr_frag() reads the other operand in the same order.
+//   forward : S^T = K Q^T,  O^T += V^T P^T          (queries on the lane: softmax statistics are register-local)
+//   dQ      : S^T, dP^T = V dO^T, dQ^T += K^T dS^T
+//   dK/dV   : S = Q K^T, dP = dO V^T (keys on the lane, K / V fragments live in registers), dV^T += dO^T P, dK^T += Q^T dS
+// No probability / dS image ever goes through LDS and no transposed tile is staged.
+// =============================================================================================
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+struct TrOff { int o0, o1; };
+// Lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3 of the group's 4 x 16 block; the groups of a
+// wave cover d-halves (lane >> 4) & 1 and reduction-row halves lane >> 5.  o0 / o1: the two reads of one 16-deep step.
+__device__ __forceinline__ TrOff tr_off(int lane) {
+    const int h = lane >> 5, dhalf = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+    const int c = 2 * dhalf + (p >> 1);
+    TrOff t;
+    t.o0 = (4 * h + q) * SLAB_BYTES + (((c ^ h) & 3) << 4) + 8 * (p & 1);
+    t.o1 = (8 + 4 * h + q) * SLAB_BYTES + (((c ^ (2 + h)) & 3) << 4) + 8 * (p & 1);
+    return t;
+}
+// A-operand fragment of X^T (rows = 32 columns of slab `slab`, reduction = 16 rows of X starting at a multiple of 16):
+// `p` = slab base + first row * 64.  EXEC must be all ones (call sites branch on wave-uniform values only).
+__device__ __forceinline__ bf16x8_t tr_frag(const char* p, const TrOff& t) {
+    const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + t.o0));
+    const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + t.o1));
+    const s16x8_t c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, c);
+}
+// Registers 8s..8s+7 of an accumulator as the operand of 16-deep step s.
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& a, int s) {
+    bf16x8_t r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)a[8 * s + j];
+    return r;
+}
+__device__ __forceinline__ void mfma16(f32x16_t& acc, const bf16x8_t a, const bf16x8_t b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+// A wave's TRANSPOSED 64 x 32 result (acc[db][reg]: row = column db*32 + acc_row(reg) of the output, lane & 31 = output
+// row) written as `nrows` rows of 64 elements: the registers of a lane hold four consecutive output columns at a time, so
+// the staging pass is eight 16-byte LDS stores, and the row pass is flush_tile's.
+__device__ __forceinline__ void flush_tile_t(float* stg, const f32x16_t (&acc)[2], bf16_t* g, long ld, int nrows, bool accumulate, int lane) {
+    if (nrows <= 0) return;                                    // wave-uniform
+    const bool vec = ((((uintptr_t)g) | (uintptr_t)(ld * 2)) & 15) == 0;
+    const int row = lane >> 1, half = lane & 1;
+    const bool mine = row < nrows;
+    bf16_t* o = g + (long)row * ld + half * 32;
+    u32x4_t prev[4];
+    if (vec && accumulate && mine) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) prev[v] = *reinterpret_cast<const u32x4_t*>(o + v * 8);
+    }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4_t v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[db][4 * g4 + j];
+            *reinterpret_cast<f32x4_t*>(stg + (lane & 31) * OUT_STAGE_LD + db * 32 + 8 * g4 + 4 * (lane >> 5)) = v;
+        }
+    __builtin_amdgcn_wave_barrier();
+    if (mine) {
+        const float* srow = stg + row * OUT_STAGE_LD + half * 32;
+        if (vec) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float x[8];
+#pragma unroll
+                for (int q4 = 0; q4 < 2; ++q4) {
+                    const f32x4_t t = *reinterpret_cast<const f32x4_t*>(srow + v * 8 + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[4 * q4 + e] = t[e];
+                }
+                bf16_t w[8];
+                if (accumulate) {
+                    __builtin_memcpy(w, &prev[v], 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += to_f32(w[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = (bf16_t)x[e];
+                u32x4_t pk;
+                __builtin_memcpy(&pk, w, 16);
+                *reinterpret_cast<u32x4_t*>(o + v * 8) = pk;
+            }
+        } else {
+            float pv[32];
+#pragma unroll
+            for (int e = 0; e < 32; ++e) pv[e] = accumulate ? to_f32(o[e]) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) o[e] = (bf16_t)(srow[e] + pv[e]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Scores of one staged entity for this wave's 32 queries, transposed, in the log2 domain: t = s * scale * log2(e) + bias
+// (bias = 0 / -inf per key from LDS), causal keys above the query removed, then p = 2^(t - max).  Returns max and sum.
+// NACT = number of key blocks this wave works on (the entity's key extent, and for causal attention the wave's diagonal):
+// a compile-time count, so the body is straight-line code the scheduler can interleave.
+template <int NKB, int NACT, bool CAUSAL>
+__device__ __forceinline__ void scores_tr(f32x16_t (&sacc)[NKB], const char* ktile, const Frag* qf, const float* biasf,
+                                          float c2, int qpos, int lane, const FragOff& fo, float& m_out, float& l_out) {
+    constexpr int SPAD = NKB * 32;
+    const int h = lane >> 5;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NACT; ++kb) {
+        sacc[kb] = zero_acc();
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const Frag a = lds_frag_o(ktile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+            mma_slab<bf16_t>(sacc[kb], a, qf[sl]);
+        }
+    }
+#pragma unroll
+    for (int kb = 0; kb < NACT; ++kb) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(biasf + kb * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = fmaf(sacc[kb][4 * g + j], c2, bias[j]);
+                if (CAUSAL && kb == NACT - 1 && (kb * 32 + 8 * g + 4 * h + j) > qpos) s = -INFINITY;     // earlier blocks lie below the diagonal
+                sacc[kb][4 * g + j] = s;
+                m = fmaxf(m, s);
+            }
+        }
+    }
+    m = wave_half_max(m);
+    const float ms = (m == -INFINITY) ? 0.f : m;
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NACT; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - ms);
+            sacc[kb][r] = pv;
+            l += pv;
+        }
+    }
+    m_out = ms;
+    l_out = wave_half_sum(l);
+}
+
+// Calls body(integral_constant<int, n>) for the run-time n in 1..NKB (wave-uniform).
+template <int NKB, typename F>
+__device__ __forceinline__ void dispatch_nact(int n, F&& body) {
+    if constexpr (NKB >= 1) if (n == 1) body(std::integral_constant<int, 1>{});
+    if constexpr (NKB >= 2) if (n == 2) body(std::integral_constant<int, 2>{});
+    if constexpr (NKB >= 3) if (n == 3) body(std::integral_constant<int, 3>{});
+    if constexpr (NKB >= 4) if (n == 4) body(std::integral_constant<int, 4>{});
+    if constexpr (NKB >= 5) if (n == 5) body(std::integral_constant<int, 5>{});
+    if constexpr (NKB >= 6) if (n == 6) body(std::integral_constant<int, 6>{});
+    if constexpr (NKB >= 7) if (n == 7) body(std::integral_constant<int, 7>{});
+}
+// Key blocks a wave works on: up to the entity's last unmasked key, and for causal attention up to the wave's own block.
+template <bool CAUSAL>
+__device__ __forceinline__ int active_blocks(int slen, int wave) {
+    const int n = (slen + 31) >> 5;
+    return CAUSAL ? min(n, wave + 1) : n;
+}
+
+template <int NKB, bool CAUSAL>
+__global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_kernel(mmsum_attn_desc d) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    constexpr int TILE = SPAD * HD * 2;
+    char* ktile = smem;
+    char* vtile = smem + TILE;
+    float* biasf = reinterpret_cast<float*>(smem + 2 * TILE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FragOff fo = frag_off<T>(lane);
+    const TrOff tro = tr_off(lane);
+    const int h = blockIdx.x, qb = blockIdx.y;
+    const int b = qb / d.qpb;
+    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
+    uint32_t rem = valid_entities(d, b, excl);
+    const int cnt = __popc(rem);
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+    const float c2 = d.scale * LOG2E_F;
+
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+    T* O = static_cast<T*>(d.out);
+
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+    Frag qf[2];
+    {
+        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) qf[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid);
+    }
+    pin_frags(qf);
+    f32x16_t oacc[2] = {zero_acc(), zero_acc()};
+
+    NatTile<T, SPAD, 2, ATT_THREADS> kreg, vreg;
+    uint8_t mreg = 1;
+    auto prefetch = [&](int n) {
+        const long ent = (long)b * d.N + n;
+        const long row0 = ent * d.S;
+        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
+        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
+        mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
+    };
+    if (rem) prefetch(__builtin_ctz(rem));
+    while (rem) {
+        rem &= rem - 1;
+        __syncthreads();
+        kreg.commit(ktile, tid);
+        vreg.commit(vtile, tid);
+        if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
+        publish_key_extent(reinterpret_cast<int*>(biasf + SPAD), mreg, d.S, tid);
+        __syncthreads();
+        const int slen = __builtin_amdgcn_readfirstlane(read_key_extent<ATT_THREADS / 64>(reinterpret_cast<const int*>(biasf + SPAD)));
+        if (rem) prefetch(__builtin_ctz(rem));
+        dispatch_nact<NKB>(active_blocks<CAUSAL>(slen, wave), [&](auto nact) {
+            constexpr int NACT = decltype(nact)::value;
+            f32x16_t sacc[NKB];
+            float m, l;
+            scores_tr<NKB, NACT, CAUSAL>(sacc, ktile, qf, biasf, c2, qpos, lane, fo, m, l);
+            const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
+            f32x16_t tmp[2] = {zero_acc(), zero_acc()};
+#pragma unroll
+            for (int kb = 0; kb < NACT; ++kb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t pb = pack8(sacc[kb], s2);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        mfma16(tmp[db], tr_frag(vtile + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                }
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] = fmaf(tmp[db][r], norm, oacc[db][r]);
+        });
+    }
+    __syncthreads();                                           // the tiles are dead: their LDS stages the output rows
+    flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), oacc, O + ((long)qb * d.T + wave * 32) * d.ldo + h * HD, d.ldo,
+                 d.T - wave * 32, false, lane);
+}
+
+// dQ (+ per-entity log-sum-exp and delta for the dK/dV kernel).  Per entity: scores and probabilities for all key blocks
+// stay in registers; dP^T = V dO^T is formed twice (once for delta, once for dS) instead of being kept, which is what lets
+// two workgroups share a CU.
+template <int NKB, bool CAUSAL>
+__global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
+                                                                                      bf16_t* __restrict__ dQ, long lddq, int accumulate_dq,
+                                                                                      float* __restrict__ stats) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    constexpr int TILE = SPAD * HD * 2;
+    char* ktile = smem;
+    char* vtile = smem + TILE;
+    float* biasf = reinterpret_cast<float*>(smem + 2 * TILE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FragOff fo = frag_off<T>(lane);
+    const TrOff tro = tr_off(lane);
+    const int h = blockIdx.x, qb = blockIdx.y;
+    const int b = qb / d.qpb;
+    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
+    uint32_t rem = valid_entities(d, b, excl);
+    const int cnt = __popc(rem);
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+    const float c2 = d.scale * LOG2E_F;
+
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+    Frag qf[2], dof[2];
+    {
+        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
+        const T* drow = dO + ((long)qb * d.T + qpos) * lddo + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            qf[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid);
+            dof[sl] = global_frag<T>(drow + sl * 32, lane, qvalid);
+        }
+    }
+    pin_frags(qf);
+    pin_frags(dof);
+    f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
+
+    NatTile<T, SPAD, 2, ATT_THREADS> kreg, vreg;
+    uint8_t mreg = 1;
+    int cur_n = 0, next_n = 0;
+    auto prefetch = [&](int n) {
+        const long ent = (long)b * d.N + n;
+        const long row0 = ent * d.S;
+        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
+        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
+        mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
+        next_n = n;
+    };
+    if (rem) prefetch(__builtin_ctz(rem));
+    while (rem) {
+        rem &= rem - 1;
+        __syncthreads();
+        kreg.commit(ktile, tid);
+        vreg.commit(vtile, tid);
+        if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
+        publish_key_extent(reinterpret_cast<int*>(biasf + SPAD), mreg, d.S, tid);
+        cur_n = next_n;
+        __syncthreads();
+        const int slen = __builtin_amdgcn_readfirstlane(read_key_extent<ATT_THREADS / 64>(reinterpret_cast<const int*>(biasf + SPAD)));
+        if (rem) prefetch(__builtin_ctz(rem));
+        dispatch_nact<NKB>(active_blocks<CAUSAL>(slen, wave), [&](auto nact) {
+            constexpr int NACT = decltype(nact)::value;
+            f32x16_t p[NKB];
+            float m, l;
+            scores_tr<NKB, NACT, CAUSAL>(p, ktile, qf, biasf, c2, qpos, lane, fo, m, l);
+            const float invl = (l > 0.f) ? 1.f / l : 0.f;
+            float delta = 0.f;                                    // sum_k p * dP, un-normalised
+#pragma unroll
+            for (int kb = 0; kb < NACT; ++kb) {
+                f32x16_t dpk = zero_acc();
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    mma_slab<T>(dpk, a, dof[sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) delta = fmaf(p[kb][r], dpk[r], delta);
+            }
+            delta = wave_half_sum(delta) * invl * inv_cnt;         // dO_e = dO / count
+            if (lane < 32 && qvalid) {
+                float* st = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
+                st[0] = m + __log2f(l);            // log-sum-exp in the log2 domain (the dK/dV kernel uses exp2)
+                st[1] = delta;
+            }
+            // dS^T = P (dP / count - delta) scale = p * (dP * ca - cb)
+            const float ca = invl * inv_cnt * d.scale, cb = invl * delta * d.scale;
+#pragma unroll
+            for (int kb = 0; kb < NACT; ++kb) {
+                f32x16_t dpk = zero_acc();
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    mma_slab<T>(dpk, a, dof[sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpk[r] = p[kb][r] * fmaf(dpk[r], ca, -cb);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t sb = pack8(dpk, s2);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        mfma16(dqacc[db], tr_frag(ktile + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
+                }
+            }
+        });
+    }
+    __syncthreads();                                           // the tiles are dead: their LDS stages the output rows
+    flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), dqacc, dQ + ((long)qb * d.T + wave * 32) * lddq + h * HD, lddq,
+                 d.T - wave * 32, accumulate_dq != 0, lane);
+}
+
+// dK / dV: one workgroup = (entity, head); a wave owns 32-key blocks (their K / V fragments stay in registers as B
+// operands) and sweeps the query chunks that attend to the entity.
+template <int NKB, bool CAUSAL>
+__global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
+                                                                                       bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv,
+                                                                                       const float* __restrict__ stats) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TQ = 64;
+    constexpr int NOWN = (NKB + 3) / 4;
+    constexpr int QT_TILE = TQ * HD * 2;
+    char* qn = smem;
+    char* don = smem + QT_TILE;
+    float* st = reinterpret_cast<float*>(smem + 2 * QT_TILE);   // [2][TQ]: lse, delta
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FragOff fo = frag_off<T>(lane);
+    const TrOff tro = tr_off(lane);
+    const float c2 = d.scale * LOG2E_F;
+    const int hh = lane >> 5;
+    const int h = blockIdx.x;
+    const long ent = blockIdx.y;
+    const int b = (int)(ent / d.N), n = (int)(ent % d.N);
+    const long row0 = ent * d.S;
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+    const bool is_null = d.null_entity && d.null_entity[ent];
+
+    Frag kf[NOWN][2], vf[NOWN][2];
+    bool keymask[NOWN];
+    f32x16_t dkacc[NOWN][2], dvacc[NOWN][2];
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int key = (wave + 4 * o) * 32 + (lane & 31);
+        const bool kvalid = key < d.S;
+        keymask[o] = !kvalid || (d.pad && d.pad[ent * d.S + (kvalid ? key : 0)]);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            kf[o][sl] = global_frag<T>(K + (row0 + key) * d.ldk + h * HD + sl * 32, lane, kvalid);
+            vf[o][sl] = global_frag<T>(V + (row0 + key) * d.ldv + h * HD + sl * 32, lane, kvalid);
+        }
+        dkacc[o][0] = dkacc[o][1] = dvacc[o][0] = dvacc[o][1] = zero_acc();
+    }
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) { pin_frags(kf[o]); pin_frags(vf[o]); }
+    const uint32_t live = valid_entities(d, b, -1);
+    const int nchunks = (d.T + TQ - 1) / TQ;
+    const int nqb = is_null ? 0 : (d.qpb - ((d.exclude_self && n < d.qpb) ? 1 : 0));
+    const int n_it = nqb * nchunks;
+    NatTile<T, TQ, 2, ATT_THREADS> qreg, doreg;
+    float streg = 0.f;
+    auto coords = [&](int it, int& qb, int& qc, int& i) {
+        const int idx = it / nchunks;
+        i = idx + ((d.exclude_self && idx >= n) ? 1 : 0);
+        qb = b * d.qpb + i;
+        qc = (it % nchunks) * TQ;
+    };
+    auto prefetch = [&](int it) {
+        int qb, qc, i;
+        coords(it, qb, qc, i);
+        const T* qbase = Q + (long)qb * d.T * d.ldq + h * HD;
+        const T* dobase = dO + (long)qb * d.T * lddo + h * HD;
+        qreg.load(qbase, d.ldq, qc, d.T, 0, HD, tid);
+        doreg.load(dobase, lddo, qc, d.T, 0, HD, tid);
+        const float* sbase = stats + (((long)qb * d.N + n) * d.H + h) * d.T * 2;
+        streg = (tid < TQ * 2 && qc + (tid >> 1) < d.T) ? sbase[(long)qc * 2 + tid] : 0.f;      // tid = 2*query + {0: lse, 1: delta}
+    };
+    if (n_it > 0) prefetch(0);
+    for (int it = 0; it < n_it; ++it) {
+        int qb, qc, i;
+        coords(it, qb, qc, i);
+        const int cnt = __popc(d.exclude_self ? (live & ~(1u << i)) : live);
+        const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+        __syncthreads();
+        qreg.commit(qn, tid);
+        doreg.commit(don, tid);
+        if (tid < TQ * 2) st[(tid & 1) * TQ + (tid >> 1)] = streg;
+        __syncthreads();
+        if (it + 1 < n_it) prefetch(it + 1);
+#pragma unroll
+        for (int o = 0; o < NOWN; ++o) {
+            const int kb = wave + 4 * o;
+            if (kb >= NKB || kb * 32 >= d.S) continue;
+            const int key = kb * 32 + (lane & 31);
+#pragma unroll
+            for (int qq = 0; qq < TQ / 32; ++qq) {
+                if (qc + qq * 32 >= d.T) continue;
+                if (CAUSAL && kb * 32 > qc + qq * 32 + 31) continue;          // every key of the block lies above every query
+                f32x16_t s = zero_acc(), dp = zero_acc();
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const Frag aq = lds_frag_o(qn + sl * (TQ * SLAB_BYTES) + qq * 32 * SLAB_BYTES, fo);
+                    mma_slab<T>(s, aq, kf[o][sl]);
+                    const Frag ad = lds_frag_o(don + sl * (TQ * SLAB_BYTES) + qq * 32 * SLAB_BYTES, fo);
+                    mma_slab<T>(dp, ad, vf[o][sl]);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ql0 = qq * 32 + 8 * g + 4 * hh;
+                    const f32x4_t lse4 = *reinterpret_cast<const f32x4_t*>(st + ql0);
+                    const f32x4_t del4 = *reinterpret_cast<const f32x4_t*>(st + TQ + ql0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g + j;
+                        const int qg = qc + ql0 + j;
+                        bool masked = keymask[o] || qg >= d.T;
+                        if (CAUSAL) masked = masked || key > qg;
+                        const float pr = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[j]));
+                        dp[r] = pr * (dp[r] * inv_cnt - del4[j]) * d.scale;     // dS
+                        s[r] = pr * inv_cnt;                                    // P / count
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8_t pb = pack8(s, s2), sb = pack8(dp, s2);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        mfma16(dvacc[o][db], tr_frag(don + db * (TQ * SLAB_BYTES) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                        mfma16(dkacc[o][db], tr_frag(qn + db * (TQ * SLAB_BYTES) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();                                           // the query tiles are dead: their LDS stages the output rows
+    float* stg = reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES);
+#pragma unroll
+    for (int o = 0; o < NOWN; ++o) {
+        const int kb = wave + 4 * o;
+        if (kb >= NKB) continue;
+        flush_tile_t(stg, dkacc[o], dK + (row0 + kb * 32) * lddk + h * HD, lddk, d.S - kb * 32, false, lane);
+        flush_tile_t(stg, dvacc[o], dV + (row0 + kb * 32) * lddv + h * HD, lddv, d.S - kb * 32, false, lane);
+    }
+}
+
 __global__ void entity_null_kernel(const uint8_t* __restrict__ pad, uint8_t* __restrict__ null_entity, int S) {
     __shared__ int any_live;
     if (threadIdx.x == 0) any_live = 0;
@@ -1166,10 +1683,26 @@ template <typename T> size_t pipe_lds(int nkb, int ntiles) {
     return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
 }
 
+template <typename T> size_t tr_lds(int nkb) {
+    const size_t need = (size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 16;
+    return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
+}
+#define LAUNCH_TR(kern, nkb, causal, grid, block, lds, s, ...)                                                        \
+    do {                                                                                                              \
+        if (nkb == 2) { if (causal) LAUNCH_LDS((kern<2, true>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<2, false>), grid, block, lds, s, __VA_ARGS__); } \
+        else if (nkb == 4) { if (causal) LAUNCH_LDS((kern<4, true>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<4, false>), grid, block, lds, s, __VA_ARGS__); } \
+        else { if (causal) LAUNCH_LDS((kern<7, true>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<7, false>), grid, block, lds, s, __VA_ARGS__); } \
+    } while (0)
+
 template <typename T>
 int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
     const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
     const int nkb = nkb_for(d.S);
+    if constexpr (sizeof(T) == 2) {
+        const size_t lds = tr_lds<T>(nkb);
+        LAUNCH_TR(attn_tr_fwd_kernel, nkb, d.causal, grid, block, lds, s, d);
+        return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+    }
     if (pipe_lds<T>(nkb, 2) <= LDS_MAX) {
         const size_t lds = pipe_lds<T>(nkb, 2);
         if (nkb == 2) if (d.causal) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2, true>), grid, block, lds, s, d); else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2, false>), grid, block, lds, s, d);
@@ -1188,6 +1721,20 @@ template <typename T>
 int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, long lddq, int accumulate_dq, void* dk, long lddk,
                void* dv, long lddv, void* stats, hipStream_t s) {
     const int nkb = nkb_for(d.S);
+    if constexpr (sizeof(T) == 2) {
+        {
+            const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
+            const size_t lds = tr_lds<T>(nkb);
+            LAUNCH_TR(attn_tr_bwd_dq_kernel, nkb, d.causal, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        }
+        {
+            const int n_ent = (d.n_qblocks / d.qpb) * d.N;
+            const dim3 grid(d.H, n_ent), block(ATT_THREADS);
+            const size_t lds = 4 * (size_t)OUT_STAGE_BYTES;
+            LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+        }
+        return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+    }
     if (sizeof(T) == 2 && nkb == 4 && ks_lds<T>(nkb) <= LDS_MAX) {   // 7 key blocks (images) spill at 256 registers: old kernel
         const dim3 grid(d.H, d.n_qblocks), block(KS_THREADS);
         const size_t lds = ks_lds<T>(nkb);

@@ -8,7 +8,7 @@ from multimodalsum_amd import kernels as kn
 
 NB = int(os.environ.get("ATTN_BENCH_B", "8"))
 CASES = [("cross_text", NB, 9, 9, 128, 128, True, False), ("self_causal", 9 * NB, 1, 1, 128, 128, False, True),
-         ("cross_img", NB, 9, 4, 196, 128, False, False), ("cross_table", NB, 9, 1, 47, 128, False, False)]
+         ("cross_img", NB, 9, 1, 196, 128, False, False), ("cross_table", NB, 9, 1, 47, 128, False, False)]
 
 
 def timeit(fn, iters=5):
