@@ -1239,16 +1239,64 @@ __device__ __forceinline__ void flush_tile_t(float* stg, const f32x16_t (&acc)[2
     __builtin_amdgcn_wave_barrier();
 }
 
-// Scores of one staged entity for this wave's 32 queries, transposed, in the log2 domain: t = s * scale * log2(e) + bias
-// (bias = 0 / -inf per key from LDS), causal keys above the query removed, then p = 2^(t - max).  Returns max and sum.
-// NACT = number of key blocks this wave works on (the entity's key extent, and for causal attention the wave's diagonal):
-// a compile-time count, so the body is straight-line code the scheduler can interleave.
-template <int NKB, int NACT, bool CAUSAL>
+// Key mask of a staged entity: additive bias (0 / -inf) per key, the key extent (index of the last unmasked key + 1: key
+// blocks past it are pure padding and are skipped) and the index of the first masked key (key blocks before it need no
+// bias at all).  slots: [0..3] extent per wave, [4..7] first masked key per wave.
+__device__ __forceinline__ void publish_key_mask(float* biasf, int* slots, uint8_t masked, int S, int spad, int tid) {
+    if (tid < spad) biasf[tid] = masked ? -INFINITY : 0.f;
+    const unsigned long long open = __ballot(tid < S && !masked), shut = __ballot(tid < spad && masked);
+    if ((tid & 63) == 0) {
+        slots[tid >> 6] = open ? tid + 64 - __builtin_clzll(open) : 0;
+        slots[4 + (tid >> 6)] = shut ? tid + __builtin_ctzll(shut) : spad;
+    }
+}
+__device__ __forceinline__ void read_key_mask(const int* slots, int& extent, int& first_masked) {
+    int e = 0, f = 1 << 30;
+#pragma unroll
+    for (int w = 0; w < ATT_THREADS / 64; ++w) {
+        e = max(e, slots[w]);
+        f = min(f, slots[4 + w]);
+    }
+    extent = __builtin_amdgcn_readfirstlane(e);
+    first_masked = __builtin_amdgcn_readfirstlane(f);
+}
+
+// A ROWS x 64 bf16 tile requested into registers with bounds-checked buffer loads and committed to LDS in the k-slab
+// layout later (same image as NatTile).  The descriptor covers exactly the `rows` valid rows of the tile, so rows past
+// them read as zeros in hardware: no per-load compare / select, and the per-thread offset is loop invariant (the step
+// between a thread's rows is a scalar offset).  THREADS / 8 rows per pass.
+template <int ROWS>
+struct BufTile {
+    static constexpr int NIT = ROWS * 8 / ATT_THREADS;
+    u32x4_t v[NIT];
+    // base: element (0, 0) of the tile; ld in elements
+    __device__ __forceinline__ void load(const bf16_t* base, long ld, int rows, int tid) {
+        const int r = rows > 0 ? rows : 0;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0,
+                                                                               r > 0 ? (int)((r - 1) * ld * 2 + 128) : 0, 0x00020000);
+        const int voff = (tid >> 3) * (int)(ld * 2) + (tid & 7) * 16;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            v[it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, it * (ATT_THREADS / 8) * (int)(ld * 2), 0));
+    }
+    __device__ __forceinline__ void commit(char* lds, int tid) const {
+        const int r = tid >> 3, cc = tid & 7;
+        char* p = lds + (cc >> 2) * (ROWS * SLAB_BYTES) + slab_off(r, cc & 3);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x4_t*>(p + it * (ATT_THREADS / 8) * SLAB_BYTES) = v[it];     // (r + 32 it) >> 2 keeps r's swizzle
+    }
+};
+
+// Scores of one staged entity for this wave's 32 queries, transposed, then p = 2^(t - max) with t = s * scale * log2(e)
+// (+ bias).  NACT = key blocks this wave works on (the entity's key extent; for causal attention up to the wave's
+// diagonal block) and NFAST = how many leading ones hold no masked key: both compile-time, so the body is straight-line.
+// A block without masked keys needs no bias: its maximum is taken over the raw products and scale, maximum and
+// exponent are one FMA + v_exp per score.  Returns max (log2 domain) and sum.
+template <int NKB, int NACT, int NFAST, bool CAUSAL>
 __device__ __forceinline__ void scores_tr(f32x16_t (&sacc)[NKB], const char* ktile, const Frag* qf, const float* biasf,
                                           float c2, int qpos, int lane, const FragOff& fo, float& m_out, float& l_out) {
     constexpr int SPAD = NKB * 32;
     const int h = lane >> 5;
-    float m = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NACT; ++kb) {
         sacc[kb] = zero_acc();
@@ -1258,28 +1306,35 @@ __device__ __forceinline__ void scores_tr(f32x16_t (&sacc)[NKB], const char* kti
             mma_slab<bf16_t>(sacc[kb], a, qf[sl]);
         }
     }
+    float mraw = -INFINITY, m = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NACT; ++kb) {
+        if (kb < NFAST && !(CAUSAL && kb == NACT - 1)) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(biasf + kb * 32 + 8 * g + 4 * h);
+            for (int r = 0; r < 16; ++r) mraw = fmaxf(mraw, sacc[kb][r]);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float s = fmaf(sacc[kb][4 * g + j], c2, bias[j]);
-                if (CAUSAL && kb == NACT - 1 && (kb * 32 + 8 * g + 4 * h + j) > qpos) s = -INFINITY;     // earlier blocks lie below the diagonal
-                sacc[kb][4 * g + j] = s;
-                m = fmaxf(m, s);
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(biasf + kb * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = fmaf(sacc[kb][4 * g + j], c2, bias[j]);
+                    if (CAUSAL && kb == NACT - 1 && (kb * 32 + 8 * g + 4 * h + j) > qpos) t = -INFINITY;     // earlier blocks lie below the diagonal
+                    sacc[kb][4 * g + j] = t;
+                    m = fmaxf(m, t);
+                }
             }
         }
     }
-    m = wave_half_max(m);
+    m = wave_half_max(fmaxf(m, mraw * c2));                  // scale > 0
     const float ms = (m == -INFINITY) ? 0.f : m;
     float l = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NACT; ++kb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - ms);
+            const float pv = (kb < NFAST && !(CAUSAL && kb == NACT - 1)) ? __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -ms))
+                                                                         : __builtin_amdgcn_exp2f(sacc[kb][r] - ms);
             sacc[kb][r] = pv;
             l += pv;
         }
@@ -1288,16 +1343,18 @@ __device__ __forceinline__ void scores_tr(f32x16_t (&sacc)[NKB], const char* kti
     l_out = wave_half_sum(l);
 }
 
-// Calls body(integral_constant<int, n>) for the run-time n in 1..NKB (wave-uniform).
+// Calls body(integral_constant<NACT>, integral_constant<NFAST>) for the wave-uniform run-time counts: NACT in 1..NKB,
+// NFAST = NACT - 1 when only the last active block can hold masked keys (trailing padding, the usual case), else 0.
 template <int NKB, typename F>
-__device__ __forceinline__ void dispatch_nact(int n, F&& body) {
-    if constexpr (NKB >= 1) if (n == 1) body(std::integral_constant<int, 1>{});
-    if constexpr (NKB >= 2) if (n == 2) body(std::integral_constant<int, 2>{});
-    if constexpr (NKB >= 3) if (n == 3) body(std::integral_constant<int, 3>{});
-    if constexpr (NKB >= 4) if (n == 4) body(std::integral_constant<int, 4>{});
-    if constexpr (NKB >= 5) if (n == 5) body(std::integral_constant<int, 5>{});
-    if constexpr (NKB >= 6) if (n == 6) body(std::integral_constant<int, 6>{});
-    if constexpr (NKB >= 7) if (n == 7) body(std::integral_constant<int, 7>{});
+__device__ __forceinline__ void dispatch_blocks(int nact, int nfull, F&& body) {
+    const bool tail_only = nfull >= nact - 1;
+#define MMSUM_CASE(N)                                                                                   \
+    if constexpr (NKB >= N) if (nact == N) {                                                            \
+        if (tail_only) body(std::integral_constant<int, N>{}, std::integral_constant<int, N - 1>{});    \
+        else body(std::integral_constant<int, N>{}, std::integral_constant<int, 0>{});                  \
+    }
+    MMSUM_CASE(1) MMSUM_CASE(2) MMSUM_CASE(3) MMSUM_CASE(4) MMSUM_CASE(5) MMSUM_CASE(6) MMSUM_CASE(7)
+#undef MMSUM_CASE
 }
 // Key blocks a wave works on: up to the entity's last unmasked key, and for causal attention up to the wave's own block.
 template <bool CAUSAL>
@@ -1306,15 +1363,27 @@ __device__ __forceinline__ int active_blocks(int slen, int wave) {
     return CAUSAL ? min(n, wave + 1) : n;
 }
 
+// Forward and dQ share the staging scheme: the K and V tiles of an entity live in one of two LDS stages; the next entity's
+// rows are requested into registers at the top of an iteration, written to the other stage in the middle of it (the loads
+// have landed by then, and nobody reads that stage: everybody passed the barrier that ended the previous iteration), and ONE
+// barrier ends the iteration.
+template <int NKB> struct TrStage {
+    static constexpr int SPAD = NKB * 32;
+    static constexpr int TILE = SPAD * HD * 2;
+    static constexpr int BYTES = 2 * TILE + SPAD * 4 + 32;
+    char* base;
+    __device__ __forceinline__ char* k() const { return base; }
+    __device__ __forceinline__ char* v() const { return base + TILE; }
+    __device__ __forceinline__ float* bias() const { return reinterpret_cast<float*>(base + 2 * TILE); }
+    __device__ __forceinline__ int* slots() const { return reinterpret_cast<int*>(base + 2 * TILE + SPAD * 4); }
+};
+
 template <int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_kernel(mmsum_attn_desc d) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SPAD = NKB * 32;
-    constexpr int TILE = SPAD * HD * 2;
-    char* ktile = smem;
-    char* vtile = smem + TILE;
-    float* biasf = reinterpret_cast<float*>(smem + 2 * TILE);
+    typedef TrStage<NKB> Stage;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const FragOff fo = frag_off<T>(lane);
@@ -1343,32 +1412,39 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
     pin_frags(qf);
     f32x16_t oacc[2] = {zero_acc(), zero_acc()};
 
-    NatTile<T, SPAD, 2, ATT_THREADS> kreg, vreg;
+    BufTile<SPAD> kreg, vreg;
     uint8_t mreg = 1;
     auto prefetch = [&](int n) {
         const long ent = (long)b * d.N + n;
         const long row0 = ent * d.S;
-        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
-        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
+        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
+        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
         mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
     };
-    if (rem) prefetch(__builtin_ctz(rem));
+    auto commit = [&](const Stage& st) {
+        kreg.commit(st.k(), tid);
+        vreg.commit(st.v(), tid);
+        publish_key_mask(st.bias(), st.slots(), mreg, d.S, SPAD, tid);
+    };
+    int cur = 0;
+    if (rem) {
+        prefetch(__builtin_ctz(rem));
+        commit(Stage{smem});
+    }
+    __syncthreads();
     while (rem) {
         rem &= rem - 1;
-        __syncthreads();
-        kreg.commit(ktile, tid);
-        vreg.commit(vtile, tid);
-        if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
-        publish_key_extent(reinterpret_cast<int*>(biasf + SPAD), mreg, d.S, tid);
-        __syncthreads();
-        const int slen = __builtin_amdgcn_readfirstlane(read_key_extent<ATT_THREADS / 64>(reinterpret_cast<const int*>(biasf + SPAD)));
+        const Stage st{smem + cur * Stage::BYTES}, nx{smem + (cur ^ 1) * Stage::BYTES};
+        int slen, fmask;
+        read_key_mask(st.slots(), slen, fmask);
         if (rem) prefetch(__builtin_ctz(rem));
-        dispatch_nact<NKB>(active_blocks<CAUSAL>(slen, wave), [&](auto nact) {
-            constexpr int NACT = decltype(nact)::value;
+        dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
+            constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
             f32x16_t sacc[NKB];
             float m, l;
-            scores_tr<NKB, NACT, CAUSAL>(sacc, ktile, qf, biasf, c2, qpos, lane, fo, m, l);
-            const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
+            scores_tr<NKB, NACT, NFAST, CAUSAL>(sacc, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
+            if (rem) commit(nx);
+            const float norm = (l > 0.f) ? inv_cnt * __builtin_amdgcn_rcpf(l) : 0.f;
             f32x16_t tmp[2] = {zero_acc(), zero_acc()};
 #pragma unroll
             for (int kb = 0; kb < NACT; ++kb) {
@@ -1377,7 +1453,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
                     const bf16x8_t pb = pack8(sacc[kb], s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        mfma16(tmp[db], tr_frag(vtile + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                        mfma16(tmp[db], tr_frag(st.v() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
                 }
             }
 #pragma unroll
@@ -1385,15 +1461,16 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[db][r] = fmaf(tmp[db][r], norm, oacc[db][r]);
         });
+        __syncthreads();
+        cur ^= 1;
     }
-    __syncthreads();                                           // the tiles are dead: their LDS stages the output rows
     flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), oacc, O + ((long)qb * d.T + wave * 32) * d.ldo + h * HD, d.ldo,
                  d.T - wave * 32, false, lane);
 }
 
-// dQ (+ per-entity log-sum-exp and delta for the dK/dV kernel).  Per entity: scores and probabilities for all key blocks
-// stay in registers; dP^T = V dO^T is formed twice (once for delta, once for dS) instead of being kept, which is what lets
-// two workgroups share a CU.
+// dQ (+ per-entity statistics for the dK/dV kernel: log-sum-exp in the log2 domain and delta' = scale * sum_k P dP, i.e.
+// delta * count * scale).  Per entity: scores and probabilities for all key blocks stay in registers; dP^T = V dO^T is formed
+// twice (once for delta, once for dS) instead of being kept, which is what lets two workgroups share a CU.
 template <int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
                                                                                       bf16_t* __restrict__ dQ, long lddq, int accumulate_dq,
@@ -1401,10 +1478,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SPAD = NKB * 32;
-    constexpr int TILE = SPAD * HD * 2;
-    char* ktile = smem;
-    char* vtile = smem + TILE;
-    float* biasf = reinterpret_cast<float*>(smem + 2 * TILE);
+    typedef TrStage<NKB> Stage;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const FragOff fo = frag_off<T>(lane);
@@ -1437,61 +1511,68 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     pin_frags(dof);
     f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
 
-    NatTile<T, SPAD, 2, ATT_THREADS> kreg, vreg;
+    BufTile<SPAD> kreg, vreg;
     uint8_t mreg = 1;
     int cur_n = 0, next_n = 0;
     auto prefetch = [&](int n) {
         const long ent = (long)b * d.N + n;
         const long row0 = ent * d.S;
-        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
-        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
+        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
+        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
         mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
         next_n = n;
     };
-    if (rem) prefetch(__builtin_ctz(rem));
+    auto commit = [&](const Stage& st) {
+        kreg.commit(st.k(), tid);
+        vreg.commit(st.v(), tid);
+        publish_key_mask(st.bias(), st.slots(), mreg, d.S, SPAD, tid);
+    };
+    int cur = 0;
+    if (rem) {
+        prefetch(__builtin_ctz(rem));
+        commit(Stage{smem});
+    }
+    __syncthreads();
     while (rem) {
         rem &= rem - 1;
-        __syncthreads();
-        kreg.commit(ktile, tid);
-        vreg.commit(vtile, tid);
-        if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
-        publish_key_extent(reinterpret_cast<int*>(biasf + SPAD), mreg, d.S, tid);
+        const Stage st{smem + cur * Stage::BYTES}, nx{smem + (cur ^ 1) * Stage::BYTES};
+        int slen, fmask;
+        read_key_mask(st.slots(), slen, fmask);
         cur_n = next_n;
-        __syncthreads();
-        const int slen = __builtin_amdgcn_readfirstlane(read_key_extent<ATT_THREADS / 64>(reinterpret_cast<const int*>(biasf + SPAD)));
         if (rem) prefetch(__builtin_ctz(rem));
-        dispatch_nact<NKB>(active_blocks<CAUSAL>(slen, wave), [&](auto nact) {
-            constexpr int NACT = decltype(nact)::value;
+        dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
+            constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
             f32x16_t p[NKB];
             float m, l;
-            scores_tr<NKB, NACT, CAUSAL>(p, ktile, qf, biasf, c2, qpos, lane, fo, m, l);
-            const float invl = (l > 0.f) ? 1.f / l : 0.f;
-            float delta = 0.f;                                    // sum_k p * dP, un-normalised
+            scores_tr<NKB, NACT, NFAST, CAUSAL>(p, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
+            if (rem) commit(nx);
+            const float invl = (l > 0.f) ? __builtin_amdgcn_rcpf(l) : 0.f;
+            float raw = 0.f;                                      // sum_k p * dP, un-normalised
 #pragma unroll
             for (int kb = 0; kb < NACT; ++kb) {
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) delta = fmaf(p[kb][r], dpk[r], delta);
+                for (int r = 0; r < 16; ++r) raw = fmaf(p[kb][r], dpk[r], raw);
             }
-            delta = wave_half_sum(delta) * invl * inv_cnt;         // dO_e = dO / count
+            const float dprime = wave_half_sum(raw) * invl * d.scale;          // delta * count * scale
             if (lane < 32 && qvalid) {
-                float* st = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
-                st[0] = m + __log2f(l);            // log-sum-exp in the log2 domain (the dK/dV kernel uses exp2)
-                st[1] = delta;
+                float* sp = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
+                sp[0] = m + __log2f(l);
+                sp[1] = dprime;
             }
             // dS^T = P (dP / count - delta) scale = p * (dP * ca - cb)
-            const float ca = invl * inv_cnt * d.scale, cb = invl * delta * d.scale;
+            const float ca = invl * inv_cnt * d.scale, cb = invl * inv_cnt * dprime;
 #pragma unroll
             for (int kb = 0; kb < NACT; ++kb) {
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
@@ -1501,18 +1582,22 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                     const bf16x8_t sb = pack8(dpk, s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        mfma16(dqacc[db], tr_frag(ktile + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
+                        mfma16(dqacc[db], tr_frag(st.k() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
                 }
             }
         });
+        __syncthreads();
+        cur ^= 1;
     }
-    __syncthreads();                                           // the tiles are dead: their LDS stages the output rows
     flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), dqacc, dQ + ((long)qb * d.T + wave * 32) * lddq + h * HD, lddq,
                  d.T - wave * 32, accumulate_dq != 0, lane);
 }
 
 // dK / dV: one workgroup = (entity, head); a wave owns 32-key blocks (their K / V fragments stay in registers as B
-// operands) and sweeps the query chunks that attend to the entity.
+// operands) and sweeps the query chunks that attend to the entity; chunks are double-buffered like the entities above.
+// Per score: p = 2^(s c2 - lse), P' = p / count (0 on this lane's key if it is masked), dS = P' (dP scale - delta').
+// Query rows past T are zero rows of the staged Q and dO, so they add nothing whatever P' is; a wave whose key block
+// holds only masked keys skips the arithmetic altogether.
 template <int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
                                                                                        bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv,
@@ -1522,9 +1607,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
     constexpr int TQ = 64;
     constexpr int NOWN = (NKB + 3) / 4;
     constexpr int QT_TILE = TQ * HD * 2;
-    char* qn = smem;
-    char* don = smem + QT_TILE;
-    float* st = reinterpret_cast<float*>(smem + 2 * QT_TILE);   // [2][TQ]: lse, delta
+    constexpr int STAGE = 2 * QT_TILE + 2 * TQ * 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const FragOff fo = frag_off<T>(lane);
@@ -1541,13 +1624,16 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
     const bool is_null = d.null_entity && d.null_entity[ent];
 
     Frag kf[NOWN][2], vf[NOWN][2];
-    bool keymask[NOWN];
+    float keep[NOWN];                                         // 1 / 0: this lane's key takes part
+    bool alive[NOWN];                                         // wave-uniform: the block has an unmasked key
     f32x16_t dkacc[NOWN][2], dvacc[NOWN][2];
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
         const int key = (wave + 4 * o) * 32 + (lane & 31);
         const bool kvalid = key < d.S;
-        keymask[o] = !kvalid || (d.pad && d.pad[ent * d.S + (kvalid ? key : 0)]);
+        const bool masked = !kvalid || (d.pad && d.pad[ent * d.S + (kvalid ? key : 0)]);
+        keep[o] = masked ? 0.f : 1.f;
+        alive[o] = __ballot(!masked) != 0;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
             kf[o][sl] = global_frag<T>(K + (row0 + key) * d.ldk + h * HD + sl * 32, lane, kvalid);
@@ -1561,7 +1647,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
     const int nchunks = (d.T + TQ - 1) / TQ;
     const int nqb = is_null ? 0 : (d.qpb - ((d.exclude_self && n < d.qpb) ? 1 : 0));
     const int n_it = nqb * nchunks;
-    NatTile<T, TQ, 2, ATT_THREADS> qreg, doreg;
+    BufTile<TQ> qreg, doreg;
     float streg = 0.f;
     auto coords = [&](int it, int& qb, int& qc, int& i) {
         const int idx = it / nchunks;
@@ -1572,30 +1658,38 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
     auto prefetch = [&](int it) {
         int qb, qc, i;
         coords(it, qb, qc, i);
-        const T* qbase = Q + (long)qb * d.T * d.ldq + h * HD;
-        const T* dobase = dO + (long)qb * d.T * lddo + h * HD;
-        qreg.load(qbase, d.ldq, qc, d.T, 0, HD, tid);
-        doreg.load(dobase, lddo, qc, d.T, 0, HD, tid);
+        qreg.load(Q + ((long)qb * d.T + qc) * d.ldq + h * HD, d.ldq, d.T - qc, tid);
+        doreg.load(dO + ((long)qb * d.T + qc) * lddo + h * HD, lddo, d.T - qc, tid);
         const float* sbase = stats + (((long)qb * d.N + n) * d.H + h) * d.T * 2;
-        streg = (tid < TQ * 2 && qc + (tid >> 1) < d.T) ? sbase[(long)qc * 2 + tid] : 0.f;      // tid = 2*query + {0: lse, 1: delta}
+        streg = (tid < TQ * 2 && qc + (tid >> 1) < d.T) ? sbase[(long)qc * 2 + tid] : 0.f;      // tid = 2*query + {0: lse, 1: delta'}
     };
-    if (n_it > 0) prefetch(0);
+    auto commit = [&](char* stage) {
+        qreg.commit(stage, tid);
+        doreg.commit(stage + QT_TILE, tid);
+        if (tid < TQ * 2) reinterpret_cast<float*>(stage + 2 * QT_TILE)[(tid & 1) * TQ + (tid >> 1)] = streg;
+    };
+    int cur = 0;
+    if (n_it > 0) {
+        prefetch(0);
+        commit(smem);
+    }
+    __syncthreads();
     for (int it = 0; it < n_it; ++it) {
         int qb, qc, i;
         coords(it, qb, qc, i);
         const int cnt = __popc(d.exclude_self ? (live & ~(1u << i)) : live);
         const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
-        __syncthreads();
-        qreg.commit(qn, tid);
-        doreg.commit(don, tid);
-        if (tid < TQ * 2) st[(tid & 1) * TQ + (tid >> 1)] = streg;
-        __syncthreads();
-        if (it + 1 < n_it) prefetch(it + 1);
+        const char* qn = smem + cur * STAGE;
+        const char* don = qn + QT_TILE;
+        const float* st = reinterpret_cast<const float*>(qn + 2 * QT_TILE);
+        const bool more = it + 1 < n_it;
+        if (more) prefetch(it + 1);
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
             const int kb = wave + 4 * o;
-            if (kb >= NKB || kb * 32 >= d.S) continue;
+            if (kb >= NKB || !alive[o]) continue;
             const int key = kb * 32 + (lane & 31);
+            const float icl = keep[o] * inv_cnt;
 #pragma unroll
             for (int qq = 0; qq < TQ / 32; ++qq) {
                 if (qc + qq * 32 >= d.T) continue;
@@ -1616,12 +1710,10 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * g + j;
-                        const int qg = qc + ql0 + j;
-                        bool masked = keymask[o] || qg >= d.T;
-                        if (CAUSAL) masked = masked || key > qg;
-                        const float pr = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[j]));
-                        dp[r] = pr * (dp[r] * inv_cnt - del4[j]) * d.scale;     // dS
-                        s[r] = pr * inv_cnt;                                    // P / count
+                        float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[j])) * icl;   // P / count
+                        if (CAUSAL && key > qc + ql0 + j) pr = 0.f;
+                        s[r] = pr;
+                        dp[r] = pr * fmaf(dp[r], d.scale, -del4[j]);                         // dS
                     }
                 }
 #pragma unroll
@@ -1635,8 +1727,10 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
                 }
             }
         }
+        if (more) commit(smem + (cur ^ 1) * STAGE);
+        __syncthreads();
+        cur ^= 1;
     }
-    __syncthreads();                                           // the query tiles are dead: their LDS stages the output rows
     float* stg = reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES);
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
@@ -1684,7 +1778,7 @@ template <typename T> size_t pipe_lds(int nkb, int ntiles) {
 }
 
 template <typename T> size_t tr_lds(int nkb) {
-    const size_t need = (size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 16;
+    const size_t need = 2 * ((size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 32);      // two TrStage
     return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
 }
 #define LAUNCH_TR(kern, nkb, causal, grid, block, lds, s, ...)                                                        \
@@ -1730,7 +1824,7 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         {
             const int n_ent = (d.n_qblocks / d.qpb) * d.N;
             const dim3 grid(d.H, n_ent), block(ATT_THREADS);
-            const size_t lds = 4 * (size_t)OUT_STAGE_BYTES;
+            const size_t lds = 4 * (size_t)OUT_STAGE_BYTES;          // >= two stages of 2 x 8 KiB tiles + statistics
             LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
         }
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;

@@ -322,8 +322,18 @@ __device__ __forceinline__ void mma_image(f32x16_t& acc, const char* img, const 
     }
 }
 
-__device__ __forceinline__ float wave_half_max(float v) { return fmaxf(v, __shfl_xor(v, 32)); }
-__device__ __forceinline__ float wave_half_sum(float v) { return v + __shfl_xor(v, 32); }
+// Combine a value with its partner lane (lane ^ 32): v_permlane32_swap exchanges the upper half of one register with the
+// lower half of another, so swapping a value with itself yields {lower, lower} and {upper, upper} -- no LDS round trip
+// (ds_bpermute, which __shfl_xor lowers to, sits on the softmax's critical path).
+__device__ __forceinline__ void wave_halves(float v, float& lo, float& hi) {
+    // inline asm with two read-write operands: two distinct registers by construction (the builtin, given the same value
+    // twice, returned {lower, lower} for both results with this compiler)
+    lo = v;
+    hi = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(lo), "+v"(hi));
+}
+__device__ __forceinline__ float wave_half_max(float v) { float a, b; wave_halves(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float wave_half_sum(float v) { float a, b; wave_halves(v, a, b); return a + b; }
 
 __device__ __forceinline__ float warp_sum(float v) {
 #pragma unroll

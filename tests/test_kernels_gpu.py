@@ -324,6 +324,8 @@ ATTN_CASES = [
     ("cross_text_full", 1, 9, 9, 128, 128, 1, True, False, False),
     ("cross_table", 2, 3, 1, 47, 12, 2, False, False, False),
     ("cross_img", 2, 2, 3, 196, 33, 1, False, False, False),
+    ("cross_text_holes", 2, 3, 3, 128, 70, 2, True, False, False),      # masked keys anywhere, not only trailing padding
+    ("cross_img_holes", 1, 2, 2, 196, 128, 1, False, False, False),
 ]
 
 
@@ -339,6 +341,10 @@ def test_attention(dtype, case):
         for n in range(N):
             L = int(torch.randint(max(1, S // 3), S + 1, (1,), generator=g))
             pad[b, n, L:] = True
+    if name.endswith("_holes"):
+        pad = pad | (torch.rand(B, N, S, generator=g) < 0.3)
+        pad[:, :, 5] = False
+        pad[0, 0, :64] = False              # first masked key of this entity lies in its third key block
     if not is_self and N > 1:
         pad[0, N - 1, :] = True            # a null entity
     if name == "cross_table":
