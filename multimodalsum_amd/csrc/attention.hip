@@ -1593,6 +1593,192 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                  d.T - wave * 32, accumulate_dq != 0, lane);
 }
 
+// ---------------------------------------------------------------------------------------------
+// One entity per business, attended by all qpb query blocks of the business (table and image memory: N == 1, no
+// leave-one-out): a workgroup stages the entity's K and V ONCE and walks its share of the query blocks, the next block's
+// Q (and dO) rows requested while the current one computes.  Nothing in the walk needs a workgroup barrier: the tiles are
+// read-only and every wave stages its own output rows.  grid = (H, businesses, splits of the qpb query blocks).
+// ---------------------------------------------------------------------------------------------
+template <int NKB>
+__global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_shared_kernel(mmsum_attn_desc d) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    typedef TrStage<NKB> Stage;
+    const Stage st{smem};
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FragOff fo = frag_off<T>(lane);
+    const TrOff tro = tr_off(lane);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int per = (d.qpb + gridDim.z - 1) / gridDim.z;
+    const int i0 = blockIdx.z * per, i1 = min(d.qpb, i0 + per);
+    const bool live = (valid_entities(d, b, -1) & 1u) != 0;
+    const float c2 = d.scale * LOG2E_F;
+    const T* Q = static_cast<const T*>(d.q);
+    T* O = static_cast<T*>(d.out);
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+
+    int slen = 0, fmask = 0;
+    if (live) {
+        BufTile<SPAD> kreg, vreg;
+        const long row0 = (long)b * d.S;
+        kreg.load(static_cast<const T*>(d.k) + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
+        vreg.load(static_cast<const T*>(d.v) + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
+        const uint8_t mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[row0 + tid] : 0);
+        kreg.commit(st.k(), tid);
+        vreg.commit(st.v(), tid);
+        publish_key_mask(st.bias(), st.slots(), mreg, d.S, SPAD, tid);
+    }
+    __syncthreads();
+    if (live) read_key_mask(st.slots(), slen, fmask);
+    float* stg = reinterpret_cast<float*>(smem + Stage::BYTES + wave * OUT_STAGE_BYTES);
+
+    auto load_q = [&](Frag (&f)[2], int i) {
+        const T* qrow = Q + (((long)b * d.qpb + i) * d.T + qpos) * d.ldq + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) f[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid && i < i1);
+    };
+    Frag qf[2], qn[2];
+    load_q(qf, i0);
+    for (int i = i0; i < i1; ++i) {
+        load_q(qn, i + 1);
+        f32x16_t oacc[2] = {zero_acc(), zero_acc()};
+        if (live) {
+            dispatch_blocks<NKB>(active_blocks<false>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
+                constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
+                f32x16_t sacc[NKB];
+                float m, l;
+                scores_tr<NKB, NACT, NFAST, false>(sacc, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
+                const float norm = (l > 0.f) ? __builtin_amdgcn_rcpf(l) : 0.f;
+#pragma unroll
+                for (int kb = 0; kb < NACT; ++kb) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8_t pb = pack8(sacc[kb], s2);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+                            mfma16(oacc[db], tr_frag(st.v() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                    }
+                }
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[db][r] *= norm;
+            });
+        }
+        flush_tile_t(stg, oacc, O + (((long)b * d.qpb + i) * d.T + wave * 32) * d.ldo + h * HD, d.ldo, d.T - wave * 32, false, lane);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) qf[sl] = qn[sl];
+    }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_shared_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
+                                                                                             bf16_t* __restrict__ dQ, long lddq, int accumulate_dq,
+                                                                                             float* __restrict__ stats) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    typedef TrStage<NKB> Stage;
+    const Stage st{smem};
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FragOff fo = frag_off<T>(lane);
+    const TrOff tro = tr_off(lane);
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int per = (d.qpb + gridDim.z - 1) / gridDim.z;
+    const int i0 = blockIdx.z * per, i1 = min(d.qpb, i0 + per);
+    const bool live = (valid_entities(d, b, -1) & 1u) != 0;
+    const float c2 = d.scale * LOG2E_F;
+    const T* Q = static_cast<const T*>(d.q);
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+
+    int slen = 0, fmask = 0;
+    if (live) {
+        BufTile<SPAD> kreg, vreg;
+        const long row0 = (long)b * d.S;
+        kreg.load(static_cast<const T*>(d.k) + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
+        vreg.load(static_cast<const T*>(d.v) + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
+        const uint8_t mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[row0 + tid] : 0);
+        kreg.commit(st.k(), tid);
+        vreg.commit(st.v(), tid);
+        publish_key_mask(st.bias(), st.slots(), mreg, d.S, SPAD, tid);
+    }
+    __syncthreads();
+    if (live) read_key_mask(st.slots(), slen, fmask);
+    float* stg = reinterpret_cast<float*>(smem + Stage::BYTES + wave * OUT_STAGE_BYTES);
+
+    auto load_q = [&](Frag (&fq)[2], Frag (&fd)[2], int i) {
+        const long row = ((long)b * d.qpb + i) * d.T + qpos;
+        const T* qrow = Q + row * d.ldq + h * HD;
+        const T* drow = dO + row * lddo + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            fq[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid && i < i1);
+            fd[sl] = global_frag<T>(drow + sl * 32, lane, qvalid && i < i1);
+        }
+    };
+    Frag qf[2], dof[2], qn[2], don[2];
+    load_q(qf, dof, i0);
+    for (int i = i0; i < i1; ++i) {
+        load_q(qn, don, i + 1);
+        const int qb = b * d.qpb + i;
+        f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
+        if (live) {
+            dispatch_blocks<NKB>(active_blocks<false>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
+                constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
+                f32x16_t p[NKB];
+                float m, l;
+                scores_tr<NKB, NACT, NFAST, false>(p, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
+                const float invl = (l > 0.f) ? __builtin_amdgcn_rcpf(l) : 0.f;
+                float raw = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < NACT; ++kb) {
+                    f32x16_t dpk = zero_acc();
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                        mma_slab<T>(dpk, a, dof[sl]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) raw = fmaf(p[kb][r], dpk[r], raw);
+                }
+                const float dprime = wave_half_sum(raw) * invl * d.scale;          // delta * count * scale, count = 1
+                if (lane < 32 && qvalid) {
+                    float* sp = stats + (((long)qb * d.H + h) * d.T + qpos) * 2;   // N == 1
+                    sp[0] = m + __log2f(l);
+                    sp[1] = dprime;
+                }
+                const float ca = invl * d.scale, cb = invl * dprime;
+#pragma unroll
+                for (int kb = 0; kb < NACT; ++kb) {
+                    f32x16_t dpk = zero_acc();
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                        mma_slab<T>(dpk, a, dof[sl]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) dpk[r] = p[kb][r] * fmaf(dpk[r], ca, -cb);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8_t sb = pack8(dpk, s2);
+#pragma unroll
+                        for (int db = 0; db < 2; ++db)
+                            mfma16(dqacc[db], tr_frag(st.k() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
+                    }
+                }
+            });
+        }
+        flush_tile_t(stg, dqacc, dQ + ((long)qb * d.T + wave * 32) * lddq + h * HD, lddq, d.T - wave * 32, accumulate_dq != 0, lane);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) { qf[sl] = qn[sl]; dof[sl] = don[sl]; }
+    }
+}
+
 // dK / dV: one workgroup = (entity, head); a wave owns 32-key blocks (their K / V fragments stay in registers as B
 // operands) and sweeps the query chunks that attend to the entity; chunks are double-buffered like the entities above.
 // Per score: p = 2^(s c2 - lse), P' = p / count (0 on this lane's key if it is masked), dS = P' (dP scale - delta').
@@ -1777,6 +1963,10 @@ template <typename T> size_t pipe_lds(int nkb, int ntiles) {
     return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
 }
 
+// One entity per business shared by its qpb > 1 query blocks (table / image memory of the decoder's cross-attention).
+inline bool shared_entity(const mmsum_attn_desc& d) { return d.N == 1 && d.qpb > 1 && !d.exclude_self && !d.causal; }
+inline int shared_splits(const mmsum_attn_desc& d) { return d.qpb % 3 == 0 ? 3 : 1; }
+template <typename T> size_t shared_lds(int nkb) { return (size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 32 + 4 * (size_t)OUT_STAGE_BYTES; }
 template <typename T> size_t tr_lds(int nkb) {
     const size_t need = 2 * ((size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 32);      // two TrStage
     return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
@@ -1793,6 +1983,14 @@ int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
     const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
     const int nkb = nkb_for(d.S);
     if constexpr (sizeof(T) == 2) {
+        if (shared_entity(d)) {
+            const dim3 sgrid(d.H, d.n_qblocks / d.qpb, shared_splits(d));
+            const size_t lds = shared_lds<T>(nkb);
+            if (nkb == 2) LAUNCH_LDS((attn_tr_fwd_shared_kernel<2>), sgrid, block, lds, s, d);
+            else if (nkb == 4) LAUNCH_LDS((attn_tr_fwd_shared_kernel<4>), sgrid, block, lds, s, d);
+            else LAUNCH_LDS((attn_tr_fwd_shared_kernel<7>), sgrid, block, lds, s, d);
+            return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+        }
         const size_t lds = tr_lds<T>(nkb);
         LAUNCH_TR(attn_tr_fwd_kernel, nkb, d.causal, grid, block, lds, s, d);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
@@ -1816,7 +2014,13 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
                void* dv, long lddv, void* stats, hipStream_t s) {
     const int nkb = nkb_for(d.S);
     if constexpr (sizeof(T) == 2) {
-        {
+        if (shared_entity(d)) {
+            const dim3 sgrid(d.H, d.n_qblocks / d.qpb, shared_splits(d)), block(ATT_THREADS);
+            const size_t lds = shared_lds<T>(nkb);
+            if (nkb == 2) LAUNCH_LDS((attn_tr_bwd_dq_shared_kernel<2>), sgrid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+            else if (nkb == 4) LAUNCH_LDS((attn_tr_bwd_dq_shared_kernel<4>), sgrid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+            else LAUNCH_LDS((attn_tr_bwd_dq_shared_kernel<7>), sgrid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+        } else {
             const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
             const size_t lds = tr_lds<T>(nkb);
             LAUNCH_TR(attn_tr_bwd_dq_kernel, nkb, d.causal, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);

@@ -326,6 +326,8 @@ ATTN_CASES = [
     ("cross_img", 2, 2, 3, 196, 33, 1, False, False, False),
     ("cross_text_holes", 2, 3, 3, 128, 70, 2, True, False, False),      # masked keys anywhere, not only trailing padding
     ("cross_img_holes", 1, 2, 2, 196, 128, 1, False, False, False),
+    ("cross_img_one_entity", 2, 9, 1, 196, 128, 1, False, False, False),   # the training layout: one image / table entity per business,
+    ("cross_table_walk", 3, 4, 1, 47, 40, 2, False, False, False),         # shared by its query blocks (a workgroup walks several of them)
 ]
 
 
@@ -347,7 +349,7 @@ def test_attention(dtype, case):
         pad[0, 0, :64] = False              # first masked key of this entity lies in its third key block
     if not is_self and N > 1:
         pad[0, N - 1, :] = True            # a null entity
-    if name == "cross_table":
+    if name in ("cross_table", "cross_table_walk"):
         pad[1, 0, :] = True                 # business without a table: output must be exactly 0
     if causal:
         pad[:, :, 0] = False
