@@ -52,7 +52,13 @@ __device__ __forceinline__ float gelu_grad_fast_f(float x) {
 // element): 0 = store T, 1 = T += , 2 = f32 += , 3 = f32 atomic += , 4 = store f32.
 enum { OUT_T = 0, OUT_T_ACC = 1, OUT_F32_ACC = 2, OUT_F32_ATOMIC = 3, OUT_F32 = 4 };
 
-template <typename T, int TM, int TN, int EPI, int OUT>
+// Position of accumulator register r of a 32x32 block for this lane.  MF16 = false: the block is one 32x32x16 MFMA result
+// (column on the lane).  MF16 = true: the block is four 16x16x32 results, registers 4q..4q+3 = quarter q = 2 (row half) + (col half),
+// each with rows 4 (lane >> 4) + e and column lane & 15.
+template <bool MF16> __device__ __forceinline__ int blk_row(int r, int lane) { return MF16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : acc_row(r, lane); }
+template <bool MF16> __device__ __forceinline__ int blk_col(int r, int lane) { return MF16 ? 16 * ((r >> 2) & 1) + (lane & 15) : (lane & 31); }
+
+template <typename T, int TM, int TN, int EPI, int OUT, bool MF16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x16_t (&acc)[TM][TN], int row0, int col0, int ks, int lane) {
     const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
     float* Cf = static_cast<float*>(p.C);
@@ -60,14 +66,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x16_t 
     T* aux = static_cast<T*>(p.aux);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = col0 + j * 32 + (lane & 31);
-        const bool col_ok = col < p.N;
-        const float bv = (has_bias && col_ok) ? p.bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = row0 + i * 32 + acc_row(r, lane);
+                const int col = col0 + j * 32 + blk_col<MF16>(r, lane);
+                const bool col_ok = col < p.N;
+                const float bv = (has_bias && col_ok) ? p.bias[col] : 0.f;
+                const int row = row0 + i * 32 + blk_row<MF16>(r, lane);
                 if (!col_ok || row >= p.M) continue;
                 float v = acc[i][j][r] * p.alpha + bv;
                 if constexpr (EPI == MMSUM_EPI_GELU) {

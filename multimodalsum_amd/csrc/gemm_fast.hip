@@ -60,7 +60,7 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Edge tiles (rows past M / columns past N inside the tile, unaligned C): every access guarded, scalar fallbacks.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false>
 __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                            char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, const float (&bv)[8]) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
@@ -121,9 +121,9 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
             float* stage = set + wm * BAND;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int col = wn * (TN * 32) + j * 32 + (lane & 31);
+                const int col = wn * (TN * 32) + j * 32;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) stage[acc_row(r, lane) * BN + col] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) stage[blk_row<MF16>(r, lane) * BN + col + blk_col<MF16>(r, lane)] = acc[i][j][r];
             }
         }
         lds_barrier();
@@ -253,7 +253,7 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
 // guards, index arithmetic and run-time flags (measured at M = 64,512, N = 4096, K = 1024: 232 us of a 696 us launch with the
 // global stores REMOVED, against 386 us for the main loop alone).  Here a thread's rows are base + compile-time constants,
 // the LDS addresses are immediates, and bias / alpha / activation / accumulate / column sums are compile-time forms.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, bool CS, int LDS_BYTES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, bool CS, int LDS_BYTES, bool MF16 = false>
 __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                   char* smem, int m0, int n0, int wm, int wn, int tid, int lane, const float (&bv)[8]) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
@@ -297,7 +297,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
     for (int it = 0; it < NIT; ++it) prefetch1(0, it);
     lds_barrier();                                    // every wave is done reading the operand stages
     const float* rd0 = stage0 + trow * BN + cc;       // this thread's read position inside a band set (+ compile-time offsets)
-    float* wr0 = stage0 + wm * BAND + (4 * (lane >> 5)) * BN + wn * (TN * 32) + (lane & 31);
+    float* wr0 = stage0 + wm * BAND + wn * (TN * 32) + (MF16 ? (4 * (lane >> 4)) * BN + (lane & 15) : (4 * (lane >> 5)) * BN + (lane & 31));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         constexpr int SETF = WAVES_M * BAND;
@@ -306,7 +306,8 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) wr0[seto + ((r & 3) + 8 * (r >> 2)) * BN + j * 32] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r)
+                wr0[seto + (MF16 ? (16 * (r >> 3) + (r & 3)) * BN + 16 * ((r >> 2) & 1) : ((r & 3) + 8 * (r >> 2)) * BN) + j * 32] = acc[i][j][r];
         lds_barrier();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -389,7 +390,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                 char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane) {
     float bv[8];
@@ -402,11 +403,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     // pass, does not fit the 128 registers left beside the accumulators: 167 spilled) and column sums keep the guarded form
     if constexpr (OUT != OUT_F32_ATOMIC && EPI != MMSUM_EPI_GELU_BWD && EPI != MMSUM_EPI_RELU_BWD) {
         if (interior && !(p.flags & MMSUM_GEMM_COLSUM)) {
-            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, false, LDS_BYTES>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv);
+            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, false, LDS_BYTES, MF16>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv);
             return;
         }
     }
-    epilogue_edge<BM, BN, WAVES_M, WAVES_N, EPI, OUT, LDS_BYTES>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, bv);
+    epilogue_edge<BM, BN, WAVES_M, WAVES_N, EPI, OUT, LDS_BYTES, MF16>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, bv);
 }
 
 __device__ __forceinline__ void dma16(const bf16_t* gsrc, char* lds_dst) {
@@ -448,7 +449,28 @@ inline int cu_count() {
 #ifndef MMSUM_GEMM_STAGGER
 #define MMSUM_GEMM_STAGGER 1
 #endif
+#ifndef MMSUM_GEMM_PINGPONG
+#define MMSUM_GEMM_PINGPONG 0
+#endif
+#ifndef MMSUM_GEMM_MFMA16
+#define MMSUM_GEMM_MFMA16 1      // NT ring: v_mfma_f32_16x16x32_bf16 (higher clock under load) instead of 32x32x16
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ Frag nt_frag(const char* slab, int row0, int lane) {
+#if MMSUM_GEMM_MFMA16
+    return lds_frag16(slab, row0, lane);
+#else
+    return lds_frag<bf16_t>(slab, row0, lane);
+#endif
+}
+__device__ __forceinline__ void nt_mma(f32x16_t& acc, const Frag& a, const Frag& b) {
+#if MMSUM_GEMM_MFMA16
+    mma_slab16(acc, a, b);
+#else
+    mma_slab<bf16_t>(acc, a, b);
+#endif
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_ring_kernel(GemmArgs p) {
@@ -541,6 +563,49 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         };
+#if MMSUM_GEMM_PINGPONG
+        // PING-PONG (8-wave tiles): two barriers per slab split it into a load phase and a matrix phase, and the two wave rows
+        // (the two waves of every SIMD) are half a slab apart, so one of them is always in its matrix phase while the other
+        // reads its 12 fragments and issues its share of the DMA.
+        if (STAGGER) {
+            Frag a[Cfg::TM], b[Cfg::TN];
+            auto load_phase = [&](int si) {
+                const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
+                const char* Bs = As + Cfg::A_BYTES;
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j) b[j] = nt_frag(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i) a[i] = nt_frag(As, wm * (Cfg::TM * 32) + i * 32, lane);
+                if (si + AHEAD < ns) issue(si + AHEAD);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            auto matrix_phase = [&]() {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[i][j], a[i], b[j]);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            if (wm == 0) {
+                for (int si = 0; si < ns; ++si) {
+                    wait_slab(si);
+                    load_phase(si);
+                    __builtin_amdgcn_s_barrier();
+                    matrix_phase();
+                }
+            } else {
+                for (int si = 0; si < ns; ++si) {
+                    wait_slab(si);
+                    if (si > 0) matrix_phase();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    load_phase(si);
+                }
+                matrix_phase();
+            }
+        } else
+#endif
         if (!(STAGGER && wm == 1)) {
             for (int si = 0; si < ns; ++si) {
                 wait_slab(si);
@@ -550,15 +615,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
                 // address arithmetic and the four DMA instructions then run under the LDS latency instead of in front of it
                 Frag b[Cfg::TN];
 #pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) b[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
-                Frag a0 = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32), lane);
+                for (int j = 0; j < Cfg::TN; ++j) b[j] = nt_frag(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+                Frag a0 = nt_frag(As, wm * (Cfg::TM * 32), lane);
                 if (si + AHEAD < ns) issue(si + AHEAD);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < Cfg::TM; ++i) {
-                    const Frag a = i == 0 ? a0 : lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
+                    const Frag a = i == 0 ? a0 : nt_frag(As, wm * (Cfg::TM * 32) + i * 32, lane);
 #pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a, b[j]);
+                    for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[i][j], a, b[j]);
                 }
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -575,35 +640,35 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
 #pragma unroll
                     for (int i = 0; i < HALF; ++i)
 #pragma unroll
-                        for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[HALF + i][j], aH[i], bH[j]);
+                        for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[HALF + i][j], aH[i], bH[j]);
                     __builtin_amdgcn_s_setprio(0);
                 }
                 __builtin_amdgcn_sched_barrier(0);                 // the reads below stay behind those MFMAs
                 Frag a[HALF];
 #pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) bH[j] = lds_frag<bf16_t>(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+                for (int j = 0; j < Cfg::TN; ++j) bH[j] = nt_frag(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) a[i] = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + i * 32, lane);
+                for (int i = 0; i < HALF; ++i) a[i] = nt_frag(As, wm * (Cfg::TM * 32) + i * 32, lane);
 #pragma unroll
-                for (int i = 0; i < HALF; ++i) aH[i] = lds_frag<bf16_t>(As, wm * (Cfg::TM * 32) + (HALF + i) * 32, lane);
+                for (int i = 0; i < HALF; ++i) aH[i] = nt_frag(As, wm * (Cfg::TM * 32) + (HALF + i) * 32, lane);
                 if (si + AHEAD < ns) issue(si + AHEAD);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int i = 0; i < HALF; ++i)
 #pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[i][j], a[i], bH[j]);
+                    for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[i][j], a[i], bH[j]);
                 __builtin_amdgcn_s_setprio(0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of this ring slot has returned before the barrier that frees it
             }
 #pragma unroll
             for (int i = 0; i < HALF; ++i)
 #pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) mma_slab<bf16_t>(acc[HALF + i][j], aH[i], bH[j]);
+                for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[HALF + i][j], aH[i], bH[j]);
         }
     }
     if constexpr (OUT == OUT_F32_ATOMIC) {
         // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
-        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT, MMSUM_GEMM_MFMA16 != 0>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
 #ifdef MMSUM_DIAG_NO_EPILOGUE     // tools/ builds only (never defined for the shipped library): main loop without the epilogue
 #pragma unroll                    // every accumulator stays live: a dead one would take its MFMAs with it
@@ -611,7 +676,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE, MMSUM_GEMM_MFMA16 != 0>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
 #endif
     }
     lds_barrier();            // the staging reads are done before the next tile's DMA lands in the same LDS (stores stay in flight)
