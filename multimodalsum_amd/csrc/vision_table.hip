@@ -26,13 +26,15 @@ inline int grid_for(long items, int per_block, int cap = 4096) {
 inline int ok() { return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP; }
 
 // ---- im2col / col2im ---------------------------------------------------------------------------
-template <typename T, int VEC>
+// A tap (kh, kw) of an output pixel is C contiguous elements on both sides: copied as raw 16-byte vectors (EV elements).
+template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int N, int H, int W, int C,
                                                      int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
-    const int cv = C / VEC;
+    constexpr int EV = 16 / sizeof(T);
+    const int cv = C / EV;
     const long total = (long)N * Ho * Wo * KH * KW * cv;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * VEC;
+        const int c = (int)(i % cv) * EV;
         long t = i / cv;
         const int kw = (int)(t % KW); t /= KW;
         const int kh = (int)(t % KH); t /= KH;
@@ -41,14 +43,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T*
         const int ho = (int)((row / Wo) % Ho);
         const int n = (int)(row / ((long)Wo * Ho));
         const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
-        T* dst = col + row * Kpad + (kh * KW + kw) * C + c;
         const bool in = h >= 0 && h < H && w >= 0 && w < W;
-        const T* src = x + (((long)n * H + h) * W + w) * C + c;
-        if constexpr (VEC == 4) {
-            st4<T>(dst, in ? ld4<T>(src) : f32x4_t{0, 0, 0, 0});
-        } else {
-            dst[0] = in ? src[0] : from_f32<T>(0.f);
-        }
+        u32x4_t v = u32x4_t{0, 0, 0, 0};
+        if (in) v = *reinterpret_cast<const u32x4_t*>(x + (((long)n * H + h) * W + w) * C + c);
+        *reinterpret_cast<u32x4_t*>(col + row * Kpad + (kh * KW + kw) * C + c) = v;
     }
     const int K = KH * KW * C;
     if (Kpad > K) {
@@ -58,19 +56,50 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T*
             col[(i / tail) * Kpad + K + (i % tail)] = from_f32<T>(0.f);
     }
 }
+// Few channels (the 7x7 stem, C = 3): a thread gathers EV consecutive columns of a row (several taps) and stores them as
+// one 16-byte vector, zero padding of the K tail included.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_few_channels_kernel(const T* __restrict__ x, T* __restrict__ col, int N, int H, int W, int C,
+                                                                  int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
+    constexpr int EV = 16 / sizeof(T);
+    const int kv = Kpad / EV, K = KH * KW * C;
+    const long total = (long)N * Ho * Wo * kv;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k0 = (int)(i % kv) * EV;
+        const long row = i / kv;
+        const int wo = (int)(row % Wo);
+        const int ho = (int)((row / Wo) % Ho);
+        const int n = (int)(row / ((long)Wo * Ho));
+        T v[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) {
+            const int k = k0 + e, tap = k / C, c = k - tap * C;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            const int h = ho * stride - pad + kh, w = wo * stride - pad + kw;
+            const bool in = k < K && h >= 0 && h < H && w >= 0 && w < W;
+            v[e] = in ? x[(((long)n * H + h) * W + w) * C + c] : from_f32<T>(0.f);
+        }
+        u32x4_t pk;
+        __builtin_memcpy(&pk, v, 16);
+        *reinterpret_cast<u32x4_t*>(col + row * Kpad + k0) = pk;
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int H, int W, int C,
                                                      int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
-    const int cv = C / 4;
+    constexpr int EV = 16 / sizeof(T);
+    const int cv = C / EV;
     const long total = (long)N * H * W * cv;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * 4;
+        const int c = (int)(i % cv) * EV;
         long t = i / cv;
         const int w = (int)(t % W); t /= W;
         const int h = (int)(t % H);
         const int n = (int)(t / H);
-        f32x4_t acc = f32x4_t{0, 0, 0, 0};
+        float acc[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) acc[e] = 0.f;
         for (int kh = 0; kh < KH; ++kh) {
             const int hh = h + pad - kh;
             if (hh < 0 || hh % stride) continue;
@@ -81,10 +110,20 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol,
                 if (ww < 0 || ww % stride) continue;
                 const int wo = ww / stride;
                 if (wo >= Wo) continue;
-                acc = acc + ld4<T>(dcol + (((long)n * Ho + ho) * Wo + wo) * Kpad + (kh * KW + kw) * C + c);
+                const T* src = dcol + (((long)n * Ho + ho) * Wo + wo) * Kpad + (kh * KW + kw) * C + c;
+                const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(src);
+                T v[EV];
+                __builtin_memcpy(v, &raw, 16);
+#pragma unroll
+                for (int e = 0; e < EV; ++e) acc[e] += to_f32(v[e]);
             }
         }
-        st4<T>(dx + (((long)n * H + h) * W + w) * C + c, acc);
+        T o[EV];
+#pragma unroll
+        for (int e = 0; e < EV; ++e) o[e] = from_f32<T>(acc[e]);
+        u32x4_t pk;
+        __builtin_memcpy(&pk, o, 16);
+        *reinterpret_cast<u32x4_t*>(dx + (((long)n * H + h) * W + w) * C + c) = pk;
     }
 }
 
@@ -116,129 +155,227 @@ __global__ __launch_bounds__(256) void matrix_to_weight_grad_kernel(const float*
 }
 
 // ---- BatchNorm ----------------------------------------------------------------------------------
-constexpr int BN_SPLITS = 128;
-// MODE 0: sums of (x, x^2).  MODE 1: sums of (dy', dy'*xhat) for the backward pass.
-// block = 16 column groups (4 channels, vector loads) x 16 row lanes; grid (C/64, splits)
+// All four kernels give a thread a FIXED group of 8 (bf16) / 4 (f32) consecutive channels and let it walk rows: the
+// per-channel constants are loop invariant registers, every access is one 16-byte vector, and several independent rows are
+// in flight per thread.  block = CG channel groups x (256 / CG) row lanes, CG = min(C / VEC, 32): a wave reads whole
+// 128..512-byte row pieces.  C % 64 == 0 in every ResNet layer (64 .. 1024); other C take VEC = 4 / scalar-free paths below.
+constexpr int BN_BLOCKS = 2048;          // workgroups a statistics pass aims for (channel blocks x row splits)
+template <typename T> struct BnVec { static constexpr int N = 16 / sizeof(T); };
+template <typename T, int N> __device__ __forceinline__ void ldv(const T* p, float (&v)[N]) {
+    if constexpr (sizeof(T) == 2) {
+        const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = (float)t[j];
+    } else {
+        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = t[j];
+    }
+}
+template <typename T, int N> __device__ __forceinline__ void stv(T* p, const float (&v)[N]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8_t t;
+#pragma unroll
+        for (int j = 0; j < N; ++j) t[j] = (bf16_t)v[j];
+        *reinterpret_cast<bf16x8_t*>(p) = t;
+    } else {
+        *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
+    }
+}
+// thread -> (channel group, row lane) of a block that spans `cgb` channel groups
+struct BnMap { int cg, rl, lanes; };
+__device__ __forceinline__ BnMap bn_map(int cgb) { return BnMap{(int)threadIdx.x % cgb, (int)threadIdx.x / cgb, 256 / cgb}; }
+inline int bn_cgb(int C, int vec) { const int g = C / vec; return g >= 32 ? 32 : (g >= 16 ? 16 : (g >= 8 ? 8 : (g >= 4 ? 4 : (g >= 2 ? 2 : 1)))); }
+
+// MODE 0: sums of (x - pivot, (x - pivot)^2), pivot = row 0 (var = E[(x-p)^2] - E[x-p]^2 does not cancel catastrophically when
+// |mean| >> std).  MODE 1: sums of (dy', dy' * (x - mean)) for the backward pass (dy' = dy where the ReLU passed).
+// grid (channel blocks, row splits); part[split][2][C].
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
-                                                         const float* __restrict__ sums, int R, int C, float eps, int relu,
+                                                         const float* __restrict__ sums, int R, int C, int cgb, int relu,
                                                          float* __restrict__ part) {
-    __shared__ float red[2][16][64];
-    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int col = blockIdx.x * 64 + cg * 4;
+    constexpr int V = BnVec<T>::N;
+    __shared__ float red[2][256 * V];
+    const BnMap m = bn_map(cgb);
+    const int col = (blockIdx.x * cgb + m.cg) * V;
     const int rows_per = (R + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
-    f32x4_t s0 = f32x4_t{0, 0, 0, 0}, s1 = f32x4_t{0, 0, 0, 0};
-    if (col < C) {
-        f32x4_t mean = f32x4_t{0, 0, 0, 0}, rstd = f32x4_t{0, 0, 0, 0};
-        if (MODE == 1) {
+    float s0[V], s1[V], ref[V];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mean[j] = sums[col + j];
-                rstd[j] = rsqrtf(sums[C + col + j] + eps);
-            }
+    for (int j = 0; j < V; ++j) s0[j] = s1[j] = ref[j] = 0.f;
+    const bool live = col < C;
+    if (live) {
+        if (MODE == 0) ldv<T, V>(a + col, ref);
+        else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) ref[j] = sums[col + j];
         }
-        // MODE 0 accumulates around a per-channel pivot (row 0) so that var = E[(x-p)^2] - E[x-p]^2 does not
-        // cancel catastrophically when |mean| >> std
-        const f32x4_t pivot = (MODE == 0) ? ld4<T>(a + col) : f32x4_t{0, 0, 0, 0};
-        for (int r = r0 + rl; r < r1; r += 16) {
-            const long o = (long)r * C + col;
-            if (MODE == 0) {
-                const f32x4_t v = ld4<T>(a + o) - pivot;
-                s0 = s0 + v;
-                s1 = s1 + v * v;
-            } else {
-                f32x4_t g = ld4<T>(a + o);
-                if (relu) {
-                    const f32x4_t yv = ld4<T>(y + o);
+        constexpr int UN = 4;
+        int r = r0 + m.rl;
+        for (; r + (UN - 1) * m.lanes < r1; r += UN * m.lanes) {
+            float av[UN][V], yv[UN][V], xv[UN][V];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (!(yv[j] > 0.f)) g[j] = 0.f;
+            for (int u = 0; u < UN; ++u) {
+                const long o = (long)(r + u * m.lanes) * C + col;
+                ldv<T, V>(a + o, av[u]);
+                if (MODE == 1) {
+                    ldv<T, V>(x + o, xv[u]);
+                    if (relu) ldv<T, V>(y + o, yv[u]);
                 }
-                s0 = s0 + g;
-                s1 = s1 + g * (ld4<T>(x + o) - mean) * rstd;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    if (MODE == 0) {
+                        const float d = av[u][j] - ref[j];
+                        s0[j] += d;
+                        s1[j] = fmaf(d, d, s1[j]);
+                    } else {
+                        const float g = (relu && !(yv[u][j] > 0.f)) ? 0.f : av[u][j];
+                        s0[j] += g;
+                        s1[j] = fmaf(g, xv[u][j] - ref[j], s1[j]);
+                    }
+                }
+        }
+        for (; r < r1; r += m.lanes) {
+            float av[V], yv[V], xv[V];
+            const long o = (long)r * C + col;
+            ldv<T, V>(a + o, av);
+            if (MODE == 1) {
+                ldv<T, V>(x + o, xv);
+                if (relu) ldv<T, V>(y + o, yv);
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                if (MODE == 0) {
+                    const float d = av[j] - ref[j];
+                    s0[j] += d;
+                    s1[j] = fmaf(d, d, s1[j]);
+                } else {
+                    const float g = (relu && !(yv[j] > 0.f)) ? 0.f : av[j];
+                    s0[j] += g;
+                    s1[j] = fmaf(g, xv[j] - ref[j], s1[j]);
+                }
             }
         }
     }
+    // fold the row lanes: red[w][rl][cg][j]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { red[0][rl][cg * 4 + j] = s0[j]; red[1][rl][cg * 4 + j] = s1[j]; }
+    for (int j = 0; j < V; ++j) {
+        red[0][(m.rl * cgb + m.cg) * V + j] = s0[j];
+        red[1][(m.rl * cgb + m.cg) * V + j] = s1[j];
+    }
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int w = threadIdx.x >> 6, c = threadIdx.x & 63;
-        if (blockIdx.x * 64 + c < C) {
+    const int ncol = cgb * V;                               // channels of this block
+    for (int i = threadIdx.x; i < 2 * ncol; i += 256) {
+        const int w = i / ncol, c = i % ncol;
+        if (blockIdx.x * ncol + c < C) {
             float t = 0.f;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) t += red[w][k][c];
-            part[(long)blockIdx.y * 2 * C + w * C + blockIdx.x * 64 + c] = t;
+            for (int k = 0; k < m.lanes; ++k) t += red[w][k * ncol + c];
+            part[(long)blockIdx.y * 2 * C + w * C + blockIdx.x * ncol + c] = t;
         }
     }
 }
-__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ part, int splits, int C2, float* __restrict__ out) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
+// Finishing passes: block = 16 columns x 16 split lanes (the partials of a column are 2 C floats apart: 16 independent
+// loads per thread and round trip).
+// backward: dsums = {sum dy', sum dy' * xhat}: the second partial carries (x - mean), rstd is applied here
+__global__ __launch_bounds__(256) void bn_finish_kernel(const float* __restrict__ part, int splits, int C, const float* __restrict__ sums,
+                                                        float eps, float* __restrict__ out) {
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;                   // over 2 C
     float s = 0.f;
-    if (col < C2) {
-#pragma unroll 4
-        for (int k = sl; k < splits; k += 4) s += part[(long)k * C2 + col];
+    if (col < 2 * C) {
+#pragma unroll 8
+        for (int k = sl; k < splits; k += 16) s += part[(long)k * 2 * C + col];
     }
     red[sl][cl] = s;
     __syncthreads();
-    if (sl == 0 && col < C2) out[col] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+    if (sl == 0 && col < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
+        out[col] = col < C ? t : t * rsqrtf(sums[col] + eps);        // sums[C + c] = variance of channel c
+    }
 }
 
 // forward statistics: shifted partial sums -> {mean, biased variance}
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __restrict__ part, int splits, int C, int R, const T* __restrict__ x,
                                                               float* __restrict__ out) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
+    __shared__ float red[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f;
     if (col < C) {
-#pragma unroll 4
-        for (int k = sl; k < splits; k += 4) { s0 += part[(long)k * 2 * C + col]; s1 += part[(long)k * 2 * C + C + col]; }
+#pragma unroll 8
+        for (int k = sl; k < splits; k += 16) { s0 += part[(long)k * 2 * C + col]; s1 += part[(long)k * 2 * C + C + col]; }
     }
     red[0][sl][cl] = s0; red[1][sl][cl] = s1;
     __syncthreads();
     if (sl == 0 && col < C) {
-        const float t0 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        const float t1 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { t0 += red[0][k][cl]; t1 += red[1][k][cl]; }
         const float m = t0 / R;
         out[col] = to_f32(x[col]) + m;
         out[C + col] = fmaxf(t1 / R - m * m, 0.f);
     }
 }
 
+// y = relu?((x - mean) rstd gamma + beta (+ residual)) = x * sc + sh (+ residual); grid (channel blocks, row splits)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual, T* __restrict__ y,
-                                                       float* __restrict__ running_mean, float* __restrict__ running_var, int R, int C,
-                                                       float eps, float momentum, int relu, int training) {
-    const int cv = C / 4;
-    const long total = (long)R * cv;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * 4;
-        const long o = (i / cv) * C + c;
-        const f32x4_t xv = ld4<T>(x + o);
-        f32x4_t out;
+                                                       const float* __restrict__ running_mean, const float* __restrict__ running_var, int R, int C,
+                                                       int cgb, float eps, int relu, int training) {
+    constexpr int V = BnVec<T>::N;
+    const BnMap m = bn_map(cgb);
+    const int col = (blockIdx.x * cgb + m.cg) * V;
+    if (col >= C) return;
+    float sc[V], sh[V];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float mean, var;
-            if (training) {
-                mean = sums[c + j];
-                var = sums[C + c + j];
-            } else {
-                mean = running_mean[c + j];
-                var = running_var[c + j];
+    for (int j = 0; j < V; ++j) {
+        const float mean = training ? sums[col + j] : running_mean[col + j];
+        const float var = training ? sums[C + col + j] : running_var[col + j];
+        sc[j] = rsqrtf(var + eps) * gamma[col + j];
+        sh[j] = beta[col + j] - mean * sc[j];
+    }
+    const int step = m.lanes * gridDim.y;
+    constexpr int UN = 4;
+    int r = blockIdx.y * m.lanes + m.rl;
+    for (; r + (UN - 1) * step < R; r += UN * step) {
+        float xv[UN][V], rv[UN][V];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const long o = (long)(r + u * step) * C + col;
+            ldv<T, V>(x + o, xv[u]);
+            if (residual) ldv<T, V>(residual + o, rv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                float o = fmaf(xv[u][j], sc[j], sh[j]);
+                if (residual) o += rv[u][j];
+                xv[u][j] = relu ? fmaxf(o, 0.f) : o;
             }
-            out[j] = (xv[j] - mean) * rsqrtf(var + eps) * gamma[c + j] + beta[c + j];
+            stv<T, V>(y + (long)(r + u * step) * C + col, xv[u]);
         }
-        if (residual) out = out + ld4<T>(residual + o);
-        if (relu) {
+    }
+    for (; r < R; r += step) {
+        float xv[V], rv[V];
+        const long o = (long)r * C + col;
+        ldv<T, V>(x + o, xv);
+        if (residual) ldv<T, V>(residual + o, rv);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) out[j] = fmaxf(out[j], 0.f);
+        for (int j = 0; j < V; ++j) {
+            float t = fmaf(xv[j], sc[j], sh[j]);
+            if (residual) t += rv[j];
+            xv[j] = relu ? fmaxf(t, 0.f) : t;
         }
-        st4<T>(y + o, out);
+        stv<T, V>(y + o, xv);
     }
 }
 // running stats update, separate launch so the apply kernel never races with it
@@ -253,38 +390,67 @@ __global__ void bn_running_kernel(const float* __restrict__ sums, float* __restr
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
 }
 
+// dx = gamma rstd (g - sum(g)/R - xhat sum(g xhat)/R) = k g + kx x + k0 with per-channel constants; dresidual = g
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                                            const float* __restrict__ sums, const float* __restrict__ dsums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, T* __restrict__ dresidual,
-                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C, float eps,
-                                                           int relu) {
-    const int cv = C / 4;
-    const long total = (long)R * cv;
-    const float invR = 1.f / R;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % cv) * 4;
-        const long o = (i / cv) * C + c;
-        f32x4_t g = ld4<T>(dy + o);
-        if (relu) {
-            const f32x4_t yv = ld4<T>(y + o);
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C, int cgb,
+                                                           float eps, int relu) {
+    constexpr int V = BnVec<T>::N;
+    const BnMap m = bn_map(cgb);
+    const int col = (blockIdx.x * cgb + m.cg) * V;
+    if (col < C) {
+        const float invR = 1.f / R;
+        float k[V], kx[V], k0[V];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (!(yv[j] > 0.f)) g[j] = 0.f;
+        for (int j = 0; j < V; ++j) {
+            const float mean = sums[col + j], rstd = rsqrtf(sums[C + col + j] + eps);
+            k[j] = gamma[col + j] * rstd;
+            kx[j] = -k[j] * rstd * dsums[C + col + j] * invR;
+            k0[j] = -k[j] * dsums[col + j] * invR - kx[j] * mean;
         }
-        const f32x4_t xv = ld4<T>(x + o);
-        f32x4_t out;
+        const int step = m.lanes * gridDim.y;
+        constexpr int UN = 2;
+        int r = blockIdx.y * m.lanes + m.rl;
+        for (; r + (UN - 1) * step < R; r += UN * step) {
+            float g[UN][V], yv[UN][V], xv[UN][V];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float mean = sums[c + j];
-            const float rstd = rsqrtf(sums[C + c + j] + eps);
-            const float xh = (xv[j] - mean) * rstd;
-            out[j] = gamma[c + j] * rstd * (g[j] - dsums[c + j] * invR - xh * dsums[C + c + j] * invR);
+            for (int u = 0; u < UN; ++u) {
+                const long o = (long)(r + u * step) * C + col;
+                ldv<T, V>(dy + o, g[u]);
+                ldv<T, V>(x + o, xv[u]);
+                if (relu) ldv<T, V>(y + o, yv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const long o = (long)(r + u * step) * C + col;
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    if (relu && !(yv[u][j] > 0.f)) g[u][j] = 0.f;
+                    xv[u][j] = fmaf(k[j], g[u][j], fmaf(kx[j], xv[u][j], k0[j]));
+                }
+                stv<T, V>(dx + o, xv[u]);
+                if (dresidual) stv<T, V>(dresidual + o, g[u]);
+            }
         }
-        st4<T>(dx + o, out);
-        if (dresidual) st4<T>(dresidual + o, g);
+        for (; r < R; r += step) {
+            float g[V], yv[V], xv[V];
+            const long o = (long)r * C + col;
+            ldv<T, V>(dy + o, g);
+            ldv<T, V>(x + o, xv);
+            if (relu) ldv<T, V>(y + o, yv);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                if (relu && !(yv[j] > 0.f)) g[j] = 0.f;
+                xv[j] = fmaf(k[j], g[j], fmaf(kx[j], xv[j], k0[j]));
+            }
+            stv<T, V>(dx + o, xv);
+            if (dresidual) stv<T, V>(dresidual + o, g);
+        }
     }
     // parameter gradients: dbeta = sum dy', dgamma = sum dy'*xhat (accumulate into the f32 arena)
-    if (blockIdx.x == 0 && dgamma != nullptr)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma != nullptr)
         for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] += dsums[c]; dgamma[c] += dsums[C + c]; }
 }
 
@@ -512,23 +678,30 @@ __global__ __launch_bounds__(256) void amazon_gather_bwd_kernel(const T* __restr
 
 extern "C" int mmsum_im2col(int dtype, const void* x, void* col, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
                             int Ho, int Wo, int Kpad, void* stream) {
-    if (N <= 0 || Kpad < KH * KW * C) return MMSUM_ERR_BAD_SHAPE;
+    const int ev = dtype == MMSUM_BF16 ? 8 : 4;
+    if (N <= 0 || Kpad < KH * KW * C || Kpad % ev) return MMSUM_ERR_BAD_SHAPE;
+    if (((uintptr_t)x | (uintptr_t)col) & 15) return MMSUM_ERR_BAD_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const bool v4 = (C % 4 == 0);
-    const long items = (long)N * Ho * Wo * KH * KW * (v4 ? C / 4 : C);
-    const dim3 grid(grid_for(items, 256)), block(256);
-    if (v4) DT_SWITCH(dtype, (im2col_kernel<bf16_t, 4><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
-                      (im2col_kernel<float, 4><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
-    else DT_SWITCH(dtype, (im2col_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
-                   (im2col_kernel<float, 1><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
+    const dim3 block(256);
+    if (C % ev == 0) {
+        const dim3 grid(grid_for((long)N * Ho * Wo * KH * KW * (C / ev), 256, 16384));
+        DT_SWITCH(dtype, (im2col_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
+                  (im2col_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
+    } else {
+        const dim3 grid(grid_for((long)N * Ho * Wo * (Kpad / ev), 256, 16384));
+        DT_SWITCH(dtype, (im2col_few_channels_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
+                  (im2col_few_channels_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
+    }
     return ok();
 }
 
 extern "C" int mmsum_col2im(int dtype, const void* dcol, void* dx, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
                             int Ho, int Wo, int Kpad, void* stream) {
-    if (N <= 0 || C % 4) return MMSUM_ERR_BAD_SHAPE;
+    const int ev = dtype == MMSUM_BF16 ? 8 : 4;
+    if (N <= 0 || C % ev || Kpad % ev) return MMSUM_ERR_BAD_SHAPE;
+    if (((uintptr_t)dcol | (uintptr_t)dx) & 15) return MMSUM_ERR_BAD_ALIGN;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for((long)N * H * W * C / 4, 256)), block(256);
+    const dim3 grid(grid_for((long)N * H * W * C / ev, 256, 16384)), block(256);
     DT_SWITCH(dtype, (col2im_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dcol, (bf16_t*)dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
               (col2im_kernel<float><<<grid, block, 0, s>>>((const float*)dcol, (float*)dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
     return ok();
@@ -549,29 +722,51 @@ extern "C" int mmsum_conv_weight_permute(int dtype, void* matrix, float* weight,
     return ok();
 }
 
-extern "C" long mmsum_bn_workspace(int C) { return (long)BN_SPLITS * 2 * C * sizeof(float); }
+// splits * C <= BN_BLOCKS * (channels of one block = 32 groups x 8): partial sums of both statistics
+extern "C" long mmsum_bn_workspace(int C) { return (long)2 * sizeof(float) * ((long)BN_BLOCKS * 256 + 2L * C); }
+
+// grid.y of the streaming kernels: enough row blocks to fill the chip (about 8 workgroups per CU) while a thread still
+// walks >= 16 rows (its per-channel constants cost ~40 instructions to set up)
+inline int bn_row_blocks(int R, int lanes, int col_blocks) {
+    int want = (BN_BLOCKS + col_blocks - 1) / col_blocks;
+    const int most = (R + lanes * 16 - 1) / (lanes * 16);
+    if (want > most) want = most;
+    return want < 1 ? 1 : want;
+}
+// row splits of the statistics passes: BN_BLOCKS workgroups in all, at least 4 rows per row lane
+inline int bn_splits(int R, int lanes, int col_blocks) {
+    int want = (BN_BLOCKS / 2 + col_blocks - 1) / col_blocks;
+    if (want > 512) want = 512;                             // the finishing pass walks the splits
+    const int most = (R + lanes * 4 - 1) / (lanes * 4);
+    if (want > most) want = most;
+    return want < 1 ? 1 : want;
+}
 
 extern "C" int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, void* stream) {
-    if (R <= 0 || C <= 0) return MMSUM_ERR_BAD_SHAPE;
+    const int vec = dtype == MMSUM_BF16 ? 8 : 4;
+    if (R <= 0 || C <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int splits = R < BN_SPLITS * 16 ? max(1, R / 16) : BN_SPLITS;
-    const dim3 grid((C + 63) / 64, splits), block(256);
+    const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
+    const int splits = bn_splits(R, 256 / cgb, cblocks);
+    const dim3 grid(cblocks, splits), block(256);
     float* part = (float*)workspace;
-    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 0><<<grid, block, 0, s>>>((const bf16_t*)x, nullptr, nullptr, nullptr, R, C, 0.f, 0, part)),
-              (bn_partial_kernel<float, 0><<<grid, block, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, R, C, 0.f, 0, part)));
-    DT_SWITCH(dtype, (bn_stats_finish_kernel<bf16_t><<<dim3((C + 63) / 64), dim3(256), 0, s>>>(part, splits, C, R, (const bf16_t*)x, sums)),
-              (bn_stats_finish_kernel<float><<<dim3((C + 63) / 64), dim3(256), 0, s>>>(part, splits, C, R, (const float*)x, sums)));
+    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 0><<<grid, block, 0, s>>>((const bf16_t*)x, nullptr, nullptr, nullptr, R, C, cgb, 0, part)),
+              (bn_partial_kernel<float, 0><<<grid, block, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, R, C, cgb, 0, part)));
+    DT_SWITCH(dtype, (bn_stats_finish_kernel<bf16_t><<<dim3((C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, R, (const bf16_t*)x, sums)),
+              (bn_stats_finish_kernel<float><<<dim3((C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, R, (const float*)x, sums)));
     return ok();
 }
 
 extern "C" int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gamma, const float* beta, const void* residual,
                               void* y, float* running_mean, float* running_var, int R, int C, float eps, float momentum, int relu,
                               int training, void* stream) {
-    if (R <= 0 || C % 4) return MMSUM_ERR_BAD_SHAPE;
+    const int vec = dtype == MMSUM_BF16 ? 8 : 4;
+    if (R <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for((long)R * C / 4, 256)), block(256);
-    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, eps, momentum, relu, training)),
-              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, eps, momentum, relu, training)));
+    const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
+    const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
+    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, relu, training)),
+              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, relu, training)));
     if (training && running_mean && running_var)
         bn_running_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sums, running_mean, running_var, R, C, momentum);
     return ok();
@@ -579,25 +774,29 @@ extern "C" int mmsum_bn_apply(int dtype, const void* x, const float* sums, const
 
 extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* sums, int R, int C, float eps,
                                    int relu, float* dsums, void* workspace, void* stream) {
-    if (R <= 0 || C <= 0) return MMSUM_ERR_BAD_SHAPE;
+    const int vec = dtype == MMSUM_BF16 ? 8 : 4;
+    if (R <= 0 || C <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int splits = R < BN_SPLITS * 16 ? max(1, R / 16) : BN_SPLITS;
-    const dim3 grid((C + 63) / 64, splits), block(256);
+    const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
+    const int splits = bn_splits(R, 256 / cgb, cblocks);
+    const dim3 grid(cblocks, splits), block(256);
     float* part = (float*)workspace;
-    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, eps, relu, part)),
-              (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, eps, relu, part)));
-    bn_finish_kernel<<<dim3((2 * C + 63) / 64), dim3(256), 0, s>>>(part, splits, 2 * C, dsums);
+    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part)),
+              (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part)));
+    bn_finish_kernel<<<dim3((2 * C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, sums, eps, dsums);
     return ok();
 }
 
 extern "C" int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
                                   const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C, float eps,
                                   int relu, void* stream) {
-    if (R <= 0 || C % 4) return MMSUM_ERR_BAD_SHAPE;
+    const int vec = dtype == MMSUM_BF16 ? 8 : 4;
+    if (R <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(grid_for((long)R * C / 4, 256)), block(256);
-    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, eps, relu)),
-              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, eps, relu)));
+    const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
+    const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
+    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu)),
+              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu)));
     return ok();
 }
 
