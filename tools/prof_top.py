@@ -3,6 +3,8 @@
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = float(sys.argv[2])
+if n <= 0:        # 0 = count the steps: one adamw_kernel launch per optimizer step
+    n = float(sum(int(r["Calls"]) for r in rows if "adamw_kernel" in r["Name"]) or 1)
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 tot = sum(int(r['TotalDurationNs']) for r in rows)
 print("total %.2f ms/step" % (tot / n / 1e6))
