@@ -486,7 +486,7 @@ __global__ void segment_sum_kernel(const float* __restrict__ x, float* __restric
 // --------------------------------------------------------------------------------------------
 // Column sums: grid (C/64 column groups, row splits); partials in workspace, then a finish pass.
 // --------------------------------------------------------------------------------------------
-constexpr int CS_SPLITS = 64;
+constexpr int CS_SPLITS = 256;           // most row splits of a column-sum pass (workspace = CS_SPLITS x C floats)
 // block = 16 column groups (4 columns each, one 8/16-byte load) x 16 row lanes; grid (C/64, splits)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ X, long ld, int R, int C, float* __restrict__ part,
@@ -514,20 +514,60 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
         part[(long)blockIdx.y * C + blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
-// block = 64 columns x 4 split lanes: the serial dependent-load chain of the naive finish is 16x shorter
+// bf16 with 16-byte addressable rows: block = 16 column groups (8 columns, one 16-byte load) x 16 row lanes, four rows in
+// flight per thread; grid (C/128, splits)
+__global__ __launch_bounds__(256) void colsum_partial_wide_kernel(const bf16_t* __restrict__ X, long ld, int R, int C, float* __restrict__ part,
+                                                                  const int* __restrict__ live) {
+    R = live_rows_of(R, live);
+    __shared__ float red[16][128];
+    const int cg = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 128 + cg * 8;
+    const int rows_per = (R + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (col < C) {                                           // C % 8 == 0 on this path
+        int r = r0 + rl;
+        for (; r + 48 < r1; r += 64) {
+            bf16x8_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8_t*>(X + (long)(r + 16 * u) * ld + col);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += (float)v[u][j];
+        }
+        for (; r < r1; r += 16) {
+            const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(X + (long)r * ld + col);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][cg * 8 + j] = s[j];
+    __syncthreads();
+    if (threadIdx.x < 128 && blockIdx.x * 128 + threadIdx.x < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+        part[(long)blockIdx.y * C + blockIdx.x * 128 + threadIdx.x] = t;
+    }
+}
+// block = 16 columns x 16 split lanes: 16 independent loads per thread and round trip
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int splits, int C, float* __restrict__ out, int accumulate) {
-    __shared__ float red[4][64];
-    const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
+    __shared__ float red[16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int col = blockIdx.x * 16 + cl;
     float s = 0.f;
     if (col < C) {
-#pragma unroll 4
-        for (int k = sl; k < splits; k += 4) s += part[(long)k * C + col];
+#pragma unroll 8
+        for (int k = sl; k < splits; k += 16) s += part[(long)k * C + col];
     }
     red[sl][cl] = s;
     __syncthreads();
     if (sl == 0 && col < C) {
-        const float t = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][cl];
         out[col] = accumulate ? out[col] + t : t;
     }
 }
@@ -790,13 +830,20 @@ extern "C" int mmsum_colsum(int dtype, const void* X, long ld, int R, int C, flo
                             const int* live_rows, void* stream) {
     if (R <= 0 || C <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    const int splits = R < CS_SPLITS * 16 ? max(1, R / 16) : CS_SPLITS;
-    const dim3 grid((C + 63) / 64, splits);
     float* part = (float*)workspace;
-    if (dtype == MMSUM_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ld, R, C, part, live_rows);
+    const bool wide = dtype == MMSUM_BF16 && C % 8 == 0 && ((uintptr_t)X & 15) == 0 && (ld * 2) % 16 == 0;
+    // about 2048 workgroups in all, at least 64 rows per split
+    const int cblocks = wide ? (C + 127) / 128 : (C + 63) / 64;
+    int splits = (2048 + cblocks - 1) / cblocks;
+    if (splits > CS_SPLITS) splits = CS_SPLITS;
+    if (splits > (R + 63) / 64) splits = (R + 63) / 64;
+    if (splits < 1) splits = 1;
+    const dim3 grid(cblocks, splits);
+    if (wide) hipLaunchKernelGGL(colsum_partial_wide_kernel, grid, dim3(256), 0, s, (const bf16_t*)X, ld, R, C, part, live_rows);
+    else if (dtype == MMSUM_BF16) hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ld, R, C, part, live_rows);
     else if (dtype == MMSUM_F32) hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ld, R, C, part, live_rows);
     else return MMSUM_ERR_BAD_DTYPE;
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 63) / 64), dim3(256), 0, s, part, splits, C, out, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((C + 15) / 16), dim3(256), 0, s, part, splits, C, out, accumulate);
     return ok();
 }
 

@@ -11,7 +11,7 @@ groups = {}
 for r in rows:
     nm = r['Name']
     key = ('gemm_fast' if ('gemm_nt_' in nm or 'gemm_tn_' in nm) else 'gemm_skinny' if 'gemm_skinny' in nm else 'rows_gather' if 'rows_gather' in nm else 'slab_reduce' if 'slab_reduce' in nm else 'gemm_generic' if 'gemm_kernel' in nm else 'attn_fwd' if ('attn_fwd' in nm or 'attn_tr_fwd' in nm)
-           else 'attn_dq' if 'attn_bwd_dq' in nm else 'attn_dkv' if 'attn_bwd_dkv' in nm else 'transpose' if 'transpose' in nm
+           else 'attn_dq' if 'bwd_dq' in nm else 'attn_dkv' if 'bwd_dkv' in nm else 'transpose' if 'transpose' in nm
            else 'bn' if 'bn_' in nm else 'im2col_col2im' if ('im2col' in nm or 'col2im' in nm) else 'colsum' if 'colsum' in nm else 'ln' if '_ln_' in nm else 'adamw' if 'adamw' in nm
            else 'loss' if 'ls_loss' in nm else 'torch' if ('at::native' in nm or 'rocclr' in nm) else 'other')
     groups[key] = groups.get(key, 0) + int(r['TotalDurationNs'])
