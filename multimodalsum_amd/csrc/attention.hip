@@ -1779,19 +1779,20 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     }
 }
 
-// dK / dV: one workgroup = (entity, head); a wave owns 32-key blocks (their K / V fragments stay in registers as B
-// operands) and sweeps the query chunks that attend to the entity; chunks are double-buffered like the entities above.
+// dK / dV: one workgroup = (entity, head, round of four key blocks); a wave owns one 32-key block (its K / V fragments stay in
+// registers as B operands) and sweeps the query chunks that attend to the entity; chunks are double-buffered like the entities above.
 // Per score: p = 2^(s c2 - lse), P' = p / count (0 on this lane's key if it is masked), dS = P' (dP scale - delta').
 // Query rows past T are zero rows of the staged Q and dO, so they add nothing whatever P' is; a wave whose key block
 // holds only masked keys skips the arithmetic altogether.
 template <int NKB, bool CAUSAL>
-__global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
                                                                                        bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv,
                                                                                        const float* __restrict__ stats) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TQ = 64;
-    constexpr int NOWN = (NKB + 3) / 4;
+    constexpr int NOWN = 1;                                  // one key block per wave; entities of more than 128 keys take gridDim.z rounds of four blocks
+    const int kb0 = blockIdx.z * 4;
     constexpr int QT_TILE = TQ * HD * 2;
     constexpr int STAGE = 2 * QT_TILE + 2 * TQ * 4;
 
@@ -1815,7 +1816,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
     f32x16_t dkacc[NOWN][2], dvacc[NOWN][2];
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
-        const int key = (wave + 4 * o) * 32 + (lane & 31);
+        const int key = (kb0 + wave + 4 * o) * 32 + (lane & 31);
         const bool kvalid = key < d.S;
         const bool masked = !kvalid || (d.pad && d.pad[ent * d.S + (kvalid ? key : 0)]);
         keep[o] = masked ? 0.f : 1.f;
@@ -1872,7 +1873,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
         if (more) prefetch(it + 1);
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
-            const int kb = wave + 4 * o;
+            const int kb = kb0 + wave + 4 * o;
             if (kb >= NKB || !alive[o]) continue;
             const int key = kb * 32 + (lane & 31);
             const float icl = keep[o] * inv_cnt;
@@ -1920,7 +1921,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dkv
     float* stg = reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES);
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
-        const int kb = wave + 4 * o;
+        const int kb = kb0 + wave + 4 * o;
         if (kb >= NKB) continue;
         flush_tile_t(stg, dkacc[o], dK + (row0 + kb * 32) * lddk + h * HD, lddk, d.S - kb * 32, false, lane);
         flush_tile_t(stg, dvacc[o], dV + (row0 + kb * 32) * lddv + h * HD, lddv, d.S - kb * 32, false, lane);
@@ -2027,7 +2028,7 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         }
         {
             const int n_ent = (d.n_qblocks / d.qpb) * d.N;
-            const dim3 grid(d.H, n_ent), block(ATT_THREADS);
+            const dim3 grid(d.H, n_ent, (nkb + 3) / 4), block(ATT_THREADS);
             const size_t lds = 4 * (size_t)OUT_STAGE_BYTES;          // >= two stages of 2 x 8 KiB tiles + statistics
             LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
         }
