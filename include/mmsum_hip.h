@@ -142,6 +142,13 @@ typedef struct {
     int n_qblocks, T, qpb, N, S, H;
     int exclude_self, causal;
     float scale;
+    /* Optional row maps (int32, device memory; bf16 only).  With a map the padded layouts above are LOGICAL: the matrices hold
+     * only the rows that exist (the padding-free encoder's [live rows, 3D] q/k/v; the compacted memory's K/V), in any order.
+     *   q_rows [n_qblocks*T]: physical row of q / out (and of dout / dq in the backward pass) of logical query row qb*T + t, or -1;
+     *   kv_rows [B*N*S]: physical row of k / v (dk / dv) of logical key row (b*N+n)*S + s, or -1.
+     * A missing query row reads as zeros and is never written.  A missing key row must be a masked key (pad != 0); its dk / dv
+     * rows do not exist.  Physical row * row pitch must stay below 2 GiB.  NULL = identity (the padded layout itself). */
+    const int* q_rows; const int* kv_rows;
 } mmsum_attn_desc;
 int mmsum_entity_null(const uint8_t* pad, uint8_t* null_entity, int n_entities, int S, void* stream);
 int mmsum_attn_fwd(int dtype, const mmsum_attn_desc* d, void* stream);

@@ -31,7 +31,8 @@ class AttnDesc(ctypes.Structure):
                 ("ldq", c_long), ("ldk", c_long), ("ldv", c_long), ("ldo", c_long),
                 ("pad", c_void_p), ("null_entity", c_void_p),
                 ("n_qblocks", c_int), ("T", c_int), ("qpb", c_int), ("N", c_int), ("S", c_int), ("H", c_int),
-                ("exclude_self", c_int), ("causal", c_int), ("scale", c_float)]
+                ("exclude_self", c_int), ("causal", c_int), ("scale", c_float),
+                ("q_rows", c_void_p), ("kv_rows", c_void_p)]
 
 
 # name -> (restype, argtypes); mirrors include/mmsum_hip.h one to one

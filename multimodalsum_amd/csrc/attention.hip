@@ -1150,6 +1150,12 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
+// Physical row of logical row i through an optional map; -1 = the row does not exist (or `valid` is false).
+__device__ __forceinline__ long phys_row(const int* map, long i, bool valid) {
+    if (!valid) return -1;
+    return map ? (long)map[i] : i;
+}
+
 struct TrOff { int o0, o1; };
 // Lane 4q+p of a 16-lane group supplies the address of row q, columns 4p..4p+3 of the group's 4 x 16 block; the groups of a
 // wave cover d-halves (lane >> 4) & 1 and reduction-row halves lane >> 5.  o0 / o1: the two reads of one 16-deep step.
@@ -1183,12 +1189,17 @@ __device__ __forceinline__ void mfma16(f32x16_t& acc, const bf16x8_t a, const bf
 // A wave's TRANSPOSED 64 x 32 result (acc[db][reg]: row = column db*32 + acc_row(reg) of the output, lane & 31 = output
 // row) written as `nrows` rows of 64 elements: the registers of a lane hold four consecutive output columns at a time, so
 // the staging pass is eight 16-byte LDS stores, and the row pass is flush_tile's.
-__device__ __forceinline__ void flush_tile_t(float* stg, const f32x16_t (&acc)[2], bf16_t* g, long ld, int nrows, bool accumulate, int lane) {
+// g = column-offset matrix base; the wave's rows are logical rows row0 .. row0 + nrows - 1, physical rows through `map`
+// (NULL = identity; -1 = the row does not exist and is skipped).
+__device__ __forceinline__ void flush_tile_t(float* stg, const f32x16_t (&acc)[2], bf16_t* g, long ld, long row0, const int* map, int nrows,
+                                             bool accumulate, int lane) {
     if (nrows <= 0) return;                                    // wave-uniform
     const bool vec = ((((uintptr_t)g) | (uintptr_t)(ld * 2)) & 15) == 0;
     const int row = lane >> 1, half = lane & 1;
-    const bool mine = row < nrows;
-    bf16_t* o = g + (long)row * ld + half * 32;
+    long prow = row0 + row;
+    if (map != nullptr) prow = row < nrows ? (long)map[row0 + row] : -1;
+    const bool mine = row < nrows && prow >= 0;
+    bf16_t* o = g + (mine ? prow : 0) * ld + half * 32;
     u32x4_t prev[4];
     if (vec && accumulate && mine) {
 #pragma unroll
@@ -1262,22 +1273,45 @@ __device__ __forceinline__ void read_key_mask(const int* slots, int& extent, int
 }
 
 // A ROWS x 64 bf16 tile requested into registers with bounds-checked buffer loads and committed to LDS in the k-slab
-// layout later (same image as NatTile).  The descriptor covers exactly the `rows` valid rows of the tile, so rows past
-// them read as zeros in hardware: no per-load compare / select, and the per-thread offset is loop invariant (the step
-// between a thread's rows is a scalar offset).  THREADS / 8 rows per pass.
+// layout later (same image as NatTile).  Without a row map the descriptor covers exactly the `rows` valid rows of the tile,
+// so rows past them read as zeros in hardware: no per-load compare / select, and the per-thread offset is loop invariant (the
+// step between a thread's rows is a scalar offset).  With a row map (compact matrices) the descriptor covers the matrix and
+// every pass takes its physical row from RowIdx -- looked up one tile AHEAD, so the tile's loads do not wait for the map --
+// with an out-of-range offset for rows that do not exist.  THREADS / 8 rows per pass.
+template <int ROWS>
+struct RowIdx {
+    static constexpr int NIT = ROWS * 8 / ATT_THREADS;
+    int v[NIT];
+    // map + first = the tile's first logical row; rows = valid logical rows of the tile
+    __device__ __forceinline__ void load(const int* map, long first, int rows, int tid) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int lr = (tid >> 3) + it * (ATT_THREADS / 8);
+            v[it] = lr < rows ? map[first + lr] : -1;
+        }
+    }
+};
 template <int ROWS>
 struct BufTile {
     static constexpr int NIT = ROWS * 8 / ATT_THREADS;
     u32x4_t v[NIT];
-    // base: element (0, 0) of the tile; ld in elements
-    __device__ __forceinline__ void load(const bf16_t* base, long ld, int rows, int tid) {
+    // mat: the matrix, column offset applied; first: first logical row of the tile; ld in elements
+    __device__ __forceinline__ void load(const bf16_t* mat, long ld, long first, int rows, int tid) {
         const int r = rows > 0 ? rows : 0;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0,
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(mat + first * ld), 0,
                                                                                r > 0 ? (int)((r - 1) * ld * 2 + 128) : 0, 0x00020000);
         const int voff = (tid >> 3) * (int)(ld * 2) + (tid & 7) * 16;
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
             v[it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, it * (ATT_THREADS / 8) * (int)(ld * 2), 0));
+    }
+    __device__ __forceinline__ void load_mapped(const bf16_t* mat, long ld, const RowIdx<ROWS>& idx, int tid) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(mat), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int voff = idx.v[it] >= 0 ? idx.v[it] * (int)(ld * 2) + (tid & 7) * 16 : (int)0x80000000u;     // past the range: zeros
+            v[it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        }
     }
     __device__ __forceinline__ void commit(char* lds, int tid) const {
         const int r = tid >> 3, cc = tid & 7;
@@ -1378,7 +1412,7 @@ template <int NKB> struct TrStage {
     __device__ __forceinline__ int* slots() const { return reinterpret_cast<int*>(base + 2 * TILE + SPAD * 4); }
 };
 
-template <int NKB, bool CAUSAL>
+template <int NKB, bool CAUSAL, bool KVMAP>
 __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_kernel(mmsum_attn_desc d) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1402,23 +1436,29 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
     T* O = static_cast<T*>(d.out);
 
     const int qpos = wave * 32 + (lane & 31);
-    const bool qvalid = qpos < d.T;
     Frag qf[2];
     {
-        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
+        const long qr = phys_row(d.q_rows, (long)qb * d.T + qpos, qpos < d.T);
+        const T* qrow = Q + (qr >= 0 ? qr : 0) * d.ldq + h * HD;
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) qf[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid);
+        for (int sl = 0; sl < 2; ++sl) qf[sl] = global_frag<T>(qrow + sl * 32, lane, qr >= 0);
     }
     pin_frags(qf);
     f32x16_t oacc[2] = {zero_acc(), zero_acc()};
 
     BufTile<SPAD> kreg, vreg;
+    RowIdx<SPAD> kvidx;                                       // physical rows of the entity to request next (kv_rows only)
     uint8_t mreg = 1;
+    auto lookup = [&](int n) { kvidx.load(d.kv_rows, ((long)b * d.N + n) * d.S, d.S, tid); };
     auto prefetch = [&](int n) {
         const long ent = (long)b * d.N + n;
-        const long row0 = ent * d.S;
-        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
-        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
+        if constexpr (KVMAP) {
+            kreg.load_mapped(K + h * HD, d.ldk, kvidx, tid);
+            vreg.load_mapped(V + h * HD, d.ldv, kvidx, tid);
+        } else {
+            kreg.load(K + h * HD, d.ldk, ent * d.S, d.S, tid);
+            vreg.load(V + h * HD, d.ldv, ent * d.S, d.S, tid);
+        }
         mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
     };
     auto commit = [&](const Stage& st) {
@@ -1428,7 +1468,9 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
     };
     int cur = 0;
     if (rem) {
+        if constexpr (KVMAP) lookup(__builtin_ctz(rem));
         prefetch(__builtin_ctz(rem));
+        if constexpr (KVMAP) if (rem & (rem - 1)) lookup(__builtin_ctz(rem & (rem - 1)));
         commit(Stage{smem});
     }
     __syncthreads();
@@ -1437,7 +1479,10 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
         const Stage st{smem + cur * Stage::BYTES}, nx{smem + (cur ^ 1) * Stage::BYTES};
         int slen, fmask;
         read_key_mask(st.slots(), slen, fmask);
-        if (rem) prefetch(__builtin_ctz(rem));
+        if (rem) {
+            prefetch(__builtin_ctz(rem));
+            if constexpr (KVMAP) if (rem & (rem - 1)) lookup(__builtin_ctz(rem & (rem - 1)));     // one entity ahead of the loads that use it
+        }
         dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
             constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
             f32x16_t sacc[NKB];
@@ -1464,14 +1509,14 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
         __syncthreads();
         cur ^= 1;
     }
-    flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), oacc, O + ((long)qb * d.T + wave * 32) * d.ldo + h * HD, d.ldo,
+    flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), oacc, O + h * HD, d.ldo, (long)qb * d.T + wave * 32, d.q_rows,
                  d.T - wave * 32, false, lane);
 }
 
 // dQ (+ per-entity statistics for the dK/dV kernel: log-sum-exp in the log2 domain and delta' = scale * sum_k P dP, i.e.
 // delta * count * scale).  Per entity: scores and probabilities for all key blocks stay in registers; dP^T = V dO^T is formed
 // twice (once for delta, once for dS) instead of being kept, which is what lets two workgroups share a CU.
-template <int NKB, bool CAUSAL>
+template <int NKB, bool CAUSAL, bool KVMAP>
 __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
                                                                                       bf16_t* __restrict__ dQ, long lddq, int accumulate_dq,
                                                                                       float* __restrict__ stats) {
@@ -1499,12 +1544,13 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     const bool qvalid = qpos < d.T;
     Frag qf[2], dof[2];
     {
-        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
-        const T* drow = dO + ((long)qb * d.T + qpos) * lddo + h * HD;
+        const long qr = phys_row(d.q_rows, (long)qb * d.T + qpos, qvalid);
+        const T* qrow = Q + (qr >= 0 ? qr : 0) * d.ldq + h * HD;
+        const T* drow = dO + (qr >= 0 ? qr : 0) * lddo + h * HD;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            qf[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid);
-            dof[sl] = global_frag<T>(drow + sl * 32, lane, qvalid);
+            qf[sl] = global_frag<T>(qrow + sl * 32, lane, qr >= 0);
+            dof[sl] = global_frag<T>(drow + sl * 32, lane, qr >= 0);
         }
     }
     pin_frags(qf);
@@ -1512,13 +1558,19 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
 
     BufTile<SPAD> kreg, vreg;
+    RowIdx<SPAD> kvidx;
     uint8_t mreg = 1;
     int cur_n = 0, next_n = 0;
+    auto lookup = [&](int n) { kvidx.load(d.kv_rows, ((long)b * d.N + n) * d.S, d.S, tid); };
     auto prefetch = [&](int n) {
         const long ent = (long)b * d.N + n;
-        const long row0 = ent * d.S;
-        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
-        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
+        if constexpr (KVMAP) {
+            kreg.load_mapped(K + h * HD, d.ldk, kvidx, tid);
+            vreg.load_mapped(V + h * HD, d.ldv, kvidx, tid);
+        } else {
+            kreg.load(K + h * HD, d.ldk, ent * d.S, d.S, tid);
+            vreg.load(V + h * HD, d.ldv, ent * d.S, d.S, tid);
+        }
         mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
         next_n = n;
     };
@@ -1529,7 +1581,9 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     };
     int cur = 0;
     if (rem) {
+        if constexpr (KVMAP) lookup(__builtin_ctz(rem));
         prefetch(__builtin_ctz(rem));
+        if constexpr (KVMAP) if (rem & (rem - 1)) lookup(__builtin_ctz(rem & (rem - 1)));
         commit(Stage{smem});
     }
     __syncthreads();
@@ -1539,7 +1593,10 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
         int slen, fmask;
         read_key_mask(st.slots(), slen, fmask);
         cur_n = next_n;
-        if (rem) prefetch(__builtin_ctz(rem));
+        if (rem) {
+            prefetch(__builtin_ctz(rem));
+            if constexpr (KVMAP) if (rem & (rem - 1)) lookup(__builtin_ctz(rem & (rem - 1)));
+        }
         dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
             constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
             f32x16_t p[NKB];
@@ -1589,7 +1646,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
         __syncthreads();
         cur ^= 1;
     }
-    flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), dqacc, dQ + ((long)qb * d.T + wave * 32) * lddq + h * HD, lddq,
+    flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), dqacc, dQ + h * HD, lddq, (long)qb * d.T + wave * 32, d.q_rows,
                  d.T - wave * 32, accumulate_dq != 0, lane);
 }
 
@@ -1624,8 +1681,15 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_sha
     if (live) {
         BufTile<SPAD> kreg, vreg;
         const long row0 = (long)b * d.S;
-        kreg.load(static_cast<const T*>(d.k) + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
-        vreg.load(static_cast<const T*>(d.v) + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
+        if (d.kv_rows) {
+            RowIdx<SPAD> kvidx;
+            kvidx.load(d.kv_rows, row0, d.S, tid);
+            kreg.load_mapped(static_cast<const T*>(d.k) + h * HD, d.ldk, kvidx, tid);
+            vreg.load_mapped(static_cast<const T*>(d.v) + h * HD, d.ldv, kvidx, tid);
+        } else {
+            kreg.load(static_cast<const T*>(d.k) + h * HD, d.ldk, row0, d.S, tid);
+            vreg.load(static_cast<const T*>(d.v) + h * HD, d.ldv, row0, d.S, tid);
+        }
         const uint8_t mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[row0 + tid] : 0);
         kreg.commit(st.k(), tid);
         vreg.commit(st.v(), tid);
@@ -1636,9 +1700,10 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_sha
     float* stg = reinterpret_cast<float*>(smem + Stage::BYTES + wave * OUT_STAGE_BYTES);
 
     auto load_q = [&](Frag (&f)[2], int i) {
-        const T* qrow = Q + (((long)b * d.qpb + i) * d.T + qpos) * d.ldq + h * HD;
+        const long qr = phys_row(d.q_rows, ((long)b * d.qpb + i) * d.T + qpos, qvalid && i < i1);
+        const T* qrow = Q + (qr >= 0 ? qr : 0) * d.ldq + h * HD;
 #pragma unroll
-        for (int sl = 0; sl < 2; ++sl) f[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid && i < i1);
+        for (int sl = 0; sl < 2; ++sl) f[sl] = global_frag<T>(qrow + sl * 32, lane, qr >= 0);
     };
     Frag qf[2], qn[2];
     load_q(qf, i0);
@@ -1668,7 +1733,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_sha
                     for (int r = 0; r < 16; ++r) oacc[db][r] *= norm;
             });
         }
-        flush_tile_t(stg, oacc, O + (((long)b * d.qpb + i) * d.T + wave * 32) * d.ldo + h * HD, d.ldo, d.T - wave * 32, false, lane);
+        flush_tile_t(stg, oacc, O + h * HD, d.ldo, ((long)b * d.qpb + i) * d.T + wave * 32, d.q_rows, d.T - wave * 32, false, lane);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) qf[sl] = qn[sl];
     }
@@ -1700,8 +1765,15 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     if (live) {
         BufTile<SPAD> kreg, vreg;
         const long row0 = (long)b * d.S;
-        kreg.load(static_cast<const T*>(d.k) + row0 * d.ldk + h * HD, d.ldk, d.S, tid);
-        vreg.load(static_cast<const T*>(d.v) + row0 * d.ldv + h * HD, d.ldv, d.S, tid);
+        if (d.kv_rows) {
+            RowIdx<SPAD> kvidx;
+            kvidx.load(d.kv_rows, row0, d.S, tid);
+            kreg.load_mapped(static_cast<const T*>(d.k) + h * HD, d.ldk, kvidx, tid);
+            vreg.load_mapped(static_cast<const T*>(d.v) + h * HD, d.ldv, kvidx, tid);
+        } else {
+            kreg.load(static_cast<const T*>(d.k) + h * HD, d.ldk, row0, d.S, tid);
+            vreg.load(static_cast<const T*>(d.v) + h * HD, d.ldv, row0, d.S, tid);
+        }
         const uint8_t mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[row0 + tid] : 0);
         kreg.commit(st.k(), tid);
         vreg.commit(st.v(), tid);
@@ -1712,13 +1784,13 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
     float* stg = reinterpret_cast<float*>(smem + Stage::BYTES + wave * OUT_STAGE_BYTES);
 
     auto load_q = [&](Frag (&fq)[2], Frag (&fd)[2], int i) {
-        const long row = ((long)b * d.qpb + i) * d.T + qpos;
-        const T* qrow = Q + row * d.ldq + h * HD;
-        const T* drow = dO + row * lddo + h * HD;
+        const long qr = phys_row(d.q_rows, ((long)b * d.qpb + i) * d.T + qpos, qvalid && i < i1);
+        const T* qrow = Q + (qr >= 0 ? qr : 0) * d.ldq + h * HD;
+        const T* drow = dO + (qr >= 0 ? qr : 0) * lddo + h * HD;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            fq[sl] = global_frag<T>(qrow + sl * 32, lane, qvalid && i < i1);
-            fd[sl] = global_frag<T>(drow + sl * 32, lane, qvalid && i < i1);
+            fq[sl] = global_frag<T>(qrow + sl * 32, lane, qr >= 0);
+            fd[sl] = global_frag<T>(drow + sl * 32, lane, qr >= 0);
         }
     };
     Frag qf[2], dof[2], qn[2], don[2];
@@ -1773,7 +1845,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                 }
             });
         }
-        flush_tile_t(stg, dqacc, dQ + ((long)qb * d.T + wave * 32) * lddq + h * HD, lddq, d.T - wave * 32, accumulate_dq != 0, lane);
+        flush_tile_t(stg, dqacc, dQ + h * HD, lddq, (long)qb * d.T + wave * 32, d.q_rows, d.T - wave * 32, accumulate_dq != 0, lane);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) { qf[sl] = qn[sl]; dof[sl] = don[sl]; }
     }
@@ -1784,7 +1856,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
 // Per score: p = 2^(s c2 - lse), P' = p / count (0 on this lane's key if it is masked), dS = P' (dP scale - delta').
 // Query rows past T are zero rows of the staged Q and dO, so they add nothing whatever P' is; a wave whose key block
 // holds only masked keys skips the arithmetic altogether.
-template <int NKB, bool CAUSAL>
+template <int NKB, bool CAUSAL, bool QMAP>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
                                                                                        bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv,
                                                                                        const float* __restrict__ stats) {
@@ -1817,14 +1889,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
 #pragma unroll
     for (int o = 0; o < NOWN; ++o) {
         const int key = (kb0 + wave + 4 * o) * 32 + (lane & 31);
-        const bool kvalid = key < d.S;
-        const bool masked = !kvalid || (d.pad && d.pad[ent * d.S + (kvalid ? key : 0)]);
+        const long kr = phys_row(d.kv_rows, row0 + key, key < d.S);
+        const bool kvalid = kr >= 0;
+        const bool masked = !kvalid || (d.pad && d.pad[ent * d.S + key]);
         keep[o] = masked ? 0.f : 1.f;
         alive[o] = __ballot(!masked) != 0;
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            kf[o][sl] = global_frag<T>(K + (row0 + key) * d.ldk + h * HD + sl * 32, lane, kvalid);
-            vf[o][sl] = global_frag<T>(V + (row0 + key) * d.ldv + h * HD + sl * 32, lane, kvalid);
+            kf[o][sl] = global_frag<T>(K + (kvalid ? kr : 0) * d.ldk + h * HD + sl * 32, lane, kvalid);
+            vf[o][sl] = global_frag<T>(V + (kvalid ? kr : 0) * d.ldv + h * HD + sl * 32, lane, kvalid);
         }
         dkacc[o][0] = dkacc[o][1] = dvacc[o][0] = dvacc[o][1] = zero_acc();
     }
@@ -1835,6 +1908,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
     const int nqb = is_null ? 0 : (d.qpb - ((d.exclude_self && n < d.qpb) ? 1 : 0));
     const int n_it = nqb * nchunks;
     BufTile<TQ> qreg, doreg;
+    RowIdx<TQ> qidx;                                          // physical rows of the chunk to request next (q_rows only)
     float streg = 0.f;
     auto coords = [&](int it, int& qb, int& qc, int& i) {
         const int idx = it / nchunks;
@@ -1842,11 +1916,21 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
         qb = b * d.qpb + i;
         qc = (it % nchunks) * TQ;
     };
+    auto lookup = [&](int it) {
+        int qb, qc, i;
+        coords(it, qb, qc, i);
+        qidx.load(d.q_rows, (long)qb * d.T + qc, d.T - qc, tid);
+    };
     auto prefetch = [&](int it) {
         int qb, qc, i;
         coords(it, qb, qc, i);
-        qreg.load(Q + ((long)qb * d.T + qc) * d.ldq + h * HD, d.ldq, d.T - qc, tid);
-        doreg.load(dO + ((long)qb * d.T + qc) * lddo + h * HD, lddo, d.T - qc, tid);
+        if constexpr (QMAP) {
+            qreg.load_mapped(Q + h * HD, d.ldq, qidx, tid);
+            doreg.load_mapped(dO + h * HD, lddo, qidx, tid);
+        } else {
+            qreg.load(Q + h * HD, d.ldq, (long)qb * d.T + qc, d.T - qc, tid);
+            doreg.load(dO + h * HD, lddo, (long)qb * d.T + qc, d.T - qc, tid);
+        }
         const float* sbase = stats + (((long)qb * d.N + n) * d.H + h) * d.T * 2;
         streg = (tid < TQ * 2 && qc + (tid >> 1) < d.T) ? sbase[(long)qc * 2 + tid] : 0.f;      // tid = 2*query + {0: lse, 1: delta'}
     };
@@ -1857,7 +1941,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
     };
     int cur = 0;
     if (n_it > 0) {
+        if constexpr (QMAP) lookup(0);
         prefetch(0);
+        if constexpr (QMAP) if (n_it > 1) lookup(1);
         commit(smem);
     }
     __syncthreads();
@@ -1870,7 +1956,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
         const char* don = qn + QT_TILE;
         const float* st = reinterpret_cast<const float*>(qn + 2 * QT_TILE);
         const bool more = it + 1 < n_it;
-        if (more) prefetch(it + 1);
+        if (more) {
+            prefetch(it + 1);
+            if constexpr (QMAP) if (it + 2 < n_it) lookup(it + 2);       // one chunk ahead of the loads that use it
+        }
 #pragma unroll
         for (int o = 0; o < NOWN; ++o) {
             const int kb = kb0 + wave + 4 * o;
@@ -1923,8 +2012,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
     for (int o = 0; o < NOWN; ++o) {
         const int kb = kb0 + wave + 4 * o;
         if (kb >= NKB) continue;
-        flush_tile_t(stg, dkacc[o], dK + (row0 + kb * 32) * lddk + h * HD, lddk, d.S - kb * 32, false, lane);
-        flush_tile_t(stg, dvacc[o], dV + (row0 + kb * 32) * lddv + h * HD, lddv, d.S - kb * 32, false, lane);
+        flush_tile_t(stg, dkacc[o], dK + h * HD, lddk, row0 + kb * 32, d.kv_rows, d.S - kb * 32, false, lane);
+        flush_tile_t(stg, dvacc[o], dV + h * HD, lddv, row0 + kb * 32, d.kv_rows, d.S - kb * 32, false, lane);
     }
 }
 
@@ -1972,11 +2061,16 @@ template <typename T> size_t tr_lds(int nkb) {
     const size_t need = 2 * ((size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 32);      // two TrStage
     return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
 }
-#define LAUNCH_TR(kern, nkb, causal, grid, block, lds, s, ...)                                                        \
+#define LAUNCH_TR(kern, nkb, causal, mapped, grid, block, lds, s, ...)                                                \
     do {                                                                                                              \
-        if (nkb == 2) { if (causal) LAUNCH_LDS((kern<2, true>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<2, false>), grid, block, lds, s, __VA_ARGS__); } \
-        else if (nkb == 4) { if (causal) LAUNCH_LDS((kern<4, true>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<4, false>), grid, block, lds, s, __VA_ARGS__); } \
-        else { if (causal) LAUNCH_LDS((kern<7, true>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<7, false>), grid, block, lds, s, __VA_ARGS__); } \
+        if (mapped) LAUNCH_TR1(kern, nkb, causal, true, grid, block, lds, s, __VA_ARGS__);                            \
+        else LAUNCH_TR1(kern, nkb, causal, false, grid, block, lds, s, __VA_ARGS__);                                  \
+    } while (0)
+#define LAUNCH_TR1(kern, nkb, causal, MP, grid, block, lds, s, ...)                                                   \
+    do {                                                                                                              \
+        if (nkb == 2) { if (causal) LAUNCH_LDS((kern<2, true, MP>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<2, false, MP>), grid, block, lds, s, __VA_ARGS__); } \
+        else if (nkb == 4) { if (causal) LAUNCH_LDS((kern<4, true, MP>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<4, false, MP>), grid, block, lds, s, __VA_ARGS__); } \
+        else { if (causal) LAUNCH_LDS((kern<7, true, MP>), grid, block, lds, s, __VA_ARGS__); else LAUNCH_LDS((kern<7, false, MP>), grid, block, lds, s, __VA_ARGS__); } \
     } while (0)
 
 template <typename T>
@@ -1993,7 +2087,7 @@ int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
         }
         const size_t lds = tr_lds<T>(nkb);
-        LAUNCH_TR(attn_tr_fwd_kernel, nkb, d.causal, grid, block, lds, s, d);
+        LAUNCH_TR(attn_tr_fwd_kernel, nkb, d.causal, d.kv_rows != nullptr, grid, block, lds, s, d);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     }
     if (pipe_lds<T>(nkb, 2) <= LDS_MAX) {
@@ -2024,13 +2118,13 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         } else {
             const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
             const size_t lds = tr_lds<T>(nkb);
-            LAUNCH_TR(attn_tr_bwd_dq_kernel, nkb, d.causal, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
+            LAUNCH_TR(attn_tr_bwd_dq_kernel, nkb, d.causal, d.kv_rows != nullptr, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
         }
         {
             const int n_ent = (d.n_qblocks / d.qpb) * d.N;
             const dim3 grid(d.H, n_ent, (nkb + 3) / 4), block(ATT_THREADS);
             const size_t lds = 4 * (size_t)OUT_STAGE_BYTES;          // >= two stages of 2 x 8 KiB tiles + statistics
-            LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
+            LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, d.q_rows != nullptr, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
         }
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     }
@@ -2070,6 +2164,7 @@ int check_desc(const mmsum_attn_desc* d, int dtype) {
         d->n_qblocks % d->qpb)
         return MMSUM_ERR_BAD_SHAPE;
     if (dtype != MMSUM_F32 && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
+    if ((d->q_rows || d->kv_rows) && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;      // row maps: the bf16 kernels only
     const long es = dtype == MMSUM_BF16 ? 2 : 4;
     if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) return MMSUM_ERR_BAD_ALIGN;
     if (((d->ldq | d->ldk | d->ldv) * es) & 15) return MMSUM_ERR_BAD_ALIGN;

@@ -166,11 +166,34 @@ class _Desc:
     pass
 
 
-def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale):
+def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale, q_rows=None, kv_rows=None):
     d = _Desc()
     d.__dict__.update(q=q, k=k, v=v, out=out, pad=pad, null=null_entity, nq=n_qblocks, T=T, qpb=qpb, N=N, S=S, H=H,
-                      excl=bool(exclude_self), causal=bool(causal), scale=scale)
+                      excl=bool(exclude_self), causal=bool(causal), scale=scale, q_rows=q_rows, kv_rows=kv_rows)
     return d
+
+
+def _expand(t, rows):
+    """Logical (padded) view of a compact matrix through a row map: absent rows read as zeros."""
+    if rows is None:
+        return t
+    sel = rows >= 0
+    out = torch.zeros(rows.numel(), t.shape[1], dtype=t.dtype)
+    out[sel] = t[rows[sel].long()]
+    return out
+
+
+def _scatter(dst, src, rows, accumulate=False):
+    """Write the existing rows of the logical matrix `src` to their physical rows of `dst`; nothing else is touched."""
+    if rows is None:
+        dst.add_(src) if accumulate else dst.copy_(src)
+        return
+    sel = rows >= 0
+    idx = rows[sel].long()
+    if accumulate:
+        dst[idx] = (dst[idx].float() + src[sel].float()).to(dst.dtype)
+    else:
+        dst[idx] = src[sel].to(dst.dtype)
 
 
 def entity_null(pad, null_entity, n_entities, S):
@@ -203,8 +226,11 @@ def _attn_ref(d, q, k, v):
 
 
 def attn_fwd(d, dtype_tensor):
+    if (d.q_rows is not None or d.kv_rows is not None) and d.q.dtype != torch.bfloat16:
+        raise RuntimeError("mmsum_attn_fwd: row maps are a bf16 feature")
     with torch.no_grad():
-        d.out.copy_(_attn_ref(d, d.q.float(), d.k.float(), d.v.float()))
+        o = _attn_ref(d, _expand(d.q, d.q_rows).float(), _expand(d.k, d.kv_rows).float(), _expand(d.v, d.kv_rows).float())
+        _scatter(d.out, o, d.q_rows)
 
 
 def attn_bwd_workspace(d):
@@ -212,17 +238,14 @@ def attn_bwd_workspace(d):
 
 
 def attn_bwd(d, dout, dq, accumulate_dq, dk, dv, stats):
-    q, k, v = (t.float().clone().requires_grad_(True) for t in (d.q, d.k, d.v))
+    q, k, v = (t.float().clone().requires_grad_(True) for t in (_expand(d.q, d.q_rows), _expand(d.k, d.kv_rows), _expand(d.v, d.kv_rows)))
     with torch.enable_grad():
         o = _attn_ref(d, q, k, v)
-        gq, gk, gv = torch.autograd.grad(o, (q, k, v), dout.float(), allow_unused=True)
+        gq, gk, gv = torch.autograd.grad(o, (q, k, v), _expand(dout, d.q_rows).float(), allow_unused=True)
     z = lambda g, t: torch.zeros_like(t) if g is None else g  # noqa: E731
-    if accumulate_dq:
-        dq.add_(z(gq, q))
-    else:
-        dq.copy_(z(gq, q))
-    dk.copy_(z(gk, k))
-    dv.copy_(z(gv, v))
+    _scatter(dq, z(gq, q), d.q_rows, accumulate=bool(accumulate_dq))
+    _scatter(dk, z(gk, k), d.kv_rows)
+    _scatter(dv, z(gv, v), d.kv_rows)
 
 
 def gate_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, out, rows_per_b):

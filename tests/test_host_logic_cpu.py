@@ -515,6 +515,59 @@ def test_padding_free_encoder_matches_oracle(monkeypatch, golden_dir, multimodal
             _close(p.grad, ref, 5e-4, 5e-6, name)
 
 
+def test_bf16_compact_step_reads_attention_through_row_maps(monkeypatch):
+    """bf16 fused step: the padding-free encoder's q/k/v and the compacted memory's K/V reach the attention kernels as compact
+    matrices + int32 row maps (no expand / compact copies around them); loss and gradients agree with the padded run of the same
+    weights to bf16 accuracy."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import MultimodalSum
+    import multimodalsum_amd.engine as eng_mod
+    kn = eng_mod.kn                                   # the emulator module the engine calls after emu.install
+    cfg = tiny_cfg()
+    bc = syn.yelp_batch(2, 3, 16, 2, cfg.vocab_size, seed=34, img_hw=64)
+    bc["img"], bc["img_mask"] = torch.zeros_like(bc["img"]), torch.zeros_like(bc["img_mask"])
+    sd = f3_state(oracle_cfg(cfg))
+    runs = {}
+    for compact in (True, False):
+        model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.bfloat16)
+        model.load_state_dict(sd)
+        model.train()
+        model._engine.p_drop = lambda: 0.0
+        model.compact_encoder = compact
+        seen = {"gathers": 0, "mapped": 0, "descs": 0}
+        og, od = kn.rows_gather, kn.make_attn_desc
+
+        def gather(*a, **k):
+            seen["gathers"] += 1
+            return og(*a, **k)
+
+        def desc(*a, **k):
+            seen["descs"] += 1
+            seen["mapped"] += int(k.get("kv_rows") is not None)
+            if k.get("kv_rows") is not None:
+                assert k["kv_rows"].dtype == torch.int32
+            return od(*a, **k)
+        monkeypatch.setattr(kn, "rows_gather", gather)
+        monkeypatch.setattr(kn, "make_attn_desc", desc)
+        loss = model(bc["reviews"], bc["reviews_mask"], bc["reviews_rating"], bc["field"], bc["field_value"], bc["img"], bc["img_mask"])[0]
+        loss.backward()
+        monkeypatch.setattr(kn, "rows_gather", og)
+        monkeypatch.setattr(kn, "make_attn_desc", od)
+        runs[compact] = (float(loss), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}, seen)
+    (lc, gc, sc), (lp, gp, sp) = runs[True], runs[False]
+    L = cfg.encoder_layers
+    # compact run: every encoder self-attention and every text / table / image cross-attention is mapped; what is left of the
+    # gathers is once per step, not per layer: the encoder's input / output (2 forward + 2 backward) and the memory's (1 + 1)
+    assert sc["mapped"] == L + 3 * cfg.decoder_layers and sc["gathers"] == 6, sc
+    assert sp["mapped"] == 0 and sp["gathers"] == 0, sp
+    assert abs(lc - lp) <= 2e-2 * abs(lp), (lc, lp)
+    for n, g in gp.items():
+        if "img_encoder" in n or n.endswith("k_proj.bias"):      # a key bias shifts every score of a row alike: its exact gradient is 0, what is left is rounding
+            continue
+        err = (gc[n].float() - g.float()).norm() / (g.float().norm() + 1e-6)
+        assert err <= 6e-2, (n, float(err))
+
+
 def test_graph_cache_keeps_one_set_per_shape(monkeypatch):
     """graphs.StepGraphs: entries are keyed by input SHAPES only (token / image counts are device-side row counts), at most
     max_live entries are kept and the least recently used one goes first; the pool restarts when no captured set is left."""

@@ -401,6 +401,92 @@ def test_attention(dtype, case):
     assert torch.equal(dq_o, dq2) and torch.equal(dk_o, dk) and torch.equal(dv_o, dv)
 
 
+MAPPED_CASES = [c for c in ATTN_CASES if c[0] in ("enc_self", "cross_text_loo", "cross_text_full", "cross_table_walk", "cross_img", "cross_text_holes")]
+
+
+@pytest.mark.parametrize("case", MAPPED_CASES, ids=[c[0] for c in MAPPED_CASES])
+def test_attention_row_maps(case):
+    """Compact operands read through row maps (the padding-free encoder's [live, 3D] q/k/v, the compacted memory's K/V): the
+    matrices hold only the rows that exist, in a shuffled order; same values as the padded layout, nothing written elsewhere."""
+    dtype = torch.bfloat16
+    name, B, qpb, N, S, T, H, exclude, causal, is_self = case
+    nq = B * qpb
+    D = H * 64
+    g = torch.Generator().manual_seed(12)
+    pad = torch.zeros(B, N, S, dtype=torch.bool)
+    for b in range(B):
+        for n in range(N):
+            L = int(torch.randint(max(1, S // 3), S + 1, (1,), generator=g))
+            pad[b, n, L:] = True
+    if name.endswith("_holes"):
+        pad = pad | (torch.rand(B, N, S, generator=g) < 0.3)
+        pad[:, :, 5] = False
+    if not is_self and N > 1:
+        pad[0, N - 1, :] = True
+    if name == "cross_table_walk":
+        pad[1, 0, :] = True
+    pad = pad.to(DEV)
+    keep = (~pad).reshape(-1)
+    nlive = int(keep.sum())
+    order = torch.randperm(nlive, generator=g).to(DEV)                  # physical position of the i-th live row
+    kv_rows = torch.full((B * N * S,), -1, dtype=torch.int32, device=DEV)
+    kv_rows[keep] = order.to(torch.int32)
+    if is_self:
+        qkv = rnd(nq * T, 3 * D, dtype=dtype, seed=1)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+        q_rows = kv_rows
+        qkeep = keep
+    else:
+        q = rnd(nq * T, D, dtype=dtype, seed=1)
+        kv = rnd(B * N * S, 2 * D, dtype=dtype, seed=2)
+        k, v = kv[:, :D], kv[:, D:]
+        q_rows, qkeep = None, torch.ones(nq * T, dtype=torch.bool, device=DEV)
+    dout = rnd(nq * T, D, dtype=dtype, seed=3) * qkeep.unsqueeze(1).to(dtype)            # absent query rows carry no gradient
+    qf, kf, vf = (t.float().contiguous().requires_grad_(True) for t in (q, k, v))
+    ref = attn_reference(qf, kf, vf, pad, nq, T, qpb, N, S, H, exclude, causal, 0.125)
+    ref.backward(dout.float())
+
+    def compact(t, rows, n):                                             # [logical rows, W] -> [n, W] at the mapped positions
+        out = torch.full((n, t.shape[1]), float("nan"), device=DEV, dtype=t.dtype)
+        sel = rows >= 0
+        out[rows[sel].long()] = t[sel]
+        return out
+    if is_self:
+        qkv_c = compact(qkv, kv_rows, nlive)
+        qc, kc, vc = qkv_c[:, :D], qkv_c[:, D:2 * D], qkv_c[:, 2 * D:]
+        dout_c = compact(dout, q_rows, nlive)
+        nqrows = nlive
+    else:
+        qc, dout_c, nqrows = q, dout, nq * T
+        kv_c = compact(torch.cat([k, v], 1), kv_rows, nlive)
+        kc, vc = kv_c[:, :D], kv_c[:, D:]
+    pad_u8 = pad.to(torch.uint8).contiguous()
+    null = torch.empty(B * N, dtype=torch.uint8, device=DEV)
+    kn.entity_null(pad_u8, null, B * N, S)
+    out = torch.full((nqrows, D), float("nan"), device=DEV, dtype=dtype)
+    desc = kn.make_attn_desc(qc, kc, vc, out, pad_u8, null, nq, T, qpb, N, S, H, exclude, causal, 0.125, q_rows=q_rows, kv_rows=kv_rows)
+    kn.attn_fwd(desc, qc)
+    ref_c = compact(ref.detach(), q_rows, nlive) if is_self else ref
+    close(out, ref_c, dtype, what=name + " mapped fwd")
+    dq = torch.full((nqrows, D), float("nan"), device=DEV, dtype=dtype)
+    dk = torch.full((nlive, D), float("nan"), device=DEV, dtype=dtype)
+    dv = torch.full((nlive, D), float("nan"), device=DEV, dtype=dtype)
+    stats = torch.empty(kn.attn_bwd_workspace(desc) // 4, device=DEV)
+    kn.attn_bwd(desc, dout_c, dq, False, dk, dv, stats)
+    close(dq, compact(qf.grad, q_rows, nlive) if is_self else qf.grad, dtype, what=name + " mapped dq")
+    close(dk, compact(kf.grad, kv_rows, nlive), dtype, what=name + " mapped dk")
+    close(dv, compact(vf.grad, kv_rows, nlive), dtype, what=name + " mapped dv")
+    # the same launch on the padded layout gives the same bits
+    out_p = torch.full((nq * T, D), float("nan"), device=DEV, dtype=dtype)
+    desc_p = kn.make_attn_desc(q, k, v, out_p, pad_u8, null, nq, T, qpb, N, S, H, exclude, causal, 0.125)
+    kn.attn_fwd(desc_p, q)
+    sel = (q_rows >= 0) if is_self else torch.ones(nq * T, dtype=torch.bool, device=DEV)
+    assert torch.equal(out_p[sel], out[q_rows[sel].long()] if is_self else out)
+    with pytest.raises(RuntimeError, match="mmsum_attn_fwd"):           # row maps are a bf16 feature: f32 refuses them
+        kn.attn_fwd(kn.make_attn_desc(qc.float(), kc.float(), vc.float(), out.float(), pad_u8, null, nq, T, qpb, N, S, H, exclude, causal,
+                                      0.125, q_rows=q_rows, kv_rows=kv_rows), qc.float())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gate(dtype):
     Bq, rows, D = 4, 6, 256

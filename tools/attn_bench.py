@@ -39,7 +39,15 @@ def main():
             lens = (torch.randn(B * N, generator=g) * 20 + 75).round().clamp(32, S).long()
             pad = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).to(torch.uint8).reshape(-1).cuda()
         null = torch.zeros(B * N, dtype=torch.uint8, device="cuda")
-        desc = kn.make_attn_desc(q, k, v, out, pad, null, nq, T, qpb, N, S, H, excl, causal, 0.125)
+        kv_rows = None
+        if os.environ.get("ATTN_BENCH_MAPS") == "1" and not causal:     # compacted memory: K / V hold the unmasked rows only, read through a row map
+            keep = pad.eq(0)
+            nlive = int(keep.sum())
+            kv_rows = torch.full((B * N * S,), -1, dtype=torch.int32, device="cuda")
+            kv_rows[keep] = torch.arange(nlive, dtype=torch.int32, device="cuda")
+            kv = kv[keep].contiguous()
+            k, v = kv[:, :D], kv[:, D:]
+        desc = kn.make_attn_desc(q, k, v, out, pad, null, nq, T, qpb, N, S, H, excl, causal, 0.125, kv_rows=kv_rows)
         dout = torch.randn(nq * T, D, device="cuda").to(dt)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
