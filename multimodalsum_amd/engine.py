@@ -279,7 +279,9 @@ class Engine:
             return 1
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         ktiles = max(1, Kred // (64 if self.dtype == torch.bfloat16 else 32))
-        sk = max(1, min(8, -(-768 // max(tiles, 1)), ktiles // 4))     # measured optimum: ~768/tiles slices (tools/wgrad_bench.py)
+        # measured optimum: ~768/tiles slices (tools/wgrad_bench.py); few-tile outputs with a very long reduction (the ResNet layer3
+        # convolutions: 16..36 tiles, 43,904 rows) keep gaining up to 32 slices (tools/wgrad_small.py: 77 -> 46 us)
+        sk = max(1, min(32, -(-768 // max(tiles, 1)), ktiles // 4))
         return sk
 
     def wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
@@ -313,7 +315,8 @@ class Engine:
     def row_maps(self, keep):
         """Index maps of the padding-free parts: keep = any tensor whose non-zero entries mark the live rows (row-major).
         c2p [R] = padded row of compact row i (-1 past the live count), p2c [R] = compact row of padded row r (-1 for
-        padding), count = the live count as a device int32 scalar.  Everything stays on the device and has static shapes:
+        padding; p2c32 = the same as int32: the row map the bf16 attention kernels read compact matrices through),
+        count = the live count as a device int32 scalar.  Everything stays on the device and has static shapes:
         the kernels read `count` when they run (their `live_rows` argument), so neither a host read nor a per-count graph
         is needed; the compact buffers are simply sized for all R rows."""
         flat = keep.reshape(-1).ne(0)
@@ -324,7 +327,7 @@ class Engine:
         c2p = torch.full((R + 1,), -1, dtype=torch.int64, device=flat.device)       # slot R swallows the padding rows' writes
         c2p.index_put_((torch.where(flat, pos, torch.full_like(pos, R)),), torch.where(flat, ar, torch.full_like(ar, -1)))
         count = flat.sum().to(torch.int32).reshape(1)
-        return NS(c2p=c2p[:R].contiguous(), p2c=p2c.contiguous(), count=count, rows=R)
+        return NS(c2p=c2p[:R].contiguous(), p2c=p2c.contiguous(), p2c32=p2c.to(torch.int32).contiguous(), count=count, rows=R)
 
     def encoder_fwd(self, ids, attention_mask, out=None, compact=False):
         """ids [Bn,S] int64, attention_mask [Bn,S] (1 = keep).  -> hidden [Bn*S, D] (batch-major rows).
@@ -392,9 +395,9 @@ class Engine:
     # ---- shared blocks ----------------------------------------------------------------------------
     def _self_block_fwd(self, lb, x, pad, Bn, T, causal, maps=None):
         """x -> LN(x + drop(out_proj(self_attention(x))))   (:288-297 / :442-461).
-        maps (padding-free encoder): x holds the valid rows first (compact layout, live count on the device); q/k/v are
-        expanded to the padded [Bn*T, 3D] layout the attention kernel reads (zeros at padding) and its output is
-        compacted again."""
+        maps (padding-free encoder): x holds the valid rows first (compact layout, live count on the device).  bf16: the
+        attention kernels read q/k/v and write their output in that layout through the row map; f32: q/k/v are expanded to the
+        padded [Bn*T, 3D] layout (zeros at padding) and the output is compacted again."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
         R = x.shape[0]
@@ -404,13 +407,15 @@ class Engine:
         c.qkv = self.empty(R, 3 * D)
         kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), c.qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)),
                 live=live)
-        if maps is not None:
+        c.mapped = maps is not None and self.dtype == torch.bfloat16      # the bf16 kernels read / write the compact layout through the row map
+        if maps is not None and not c.mapped:
             c.qkv = kn.rows_gather(c.qkv, self.empty(Bn * T, 3 * D), maps.p2c)
-        attn = self.empty(Bn * T, D)
+        rmap = maps.p2c32 if c.mapped else None
+        attn = self.empty(R if c.mapped else Bn * T, D)
         c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn, pad, None, Bn, T, 1, 1, T, H,
-                                   False, causal, 64 ** -0.5)
+                                   False, causal, 64 ** -0.5, q_rows=rmap, kv_rows=rmap)
         kn.attn_fwd(c.desc, x)
-        c.attn = attn if maps is None else kn.rows_gather(attn, self.empty(R, D), maps.c2p, live=live)
+        c.attn = attn if (maps is None or c.mapped) else kn.rows_gather(attn, self.empty(R, D), maps.c2p, live=live)
         c.o = self.empty(R, D)
         kn.gemm(c.attn, a.w(lb + "self_attn.out_proj.weight"), c.o, bias=a.f32(lb + "self_attn.out_proj.bias"), live=live)
         y = self.empty(R, D)
@@ -433,12 +438,12 @@ class Engine:
         dattn = self.empty(R, D)
         self.dgrad(do, lb + "self_attn.out_proj.weight", a.w(lb + "self_attn.out_proj.weight"), dattn, live=live)
         Rp = c.Bn * c.T
-        if c.maps is not None:
+        if c.maps is not None and not c.mapped:
             dattn = kn.rows_gather(dattn, self.empty(Rp, D), c.maps.p2c)
-        dqkv = self.empty(Rp, 3 * D)
+        dqkv = self.empty(R if c.mapped else Rp, 3 * D)
         stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
         kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
-        if c.maps is not None:
+        if c.maps is not None and not c.mapped:
             dqkv = kn.rows_gather(dqkv, self.empty(R, 3 * D), c.maps.c2p, live=live)
         self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)), bias_g=a.gspan(q + ".bias", v + ".bias", (3 * D,)),
                    live=live)
@@ -580,14 +585,19 @@ class Engine:
         c.kv = self.empty(dc.mem_c.shape[0], 2 * D)
         kn.gemm(dc.mem_c, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), c.kv,
                 bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)), live=mlive)                      # :788-789, hoisted
-        if dc.mem_maps is not None:
+        c.mapped = dc.mem_maps is not None and self.dtype == torch.bfloat16     # bf16: K / V stay compact, read through the row map
+        if dc.mem_maps is not None and not c.mapped:
             c.kv = kn.rows_gather(c.kv, self.empty(L.rows, 2 * D), dc.mem_maps.p2c)
         c.heads = self.empty(nm * Rq, D)
         c.descs = []
         for m, ((N, S), pad) in enumerate(zip(L.mods, dc.pads)):
             rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
-            d = kn.make_attn_desc(c.q, c.kv[rows, :D], c.kv[rows, D:], c.heads[m * Rq:(m + 1) * Rq], pad, dc.nulls[m],
-                                  dc.Bd, dc.T, dc.qpb, N, S, H, dc.exclude_self and m == 0, False, 64 ** -0.5)
+            if c.mapped:      # physical rows are rows of the whole compact matrix; the map is the modality's slice of padded -> compact
+                d = kn.make_attn_desc(c.q, c.kv[:, :D], c.kv[:, D:], c.heads[m * Rq:(m + 1) * Rq], pad, dc.nulls[m], dc.Bd, dc.T, dc.qpb, N, S,
+                                      H, dc.exclude_self and m == 0, False, 64 ** -0.5, kv_rows=dc.mem_maps.p2c32[rows])
+            else:
+                d = kn.make_attn_desc(c.q, c.kv[rows, :D], c.kv[rows, D:], c.heads[m * Rq:(m + 1) * Rq], pad, dc.nulls[m],
+                                      dc.Bd, dc.T, dc.qpb, N, S, H, dc.exclude_self and m == 0, False, 64 ** -0.5)
             kn.attn_fwd(d, x)                                                                              # :819-869
             c.descs.append(d)
         c.y = self.empty(nm * Rq, D)
@@ -638,15 +648,16 @@ class Engine:
         dheads = self.empty(nm * Rq, D)
         self.dgrad(dyy, pre + "out_proj.weight", a.w(pre + "out_proj.weight"), dheads)
         dq = self.empty(Rq, D)
-        dkv = self.empty(L.rows, 2 * D)
+        dkv = self.empty(dc.mem_maps.rows if c.mapped else L.rows, 2 * D)
         for m, (N, S) in enumerate(L.mods):
-            rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
+            rows = slice(None) if c.mapped else slice(L.offs[m], L.offs[m] + L.B * N * S)
             stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
             kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
         mlive = None
         if dc.mem_maps is not None:
             mlive = dc.mem_maps.count
-            dkv = kn.rows_gather(dkv, self.empty(dc.mem_maps.rows, 2 * D), dc.mem_maps.c2p, live=mlive)
+            if not c.mapped:
+                dkv = kn.rows_gather(dkv, self.empty(dc.mem_maps.rows, 2 * D), dc.mem_maps.c2p, live=mlive)
         self.wgrad(dkv, dc.mem_c, gview=a.gspan(k + ".weight", v + ".weight", (2 * D, D)), bias_g=a.gspan(k + ".bias", v + ".bias", (2 * D,)),
                    live=mlive)
         self.dgrad(dkv, k + ".weight", a.wspan(k + ".weight", v + ".weight", (2 * D, D)), dmem, accumulate=not first, live=mlive)
