@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MMSUM_ABI_VERSION 2
+#define MMSUM_ABI_VERSION 3
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -267,15 +267,20 @@ int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* pr
  * min_length; -1 = none) and the no-repeat-n-gram bans (`banned` [rows, nban] int32, -1 padded, may be NULL), + beam_scores
  * [rows], and the top 2*num_beams of each business's num_beams * V candidates (:2925): out_scores / out_ids
  * [rows / num_beams, 2 * num_beams], best first, id = beam * V + token, ties by lower id.  The banned positions of `logits`
- * are overwritten with -inf.  row_scores / row_tokens: workspaces of rows * 2 * num_beams elements.  num_beams <= 8.
+ * are overwritten with -inf.  workspace: mmsum_beam_topk_workspace() bytes (per-chunk statistics and candidates: the logits are
+ * read once by rows x 8 chunk blocks).  num_beams <= 8, V <= 65,536.
  * mmsum_decode_self_attn: single-query self-attention of every hypothesis over its K/V cache rows (:776-815), reached
  * through an ancestor table: key s (< len) of row r is row ancestors[r * Tmax + s] * Tmax + s of k_cache / v_cache
- * ([rows * Tmax, H*64]).  A beam reorder (_reorder_cache :3104-3115) is then a gather of the table, not of the caches. */
+ * ([rows * Tmax, H*64]).  A beam reorder (_reorder_cache :3104-3115) is then a gather of the table, not of the caches.
+ * k_new / v_new [rows, H*64] (optional, both or neither): this step's key / value projections (position len - 1, where
+ * ancestors[r, len - 1] must be r): the kernel stores them into the caches and uses them for that position, which replaces the
+ * cache append of the reference (:804-815). */
+long mmsum_beam_topk_workspace(int rows, int num_beams);
 int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const float* beam_scores, const int* banned, int nban, int force_token,
-                    int ban_token, int rows, int num_beams, float* row_scores, int* row_tokens, float* out_scores, long long* out_ids,
-                    void* stream);
-int mmsum_decode_self_attn(int dtype, const void* q, long ldq, const void* k_cache, const void* v_cache, long ld_cache, const int* ancestors,
-                           void* out, long ldo, int rows, int H, int len, int Tmax, float scale, void* stream);
+                    int ban_token, int rows, int num_beams, void* workspace, float* out_scores, long long* out_ids, void* stream);
+int mmsum_decode_self_attn(int dtype, const void* q, long ldq, void* k_cache, void* v_cache, long ld_cache, const int* ancestors,
+                           void* out, long ldo, int rows, int H, int len, int Tmax, float scale, const void* k_new, const void* v_new,
+                           long ld_new, void* stream);
 
 #ifdef __cplusplus
 }

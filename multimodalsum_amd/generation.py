@@ -125,8 +125,6 @@ class DecodeSession:
         self.tokens = torch.zeros(R, 1, dtype=torch.long, device=dev)
         self.logits = e.empty(R, e.Vpad)
         K = 2 * num_beams
-        self.row_scores = torch.zeros(R * K, dtype=torch.float32, device=dev)
-        self.row_tokens = torch.zeros(R * K, dtype=torch.int32, device=dev)
         self.out_scores = torch.zeros(layout.B, K, dtype=torch.float32, device=dev)
         self.out_ids = torch.zeros(layout.B, K, dtype=torch.int64, device=dev)
         self.h_out_scores = torch.zeros(layout.B, K, dtype=torch.float32, pin_memory=pin)
@@ -214,10 +212,8 @@ class DecodeSession:
             q, k, v = e._attn_names(lb, "self_attn")
             qkv = e.empty(R, 3 * D)
             kn.gemm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)))
-            self.kc[i].view(R, Tm, D)[:, t].copy_(qkv[:, D:2 * D])
-            self.vc[i].view(R, Tm, D)[:, t].copy_(qkv[:, 2 * D:])
-            att = e.empty(R, D)
-            kn.decode_self_attn(qkv[:, :D], self.kc[i], self.vc[i], anc, att, H, t + 1, Tm, scale)
+            att = e.empty(R, D)           # the kernel appends this step's K / V to the caches itself (position t of every row)
+            kn.decode_self_attn(qkv[:, :D], self.kc[i], self.vc[i], anc, att, H, t + 1, Tm, scale, k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
             o = e.empty(R, D)
             kn.gemm(att, a.w(lb + "self_attn.out_proj.weight"), o, bias=a.f32(lb + "self_attn.out_proj.bias"))
             y = e.empty(R, D)
@@ -271,8 +267,7 @@ class DecodeSession:
         force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)      # :3084-3089
         ban = eos if (eos is not None and cur_len < self.min_length) else -1
         banned = self.d_int[2 * R:].view(R, self.nban) if self.nban else None
-        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.row_scores, self.row_tokens, self.out_scores,
-                     self.out_ids)
+        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids)
 
 
 def _session(engine, layout, num_beams, max_length, has_rating, min_length, ngram):

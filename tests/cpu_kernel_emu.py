@@ -474,7 +474,7 @@ def rows_gather(src, dst, row_map, live=None):
     return dst
 
 
-def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, row_scores, row_tokens, out_scores, out_ids):
+def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids):
     """Contract of mmsum_beam_topk restated with torch ops in the reference's order (adjust_logits, log_softmax, bans, + beam
     score, topk over [B, beams * V]); ties by lower flat index."""
     x = logits[:, :V].float().clone()
@@ -498,8 +498,12 @@ def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams,
     out_ids.copy_(order.indices[:, :K])
 
 
-def decode_self_attn(q, k_cache, v_cache, ancestors, out, H, length, Tmax, scale):
+def decode_self_attn(q, k_cache, v_cache, ancestors, out, H, length, Tmax, scale, k_new=None, v_new=None):
     R, D = q.shape[0], q.shape[1]
+    if k_new is not None:            # the kernel appends this step's projections at position length - 1 of every row
+        assert bool((ancestors[:, length - 1] == torch.arange(R, dtype=ancestors.dtype)).all())
+        k_cache.view(R, Tmax, D)[:, length - 1].copy_(k_new)
+        v_cache.view(R, Tmax, D)[:, length - 1].copy_(v_new)
     hd = D // H
     s = torch.arange(length)
     for r in range(R):

@@ -797,11 +797,9 @@ def test_beam_topk(dtype, num_beams, V):
                         sc[r, t] = float("-inf")
         cand = (sc + beam_scores[:, None]).view(B, num_beams * V)
         want_s, want_i = torch.topk(cand, K, dim=1)
-        row_s = torch.zeros(R * K, device=DEV)
-        row_t = torch.zeros(R * K, dtype=torch.int32, device=DEV)
         out_s = torch.zeros(B, K, device=DEV)
         out_i = torch.zeros(B, K, dtype=torch.int64, device=DEV)
-        kn.beam_topk(logits, V, beam_scores, banned, force, ban, num_beams, row_s, row_t, out_s, out_i)
+        kn.beam_topk(logits, V, beam_scores, banned, force, ban, num_beams, out_s, out_i)
         finite = torch.isfinite(want_s)
         assert torch.equal(torch.isfinite(out_s), finite), (force, ban)
         tol = 2e-4
@@ -842,3 +840,17 @@ def test_decode_self_attn_through_ancestor_table(dtype):
             p = torch.softmax(torch.einsum("hd,shd->hs", q[r, :D].float().view(H, 64) * 0.125, k), dim=-1)
             ref[r] = torch.einsum("hs,shd->hd", p, v).reshape(D)
         close(out, ref, dtype, what="decode self-attention, length %d" % length)
+        # the step's own K / V handed in: appended to the caches by the kernel and used for position length - 1
+        anc2 = anc.clone()
+        anc2[:, length - 1] = torch.arange(R, dtype=torch.int32, device=DEV)
+        kv_new = torch.randn(R, 2 * D, generator=g).to(DEV).to(dtype)
+        kc2, vc2 = kc.clone(), vc.clone()
+        out2 = torch.full((R, D), float("nan"), device=DEV, dtype=dtype)
+        kn.decode_self_attn(q[:, :D], kc2, vc2, anc2, out2, H, length, Tmax, 0.125, k_new=kv_new[:, :D], v_new=kv_new[:, D:])
+        kc3, vc3 = kc.clone(), vc.clone()
+        kc3.view(R, Tmax, D)[:, length - 1] = kv_new[:, :D]
+        vc3.view(R, Tmax, D)[:, length - 1] = kv_new[:, D:]
+        assert torch.equal(kc2, kc3) and torch.equal(vc2, vc3)
+        out3 = torch.full((R, D), float("nan"), device=DEV, dtype=dtype)
+        kn.decode_self_attn(q[:, :D], kc3, vc3, anc2, out3, H, length, Tmax, 0.125)
+        assert torch.equal(out2, out3)
