@@ -4,21 +4,26 @@
 // one workgroup on a 128- or 256-column tile, i.e. 8 workgroups for N = 1024 -- 3 % of the chip pulling the
 // weights (measured 26 us per product, half of a decode step).  Here a workgroup owns 32 output columns, its four
 // waves split K four ways and read both operands straight from global memory in the MFMA operand layout (two 16-byte
-// loads per lane per 32-deep slab and operand, no LDS in the loop), the partial accumulators meet in LDS and wave 0
-// applies bias / GELU and stores.  N = 1024 gives 32 workgroups of 4 waves, 128 waves streaming.
+// loads per lane per 32-deep slab and operand, no LDS in the loop), the partial accumulators meet in LDS and the waves
+// share the bias / GELU / store work.  N = 1024 gives 32 workgroups of 4 (or 8, see below) waves streaming.
 #include "gemm_common.h"
 
 namespace {
 
-template <int MT, int EPI>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
-    __shared__ float red[3][MT][16][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// NW waves split K NW ways.  Four waves keep every load of a K = 1024 product in flight at once (8 slabs per wave); products with a
+// longer reduction or more than 32 rows take eight waves (K = 4096: two batches of 8 slabs per wave instead of four; 96 rows: a third of
+// the fragment loads and MFMAs per wave).  The partial accumulators of ALL waves meet in LDS and every wave finishes its share of the
+// accumulator registers (sum, bias / GELU, store), instead of one wave adding up seven others.
+template <int MT, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float (*red)[MT][16][64] = reinterpret_cast<float (*)[MT][16][64]>(smem_raw);      // [NW][MT][16][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * 32;
     const bf16_t* A = static_cast<const bf16_t*>(p.A);
     const bf16_t* A2 = static_cast<const bf16_t*>(p.A2);
     const bf16_t* B = static_cast<const bf16_t*>(p.B);
-    const int nslab = p.K / 32, per = nslab / 4;
+    const int nslab = p.K / 32, per = nslab / NW;
     const int s0 = wave * per, s1 = s0 + per;
     const int ln = lane & 31;
     const int nrow = n0 + ln;
@@ -40,27 +45,24 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
             mma_slab<bf16_t>(acc[mt], a, b);
         }
     }
-    if (wave > 0) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[wave - 1][mt][r][lane] = acc[mt][r];
-    }
+        for (int r = 0; r < 16; ++r) red[wave][mt][r][lane] = acc[mt][r];
     __syncthreads();
-    if (wave == 0) {
-        const bool col_ok = nrow < p.N;
-        const float bv = ((p.flags & MMSUM_GEMM_BIAS) && col_ok) ? p.bias[nrow] : 0.f;
-        bf16_t* C = static_cast<bf16_t*>(p.C);
+    // wave w finishes accumulator registers w, w + NW, ... of the MT * 16
+    const bool col_ok = nrow < p.N;
+    const float bv = ((p.flags & MMSUM_GEMM_BIAS) && col_ok) ? p.bias[nrow] : 0.f;
+    bf16_t* C = static_cast<bf16_t*>(p.C);
+    for (int i = wave; i < MT * 16; i += NW) {
+        const int mt = i / 16, r = i % 16;
+        float v = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[mt][r] + red[0][mt][r][lane] + red[1][mt][r][lane] + red[2][mt][r][lane];
-                v = v * p.alpha + bv;
-                if constexpr (EPI == MMSUM_EPI_GELU) v = gelu_fast_f(v);
-                const int m = mt * 32 + acc_row(r, lane);
-                if (col_ok && m < p.M) C[(long)m * p.ldc + nrow] = (bf16_t)v;
-            }
+        for (int w = 0; w < NW; ++w) v += red[w][mt][r][lane];
+        v = v * p.alpha + bv;
+        if constexpr (EPI == MMSUM_EPI_GELU) v = gelu_fast_f(v);
+        const int m = mt * 32 + acc_row(r, lane);
+        if (col_ok && m < p.M) C[(long)m * p.ldc + nrow] = (bf16_t)v;
     }
 }
 
@@ -76,18 +78,32 @@ bool gemm_skinny_eligible(int dtype, const GemmArgs& a) {
     return true;
 }
 
+template <int MT, int EPI, int NW>
+int launch_skinny_one(const GemmArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)NW * MT * 16 * 64 * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<MT, EPI, NW>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MMSUM_ERR_HIP;
+    gemm_skinny_kernel<MT, EPI, NW><<<dim3((a.N + 31) / 32), dim3(NW * 64), lds, stream>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7;
-    const dim3 grid((a.N + 31) / 32), block(256);
-#define SKINNY(MT)                                                                                         \
-    do {                                                                                                   \
-        if (epi == MMSUM_EPI_GELU) gemm_skinny_kernel<MT, MMSUM_EPI_GELU><<<grid, block, 0, stream>>>(a);   \
-        else gemm_skinny_kernel<MT, MMSUM_EPI_NONE><<<grid, block, 0, stream>>>(a);                         \
+    // eight waves for a long reduction or more than 32 rows (K % 256 == 0 then; eligibility guarantees K % 128)
+    const bool wide = (a.K >= 2048 || a.M > 32) && a.K % 256 == 0 && a.M <= 96;
+    // (sixteen waves for K = 4096 measured the same 16.7 us as eight: 32 workgroups stream the 8 MB of weights at ~16 GB/s per CU,
+    // which is what bounds that product, not the number of loads in flight)
+#define SKINNY(MT)                                                                                                     \
+    do {                                                                                                               \
+        if (wide) return epi == MMSUM_EPI_GELU ? launch_skinny_one<MT, MMSUM_EPI_GELU, 8>(a, stream)                   \
+                                               : launch_skinny_one<MT, MMSUM_EPI_NONE, 8>(a, stream);                  \
+        return epi == MMSUM_EPI_GELU ? launch_skinny_one<MT, MMSUM_EPI_GELU, 4>(a, stream)                             \
+                                     : launch_skinny_one<MT, MMSUM_EPI_NONE, 4>(a, stream);                            \
     } while (0)
     if (a.M <= 32) SKINNY(1);
     else if (a.M <= 64) SKINNY(2);
     else if (a.M <= 96) SKINNY(3);
     else SKINNY(4);
 #undef SKINNY
-    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
