@@ -66,6 +66,62 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
     }
 }
 
+// The same product on 16-column workgroups and v_mfma_f32_16x16x32_bf16 (lane (r = l & 15, g = l >> 4) holds 8 consecutive k of row r:
+// one 16-byte load per lane, operand and slab): twice the workgroups for the same N.  A workgroup streams its weights at only ~16 GB/s
+// (measured: the K = 4096, N = 1024 product took 16.7 us on 32 workgroups whatever the number of loads in flight), so the products with
+// N <= 4096 -- everything in the decode step but the LM head -- are bounded by how many CUs pull weights.  MB = 16-row blocks of x.
+template <int MB, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float (*red)[MB][4][64] = reinterpret_cast<float (*)[MB][4][64]>(smem_raw);       // [NW][MB][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16;
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* A2 = static_cast<const bf16_t*>(p.A2);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+    const int nslab = p.K / 32, per = nslab / NW;
+    const int s0 = wave * per, s1 = s0 + per;
+    const int lr = lane & 15, kg = (lane >> 4) * 8;
+    const int nrow = n0 + lr;
+    const bf16_t* brow = B + (long)(nrow < p.N ? nrow : p.N - 1) * p.ldb + kg;
+    f32x4_t acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) {
+        int k0 = s * 32;
+        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(brow + k0);
+        const bf16_t* Ab = A;
+        long lda = p.lda;
+        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int m = mb * 16 + lr;
+            u32x4_t a = u32x4_t{0, 0, 0, 0};
+            if (m < p.M) a = *reinterpret_cast<const u32x4_t*>(Ab + (long)m * lda + k0 + kg);
+            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[mb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][mb][e][lane] = acc[mb][e];
+    __syncthreads();
+    const bool col_ok = nrow < p.N;
+    const float bv = ((p.flags & MMSUM_GEMM_BIAS) && col_ok) ? p.bias[nrow] : 0.f;
+    bf16_t* C = static_cast<bf16_t*>(p.C);
+    for (int i = wave; i < MB * 4; i += NW) {
+        const int mb = i / 4, e = i % 4;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][mb][e][lane];
+        v = v * p.alpha + bv;
+        if constexpr (EPI == MMSUM_EPI_GELU) v = gelu_fast_f(v);
+        const int m = mb * 16 + 4 * (lane >> 4) + e;          // 16x16 result: row 4 (l >> 4) + e, column l & 15
+        if (col_ok && m < p.M) C[(long)m * p.ldc + nrow] = (bf16_t)v;
+    }
+}
+
 }  // namespace
 
 bool gemm_skinny_eligible(int dtype, const GemmArgs& a) {
@@ -88,8 +144,32 @@ int launch_skinny_one(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
+template <int MB, int EPI, int NW>
+int launch_skinny16_one(const GemmArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)NW * MB * 4 * 64 * sizeof(float);
+    gemm_skinny16_kernel<MB, EPI, NW><<<dim3((a.N + 15) / 16), dim3(NW * 64), lds, stream>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7;
+    if (a.N <= 4096 && a.M <= 96 && a.K % 256 == 0) {          // 16-column workgroups: more CUs on the weight stream
+        const bool w8 = a.K >= 2048 || a.M > 32;
+#define SK16(MB)                                                                                                          \
+        do {                                                                                                              \
+            if (w8) return epi == MMSUM_EPI_GELU ? launch_skinny16_one<MB, MMSUM_EPI_GELU, 8>(a, stream)                  \
+                                                 : launch_skinny16_one<MB, MMSUM_EPI_NONE, 8>(a, stream);                 \
+            return epi == MMSUM_EPI_GELU ? launch_skinny16_one<MB, MMSUM_EPI_GELU, 4>(a, stream)                          \
+                                         : launch_skinny16_one<MB, MMSUM_EPI_NONE, 4>(a, stream);                         \
+        } while (0)
+        if (a.M <= 16) SK16(1);
+        else if (a.M <= 32) SK16(2);
+        else if (a.M <= 48) SK16(3);
+        else if (a.M <= 64) SK16(4);
+        else if (a.M <= 80) SK16(5);
+        else SK16(6);
+#undef SK16
+    }
     // eight waves for a long reduction or more than 32 rows (K % 256 == 0 then; eligibility guarantees K % 128)
     const bool wide = (a.K >= 2048 || a.M > 32) && a.K % 256 == 0 && a.M <= 96;
     // (sixteen waves for K = 4096 measured the same 16.7 us as eight: 32 workgroups stream the 8 MB of weights at ~16 GB/s per CU,
