@@ -233,8 +233,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     const long slab = (long)rows * cols;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int r = (int)(i / cv), c = (int)(i % cv) * 4;
-        f32x4_t s = *reinterpret_cast<const f32x4_t*>(ws + (long)r * cols + c);
-        for (int k = 1; k < nslabs; ++k) s = s + *reinterpret_cast<const f32x4_t*>(ws + k * slab + (long)r * cols + c);
+        // four slabs in flight per thread (the slab count is a run-time value: without this the loop is one dependent load at a time);
+        // the order of the additions is fixed, so the result does not depend on the launch geometry
+        const float* w0 = ws + (long)r * cols + c;
+        f32x4_t s = *reinterpret_cast<const f32x4_t*>(w0);
+        int k = 1;
+        for (; k + 3 < nslabs; k += 4) {
+            const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(w0 + k * slab), a1 = *reinterpret_cast<const f32x4_t*>(w0 + (k + 1) * slab);
+            const f32x4_t a2 = *reinterpret_cast<const f32x4_t*>(w0 + (k + 2) * slab), a3 = *reinterpret_cast<const f32x4_t*>(w0 + (k + 3) * slab);
+            s = (((s + a0) + a1) + a2) + a3;
+        }
+        for (; k < nslabs; ++k) s = s + *reinterpret_cast<const f32x4_t*>(w0 + k * slab);
         float* o = out + (long)r * ldo + c;
         if (accumulate) s = s + *reinterpret_cast<const f32x4_t*>(o);
         *reinterpret_cast<f32x4_t*>(o) = s;
