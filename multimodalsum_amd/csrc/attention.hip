@@ -1862,7 +1862,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
                                                                                        const float* __restrict__ stats) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TQ = 64;
+    constexpr int TQ = 128;                                  // query rows per staged chunk: a whole query block per iteration
     constexpr int NOWN = 1;                                  // one key block per wave; entities of more than 128 keys take gridDim.z rounds of four blocks
     const int kb0 = blockIdx.z * 4;
     constexpr int QT_TILE = TQ * HD * 2;
@@ -2123,7 +2123,7 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         {
             const int n_ent = (d.n_qblocks / d.qpb) * d.N;
             const dim3 grid(d.H, n_ent, (nkb + 3) / 4), block(ATT_THREADS);
-            const size_t lds = 4 * (size_t)OUT_STAGE_BYTES;          // >= two stages of 2 x 8 KiB tiles + statistics
+            const size_t lds = 2 * (2 * (size_t)128 * HD * sizeof(T) + 2 * 128 * sizeof(float));      // two stages of Q + dO tiles + statistics (> the output staging)
             LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, d.q_rows != nullptr, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
         }
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
