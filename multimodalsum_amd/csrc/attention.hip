@@ -1,17 +1,17 @@
 // Entity attention for gfx950: encoder self-attention, causal decoder self-attention and the
 // reference's per-entity cross-attention with entity mean (modeling_multimodalsum.py:752-875),
-// forward and backward, bf16 or f32 operands with f32 softmax/accumulation.  head_dim = 64.
+// forward and backward, f32 softmax / accumulation.  head_dim = 64.
 //
-// Forward / dQ kernels: one workgroup = (query block of <=128 rows, head); 4 waves x 32 query rows.
-//   Scores are computed TRANSPOSED (S^T = K Q^T: keys on accumulator rows, the query on the lane),
-//   so the row softmax is register-local plus one cross-half shuffle, and the probabilities go to
-//   LDS through the cheap transposed accumulator store to become the A operand of P.V.
-//   One LDS tile region is reused per entity: K (natural) -> V^T (forward) or V -> K^T (dQ).
-//   The [N,B,H,T,hd] per-entity outputs of the reference are never materialised: 1/(count*l) is
-//   folded into P and every entity accumulates into the same O registers.
-// dK/dV kernel: one workgroup = (entity, head); waves own 32-key blocks and sweep the query
-//   blocks that attend to the entity (8 of the 9 leave-one-out passes for a review), so dK/dV need
-//   no atomics.  Softmax statistics (log-sum-exp, delta) come from the dQ kernel via `stats`.
+// Two kernel families share the decomposition -- forward / dQ: one workgroup = (query block of <= 128 rows, head), 4 waves x 32
+// query rows, scores computed TRANSPOSED (S^T = K Q^T: keys on accumulator rows, the query on the lane) so the row softmax is
+// register-local; dK/dV: one workgroup = (entity, head), waves own 32-key blocks and sweep the query blocks that attend to the
+// entity (8 of the 9 leave-one-out passes for a review), so dK/dV need no atomics; softmax statistics (log-sum-exp, delta) go
+// from the dQ kernel to the dK/dV kernel via `stats`; the [N,B,H,T,hd] per-entity outputs of the reference are never
+// materialised (1/(count*l) is folded in and every entity accumulates into the same registers):
+//   * bf16 (the step): attn_tr_* in the second half of this file -- transposing LDS reads, P / dS kept in registers as MFMA
+//     operands, compact operands through row maps;
+//   * f32 (parity mode): attn_*_pipe_kernel / attn_*_kernel -- tiles prefetched into registers, P / dS through an LDS image,
+//     transposed tiles staged separately.
 #include "mmsum_device.h"
 #include "mmsum_kernels.h"
 #include <stdlib.h>
@@ -779,213 +779,6 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
     flush_tile<T>(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), dqacc, dQ + ((long)qb * d.T + wave * 32) * lddq + h * HD, lddq,
                   d.T - wave * 32, accumulate_dq != 0, lane);
 }
-
-// ---------------------------------------------------------------------------------------------
-// dQ with the keys split over two wave groups (bf16, NKB >= 3: the text and image entities).
-// The 4-wave kernel above needs ~420 registers per wave for a 128-key entity (scores, dP, the prefetched tiles), so
-// one wave per SIMD is resident and the matrix pipe idles through every softmax / LDS round trip (PMC: ~20 % MFMA
-// utilisation).  Here a workgroup has 8 waves: wave (qw, kg) owns query rows 32 qw .. 32 qw+31 and key blocks
-// kg * KB0 .. of the entity, so a wave holds half the score / dP registers and two waves share each SIMD.  Per entity
-// the two halves exchange (row max, row sum) and the delta partial through LDS; their dQ partials meet once at the end.
-// ---------------------------------------------------------------------------------------------
-constexpr int KS_THREADS = 512;
-template <typename T, int NKB, bool CAUSAL>
-__global__ __launch_bounds__(KS_THREADS) void attn_bwd_dq_ks_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
-                                                                    T* __restrict__ dQ, long lddq, int accumulate_dq,
-                                                                    float* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SPAD = NKB * 32;
-    constexpr int NS = AttnTraits<T>::kSlabsHD;
-    constexpr int TILE = SPAD * HD * sizeof(T);
-    constexpr int KB0 = (NKB + 1) / 2;                       // key blocks of group 0; group 1 takes the rest
-    constexpr bool KEEP_DP = KB0 <= 2;
-    char* ktile = smem;
-    char* vtile = smem + TILE;
-    char* kttile = smem + 2 * TILE;
-    char* img = smem + 3 * TILE + (threadIdx.x >> 6) * ImageTraits<T>::kBytes;
-    float* biasf = reinterpret_cast<float*>(smem + 3 * TILE + 8 * ImageTraits<T>::kBytes);
-    float* xch = biasf + SPAD;                               // [parity 2][kind 3][group 2][128 query rows]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qw = wave & 3, kg = wave >> 2;
-    const int kb_lo = kg * KB0, kb_hi = kg == 0 ? KB0 : NKB;
-    const FragOff fo = frag_off<T>(lane);
-    const int h = blockIdx.x, qb = blockIdx.y;
-    const int b = qb / d.qpb;
-    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
-    uint32_t rem = valid_entities(d, b, excl);
-    const int cnt = __popc(rem);
-    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
-    const float c2 = d.scale * LOG2E_F;
-    const int hh = lane >> 5;
-
-    const T* Q = static_cast<const T*>(d.q);
-    const T* K = static_cast<const T*>(d.k);
-    const T* V = static_cast<const T*>(d.v);
-
-    const int qpos = qw * 32 + (lane & 31);
-    const bool qvalid = qpos < d.T;
-    Frag qf[NS], dof[NS];
-    {
-        const T* qrow = Q + ((long)qb * d.T + qpos) * d.ldq + h * HD;
-        const T* drow = dO + ((long)qb * d.T + qpos) * lddo + h * HD;
-#pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            qf[sl] = global_frag<T>(qrow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
-            dof[sl] = global_frag<T>(drow + sl * ElemTraits<T>::kPerSlab, lane, qvalid);
-        }
-    }
-    pin_frags(qf);
-    pin_frags(dof);
-    f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
-
-    NatTile<T, SPAD, NS, KS_THREADS> kreg, vreg;
-    TrTile<T, HD, NKB * AttnTraits<T>::kSlabsPer32, KS_THREADS> ktreg;
-    uint8_t mreg = 1;
-    int cur_n = 0, next_n = 0, parity = 0;
-    auto prefetch = [&](int n) {
-        const long ent = (long)b * d.N + n;
-        const long row0 = ent * d.S;
-        kreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, d.S, 0, HD, tid);
-        vreg.load(V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
-        ktreg.load(K + row0 * d.ldk + h * HD, d.ldk, 0, HD, 0, d.S, tid);
-        mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[ent * d.S + tid] : 0);
-        next_n = n;
-    };
-    if (rem) prefetch(__builtin_ctz(rem));
-    while (rem) {
-        rem &= rem - 1;
-        __syncthreads();
-        kreg.commit(ktile, tid);
-        vreg.commit(vtile, tid);
-        ktreg.commit(kttile, tid);
-        if (tid < SPAD) biasf[tid] = mreg ? -INFINITY : 0.f;
-        publish_key_extent(reinterpret_cast<int*>(xch + 2 * 3 * 2 * 128), mreg, d.S, tid);
-        cur_n = next_n;
-        __syncthreads();
-        const int slen = read_key_extent<KS_THREADS / 64>(reinterpret_cast<const int*>(xch + 2 * 3 * 2 * 128));
-        if (rem) prefetch(__builtin_ctz(rem));
-        float* xm = xch + parity * (3 * 2 * 128);
-        float* xl = xm + 2 * 128;
-        float* xd = xl + 2 * 128;
-        parity ^= 1;
-        // ---- scores of this group's key blocks, local max
-        f32x16_t p[KB0];
-        float m = -INFINITY;
-#pragma unroll
-        for (int kl = 0; kl < KB0; ++kl) {
-            const int kb = kb_lo + kl;
-            const bool active = kb < kb_hi && (kb * 32 < slen) && (!CAUSAL || kb <= qw);
-            p[kl] = zero_acc();
-            if (active) {
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    const Frag a = lds_frag_o(ktile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-                    mma_slab<T>(p[kl], a, qf[sl]);
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(biasf + kb * 32 + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float sc = fmaf(p[kl][4 * g + j], c2, bias[j]);
-                        if (CAUSAL && kb == qw && (kb * 32 + 8 * g + 4 * hh + j) > qpos) sc = -INFINITY;
-                        p[kl][4 * g + j] = sc;
-                        m = fmaxf(m, sc);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) p[kl][r] = -INFINITY;
-            }
-        }
-        m = wave_half_max(m);
-        if (lane < 32) xm[kg * 128 + qpos] = m;
-        __syncthreads();
-        m = fmaxf(xm[qpos], xm[128 + qpos]);
-        const float ms = (m == -INFINITY) ? 0.f : m;
-        float l = 0.f;
-#pragma unroll
-        for (int kl = 0; kl < KB0; ++kl)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(p[kl][r] - ms);       // exp2(-inf) = 0 for masked / inactive keys
-                p[kl][r] = pv;
-                l += pv;
-            }
-        l = wave_half_sum(l);
-        if (lane < 32) xl[kg * 128 + qpos] = l;
-        // ---- dP^T = V dO^T for this group's key blocks; delta partial
-        f32x16_t dpkeep[KEEP_DP ? KB0 : 1];
-        float delta = 0.f;
-#pragma unroll
-        for (int kl = 0; kl < KB0; ++kl) {
-            const int kb = kb_lo + kl;
-            if (kb < kb_hi && kb * 32 < slen && (!CAUSAL || kb <= qw)) {
-                f32x16_t dpk = zero_acc();
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl) {
-                    const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-                    mma_slab<T>(dpk, a, dof[sl]);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) delta += p[kl][r] * dpk[r];           // un-normalised: scaled by 1/l below
-                if constexpr (KEEP_DP) dpkeep[kl] = dpk;
-            }
-        }
-        delta = wave_half_sum(delta);
-        if (lane < 32) xd[kg * 128 + qpos] = delta;
-        __syncthreads();
-        l = xl[qpos] + xl[128 + qpos];
-        const float invl = (l > 0.f) ? 1.f / l : 0.f;
-        delta = (xd[qpos] + xd[128 + qpos]) * invl * inv_cnt;                       // dO_e = dO / count
-        if (kg == 0 && lane < 32 && qvalid) {
-            float* st = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
-            st[0] = ms + __log2f(l);           // log-sum-exp in the log2 domain (the dK/dV kernel uses exp2)
-            st[1] = delta;
-        }
-        // ---- dS^T -> image -> dQ += dS K
-#pragma unroll
-        for (int kl = 0; kl < KB0; ++kl) {
-            const int kb = kb_lo + kl;
-            if (kb < kb_hi && kb * 32 < slen && (!CAUSAL || kb <= qw)) {
-                f32x16_t dpk;
-                if constexpr (KEEP_DP) {
-                    dpk = dpkeep[kl];
-                } else {
-                    dpk = zero_acc();
-#pragma unroll
-                    for (int sl = 0; sl < NS; ++sl) {
-                        const Frag a = lds_frag_o(vtile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-                        mma_slab<T>(dpk, a, dof[sl]);
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dpk[r] = (p[kl][r] * invl) * (dpk[r] * inv_cnt - delta) * d.scale;   // dS^T
-                acc_to_image<T>(img, dpk, lane);
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    mma_image_o<T>(dqacc[db], img, kttile + kb * AttnTraits<T>::kSlabsPer32 * (HD * SLAB_BYTES) + db * 32 * SLAB_BYTES, HD * SLAB_BYTES, fo);
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-    // ---- the two key groups' dQ partials meet in the output staging area (the tiles are dead now)
-    __syncthreads();
-    float* stg = reinterpret_cast<float*>(smem + qw * OUT_STAGE_BYTES);
-    if (kg == 1) {
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) stg[acc_row(r, lane) * OUT_STAGE_LD + db * 32 + (lane & 31)] = dqacc[db][r];
-    }
-    __syncthreads();
-    if (kg == 0)
-        flush_tile<T, true>(stg, dqacc, dQ + ((long)qb * d.T + qw * 32) * lddq + h * HD, lddq, d.T - qw * 32, accumulate_dq != 0, lane);
-}
-
-template <typename T> size_t ks_lds(int nkb) { return (size_t)3 * nkb * 32 * HD * sizeof(T) + 8 * ImageTraits<T>::kBytes + nkb * 32 * sizeof(float) + 2 * 3 * 2 * 128 * sizeof(float) + 48; }
 
 template <typename T, int NKB, bool CAUSAL>
 __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) void attn_bwd_dkv_pipe_kernel(mmsum_attn_desc d, const T* __restrict__ dO, long lddo,
@@ -2089,19 +1882,19 @@ int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
         const size_t lds = tr_lds<T>(nkb);
         LAUNCH_TR(attn_tr_fwd_kernel, nkb, d.causal, d.kv_rows != nullptr, grid, block, lds, s, d);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
-    }
-    if (pipe_lds<T>(nkb, 2) <= LDS_MAX) {
+    } else if (pipe_lds<T>(nkb, 2) <= LDS_MAX) {            // f32 (parity mode): the register-prefetch kernels
         const size_t lds = pipe_lds<T>(nkb, 2);
         if (nkb == 2) if (d.causal) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2, true>), grid, block, lds, s, d); else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 2, false>), grid, block, lds, s, d);
         else if (nkb == 4) if (d.causal) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 4, true>), grid, block, lds, s, d); else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 4, false>), grid, block, lds, s, d);
         else if (d.causal) LAUNCH_LDS((attn_fwd_pipe_kernel<T, 7, true>), grid, block, lds, s, d); else LAUNCH_LDS((attn_fwd_pipe_kernel<T, 7, false>), grid, block, lds, s, d);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+    } else {
+        const size_t lds = fwd_lds<T>(nkb);
+        if (nkb == 2) LAUNCH_LDS((attn_fwd_kernel<T, 2>), grid, block, lds, s, d);
+        else if (nkb == 4) LAUNCH_LDS((attn_fwd_kernel<T, 4>), grid, block, lds, s, d);
+        else LAUNCH_LDS((attn_fwd_kernel<T, 7>), grid, block, lds, s, d);
+        return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     }
-    const size_t lds = fwd_lds<T>(nkb);
-    if (nkb == 2) LAUNCH_LDS((attn_fwd_kernel<T, 2>), grid, block, lds, s, d);
-    else if (nkb == 4) LAUNCH_LDS((attn_fwd_kernel<T, 4>), grid, block, lds, s, d);
-    else LAUNCH_LDS((attn_fwd_kernel<T, 7>), grid, block, lds, s, d);
-    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
 template <typename T>
@@ -2127,15 +1920,8 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
             LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, d.q_rows != nullptr, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
         }
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
-    }
-    if (sizeof(T) == 2 && nkb == 4 && ks_lds<T>(nkb) <= LDS_MAX) {   // 7 key blocks (images) spill at 256 registers: old kernel
-        const dim3 grid(d.H, d.n_qblocks), block(KS_THREADS);
-        const size_t lds = ks_lds<T>(nkb);
-        if constexpr (sizeof(T) == 2) {
-            if (d.causal) LAUNCH_LDS((attn_bwd_dq_ks_kernel<T, 4, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
-            else LAUNCH_LDS((attn_bwd_dq_ks_kernel<T, 4, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
-        }
-    } else if (pipe_lds<T>(nkb, 3) <= LDS_MAX) {
+    } else {            // f32 (parity mode): the register-prefetch kernels
+    if (pipe_lds<T>(nkb, 3) <= LDS_MAX) {
         const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
         const size_t lds = pipe_lds<T>(nkb, 3);
         if (nkb == 2) if (d.causal) LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 2, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats); else LAUNCH_LDS((attn_bwd_dq_pipe_kernel<T, 2, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
@@ -2157,6 +1943,7 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         else if (d.causal) LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 7, true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats); else LAUNCH_LDS((attn_bwd_dkv_pipe_kernel<T, 7, false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
     }
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+    }
 }
 
 int check_desc(const mmsum_attn_desc* d, int dtype) {
