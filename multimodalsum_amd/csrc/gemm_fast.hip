@@ -952,7 +952,11 @@ int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {
+#if defined(MMSUM_GEMM_W4) && MMSUM_GEMM_W4      // tools/ builds only: four waves with 128x128 wave tiles (two thirds of the LDS read bytes per FLOP)
+        case TILE_256x256: return launch_cfg<256, 256, 2, 2>(a, stream);
+#else
         case TILE_256x256: return launch_cfg<256, 256, 2, 4>(a, stream);
+#endif
         case TILE_256x128: return launch_cfg<256, 128, 4, 2>(a, stream);
         default: return launch_cfg<128, 128, 2, 2>(a, stream);
     }
