@@ -472,6 +472,36 @@ __device__ __forceinline__ void nt_mma(f32x16_t& acc, const Frag& a, const Frag&
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64-deep stages with 128-byte LDS rows (the four-wave kernel below).  A 32-deep stage takes 64 bytes of every operand row,
+// HALF a cache line per DMA row: twice the L2 requests the bytes need (TCC_REQ: 62 bytes per request against 120).  Here
+// eight consecutive lanes of a DMA instruction fetch one 128-byte row (one request).
+//   LDS image: row r at r * 128; 16-byte chunk c (k = 8c..8c+7) of row r at position c ^ ((r >> 1) & 7): a 16x16x32
+//   fragment read (lane = row & 15, k group lane >> 4) then spreads each of ds_read_b128's 16-lane groups over all 64 banks.
+//   The DMA writes LDS linearly (lane L -> byte 16 L of the piece), so the XOR sits on the SOURCE chunk of the lane.
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+struct K64Cfg {
+    static constexpr int NW = WAVES_M * WAVES_N;
+    static constexpr int ROWB = 128;
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    static constexpr int PA = BM / 8, PB = BN / 8;                 // 1-KiB pieces: 8 rows x 128 B
+    static constexpr int PPW = (PA + PB) / NW, PAW = PA / NW, PBW = PB / NW;
+    static_assert(PA % NW == 0 && PB % NW == 0, "pieces must split evenly over the waves");
+};
+
+// One 1-KiB piece of an operand stage: 8 rows x 128 B through a buffer load whose resource starts at the tile's first row
+// (uniform), whose per-lane offset (row, chunk) is fixed for the tile and whose k offset is a scalar: no address arithmetic
+// per instruction.  I = index among this wave's pieces of the operand; `stage` = LDS base of the operand's stage.
+template <typename C, int I>
+__device__ __forceinline__ void k64_piece(char* stage, const bf16_t* base, int voff, int k0, int wave) {
+#if defined(__HIP_DEVICE_COMPILE__)        // the host pass of hipcc rejects the buffer-resource builtins inside templates
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(base), 0, 0x7fffffff, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr)(stage + (I * C::NW + wave) * 1024), 16, voff, k0 * 2, 0, 0);
+#endif
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_ring_kernel(GemmArgs p) {
     static_assert(NSTAGE == 4 || NSTAGE == 3, "the wait counts below are written for a 3- or 4-stage ring");
@@ -533,7 +563,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
     auto issue = [&](int si) {          // si: slab index relative to s_beg
         char* As = smem + (si % NSTAGE) * Cfg::STAGE;
         char* Bs = As + Cfg::A_BYTES;
+#ifdef MMSUM_DIAG_NO_DMA           // tools/ builds only: the main loop without its global loads (after the first three slabs)
+        if (si >= 3) return;
+#endif
+#ifdef MMSUM_DIAG_DMA_SAME_K       // tools/ builds only: every slab fetches the first 32 columns again (all L2 hits, same request count)
+        int k0 = 0;
+#else
         int k0 = (s_beg + si) * 32;
+#endif
         const int kb = k0;
         const bool second = A2 != nullptr && k0 >= p.ksplit;
         const bf16_t* Ab = second ? A2 : A;
@@ -683,6 +720,205 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
     }
 }
 
+
+#ifndef MMSUM_GEMM_W4K64
+#define MMSUM_GEMM_W4K64 1
+#endif
+// ---------------------------------------------------------------------------------------------
+// Four-wave form of the 256x256 NT tile: 2 x 2 waves, each a 128x128 block (256 accumulator registers = every AGPR, one
+// wave per SIMD), 64-deep stages in the 128-byte-row image above.
+// Why four waves: with eight, every 64 k of a tile move 64 KB into LDS and 192 KB out of it (each wave reads 128 + 64
+// operand rows), and the LDS -- about 64 B/clk for the DMA's writes, 256 for reads -- is then busy ~1800 of the 2048 cycles
+// the MFMAs need: the eight-wave loop runs at 1.6 PFLOP/s without its DMA and at 1.1 with a DMA that only hits L2, in
+// whatever order the instructions come (32- or 64-deep stages, staggered wave rows, pieces spread between MFMAs).
+// 128x128 wave tiles read 128 KB: 1.74 / 1.30 PFLOP/s for the same two measurements.
+// One wave per SIMD has nobody to hide behind, so the loop is software-pipelined in the source and the MFMAs are inline asm
+// (accumulators pinned in AGPRs; "memory" keeps the reads and DMA written between groups of four where they are):
+//   phase 0 of stage s: 64 MFMAs on the first 32 k (set X) | 16 fragment reads of the second 32 k (set Y) | DMA: A of stage s+2
+//   wait (own DMA of stage s+1) ; barrier                  -- one per stage, between its halves
+//   phase 1:            64 MFMAs on Y | 16 reads of stage s+1's first 32 k (X) | DMA: B of stage s+2
+// LDS = 160 KB: THREE stages of A (32 KB each) and TWO of B.  B is the weight matrix (a few MB, L2-resident, shared by every
+// tile of a column): one stage ahead is enough.  A streams from HBM: its DMA runs two stages ahead, so at the barrier only
+// the 8 youngest pieces (A of stage s+2) may still be in flight -- s_waitcnt vmcnt(8), not 0.
+// ---------------------------------------------------------------------------------------------
+template <int EPI, int OUT>
+__global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 2, TM = 4, TN = 4;
+    using C = K64Cfg<BM, BN, WAVES_M, WAVES_N>;
+    static_assert(C::PAW == 8 && C::PBW == 8, "8 + 8 pieces per wave and stage: one behind each group of four MFMAs");
+    constexpr int B_BASE = 3 * C::A_BYTES;                        // [A0 | A1 | A2 | B0 | B1]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int m_cap;
+    apply_live_rows(p, m_cap);
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
+    const int total = tiles * p.splitk;
+    void* const C0 = p.C;
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* A2 = static_cast<const bf16_t*>(p.A2);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+    // fragment geometry: lane -> row lane & 15 of a 16-row block, k group lane >> 4; the second 32 k of a stage = offset ^ 64
+    const int r16 = lane & 15, kg = lane >> 4;
+    const int fo = r16 * C::ROWB + (((kg ^ (r16 >> 1)) & 7) << 4);
+    const int a_frag0 = wm * (TM * 32) * C::ROWB + fo, b_frag0 = B_BASE + wn * (TN * 32) * C::ROWB + fo;
+    const int ydelta = (fo ^ 64) - fo;
+
+    for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
+    const int wg = xcd_remap(vid, total);
+    const int ks = wg / tiles;
+    p.C = (p.flags & MMSUM_GEMM_SLABS) ? static_cast<void*>(static_cast<float*>(C0) + (long)ks * m_cap * p.ldc) : C0;
+    const int t = wg % tiles;
+    int tm, tn;
+    tile_coords(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nslab_total = p.K / 32;
+    const int per = ((nslab_total + p.splitk - 1) / p.splitk + 1) & ~1;
+    const int s_beg = ks * per, s_end = min(nslab_total, s_beg + per);
+    const int nst = (s_end - s_beg) / 2, k_beg = s_beg * 32;
+
+    // 256 accumulator registers = all AGPRs of the wave: the MFMAs are issued from inline asm with "+a" operands so that the
+    // accumulators never move (left to the compiler they were copied to VGPRs and back around every MFMA: 600 moves per 128)
+    f32x4_t c[TM][TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[i][j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // DMA sources: lane -> (row = lane >> 3 of the piece, chunk position lane & 7); rows past the edge re-read the last one
+    int offA[C::PAW], offA2[C::PAW], offB[C::PBW];
+#pragma unroll
+    for (int i = 0; i < C::PAW; ++i) {
+        const int row = (i * C::NW + wave) * 8 + (lane >> 3);
+        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+        const int ra = m0 + row < p.M ? row : p.M - 1 - m0, rb = n0 + row < p.N ? row : p.N - 1 - n0;
+        offA[i] = ra * (int)p.lda * 2 + ch;
+        offA2[i] = ra * (int)p.lda2 * 2 + ch;
+        offB[i] = rb * (int)p.ldb * 2 + ch;
+    }
+    const bf16_t* baseA = A + (long)m0 * p.lda;
+    const bf16_t* baseA2 = A2 ? A2 + (long)m0 * p.lda2 : A;
+    const bf16_t* baseB = B + (long)n0 * p.ldb;
+    // piece I of A / B of stage `st` (stage index relative to k_beg)
+#define W4_A(I, ST)                                                                                    \
+    {                                                                                                  \
+        const int k0_ = k_beg + (ST) * 64;                                                             \
+        const bool second_ = A2 != nullptr && k0_ >= p.ksplit;                                         \
+        k64_piece<C, I>(smem + ((ST) % 3) * C::A_BYTES, second_ ? baseA2 : baseA, second_ ? offA2[I] : offA[I], second_ ? k0_ - p.ksplit : k0_, wave); \
+    }
+#define W4_B(I, ST) k64_piece<C, I>(smem + B_BASE + ((ST) & 1) * C::B_BYTES, baseB, offB[I], k_beg + (ST) * 64, wave);
+#define W4_ALL(M, ST) M(0, ST) M(1, ST) M(2, ST) M(3, ST) M(4, ST) M(5, ST) M(6, ST) M(7, ST)
+    if (nst > 0) {
+        Frag aX[TM], bX[TN], aY[TM], bY[TN];
+        // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)
+        W4_ALL(W4_A, 0) W4_ALL(W4_B, 0)
+        if (nst > 1) { W4_ALL(W4_A, 1) W4_ALL(W4_B, 1) wait_vmcnt<16>(); } else { wait_vmcnt<0>(); }
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) bX[j].c[h] = *reinterpret_cast<const u32x4_t*>(smem + b_frag0 + (j * 32 + h * 16) * C::ROWB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) aX[i].c[h] = *reinterpret_cast<const u32x4_t*>(smem + a_frag0 + (i * 32 + h * 16) * C::ROWB);
+        // four MFMAs: A block I x B block J (quarters q = 2 si + sj)
+#define W4_MMA(FA, FB, I, J)                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                  \
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c[I][J][q]) : "v"(FA[I].c[q >> 1]), "v"(FB[J].c[q & 1]) : "memory");
+        // LEFT = stages after this one: >= 2 steady state; 1: nothing left to request; 0: the last stage
+        auto stage = [&](int st, int abuf, auto left_c) {
+            constexpr int LEFT = decltype(left_c)::value;
+            const char* As = smem + abuf * C::A_BYTES + a_frag0;
+            const char* Bs = smem + (st & 1) * C::B_BYTES + b_frag0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                W4_MMA(aX, bX, g >> 2, g & 3)
+                if (g < 8) bY[g >> 1].c[g & 1] = *reinterpret_cast<const u32x4_t*>(Bs + ((g >> 1) * 32 + (g & 1) * 16) * C::ROWB + ydelta);
+                else aY[(g - 8) >> 1].c[g & 1] = *reinterpret_cast<const u32x4_t*>(As + (((g - 8) >> 1) * 32 + (g & 1) * 16) * C::ROWB + ydelta);
+                // A of stage st+2 into the A stage that stage st-1 left at the previous barrier (one piece behind every other group)
+                if constexpr (LEFT >= 2) {
+                    switch (g) {
+                        case 0: W4_A(0, st + 2) break; case 2: W4_A(1, st + 2) break; case 4: W4_A(2, st + 2) break; case 6: W4_A(3, st + 2) break;
+                        case 8: W4_A(4, st + 2) break; case 10: W4_A(5, st + 2) break; case 12: W4_A(6, st + 2) break; case 14: W4_A(7, st + 2) break;
+                        default: break;
+                    }
+                }
+            }
+            if constexpr (LEFT >= 2) wait_vmcnt<8>(); else if constexpr (LEFT == 1) wait_vmcnt<0>();     // stage st+1 has landed; A of st+2 may be in flight
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int anext = abuf == 2 ? 0 : abuf + 1;
+            const char* An = smem + anext * C::A_BYTES + a_frag0;
+            const char* Bn = smem + ((st + 1) & 1) * C::B_BYTES + b_frag0;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                W4_MMA(aY, bY, g >> 2, g & 3)
+                if constexpr (LEFT >= 1) {
+                    if (g < 8) bX[g >> 1].c[g & 1] = *reinterpret_cast<const u32x4_t*>(Bn + ((g >> 1) * 32 + (g & 1) * 16) * C::ROWB);
+                    else aX[(g - 8) >> 1].c[g & 1] = *reinterpret_cast<const u32x4_t*>(An + (((g - 8) >> 1) * 32 + (g & 1) * 16) * C::ROWB);
+                }
+                // B of stage st+2 into the B stage this one leaves
+                if constexpr (LEFT >= 2) {
+                    switch (g) {
+                        case 0: W4_B(0, st + 2) break; case 2: W4_B(1, st + 2) break; case 4: W4_B(2, st + 2) break; case 6: W4_B(3, st + 2) break;
+                        case 8: W4_B(4, st + 2) break; case 10: W4_B(5, st + 2) break; case 12: W4_B(6, st + 2) break; case 14: W4_B(7, st + 2) break;
+                        default: break;
+                    }
+                }
+            }
+        };
+        int st = 0, abuf = 0;
+        for (; st + 2 < nst; ++st) { stage(st, abuf, std::integral_constant<int, 2>{}); abuf = abuf == 2 ? 0 : abuf + 1; }
+        if (st + 1 < nst) { stage(st, abuf, std::integral_constant<int, 1>{}); abuf = abuf == 2 ? 0 : abuf + 1; ++st; }
+        stage(st, abuf, std::integral_constant<int, 0>{});
+        asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // MFMAs issued from inline asm: the compiler does not know results are still in the pipeline
+#undef W4_MMA
+    }
+#undef W4_ALL
+#undef W4_B
+#undef W4_A
+    f32x16_t acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = c[i][j][r >> 2][r & 3];
+    if constexpr (OUT == OUT_F32_ATOMIC) {
+        gemm_epilogue<bf16_t, TM, TN, EPI, OUT, true>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+    } else {
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, 3 * C::A_BYTES + 2 * C::B_BYTES, true>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+    }
+    lds_barrier();
+    }
+}
+
+template <int EPI, int OUT>
+int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
+    using C = K64Cfg<256, 256, 2, 2>;
+    const size_t lds = 3 * C::A_BYTES + 2 * C::B_BYTES;             // 160 KB: the whole LDS of a CU
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w4_kernel<EPI, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MMSUM_ERR_HIP;
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
+    const int cap = cu_count();
+    gemm_nt_w4_kernel<EPI, OUT><<<dim3(tiles > cap ? cap : tiles), dim3(256), lds, stream>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+int launch_w4(const GemmArgs& a, hipStream_t stream) {
+    const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
+#define W4_CASE(E, O) if (epi == E && out == O) return launch_w4_one<E, O>(a, stream);
+    W4_CASE(MMSUM_EPI_NONE, OUT_T) W4_CASE(MMSUM_EPI_NONE, OUT_T_ACC) W4_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
+    W4_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) W4_CASE(MMSUM_EPI_NONE, OUT_F32)
+    W4_CASE(MMSUM_EPI_GELU, OUT_T) W4_CASE(MMSUM_EPI_GELU_BWD, OUT_T) W4_CASE(MMSUM_EPI_RELU, OUT_T) W4_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
+#undef W4_CASE
+    return MMSUM_ERR_BAD_SHAPE;
+}
 
 // ---------------------------------------------------------------------------------------------
 // "TN" ring kernel: C[m][n] = sum_k A[k][m] * B[k][n] with BOTH operands reduction-major (A [K,M],
@@ -954,6 +1190,8 @@ int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {
 #if defined(MMSUM_GEMM_W4) && MMSUM_GEMM_W4      // tools/ builds only: four waves with 128x128 wave tiles (two thirds of the LDS read bytes per FLOP)
         case TILE_256x256: return launch_cfg<256, 256, 2, 2>(a, stream);
+#elif MMSUM_GEMM_W4K64
+        case TILE_256x256: return launch_w4(a, stream);
 #else
         case TILE_256x256: return launch_cfg<256, 256, 2, 4>(a, stream);
 #endif

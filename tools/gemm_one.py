@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Runs ONE bf16 GEMM shape a few times (for rocprofv3 --pmc passes).
-usage: gemm_one.py M N K [nt|tn|gelu] [iters]     gelu = x W^T + bias, GELU, pre-activation saved (the step's dominant kernel)"""
+usage: gemm_one.py M N K [nt|tn|gelu|blas] [iters]     gelu = x W^T + bias, GELU, pre-activation saved (the step's dominant kernel);
+blas = the same NT product through torch.matmul (hipBLASLt), for counter comparisons"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,6 +23,8 @@ bias = torch.randn(N, device="cuda", generator=g) if mode == "gelu" else None
 for _ in range(iters):
     if mode == "gelu":
         kn.gemm(a, b, out, bias=bias, epi=kn.EPI_GELU, aux=aux)
+    elif mode == "blas":
+        torch.matmul(a, b.t(), out=out)
     else:
         kn.gemm(a, b, out, a_t=tn, b_t=tn)
 torch.cuda.synchronize()
