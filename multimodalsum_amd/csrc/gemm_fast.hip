@@ -59,10 +59,19 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Where a pass of the staged epilogue takes the accumulators of row band i from: the kernel's register array, or (four-wave TN
+// kernel) accumulators that live in named AGPRs and are read out one band at a time.
+struct AccArray {
+    template <int TN> __device__ __forceinline__ void operator()(int i, const f32x16_t (*acc)[TN], f32x16_t (&band)[TN]) const {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) band[j] = acc[i][j];
+    }
+};
+
 // Edge tiles (rows past M / columns past N inside the tile, unaligned C): every access guarded, scalar fallbacks.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false, typename AccSrc = AccArray>
 __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
-                                           char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, const float (&bv)[8]) {
+                                           char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, const float (&bv)[8], AccSrc src = AccSrc{}) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr int CPR = BN / 8;                       // 8-column chunks per row
@@ -119,11 +128,13 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
         if (NSETS == 1 && i > 0) lds_barrier();
         {
             float* stage = set + wm * BAND;
+            f32x16_t band[TN];
+            src(i, acc, band);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = wn * (TN * 32) + j * 32;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) stage[blk_row<MF16>(r, lane) * BN + col + blk_col<MF16>(r, lane)] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) stage[blk_row<MF16>(r, lane) * BN + col + blk_col<MF16>(r, lane)] = band[j][r];
             }
         }
         lds_barrier();
@@ -253,9 +264,9 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
 // guards, index arithmetic and run-time flags (measured at M = 64,512, N = 4096, K = 1024: 232 us of a 696 us launch with the
 // global stores REMOVED, against 386 us for the main loop alone).  Here a thread's rows are base + compile-time constants,
 // the LDS addresses are immediates, and bias / alpha / activation / accumulate / column sums are compile-time forms.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, bool CS, int LDS_BYTES, bool MF16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, bool CS, int LDS_BYTES, bool MF16 = false, typename AccSrc = AccArray>
 __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
-                                                  char* smem, int m0, int n0, int wm, int wn, int tid, int lane, const float (&bv)[8]) {
+                                                  char* smem, int m0, int n0, int wm, int wn, int tid, int lane, const float (&bv)[8], AccSrc src = AccSrc{}) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
     constexpr int CPR = BN / 8, BAND = 32 * BN;
@@ -303,11 +314,13 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
         constexpr int SETF = WAVES_M * BAND;
         const int seto = (NSETS == 2 ? (i & 1) * SETF : 0);
         if (NSETS == 1 && i > 0) lds_barrier();
+        f32x16_t band[TN];
+        src(i, acc, band);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                wr0[seto + (MF16 ? (16 * (r >> 3) + (r & 3)) * BN + 16 * ((r >> 2) & 1) : ((r & 3) + 8 * (r >> 2)) * BN) + j * 32] = acc[i][j][r];
+                wr0[seto + (MF16 ? (16 * (r >> 3) + (r & 3)) * BN + 16 * ((r >> 2) & 1) : ((r & 3) + 8 * (r >> 2)) * BN) + j * 32] = band[j][r];
         lds_barrier();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -390,9 +403,9 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false, typename AccSrc = AccArray>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
-                                                char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane) {
+                                                char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, AccSrc src = AccSrc{}) {
     float bv[8];
     epilogue_bias<BN, WAVES_M * WAVES_N * 64>(p, n0, ks, tid, bv);
     constexpr bool kF32 = (OUT == OUT_F32_ACC || OUT == OUT_F32_ATOMIC || OUT == OUT_F32);
@@ -403,11 +416,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     // pass, does not fit the 128 registers left beside the accumulators: 167 spilled) and column sums keep the guarded form
     if constexpr (OUT != OUT_F32_ATOMIC && EPI != MMSUM_EPI_GELU_BWD && EPI != MMSUM_EPI_RELU_BWD) {
         if (interior && !(p.flags & MMSUM_GEMM_COLSUM)) {
-            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, false, LDS_BYTES, MF16>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv);
+            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, false, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
             return;
         }
     }
-    epilogue_edge<BM, BN, WAVES_M, WAVES_N, EPI, OUT, LDS_BYTES, MF16>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, bv);
+    epilogue_edge<BM, BN, WAVES_M, WAVES_N, EPI, OUT, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, bv, src);
 }
 
 __device__ __forceinline__ void dma16(const bf16_t* gsrc, char* lds_dst) {
@@ -899,27 +912,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     }
 }
 
-template <int EPI, int OUT>
-int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
-    using C = K64Cfg<256, 256, 2, 2>;
-    const size_t lds = 3 * C::A_BYTES + 2 * C::B_BYTES;             // 160 KB: the whole LDS of a CU
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w4_kernel<EPI, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
-    const int cap = cu_count();
-    gemm_nt_w4_kernel<EPI, OUT><<<dim3(tiles > cap ? cap : tiles), dim3(256), lds, stream>>>(a);
-    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
-}
-int launch_w4(const GemmArgs& a, hipStream_t stream) {
-    const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
-#define W4_CASE(E, O) if (epi == E && out == O) return launch_w4_one<E, O>(a, stream);
-    W4_CASE(MMSUM_EPI_NONE, OUT_T) W4_CASE(MMSUM_EPI_NONE, OUT_T_ACC) W4_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
-    W4_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) W4_CASE(MMSUM_EPI_NONE, OUT_F32)
-    W4_CASE(MMSUM_EPI_GELU, OUT_T) W4_CASE(MMSUM_EPI_GELU_BWD, OUT_T) W4_CASE(MMSUM_EPI_RELU, OUT_T) W4_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
-#undef W4_CASE
-    return MMSUM_ERR_BAD_SHAPE;
-}
-
 // ---------------------------------------------------------------------------------------------
 // "TN" ring kernel: C[m][n] = sum_k A[k][m] * B[k][n] with BOTH operands reduction-major (A [K,M],
 // B [K,N], row-major).  This is the weight-gradient product dW = dy^T x taken straight from the
@@ -1063,6 +1055,207 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_ring_kernel(Gem
     }
 }
 
+#ifndef MMSUM_GEMM_TN_W4
+#define MMSUM_GEMM_TN_W4 1
+#endif
+// ---------------------------------------------------------------------------------------------
+// Four-wave form of the 256x256 TN tile (see gemm_nt_w4_kernel for why four waves): 2 x 2 waves of 128x128, the same 4-stage
+// ring of 32-deep stages and transposing reads as gemm_tn_ring_kernel, 256 accumulator registers pinned in AGPRs, and the
+// loop software-pipelined in the source: the 32 MFMAs of a stage run on fragments read during the previous stage, while the
+// next stage's 32 transposing reads (one pair behind every other MFMA) and the 8 DMA pieces of the stage three ahead (one
+// behind every fourth) are issued between them.  One barrier per stage; at it only the youngest 8 pieces may be in flight.
+// ---------------------------------------------------------------------------------------------
+#include "gemm_tn_w4_acc.inc"
+typedef __attribute__((ext_vector_type(4))) short tn_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short tn_s16x8_t;
+typedef __attribute__((address_space(3))) tn_s16x4_t* tn_lds_s16x4_ptr;
+
+template <int OUT>
+__global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
+    constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 2, TM = 4, TN = 4;
+    using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N>;
+    constexpr int ROWB = BM * 2;                                   // 512-byte LDS rows (one reduction row of 256 columns) for A and B
+    static_assert(Cfg::PPW == 8 && Cfg::PA == 4 * Cfg::NW, "8 pieces per wave and stage: 4 of A, 4 of B");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    int m_cap;
+    apply_live_rows(p, m_cap);                    // reduction-major product: the live count limits K
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = tiles_m * tiles_n;
+    const int ks = wg / tiles;
+    if (p.flags & MMSUM_GEMM_SLABS) p.C = static_cast<float*>(p.C) + (long)ks * p.M * p.ldc;
+    const int t = wg % tiles;
+    int tm, tn;
+    tile_coords(t, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nslab_total = (p.K + 31) / 32;
+    const int per = (nslab_total + p.splitk - 1) / p.splitk;
+    const int s_beg = ks * per, s_end = min(nslab_total, s_beg + per);
+    const int ns = s_end - s_beg;
+    const bf16_t* A = static_cast<const bf16_t*>(p.A);
+    const bf16_t* B = static_cast<const bf16_t*>(p.B);
+
+    // accumulator (i, j) = a[16 (4 i + j) : +15]: all 256 AGPRs, addressed by name (gemm_tn_w4_acc.inc).  The compiler does not know
+    // they are in use: nothing else in this kernel may need an AGPR (register pressure stays below 256 VGPRs; the epilogue takes
+    // the accumulators one row band -- 64 registers -- at a time).
+    {
+        const bf16x8_t zero = __builtin_bit_cast(bf16x8_t, u32x4_t{0u, 0u, 0u, 0u});
+        TNW4_ZERO(zero)
+    }
+
+    // transposing-read lane geometry (as in gemm_tn_ring_kernel): group g = lane >> 4 -> (16-column half g & 1, k half g >> 1);
+    // lane 4q+p of the group addresses row q, columns 4p..4p+3 of its 4 x 16 block.  Byte offsets inside a stage.
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int offA[TM], offB[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) offA[i] = (8 * (g >> 1) + q) * ROWB + (((wm * TM + i) ^ q) * 64) + 32 * (g & 1) + 8 * pp;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) offB[j] = Cfg::A_BYTES + (8 * (g >> 1) + q) * ROWB + (((wn * TN + j) ^ q) * 64) + 32 * (g & 1) + 8 * pp;
+    // operand of 16-deep step s16 of a 32-column block: rows 16 s16 + {0..3, 4..7} (+8 for the upper half-wave)
+    auto tr_frag = [&](const char* stage, int off, int s16) {
+        const char* ptr = stage + off + s16 * (16 * ROWB);
+        const tn_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds_s16x4_ptr)(ptr));
+        const tn_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tn_lds_s16x4_ptr)(ptr + 4 * ROWB));
+        return __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    // DMA sources: buffer loads.  The resource of a stage starts at the stage's first reduction row and the tile's first column
+    // and ends with the matrix (rows past K read as zeros in hardware); a lane's (row in the stage, column) is a 32-bit offset
+    // fixed for the tile, out of range for columns past M / N.
+    int voff[Cfg::PPW];
+#pragma unroll
+    for (int i = 0; i < Cfg::PPW; ++i) {
+        const bool isA = i * Cfg::NW < Cfg::PA;
+        const int piece = isA ? i * Cfg::NW + wave : i * Cfg::NW - Cfg::PA + wave;
+        constexpr int CPR = ROWB / 16, RPP = 1024 / ROWB;
+        const int r = piece * RPP + lane / CPR, pcn = lane % CPR;
+        const int c64 = (pcn >> 2) ^ (r & 3);
+        const int col = (c64 * 4 + (pcn & 3)) * 8;                  // inside the tile
+        const int lim = isA ? p.M - m0 : p.N - n0;
+        voff[i] = col < lim ? (r * (int)(isA ? p.lda : p.ldb) + col) * 2 : (int)0x80000000u;
+    }
+    // The DMA is issued from inline asm: to the compiler a buffer_load ... lds is a store to LDS that the transposing reads
+    // behind it might alias, and it answers with s_waitcnt vmcnt(0) after every piece (measured: the loop at a quarter of its
+    // speed).  Its ordering is by hand anyway: counted vmcnt waits and the stage barrier.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue_piece = [&](auto ic, int si) {
+        constexpr int i = decltype(ic)::value;
+        constexpr bool isA = i * Cfg::NW < Cfg::PA;
+        const uint32_t dst = lds0 + (si & 3) * Cfg::STAGE + (isA ? (i * Cfg::NW + wave) * 1024 : Cfg::A_BYTES + (i * Cfg::NW - Cfg::PA + wave) * 1024);
+        const long k0 = (long)(s_beg + si) * 32;
+        const long ld = isA ? p.lda : p.ldb;
+        const uintptr_t base = (uintptr_t)((isA ? A + m0 : B + n0) + k0 * ld);
+        const long rows_left = (long)p.K - k0;                        // > 0: only existing stages are requested
+        const long bytes = ((rows_left - 1) * ld + (((isA ? p.M - m0 : p.N - n0) + 7) & ~7)) * 2;      // whole 16-byte chunks of the last row (the pitch covers them)
+        u32x4_t rsrc;                                                 // raw buffer resource: base, stride 0, num_records, dword 3 as make_buffer_rsrc's
+        rsrc[0] = (uint32_t)base;
+        rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
+        rsrc[2] = bytes > 0x7fffffffL ? 0x7fffffffu : (uint32_t)bytes;
+        rsrc[3] = 0x00020000u;
+        unsigned keep;
+        const int vo = voff[i];                                       // (an asm operand cannot name a captured array element)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(vo), "s"(dst), "s"(rsrc) : "memory");
+    };
+    // Reduction rows past K in the last stage: a lane of an LDS-DMA whose source lies outside the buffer may leave its LDS bytes as
+    // they were, so those rows of the stage are zeroed by hand when the stage is requested (the slot is free by then, and the
+    // DMA writes other rows).  Zeros add nothing to the reduction: any K works.
+    const int k_tail = p.K & 31;                                   // rows of the last stage that exist (0 = all 32)
+    auto zero_tail = [&](int si) {
+        if (k_tail != 0 && s_beg + si == nslab_total - 1) {
+            char* slot = smem + (si & 3) * Cfg::STAGE;
+            for (int o = k_tail * ROWB + tid * 16; o < 32 * ROWB; o += 256 * 16) {
+                *reinterpret_cast<u32x4_t*>(slot + o) = u32x4_t{0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4_t*>(slot + Cfg::A_BYTES + o) = u32x4_t{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+#define TNW4_ISSUE_ALL(SI) { zero_tail(SI); issue_piece(std::integral_constant<int, 0>{}, SI); issue_piece(std::integral_constant<int, 1>{}, SI); \
+                             issue_piece(std::integral_constant<int, 2>{}, SI); issue_piece(std::integral_constant<int, 3>{}, SI); \
+                             issue_piece(std::integral_constant<int, 4>{}, SI); issue_piece(std::integral_constant<int, 5>{}, SI); \
+                             issue_piece(std::integral_constant<int, 6>{}, SI); issue_piece(std::integral_constant<int, 7>{}, SI); }
+
+    if (ns > 0) {
+        bf16x8_t aX[TM][2], bX[TN][2], aY[TM][2], bY[TN][2];
+        TNW4_ISSUE_ALL(0)
+        if (ns > 1) TNW4_ISSUE_ALL(1)
+        if (ns > 2) TNW4_ISSUE_ALL(2)
+        if (ns > 2) wait_vmcnt<16>(); else if (ns > 1) wait_vmcnt<8>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // zero_tail's stores
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int s16 = 0; s16 < 2; ++s16) { aX[i][s16] = tr_frag(smem, offA[i], s16); bX[i][s16] = tr_frag(smem, offB[i], s16); }
+        // LEFT = stages after this one (capped at 3): >= 3 request stage si+3; >= 2: stage si+2 is in flight at the barrier
+        auto stage = [&](int si, bf16x8_t (&aC)[TM][2], bf16x8_t (&bC)[TN][2], bf16x8_t (&aN)[TM][2], bf16x8_t (&bN)[TN][2], auto left_c) {
+            constexpr int LEFT = decltype(left_c)::value;
+#ifdef MMSUM_DIAG_TNW4_DRAIN        // tools/ builds only: every request retired at every barrier
+            wait_vmcnt<0>();
+#else
+            if constexpr (LEFT >= 2) wait_vmcnt<8>(); else if constexpr (LEFT == 1) wait_vmcnt<0>();     // stage si+1 has landed
+#endif
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const char* nxt = smem + ((si + 1) & 3) * Cfg::STAGE;
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                const int s16 = m >> 4, i = (m >> 2) & 3, j = m & 3;
+                TNW4_MFMA(4 * i + j, aC[i][s16], bC[j][s16])
+                if constexpr (LEFT >= 1) {
+                    if ((m & 1) == 0) {
+                        const int f = m >> 1;                           // 0..7: A fragments (block f >> 1, step f & 1); 8..15: B
+                        if (f < 8) aN[f >> 1][f & 1] = tr_frag(nxt, offA[f >> 1], f & 1);
+                        else bN[(f - 8) >> 1][f & 1] = tr_frag(nxt, offB[(f - 8) >> 1], f & 1);
+                    }
+                }
+                if constexpr (LEFT >= 3) {
+                    switch (m) {
+                        case 1: issue_piece(std::integral_constant<int, 0>{}, si + 3); break;
+                        case 5: issue_piece(std::integral_constant<int, 1>{}, si + 3); break;
+                        case 9: issue_piece(std::integral_constant<int, 2>{}, si + 3); break;
+                        case 13: issue_piece(std::integral_constant<int, 3>{}, si + 3); break;
+                        case 17: issue_piece(std::integral_constant<int, 4>{}, si + 3); break;
+                        case 21: issue_piece(std::integral_constant<int, 5>{}, si + 3); break;
+                        case 25: issue_piece(std::integral_constant<int, 6>{}, si + 3); break;
+                        case 29: issue_piece(std::integral_constant<int, 7>{}, si + 3); break;
+                        default: break;
+                    }
+                }
+            }
+            if constexpr (LEFT >= 3) zero_tail(si + 3);
+        };
+#define TNW4_XY(SI, L) stage(SI, aX, bX, aY, bY, std::integral_constant<int, L>{});
+#define TNW4_YX(SI, L) stage(SI, aY, bY, aX, bX, std::integral_constant<int, L>{});
+        int si = 0;
+        for (; si + 4 < ns; si += 2) { TNW4_XY(si, 3) TNW4_YX(si + 1, 3) }
+        switch (ns - si) {                                             // 1..4 stages left, set X current
+            case 4: TNW4_XY(si, 3) TNW4_YX(si + 1, 2) TNW4_XY(si + 2, 1) TNW4_YX(si + 3, 0) break;
+            case 3: TNW4_XY(si, 2) TNW4_YX(si + 1, 1) TNW4_XY(si + 2, 0) break;
+            case 2: TNW4_XY(si, 1) TNW4_YX(si + 1, 0) break;
+            default: TNW4_XY(si, 0) break;
+        }
+#undef TNW4_XY
+#undef TNW4_YX
+        asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // MFMAs issued from inline asm: results may still be in the pipeline
+    }
+#undef TNW4_ISSUE_ALL
+    asm volatile("s_nop 15\n s_nop 15" ::: "memory");          // MFMAs issued from inline asm: results may still be in the pipeline
+    struct NamedAcc {
+        __device__ __forceinline__ void operator()(int i, const f32x16_t (*)[TN], f32x16_t (&band)[TN]) const {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { TNW4_READ(4 * i + j, band[j]) }
+        }
+    };
+    static_assert(OUT != OUT_F32_ATOMIC, "the atomic epilogue wants the whole accumulator array");
+    f32x16_t unused[TM][TN];
+    epilogue_staged<BM, BN, WAVES_M, WAVES_N, MMSUM_EPI_NONE, OUT, 4 * (BM + BN) * SLAB_BYTES, false, NamedAcc>(p, unused, smem, m0, n0, ks, wm, wn, tid, lane, NamedAcc{});
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int OUT>
 int launch_tn_one(const GemmArgs& a, hipStream_t stream) {
     using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
@@ -1122,6 +1315,29 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return MMSUM_ERR_BAD_SHAPE;
 }
 
+template <int EPI, int OUT>
+int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
+    using C = K64Cfg<256, 256, 2, 2>;
+    const size_t lds = 3 * C::A_BYTES + 2 * C::B_BYTES;             // 160 KB: the whole LDS of a CU
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w4_kernel<EPI, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MMSUM_ERR_HIP;
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
+    const int cap = cu_count();
+    gemm_nt_w4_kernel<EPI, OUT><<<dim3(tiles > cap ? cap : tiles), dim3(256), lds, stream>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+int launch_w4(const GemmArgs& a, hipStream_t stream) {
+    const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
+#define W4_CASE(E, O) if (epi == E && out == O) return launch_w4_one<E, O>(a, stream);
+    W4_CASE(MMSUM_EPI_NONE, OUT_T) W4_CASE(MMSUM_EPI_NONE, OUT_T_ACC) W4_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
+    W4_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) W4_CASE(MMSUM_EPI_NONE, OUT_F32)
+    W4_CASE(MMSUM_EPI_GELU, OUT_T) W4_CASE(MMSUM_EPI_RELU, OUT_T)
+#undef W4_CASE
+    // GELU' / ReLU' (the guarded epilogue with a saved operand: 512 threads write a tile back faster than 256; measured in the
+    // step: 549 us on the eight-wave ring against 585 us here) and anything else stay on the eight-wave ring kernel
+    return launch_cfg<256, 256, 2, 4>(a, stream);
+}
+
 // Tile shape that keeps the 256 CUs busiest for a problem: fraction of the last round of workgroups that is filled x
 // fraction of the padded tile area that is real x relative main-loop efficiency of the shape (operand bytes per FLOP halve
 // from 128^2 to 256^2 and the L2 -> LDS DMA rate, not the MFMA rate, bounds the small tiles: measured 0.50 and 0.72).
@@ -1178,9 +1394,32 @@ bool gemm_tn_eligible(int dtype, const GemmArgs& a) {
     return epilogue_reads_vectorisable(a);
 }
 
+template <int OUT>
+int launch_tn_w4_one(const GemmArgs& a, hipStream_t stream) {
+    using R = RingCfg<256, 256, 2, 2>;
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const size_t lds = R::NSTAGE * R::STAGE;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_w4_kernel<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MMSUM_ERR_HIP;
+    gemm_tn_w4_kernel<OUT><<<dim3(tiles * a.splitk), dim3(256), lds, stream>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+int launch_tn_w4(const GemmArgs& a, hipStream_t stream) {
+    switch (out_mode_of(a)) {
+        case OUT_T: return launch_tn_w4_one<OUT_T>(a, stream);
+        case OUT_F32_ACC: return launch_tn_w4_one<OUT_F32_ACC>(a, stream);
+        case OUT_F32: return launch_tn_w4_one<OUT_F32>(a, stream);
+        default: return launch_tn_cfg<256, 256, 2, 4>(a, stream);       // f32 atomics: the eight-wave kernel
+    }
+}
+
 int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {
+#if MMSUM_GEMM_TN_W4
+        case TILE_256x256: return launch_tn_w4(a, stream);
+#else
         case TILE_256x256: return launch_tn_cfg<256, 256, 2, 4>(a, stream);
+#endif
         case TILE_256x128: return launch_tn_cfg<256, 128, 4, 2>(a, stream);
         default: return launch_tn_cfg<128, 128, 2, 2>(a, stream);
     }
