@@ -149,8 +149,8 @@ def run_step(args, model, opt, sch, b):
 # ------------------------------------------------------------------------------------------------
 def probe_dominant_kernel(args, model, runner, opt, sch, b, cfg):
     """One more training step, issued eagerly (no graph replay), with a HIP event pair around every launch of the step's
-    dominant kernel: the FFN up-projection + bias + GELU (+ saved pre-activation) NT GEMM, `gemm_nt_ring_kernel<256,256,2,4,
-    EPI_GELU,OUT_T>` -- 24 launches per step (12 decoder layers on all 9*B*128 rows, 12 encoder layers on the valid rows).
+    dominant kernel: the FFN up-projection + bias + GELU (+ saved pre-activation) NT GEMM, `gemm_nt_w4_kernel<EPI_GELU,
+    OUT_T>` -- 24 launches per step (12 decoder layers on all 9*B*128 rows, 12 encoder layers on the valid rows).
     Events are recorded on the stream the kernel is launched on (torch's current stream at the call)."""
     import torch
     from multimodalsum_amd import engine as eng_mod, kernels as kn
@@ -194,8 +194,8 @@ def probe_dominant_kernel(args, model, runner, opt, sch, b, cfg):
     M = dec[0][1]
     avg = sum(ms for ms, _ in dec) / len(dec)
     fl = 2.0 * M * Fd * D
-    out = {"kernel": "gemm_nt_ring_kernel<%d,%d,2,4,EPI_GELU,OUT_T> (bf16 NT GEMM x W^T + bias, GELU, pre-activation saved; 4-stage LDS-DMA ring; "
-                     "%d persistent workgroups)" % (plan[1], plan[2], plan[3]) if args.dtype == "bf16" else "gemm_kernel<f32,NT,EPI_GELU>",
+    out = {"kernel": "gemm_nt_w4_kernel<EPI_GELU,OUT_T> (bf16 NT GEMM x W^T + bias, GELU, pre-activation saved; %dx%d tile, four waves of 128x128, "
+                     "64-deep LDS-DMA stages; %d persistent workgroups)" % (plan[1], plan[2], plan[3]) if args.dtype == "bf16" else "gemm_kernel<f32,NT,EPI_GELU>",
            "shape": [M, Fd, D], "launches_timed": len(dec), "avg_launch_ms": avg, "min_launch_ms": min(ms for ms, _ in dec),
            "max_launch_ms": max(ms for ms, _ in dec), "flops_per_launch": fl, "achieved": fl / avg / 1e9,
            "algorithmic_bytes_per_launch": 2.0 * (M * D + Fd * D + 2 * M * Fd) + 4.0 * Fd,

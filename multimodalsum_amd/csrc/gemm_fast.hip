@@ -5,10 +5,11 @@
 //   TN:  C[m][n] = sum_k A[k][m] * B[k][n],   A [K,M], B [K,N] both reduction-major
 //        (weight gradients dy^T x straight from the activations)
 //
-// Tile BM x BN, WAVES_M x WAVES_N waves, each wave (BM/WAVES_M) x (BN/WAVES_N) as MFMA 32x32x16 tiles.  Operands live in
-// LDS in the k-slab format of mmsum_device.h; the DMA writes LDS linearly (wave-uniform base + lane*16 B), so the XOR
-// swizzle is applied to the per-lane SOURCE address and again on the fragment read (guide rule 21: linear destination +
-// swizzled source + swizzled read).  Rows past M/N are clamped (their results are never stored).
+// 256x256 tiles (the step's products) run on FOUR waves of 128x128 each (gemm_nt_w4_kernel, gemm_tn_w4_kernel: one wave per
+// SIMD, accumulators in all 256 AGPRs, source-level software pipeline); 256x128 / 128x128 tiles and the GELU' / ReLU'
+// epilogues on the eight- / four-wave ring kernels (gemm_nt_ring_kernel, gemm_tn_ring_kernel).  Operands live in LDS in a
+// swizzled image that the DMA writes linearly (wave-uniform base + lane*16 B): the XOR is applied to the per-lane SOURCE
+// address and again on the fragment read (guide rule 21).  Rows past M/N are clamped (their results are never stored).
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -1427,9 +1428,7 @@ int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {
-#if defined(MMSUM_GEMM_W4) && MMSUM_GEMM_W4      // tools/ builds only: four waves with 128x128 wave tiles (two thirds of the LDS read bytes per FLOP)
-        case TILE_256x256: return launch_cfg<256, 256, 2, 2>(a, stream);
-#elif MMSUM_GEMM_W4K64
+#if MMSUM_GEMM_W4K64
         case TILE_256x256: return launch_w4(a, stream);
 #else
         case TILE_256x256: return launch_cfg<256, 256, 2, 4>(a, stream);

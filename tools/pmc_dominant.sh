@@ -5,4 +5,4 @@ for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_C
   rocprofv3 --output-format csv --kernel-trace --pmc $ctr -d $R/gpurun_out/pmcF_$tag -o $tag -- python3 $R/tools/gemm_one.py 64512 4096 1024 gelu 6 > $R/gpurun_out/pmcF_$tag.log 2>&1
 done
 cd $R
-python tools/pmc_summary.py gemm_nt_ring gpurun_out/pmcF_f/f_counter_collection.csv gpurun_out/pmcF_w/w_counter_collection.csv gpurun_out/pmcF_s/s_counter_collection.csv gpurun_out/pmcF_t/t_counter_collection.csv
+python tools/pmc_summary.py gemm_nt_w4 gpurun_out/pmcF_f/f_counter_collection.csv gpurun_out/pmcF_w/w_counter_collection.csv gpurun_out/pmcF_s/s_counter_collection.csv gpurun_out/pmcF_t/t_counter_collection.csv
