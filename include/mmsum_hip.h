@@ -71,8 +71,9 @@ int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, in
  * plan[0] = kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (fewer than tiles * splitk:
  * persistent workgroups walk the tile list).  Tests use it to assert that a shape reaches the kernel they mean to cover. */
 enum { MMSUM_PLAN_GENERIC = 0,   /* gemm_kernel: register-staged 128x128, f32 or bf16, any layout */
-       MMSUM_PLAN_NT_RING = 1,   /* gemm_nt_ring_kernel: bf16, K-contiguous operands, 4-stage LDS-DMA ring */
-       MMSUM_PLAN_TN_RING = 2,   /* gemm_tn_ring_kernel: bf16, reduction-major operands (weight gradients) */
+       MMSUM_PLAN_NT_RING = 1,   /* LDS-DMA kernels for bf16 K-contiguous operands: gemm_nt_w4_kernel (256x256 tiles, four waves) or
+                                    gemm_nt_ring_kernel (smaller tiles, GELU' / ReLU' epilogues) */
+       MMSUM_PLAN_TN_RING = 2,   /* the same pair for reduction-major operands (weight gradients): gemm_tn_w4_kernel / gemm_tn_ring_kernel */
        MMSUM_PLAN_SKINNY = 3 };  /* gemm_skinny_kernel: M <= 128 weight-streaming (decode steps) */
 int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                     const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
