@@ -13,6 +13,6 @@ for mode in nt blas; do
   done
 done
 cd $R
-echo "== ring kernel"; python tools/pmc_summary.py gemm_nt_ring gpurun_out/pbr_nt_1/p_counter_collection.csv gpurun_out/pbr_nt_2/p_counter_collection.csv gpurun_out/pbr_nt_3/p_counter_collection.csv
+echo "== mmsum_gemm (gemm_nt_w4_kernel for 256x256 tiles)"; python tools/pmc_summary.py gemm_nt_ gpurun_out/pbr_nt_1/p_counter_collection.csv gpurun_out/pbr_nt_2/p_counter_collection.csv gpurun_out/pbr_nt_3/p_counter_collection.csv
 echo "== hipBLASLt"; python tools/pmc_summary.py Cijk gpurun_out/pbr_blas_1/p_counter_collection.csv gpurun_out/pbr_blas_2/p_counter_collection.csv gpurun_out/pbr_blas_3/p_counter_collection.csv
 grep -h "Cijk" gpurun_out/pbr_blas_1/p_kernel_trace.csv | head -1 | cut -c1-400
