@@ -277,11 +277,16 @@ class Engine:
     def splitk(self, M, N, Kred):
         if self.deterministic:
             return 1
-        tiles = ((M + 127) // 128) * ((N + 127) // 128)
         ktiles = max(1, Kred // (64 if self.dtype == torch.bfloat16 else 32))
-        # measured optimum: ~768/tiles slices (tools/wgrad_bench.py); few-tile outputs with a very long reduction (the ResNet layer3
-        # convolutions: 16..36 tiles, 43,904 rows) keep gaining up to 32 slices (tools/wgrad_small.py: 77 -> 46 us)
-        sk = max(1, min(32, -(-768 // max(tiles, 1)), ktiles // 4))
+        # one 256x256 tile per CU and launch: the TN kernel is not persistent, so tiles x slices should come as close to the 256
+        # CUs as it can from below (tools/tn_sk_sweep.py at R = 64,512: dW[4096,1024] 521 us at 3 slices = 192 workgroups, 451 us
+        # at 4 = 256, 613 us at 5 = 320); few-tile outputs with a very long reduction (the ResNet layer3 convolutions: 4..9 tiles,
+        # 43,904 rows) keep gaining up to 32 slices (tools/wgrad_small.py: 77 -> 46 us)
+        if self.dtype != torch.bfloat16:                       # f32 parity mode (generic kernel, 128x128 tiles): the round-1 rule
+            tiles = ((M + 127) // 128) * ((N + 127) // 128)
+            return max(1, min(32, -(-768 // max(tiles, 1)), ktiles // 4))
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        sk = max(1, min(32, 256 // tiles if tiles <= 256 else 1, ktiles // 4))
         return sk
 
     def wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
