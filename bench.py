@@ -11,11 +11,15 @@ running under torch.distributed.run (WORLD_SIZE set, the driver's form of the la
 Prints ONE JSON line (rank 0).  `value` is whole-job businesses/s with inputs resident in HBM -- a fresh batch with
 fresh review lengths and image counts is generated ON THE DEVICE inside every timed step.
 `roofline` describes the step's dominant kernel as it runs IN the step: after the timed region one more step is
-issued eagerly with HIP events around every launch of that kernel (on its launch stream), so `achieved` is its
-algorithmic FLOPs / its in-step duration; `roofline.step` prices the whole step against the dense bf16 MFMA peak with
-the canonical algorithmic FLOP count of SURVEY.md section 8d (padded rows, K/V projections once per step) and, beside
-it, with the FLOPs actually executed (valid rows only).  `cpu_baseline` times the CPU oracle (the restated reference
-algorithm, literal) on the host cores: whole B=1 steps of the same configuration, no extrapolation.
+issued eagerly with HIP events around every GEMM and attention launch (on the launch stream), so `achieved` is the
+kernel's algorithmic FLOPs / its in-step duration, time-weighted over all its launches of the step, and
+`roofline.families` gives the same for the two kernel families that make the step (every GEMM; every attention
+launch), so the step number can be decomposed from the JSON line; `roofline.step` prices the whole step against the
+dense bf16 MFMA peak with the canonical algorithmic FLOP count of SURVEY.md section 8d (padded rows, K/V projections
+once per step) and, beside it, with the FLOPs actually executed (valid rows only).  `cpu_baseline` times the CPU
+oracle (the restated reference algorithm, literal) on the host cores: whole B=1 steps of the same configuration
+(forward, backward, clip, AdamW), no extrapolation.  `also` carries the other BASELINE configurations measured in
+the same run (text-only step, the reference-style per-GPU batch of 8, beam-search generation), a few steps each.
 """
 import argparse
 import json
@@ -64,9 +68,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=56,
-                    help="businesses per GPU per step (56: 9*56*128 decoder rows = 252 x 256-row GEMM tiles; ~105 GB of the 288 GB.  "
-                         "28 is 4 %% slower per business, 8 is BASELINE C4's reference-style batch)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="businesses per GPU per step; default 56 for the training workloads (9*56*128 decoder rows = 252 x 256-row GEMM "
+                         "tiles; ~105 GB of the 288 GB; 28 is 4 %% slower per business, 8 is BASELINE C4's reference-style batch) and 8 "
+                         "for --workload generate (test.py:176)")
     ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text", "generate"],
                     help="multimodal / text: the training step (BASELINE configs 4 / 2); generate: test.py's beam search (BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -75,8 +80,14 @@ def parse(argv=None):
     ap.add_argument("--no-graphs", action="store_true", help="issue every kernel from Python instead of replaying captured HIP graphs")
     ap.add_argument("--fixed-batches", action="store_true", help="alternate two pre-generated batches instead of generating one per step")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the wire")
+    ap.add_argument("--ddp-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra configurations (text-only step, batch 8, generation)")
     ap.add_argument("--master-port", type=int, default=29517)
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.batch is None:
+        args.batch = 8 if args.workload == "generate" else 56
+    return args
 
 
 # ------------------------------------------------------------------------------------------------
@@ -145,67 +156,123 @@ def run_step(args, model, opt, sch, b):
 
 
 # ------------------------------------------------------------------------------------------------
-# the dominant kernel, timed where it runs: inside a step
+# the dominant kernel and the two kernel families, timed where they run: inside a step
 # ------------------------------------------------------------------------------------------------
-def probe_dominant_kernel(args, model, runner, opt, sch, b, cfg):
-    """One more training step, issued eagerly (no graph replay), with a HIP event pair around every launch of the step's
-    dominant kernel: the FFN up-projection + bias + GELU (+ saved pre-activation) NT GEMM, `gemm_nt_w4_kernel<EPI_GELU,
-    OUT_T>` -- 24 launches per step (12 decoder layers on all 9*B*128 rows, 12 encoder layers on the valid rows).
-    Events are recorded on the stream the kernel is launched on (torch's current stream at the call)."""
+def probe_step_kernels(args, model, runner, opt, sch, b, cfg):
+    """One more training step, issued eagerly (no graph replay, image / table branch on the main stream so that nothing runs
+    beside the kernel being timed), with a HIP event pair around EVERY GEMM launch and every attention launch.  Events are
+    recorded on the stream the kernel is launched on (torch's current stream at the call).
+    Returns (dominant, families):
+      dominant: the FFN up-projection + bias + GELU (+ saved pre-activation) NT GEMM, `gemm_nt_w4_kernel<EPI_GELU, OUT_T>` --
+                24 launches per step (12 decoder layers on all 9*B*128 rows, 12 encoder layers on the valid rows); `achieved`
+                is time-weighted over all of them, the decoder / encoder split is kept beside it;
+      families: {"gemm": ..., "gemm_nt": ..., "gemm_tn": ..., "attention": ...}: launches, milliseconds and FLOPs of the step."""
     import torch
     from multimodalsum_amd import engine as eng_mod, kernels as kn
     e = model._engine
     Fd, D = cfg.decoder_ffn_dim, cfg.d_model
-    real = kn.gemm
-    rec = []
+    real_gemm, real_fwd, real_bwd = kn.gemm, kn.attn_fwd, kn.attn_bwd
+    gemms, attns = [], []
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
 
     def timed_gemm(a, w, out, *pos, **kw):
-        hit = (kw.get("epi") == kn.EPI_GELU and not kw.get("a_t") and not kw.get("b_t") and w.shape == (Fd, D) and a.shape[0] >= 4096)
-        if not hit:
-            return real(a, w, out, *pos, **kw)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_t, b_t = bool(kw.get("a_t")), bool(kw.get("b_t"))
+        M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
+        N = w.shape[1] if b_t else w.shape[0]
+        if kw.get("a2") is not None:
+            K += kw["a2"].shape[1]
+        e0, e1 = ev(), ev()
         e0.record()
-        r = real(a, w, out, *pos, **kw)
+        r = real_gemm(a, w, out, *pos, **kw)
         e1.record()
-        rec.append((e0, e1, a.shape[0], kw.get("live")))
+        gemms.append((e0, e1, M, N, K, a_t and b_t, kw.get("live"), kw.get("epi") == kn.EPI_GELU and not a_t and w.shape == (Fd, D) and M >= 4096))
         return r
+
+    def attn_flops(d, mult):      # canonical: every padded key, the full T x S rectangle also under the causal mask; head_dim 64
+        return mult * 4.0 * d.n_qblocks * d.T * d.H * 64 * d.S * (d.N - (1 if d.exclude_self else 0))
+
+    def timed_fwd(desc, t):
+        e0, e1 = ev(), ev()
+        e0.record()
+        real_fwd(desc, t)
+        e1.record()
+        attns.append((e0, e1, attn_flops(desc, 1.0)))
+
+    def timed_bwd(desc, *a):
+        e0, e1 = ev(), ev()
+        e0.record()
+        real_bwd(desc, *a)
+        e1.record()
+        attns.append((e0, e1, attn_flops(desc, 2.5)))       # five products against the forward's two
 
     graphs = getattr(model, "_step_graphs", None)
     object.__setattr__(model, "_step_graphs", None)
-    eng_mod.kn.gemm = timed_gemm
+    had_side = hasattr(e, "_side_stream")
+    side = getattr(e, "_side_stream", None)
+    e._side_stream = None
+    kn.gemm, kn.attn_fwd, kn.attn_bwd = timed_gemm, timed_fwd, timed_bwd
     try:
         run_step(args, runner, opt, sch, b)
         torch.cuda.synchronize()
     finally:
-        eng_mod.kn.gemm = real
+        kn.gemm, kn.attn_fwd, kn.attn_bwd = real_gemm, real_fwd, real_bwd
         object.__setattr__(model, "_step_graphs", graphs)
-    dec, enc = [], []
-    for e0, e1, rows, live in rec:
-        ms = e0.elapsed_time(e1)
-        if live is None:
-            dec.append((ms, rows))
+        if had_side:
+            e._side_stream = side
         else:
-            enc.append((ms, int(live.item())))
+            del e._side_stream
+    fam = {k: {"launches": 0, "ms": 0.0, "flops": 0.0} for k in ("gemm_nt", "gemm_tn", "attention")}
+    dec, enc = [], []
+    for e0, e1, M, N, K, tn, live, dominant in gemms:
+        ms = e0.elapsed_time(e1)
+        lv = int(live.item()) if live is not None else None
+        if lv is not None:
+            M, K = (M, min(K, lv)) if tn else (min(M, lv), K)
+        f = fam["gemm_tn" if tn else "gemm_nt"]
+        f["launches"] += 1
+        f["ms"] += ms
+        f["flops"] += 2.0 * M * N * K
+        if dominant:
+            (dec if lv is None else enc).append((ms, M))
+    for e0, e1, fl in attns:
+        f = fam["attention"]
+        f["launches"] += 1
+        f["ms"] += e0.elapsed_time(e1)
+        f["flops"] += fl
+    fam["gemm"] = {k: fam["gemm_nt"][k] + fam["gemm_tn"][k] for k in ("launches", "ms", "flops")}
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+    for f in fam.values():
+        f["achieved"] = f["flops"] / f["ms"] / 1e9 if f["ms"] > 0 else None
+        f["frac"] = f["achieved"] / peak if f["achieved"] else None
+    fam["note"] = ("one eager step after the timed region, HIP events around every launch; gemm = every mmsum_gemm launch at its live row "
+                   "count (executed FLOPs), attention = every mmsum_attn_fwd / mmsum_attn_bwd launch priced at the canonical count (all "
+                   "padded keys, full rectangle under the causal mask, backward = 2.5 x forward)")
     if not dec:
-        return None
-    plan = kn.gemm_plan(torch.empty(dec[0][1], D, device=e.device, dtype=e.dtype), torch.empty(Fd, D, device=e.device, dtype=e.dtype),
-                        torch.empty(dec[0][1], Fd, device=e.device, dtype=e.dtype), epi=kn.EPI_GELU,
-                        bias=torch.empty(Fd, device=e.device), aux=torch.empty(dec[0][1], Fd, device=e.device, dtype=e.dtype))
+        return None, fam
     M = dec[0][1]
-    avg = sum(ms for ms, _ in dec) / len(dec)
-    fl = 2.0 * M * Fd * D
+    plan = kn.gemm_plan(torch.empty(M, D, device=e.device, dtype=e.dtype), torch.empty(Fd, D, device=e.device, dtype=e.dtype),
+                        torch.empty(M, Fd, device=e.device, dtype=e.dtype), epi=kn.EPI_GELU,
+                        bias=torch.empty(Fd, device=e.device), aux=torch.empty(M, Fd, device=e.device, dtype=e.dtype))
+    every = dec + enc
+    tot_ms = sum(ms for ms, _ in every)
+    tot_fl = sum(2.0 * rows * Fd * D for _, rows in every)
+    davg = sum(ms for ms, _ in dec) / len(dec)
     out = {"kernel": "gemm_nt_w4_kernel<EPI_GELU,OUT_T> (bf16 NT GEMM x W^T + bias, GELU, pre-activation saved; %dx%d tile, four waves of 128x128, "
                      "64-deep LDS-DMA stages; %d persistent workgroups)" % (plan[1], plan[2], plan[3]) if args.dtype == "bf16" else "gemm_kernel<f32,NT,EPI_GELU>",
-           "shape": [M, Fd, D], "launches_timed": len(dec), "avg_launch_ms": avg, "min_launch_ms": min(ms for ms, _ in dec),
-           "max_launch_ms": max(ms for ms, _ in dec), "flops_per_launch": fl, "achieved": fl / avg / 1e9,
+           "shape": [M, Fd, D], "launches_timed": len(every), "avg_launch_ms": tot_ms / len(every), "flops_per_launch": tot_fl / len(every),
+           "achieved": tot_fl / tot_ms / 1e9,
            "algorithmic_bytes_per_launch": 2.0 * (M * D + Fd * D + 2 * M * Fd) + 4.0 * Fd,
-           "measured": "HIP events around each in-step launch (one eager step after the timed region)"}
+           "measured": "HIP events around each in-step launch (one eager step after the timed region); achieved = FLOPs of all launches / their time",
+           "decoder_calls": {"launches_timed": len(dec), "rows": M, "avg_launch_ms": davg, "min_launch_ms": min(ms for ms, _ in dec),
+                             "max_launch_ms": max(ms for ms, _ in dec), "achieved": 2.0 * M * Fd * D / davg / 1e9}}
     if enc:
         eavg = sum(ms for ms, _ in enc) / len(enc)
         erows = sum(r for _, r in enc) / len(enc)
         out["encoder_calls"] = {"launches_timed": len(enc), "live_rows": erows, "avg_launch_ms": eavg,
                                 "achieved": 2.0 * erows * Fd * D / eavg / 1e9}
-    return out
+    return out, fam
 
 
 def pmc_traffic(shape):
@@ -243,8 +310,9 @@ def host_cores():
 def cpu_baseline(workload, budget_s=75.0, max_steps=3):
     """the reference algorithm (CPU oracle, literal: 9 sequential decoder passes, K/V re-projected per
     pass, unfused loss, PyTorch fp32) on the host cores -- one B=1 step of the SAME configuration as the GPU run (BART-large
-    12+12 layers, 9 reviews x 128 tokens, 4 images of 224x224, table), forward + backward, no optimiser (the reference's
-    optimiser step is a few per cent of its step).  1 warm-up + up to `max_steps` timed steps within `budget_s`.
+    12+12 layers, 9 reviews x 128 tokens, 4 images of 224x224, table): forward + backward + clip_grad_norm_(1.0) + HF-AdamW over
+    the decay group (quirk Q1: the no-decay group is empty), i.e. the step the GPU side times.  1 warm-up + up to `max_steps`
+    timed steps within `budget_s`.
     Weights are random (uniform, the formula init's spread): the closed-form init costs ~50 s at this size and the timing
     does not depend on the values."""
     import torch
@@ -279,6 +347,10 @@ def cpu_baseline(workload, budget_s=75.0, max_steps=3):
     I = 4 if multimodal else 1
     b = syn.yelp_batch(1, 9, 128, I, cfg.vocab_size, seed=1234, img_hw=224 if multimodal else 8)
 
+    decay = [k for k, v in sd.items() if v.requires_grad and not any(nd in k for nd in so.NO_DECAY)]     # train_utils.py:49-57 with Q1
+    moments = {k: (torch.zeros_like(sd[k]), torch.zeros_like(sd[k])) for k in decay}
+    nstep = [0]
+
     def step():
         for v in sd.values():
             v.grad = None
@@ -288,6 +360,12 @@ def cpu_baseline(workload, budget_s=75.0, max_steps=3):
         else:
             loss = so.text_step_loss(sd, ocfg, b["reviews"], b["reviews_mask"], b["reviews_rating"], None, training=True)
         loss.backward()
+        nstep[0] += 1
+        with torch.no_grad():
+            so.clip_grad_norm([v.grad for v in sd.values() if getattr(v, "grad", None) is not None], 1.0)     # multimodal_train.py:361-362
+            for k in decay:
+                if sd[k].grad is not None:
+                    so.adamw_step(sd[k], sd[k].grad, moments[k][0], moments[k][1], nstep[0], 1e-5, weight_decay=0.01)
 
     t_w = time.time()
     step()                       # warm-up (allocator, thread pool)
@@ -306,7 +384,8 @@ def cpu_baseline(workload, budget_s=75.0, max_steps=3):
     q_extra = L * 9 * (2 if multimodal else 0) * 2 * 128 * D * D
     literal = f + 3.0 * (kv_lit - kv + q_extra)
     return {"value": 1.0 / dt, "unit": "businesses/s", "cores": cores, "kind": "port",
-            "sample": "CPU oracle (PyTorch fp32, the reference algorithm restated literally) on %d host cores: whole forward+backward steps of "
+            "sample": "CPU oracle (PyTorch fp32, the reference algorithm restated literally) on %d host cores: whole training steps (forward, "
+                      "backward, clip_grad_norm_ 1.0, HF-AdamW on the Q1 decay group; uniform-random weights of the formula init's spread) of "
                       "the bench configuration at B=1 (BART-large 12+12 layers, 9 reviews x 128 tokens%s): 1 warm-up (%.1f s) + %d timed steps, "
                       "%.1f s each (%.0f GFLOP/s on the reference-literal %.2f TFLOP/step); measured, not extrapolated"
                       % (cores, ", 4 images 224x224 through ResNet101, 47-field table" if multimodal else "", t_w, len(times), dt,
@@ -330,20 +409,14 @@ def cpu_baseline_bounded(args, budget_s=420):
                 "sample": "cpu baseline exceeded its %d s budget on this host" % budget_s}
 
 
-def bench_generate(args):
-    """BASELINE config 5 (test.py:137-164): B=8 businesses (test.py:176) x 8 reviews x 128 tokens + table + 4 images through the three
-    encoders, then 4-beam search, max_length 128, no_repeat_ngram_size 3, early_stopping; bf16, random-init weights (they never
-    emit EOS early, so every summary runs to max_length: the worst case).  One 'step' = one generate() call of the batch."""
+def run_generate(model, cfg, device, B, steps, warmup, dtype_name):
+    """BASELINE config 5 (test.py:137-164): B businesses (test.py:176: 8) x 8 reviews x 128 tokens + table + 4 images through the three
+    encoders, then 4-beam search, max_length 128, no_repeat_ngram_size 3, early_stopping; random-init weights (they never emit EOS
+    early, so every summary runs to max_length: the worst case).  One 'step' = one generate() call of the batch."""
     import torch
-    import multimodalsum_amd as mm
     from multimodalsum_amd import synthetic as syn
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    device = torch.device("cuda", 0)
-    cfg = mm.BartConfig.from_json_file(os.path.join(ROOT, "cfg", "bart-large.json"))
-    model = mm.MultimodalSum(config=cfg, label_smoothing=0.1, device=device, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    was_training = model.training
     model.eval()
-    B = 8 if args.batch == 56 else args.batch
     max_length, beams = 128, 4
     b = syn.batch_to(syn.yelp_batch(B, 8, 128, 4, cfg.vocab_size, seed=7, img_hw=224), device)
 
@@ -353,98 +426,67 @@ def bench_generate(args):
             rd = torch.zeros(B, 1, device=device)                                  # test.py:155
             return model.bart_model.generate(th, tm, tabh, tabm, ih, im, rating_diff=rd, num_beams=beams, length_penalty=1.0, max_length=max_length,
                                              no_repeat_ngram_size=3, early_stopping=True)
-    for _ in range(max(1, args.warmup)):       # the first call captures the per-position decode graphs
+    for _ in range(max(1, warmup)):       # the first call captures the per-position decode graphs
         out = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = run()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    steps = out.shape[1] - 1
-    print(json.dumps({"metric": "generated summaries/sec (4-beam search, max_length 128) BART-large multimodal", "value": B / dt, "unit": "summaries/s",
-                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
-                      "vs_baseline": None, "dtype": args.dtype, "data": "synthetic Yelp-shaped test batch (seeded), formula-initialised weights",
-                      "config": {"workload": "test.py beam-search generation (beam=4, max_len=128, no_repeat_ngram_size=3, early_stopping) full multimodal: "
-                                             "8 reviews x 128 tok + table + 4 images per business", "per_gpu_batch": B, "num_beams": beams},
-                      "decode_steps": steps, "ms_per_decode_step": dt * 1e3 / max(steps, 1), "tokens_per_s": B * steps / dt,
-                      "peak_hbm_gb": round(torch.cuda.max_memory_reserved() / 2**30, 1)}), flush=True)
+    dt = (time.perf_counter() - t0) / steps
+    model.train(was_training)
+    nsteps = out.shape[1] - 1
+    return {"metric": "generated summaries/sec (4-beam search, max_length 128) BART-large multimodal", "value": B / dt, "unit": "summaries/s",
+            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic Yelp-shaped test batch (seeded), formula-initialised weights",
+            "config": {"workload": "test.py beam-search generation (beam=4, max_len=128, no_repeat_ngram_size=3, early_stopping) full multimodal: "
+                                   "8 reviews x 128 tok + table + 4 images per business", "per_gpu_batch": B, "num_beams": beams},
+            "decode_steps": nsteps, "ms_per_decode_step": dt * 1e3 / max(nsteps, 1), "tokens_per_s": B * nsteps / dt}
 
 
-def main():
-    args = parse()
-    if args.workload == "generate":
-        return bench_generate(args)
-    env_world = os.environ.get("WORLD_SIZE")
-    if env_world is None and args.gpus > 1:
-        spawn_ranks(args)                       # does not return
-    world = int(env_world or "1")
-    if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+def bench_generate(args):
     import torch
+    import multimodalsum_amd as mm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    force_ddp = os.environ.get("MMSUM_FORCE_DDP") == "1"          # debugging aid: run the RCCL gradient path at world size 1
-    dist = None
-    if world > 1 or force_ddp:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(args.master_port))
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
-    import multimodalsum_amd as mm
-    from multimodalsum_amd import optim
-    cfg, model = build(args, device)
-    ddp = None
-    if world > 1 or force_ddp:
-        ddp = mm.DistributedDataParallel(model, delay_allreduce=True, always_reduce=force_ddp, collect_stats=True,
-                                         grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
-    runner = ddp if ddp is not None else model
-    opt = optim.get_optimizer(1e-5, NO_DECAY, model.named_parameters(), None)
-    sch = optim.get_linear_schedule_with_warmup(opt, 100, 100000)
-    next_batch = batch_source(args, cfg, device, rank)
+    device = torch.device("cuda", 0)
+    cfg = mm.BartConfig.from_json_file(os.path.join(ROOT, "cfg", "bart-large.json"))
+    model = mm.MultimodalSum(config=cfg, label_smoothing=0.1, device=device, dtype=torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    out = run_generate(model, cfg, device, args.batch, args.steps, args.warmup, args.dtype)
+    out["peak_hbm_gb"] = round(torch.cuda.max_memory_reserved() / 2**30, 1)
+    print(json.dumps(out), flush=True)
 
-    def sync():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
 
-    priming = 0
-    if not args.no_graphs:
-        model.enable_step_graphs()
-        priming = 2                         # un-timed: one eager step, one that captures the HIP graphs
-        for i in range(priming):
-            run_step(args, runner, opt, sch, next_batch())
-    for i in range(args.warmup):
-        run_step(args, runner, opt, sch, next_batch())
-    stats_skip = len(ddp.stats) if ddp is not None else 0
-    live_rows = []
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        b = next_batch()                   # generated on the device inside the timed step
-        loss = run_step(args, runner, opt, sch, b)
-        live_rows.append((b["reviews_mask"].sum(), b["img_mask"].sum() if args.workload == "multimodal" else None))   # device scalars, read after the region
-    sync()
-    dt = time.perf_counter() - t0
+def timed_steps(args, model, runner, opt, sch, next_batch, steps, warmup, sync):
+    """`warmup` un-timed and `steps` timed training steps (after two priming steps when the step graphs are on: one eager, one
+    that captures).  Returns (seconds of the timed region, last loss, the timed steps' device-side live counts, priming steps)."""
+    stats_skip = None
+    dt, loss, live_rows, priming, b = timed_steps(args, model, runner, opt, sch, next_batch, args.steps, args.warmup, sync)
+    if ddp is not None:
+        stats_skip = max(0, len(ddp.stats) - args.steps)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.item())
+    live_rows = [(float(t), float(im) if im is not None else 0.0) for t, im in live_rows]      # the device scalars, now that the region is over
     comm = ddp.comm_stats(skip=stats_skip) if ddp is not None else None
     graphs = getattr(model, "_step_graphs", None)
     captures = graphs.captures if graphs is not None else 0
     peak_gb = round(torch.cuda.max_memory_reserved() / 2**30, 1)
-    probe = None
+    probe, families = None, None
     if rank == 0 and not args.no_kernel_probe and world == 1:
-        probe = probe_dominant_kernel(args, model, runner, opt, sch, b, cfg)
+        probe, families = probe_step_kernels(args, model, runner, opt, sch, b, cfg)
+    also = None
+    if rank == 0 and world == 1 and not args.no_also and args.workload == "multimodal" and args.dtype == "bf16" and not args.no_graphs:
+        also = also_configs(args, cfg, model, device)
+        object.__setattr__(model, "_step_graphs", None)        # release the headline model before the text-only one is built
+        del runner, opt, sch, next_batch, b, loss, graphs
+        model = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        also["text_only_B56"] = also_text_only(args, cfg, device)
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
@@ -452,8 +494,8 @@ def main():
         I = 4 if multimodal else 1
         dims = (cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, I)
         fpb = flops_per_business(*dims, multimodal=multimodal)
-        text_rows = sum(float(t) for t, _ in live_rows) / len(live_rows) / args.batch
-        mem_rows = text_rows + ((47 + 196 * sum(float(im) for _, im in live_rows) / len(live_rows) / args.batch) if multimodal else 0)
+        text_rows = sum(t for t, _ in live_rows) / len(live_rows) / args.batch
+        mem_rows = text_rows + ((47 + 196 * sum(im for _, im in live_rows) / len(live_rows) / args.batch) if multimodal else 0)
         fpb_exec = flops_per_business(*dims, multimodal=multimodal, enc_rows=text_rows, mem_rows=mem_rows)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = value / world * fpb / 1e12
@@ -470,6 +512,8 @@ def main():
             roof = {"bound": "mfma", "achieved": probe["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": probe["achieved"] / peak,
                     "traffic": traffic, "traffic_source": src, "step": step_roof}
             roof.update({k: v for k, v in probe.items() if k != "achieved"})
+        if families is not None:
+            roof["families"] = families
         out = {"metric": "training samples/sec (businesses/sec) BART-large multimodal" if multimodal else
                "training samples/sec (businesses/sec) BART-large text-only",
                "value": value, "unit": "businesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -486,6 +530,8 @@ def main():
                "graph_captures": captures, "final_loss": loss_val, "peak_hbm_gb": peak_gb, "roofline": roof}
         if comm is not None:
             out["comm"] = comm
+        if also is not None:
+            out["also"] = also
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_bounded(args)
     if dist is not None:

@@ -24,8 +24,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
+#pragma GCC visibility push(default)
 
-#define MMSUM_ABI_VERSION 3
+#define MMSUM_ABI_VERSION 4
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -67,17 +69,19 @@ int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, in
                void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
                const float* alpha_dev, int flags, int splitk, const int* live_rows, void* stream);
 
-/* What mmsum_gemm would launch for these arguments (pure: no device work, pointers are only checked for alignment / NULL):
+/* What mmsum_gemm would launch for these arguments (pure: no device work, pointers are only checked for alignment / NULL --
+ * live_rows and alpha_dev too: kernel selection depends on whether they are given, e.g. the weight-streaming kernel takes
+ * neither):
  * plan[0] = kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (fewer than tiles * splitk:
  * persistent workgroups walk the tile list).  Tests use it to assert that a shape reaches the kernel they mean to cover. */
 enum { MMSUM_PLAN_GENERIC = 0,   /* gemm_kernel: register-staged 128x128, f32 or bf16, any layout */
        MMSUM_PLAN_NT_RING = 1,   /* LDS-DMA kernels for bf16 K-contiguous operands: gemm_nt_w4_kernel (256x256 tiles, four waves) or
-                                    gemm_nt_ring_kernel (smaller tiles, GELU' / ReLU' epilogues) */
+                                    gemm_nt_ring_kernel (smaller tiles) */
        MMSUM_PLAN_TN_RING = 2,   /* the same pair for reduction-major operands (weight gradients): gemm_tn_w4_kernel / gemm_tn_ring_kernel */
        MMSUM_PLAN_SKINNY = 3 };  /* gemm_skinny_kernel: M <= 128 weight-streaming (decode steps) */
 int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                     const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
-                    int splitk, int* plan);
+                    int splitk, const int* live_rows, const float* alpha_dev, int* plan);
 
 /* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
 int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
@@ -283,6 +287,7 @@ int mmsum_decode_self_attn(int dtype, const void* q, long ldq, void* k_cache, vo
                            void* out, long ldo, int rows, int H, int len, int Tmax, float scale, const void* k_new, const void* v_new,
                            long ld_new, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

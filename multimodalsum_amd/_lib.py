@@ -19,7 +19,7 @@ GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
 GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM = 0x40, 0x80, 0x100, 0x200
 PLAN_GENERIC, PLAN_NT_RING, PLAN_TN_RING, PLAN_SKINNY = 0, 1, 2, 3
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def gemm_epi(e):
@@ -42,7 +42,7 @@ SIGNATURES = {
     "mmsum_gemm": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p,
                            c_void_p, c_long, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mmsum_gemm_plan": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
-                                c_long, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int)]),
+                                c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "mmsum_slab_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_void_p]),
     "mmsum_colsum_workspace": (c_long, [c_int]),
     "mmsum_colsum": (c_int, [c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),

@@ -212,10 +212,10 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
 // means persistent workgroups walking the tile list).  Lets tests assert that a shape reaches the kernel they mean to cover.
 extern "C" int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                                const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
-                               int splitk, int* plan) {
-    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, C, ldc, aux, ldaux, M, N, K, flags, splitk, nullptr);
+                               int splitk, const int* live_rows, const float* alpha_dev, int* plan) {
+    const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, C, ldc, aux, ldaux, M, N, K, flags, splitk, live_rows);
     if (rc != MMSUM_OK) return rc;
-    GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, nullptr, nullptr};
+    GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, live_rows, alpha_dev};
     GemmPlan g;
     if (gemm_skinny_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 32, (a.N + 31) / 32};
     else if (gemm_glds_eligible(dtype, a)) g = plan_gemm_glds(a);

@@ -6,8 +6,8 @@
 //        (weight gradients dy^T x straight from the activations)
 //
 // 256x256 tiles (the step's products) run on FOUR waves of 128x128 each (gemm_nt_w4_kernel, gemm_tn_w4_kernel: one wave per
-// SIMD, accumulators in all 256 AGPRs, source-level software pipeline); 256x128 / 128x128 tiles and the GELU' / ReLU'
-// epilogues on the eight- / four-wave ring kernels (gemm_nt_ring_kernel, gemm_tn_ring_kernel).  Operands live in LDS in a
+// SIMD, accumulators in all 256 AGPRs, source-level software pipeline, every epilogue form); 256x128 / 128x128 tiles (small
+// outputs) on the eight- / four-wave ring kernels (gemm_nt_ring_kernel, gemm_tn_ring_kernel).  Operands live in LDS in a
 // swizzled image that the DMA writes linearly (wave-uniform base + lane*16 B): the XOR is applied to the per-lane SOURCE
 // address and again on the fragment read (guide rule 21).  Rows past M/N are clamped (their results are never stored).
 #include "gemm_common.h"
@@ -180,10 +180,8 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
                         for (int e = 0; e < nvalid; ++e) aux[oa + e] = (bf16_t)v[e];
                     }
                 }
-#if !defined(MMSUM_DIAG_EPI) || MMSUM_DIAG_EPI != 3        // tools/ builds only: 3 = no GELU arithmetic
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_fast_f(v[e]);
-#endif
             } else if constexpr (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD) {
                 bf16_t t[8];                          // always the prefetched vector: the host admits these epilogues for
                 __builtin_memcpy(t, &aux_now, 16);                  // aligned operands and N % 8 == 0 only (no scalar path)
@@ -200,11 +198,6 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
 #pragma unroll
                 for (int e = 0; e < 8; ++e) csum[e] += (e < nvalid) ? (float)(bf16_t)v[e] : 0.f;     // what a separate pass over the bf16 result would add
             }
-#if defined(MMSUM_DIAG_EPI) && MMSUM_DIAG_EPI == 2           // tools/ builds only: 2 = everything but the stores of C
-#pragma unroll
-            for (int e = 0; e < 8; ++e) csum[e] += v[e];
-            if (csum[0] != 12345.678f) continue;
-#endif
             if constexpr (OUT == OUT_T_ACC) {
                 bf16_t t[8];
                 __builtin_memcpy(t, &c_now, 16);
@@ -240,9 +233,6 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
             }
         }
     }
-#if defined(MMSUM_DIAG_EPI) && MMSUM_DIAG_EPI == 2
-    if (csum[1] == 12345.678f) Cf[0] = csum[2] + csum[7];
-#endif
     if (do_colsum) {
         // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
         lds_barrier();
@@ -404,20 +394,25 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false, typename AccSrc = AccArray>
+// WIDE = the workgroup has the whole 512-register file per wave (the four-wave kernels: accumulators in AGPRs, 256 VGPRs for the
+// epilogue): GELU' / ReLU' and the column sums then take the lean form too, and CS (column sums of the stored tile) is a
+// compile-time property of the kernel -- one lean body per instantiation keeps the lane-constant addresses the compiler hoists
+// out of the tile loop inside the register file.  On the eight-wave kernels (128 registers beside the accumulators) the
+// derivative arithmetic of a pass spilled 167 registers in the lean form: they keep the guarded one, with column sums by flag.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false, typename AccSrc = AccArray,
+          bool WIDE = false, bool CS = false>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                 char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, AccSrc src = AccSrc{}) {
     float bv[8];
     epilogue_bias<BN, WAVES_M * WAVES_N * 64>(p, n0, ks, tid, bv);
     constexpr bool kF32 = (OUT == OUT_F32_ACC || OUT == OUT_F32_ATOMIC || OUT == OUT_F32);
+    constexpr bool kAuxIn = (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD);
     const bool aligned = (((uintptr_t)p.C) & 15) == 0 && (p.ldc & (kF32 ? 3 : 7)) == 0 &&
                          (p.aux == nullptr || ((((uintptr_t)p.aux) & 15) == 0 && (p.ldaux & 7) == 0));
     const bool interior = m0 + BM <= p.M && n0 + BN <= p.N && aligned;        // workgroup-uniform
-    // the lean path serves the epilogues without a saved operand; GELU' / ReLU' (whose derivative arithmetic, unrolled over a
-    // pass, does not fit the 128 registers left beside the accumulators: 167 spilled) and column sums keep the guarded form
-    if constexpr (OUT != OUT_F32_ATOMIC && EPI != MMSUM_EPI_GELU_BWD && EPI != MMSUM_EPI_RELU_BWD) {
-        if (interior && !(p.flags & MMSUM_GEMM_COLSUM)) {
-            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, false, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
+    if constexpr (OUT != OUT_F32_ATOMIC && (WIDE || !kAuxIn)) {
+        if (interior && (WIDE || !(p.flags & MMSUM_GEMM_COLSUM))) {
+            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, WIDE && CS, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
             return;
         }
     }
@@ -460,31 +455,11 @@ inline int cu_count() {
     return n;
 }
 
-#ifndef MMSUM_GEMM_STAGGER
-#define MMSUM_GEMM_STAGGER 1
-#endif
-#ifndef MMSUM_GEMM_PINGPONG
-#define MMSUM_GEMM_PINGPONG 0
-#endif
-#ifndef MMSUM_GEMM_MFMA16
-#define MMSUM_GEMM_MFMA16 1      // NT ring: v_mfma_f32_16x16x32_bf16 (higher clock under load) instead of 32x32x16
-#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-__device__ __forceinline__ Frag nt_frag(const char* slab, int row0, int lane) {
-#if MMSUM_GEMM_MFMA16
-    return lds_frag16(slab, row0, lane);
-#else
-    return lds_frag<bf16_t>(slab, row0, lane);
-#endif
-}
-__device__ __forceinline__ void nt_mma(f32x16_t& acc, const Frag& a, const Frag& b) {
-#if MMSUM_GEMM_MFMA16
-    mma_slab16(acc, a, b);
-#else
-    mma_slab<bf16_t>(acc, a, b);
-#endif
-}
+// NT ring kernels: v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on this shape than on 32x32x16 at equal cycles per FLOP)
+__device__ __forceinline__ Frag nt_frag(const char* slab, int row0, int lane) { return lds_frag16(slab, row0, lane); }
+__device__ __forceinline__ void nt_mma(f32x16_t& acc, const Frag& a, const Frag& b) { mma_slab16(acc, a, b); }
 
 // ---------------------------------------------------------------------------------------------
 // 64-deep stages with 128-byte LDS rows (the four-wave kernel below).  A 32-deep stage takes 64 bytes of every operand row,
@@ -516,10 +491,9 @@ __device__ __forceinline__ void k64_piece(char* stage, const bf16_t* base, int v
 #endif
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int NSTAGE = 4, int MIN_WAVES_EU = 1>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_ring_kernel(GemmArgs p) {
-    static_assert(NSTAGE == 4 || NSTAGE == 3, "the wait counts below are written for a 3- or 4-stage ring");
-    constexpr int AHEAD = NSTAGE - 1;               // slabs of DMA in flight beyond the one being consumed: 3 (one workgroup per CU) or 2
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(GemmArgs p) {
+    constexpr int NSTAGE = 4, AHEAD = NSTAGE - 1;   // three slabs of DMA in flight beyond the one being consumed
     using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -577,14 +551,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
     auto issue = [&](int si) {          // si: slab index relative to s_beg
         char* As = smem + (si % NSTAGE) * Cfg::STAGE;
         char* Bs = As + Cfg::A_BYTES;
-#ifdef MMSUM_DIAG_NO_DMA           // tools/ builds only: the main loop without its global loads (after the first three slabs)
-        if (si >= 3) return;
-#endif
-#ifdef MMSUM_DIAG_DMA_SAME_K       // tools/ builds only: every slab fetches the first 32 columns again (all L2 hits, same request count)
-        int k0 = 0;
-#else
         int k0 = (s_beg + si) * 32;
-#endif
         const int kb = k0;
         const bool second = A2 != nullptr && k0 >= p.ksplit;
         const bf16_t* Ab = second ? A2 : A;
@@ -600,13 +567,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
         issue(0);
         if (ns > 1) issue(1);
         if (AHEAD > 2 && ns > 2) issue(2);
-        // STAGGER (8-wave tiles): the two waves of a SIMD (wave w and w + 4: wave rows 0 and 1) run the same program, so without
-        // help they read LDS together, issue their DMA together (an LDS-DMA instruction costs its wave 100-185 cycles of issue
-        // among MFMAs) and then compete for the matrix pipe together.  The second wave row therefore runs HALF A SLAB LATE:
-        // after the barrier it first issues the MFMAs of the previous slab's second half (operands kept in registers across
-        // the barrier) -- while the first row reads and issues DMA --, and reads / issues DMA while the first row computes.
-        constexpr bool STAGGER = MMSUM_GEMM_STAGGER && WAVES_M == 2 && Cfg::TM == 4;
-        constexpr int HALF = Cfg::TM / 2;
         auto wait_slab = [&](int si) {
             const int ahead = ns - 1 - si;                       // slabs issued after slab si (capped at AHEAD - 1)
             if (AHEAD > 2 && ahead >= 2) wait_vmcnt<2 * Cfg::PPW>();
@@ -614,130 +574,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         };
-#if MMSUM_GEMM_PINGPONG
-        // PING-PONG (8-wave tiles): two barriers per slab split it into a load phase and a matrix phase, and the two wave rows
-        // (the two waves of every SIMD) are half a slab apart, so one of them is always in its matrix phase while the other
-        // reads its 12 fragments and issues its share of the DMA.
-        if (STAGGER) {
-            Frag a[Cfg::TM], b[Cfg::TN];
-            auto load_phase = [&](int si) {
-                const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
-                const char* Bs = As + Cfg::A_BYTES;
+        for (int si = 0; si < ns; ++si) {
+            wait_slab(si);
+            const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
+            const char* Bs = As + Cfg::A_BYTES;
+            // this slab's first fragments are requested BEFORE the DMA of slab si+3 is issued (different ring slots): the
+            // address arithmetic and the DMA instructions then run under the LDS latency instead of in front of it
+            Frag b[Cfg::TN];
 #pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) b[j] = nt_frag(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+            for (int j = 0; j < Cfg::TN; ++j) b[j] = nt_frag(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
+            Frag a0 = nt_frag(As, wm * (Cfg::TM * 32), lane);
+            if (si + AHEAD < ns) issue(si + AHEAD);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i) a[i] = nt_frag(As, wm * (Cfg::TM * 32) + i * 32, lane);
-                if (si + AHEAD < ns) issue(si + AHEAD);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            };
-            auto matrix_phase = [&]() {
-                __builtin_amdgcn_s_setprio(1);
+            for (int i = 0; i < Cfg::TM; ++i) {
+                const Frag a = i == 0 ? a0 : nt_frag(As, wm * (Cfg::TM * 32) + i * 32, lane);
 #pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[i][j], a[i], b[j]);
-                __builtin_amdgcn_s_setprio(0);
-            };
-            if (wm == 0) {
-                for (int si = 0; si < ns; ++si) {
-                    wait_slab(si);
-                    load_phase(si);
-                    __builtin_amdgcn_s_barrier();
-                    matrix_phase();
-                }
-            } else {
-                for (int si = 0; si < ns; ++si) {
-                    wait_slab(si);
-                    if (si > 0) matrix_phase();
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    load_phase(si);
-                }
-                matrix_phase();
+                for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[i][j], a, b[j]);
             }
-        } else
-#endif
-        if (!(STAGGER && wm == 1)) {
-            for (int si = 0; si < ns; ++si) {
-                wait_slab(si);
-                const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
-                const char* Bs = As + Cfg::A_BYTES;
-                // this slab's first fragments are requested BEFORE the DMA of slab si+3 is issued (different ring slots): the
-                // address arithmetic and the four DMA instructions then run under the LDS latency instead of in front of it
-                Frag b[Cfg::TN];
-#pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) b[j] = nt_frag(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
-                Frag a0 = nt_frag(As, wm * (Cfg::TM * 32), lane);
-                if (si + AHEAD < ns) issue(si + AHEAD);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < Cfg::TM; ++i) {
-                    const Frag a = i == 0 ? a0 : nt_frag(As, wm * (Cfg::TM * 32) + i * 32, lane);
-#pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[i][j], a, b[j]);
-                }
-                __builtin_amdgcn_s_setprio(0);
-            }
-        } else {
-            // the late wave row: same barriers, its matrix work shifted by half a slab (separate loop: the two programs share
-            // no basic block, so neither constrains the other's registers)
-            Frag aH[HALF], bH[Cfg::TN];
-            for (int si = 0; si < ns; ++si) {
-                wait_slab(si);
-                const char* As = smem + (si % NSTAGE) * Cfg::STAGE;
-                const char* Bs = As + Cfg::A_BYTES;
-                if (si > 0) {
-                    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                    for (int i = 0; i < HALF; ++i)
-#pragma unroll
-                        for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[HALF + i][j], aH[i], bH[j]);
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                __builtin_amdgcn_sched_barrier(0);                 // the reads below stay behind those MFMAs
-                Frag a[HALF];
-#pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) bH[j] = nt_frag(Bs, wn * (Cfg::TN * 32) + j * 32, lane);
-#pragma unroll
-                for (int i = 0; i < HALF; ++i) a[i] = nt_frag(As, wm * (Cfg::TM * 32) + i * 32, lane);
-#pragma unroll
-                for (int i = 0; i < HALF; ++i) aH[i] = nt_frag(As, wm * (Cfg::TM * 32) + (HALF + i) * 32, lane);
-                if (si + AHEAD < ns) issue(si + AHEAD);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int i = 0; i < HALF; ++i)
-#pragma unroll
-                    for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[i][j], a[i], bH[j]);
-                __builtin_amdgcn_s_setprio(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every read of this ring slot has returned before the barrier that frees it
-            }
-#pragma unroll
-            for (int i = 0; i < HALF; ++i)
-#pragma unroll
-                for (int j = 0; j < Cfg::TN; ++j) nt_mma(acc[HALF + i][j], aH[i], bH[j]);
+            __builtin_amdgcn_s_setprio(0);
         }
     }
     if constexpr (OUT == OUT_F32_ATOMIC) {
         // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
-        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT, MMSUM_GEMM_MFMA16 != 0>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT, true>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
-#ifdef MMSUM_DIAG_NO_EPILOGUE     // tools/ builds only (never defined for the shipped library): main loop without the epilogue
-#pragma unroll                    // every accumulator stays live: a dead one would take its MFMAs with it
-        for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) asm volatile("" ::"v"(acc[i][j]));
-#else
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE, MMSUM_GEMM_MFMA16 != 0>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
-#endif
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE, true>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
     }
     lds_barrier();            // the staging reads are done before the next tile's DMA lands in the same LDS (stores stay in flight)
     }
 }
 
 
-#ifndef MMSUM_GEMM_W4K64
-#define MMSUM_GEMM_W4K64 1
-#endif
 // ---------------------------------------------------------------------------------------------
 // Four-wave form of the 256x256 NT tile: 2 x 2 waves, each a 128x128 block (256 accumulator registers = every AGPR, one
 // wave per SIMD), 64-deep stages in the 128-byte-row image above.
@@ -755,7 +623,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, MIN_WAVES_EU) void gemm_nt_r
 // tile of a column): one stage ahead is enough.  A streams from HBM: its DMA runs two stages ahead, so at the barrier only
 // the 8 youngest pieces (A of stage s+2) may still be in flight -- s_waitcnt vmcnt(8), not 0.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool CS = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 2, TM = 4, TN = 4;
     using C = K64Cfg<BM, BN, WAVES_M, WAVES_N>;
@@ -907,7 +775,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     if constexpr (OUT == OUT_F32_ATOMIC) {
         gemm_epilogue<bf16_t, TM, TN, EPI, OUT, true>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, 3 * C::A_BYTES + 2 * C::B_BYTES, true>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, 3 * C::A_BYTES + 2 * C::B_BYTES, true, AccArray, true, CS>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
     }
     lds_barrier();
     }
@@ -1056,9 +924,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_tn_ring_kernel(Gem
     }
 }
 
-#ifndef MMSUM_GEMM_TN_W4
-#define MMSUM_GEMM_TN_W4 1
-#endif
 // ---------------------------------------------------------------------------------------------
 // Four-wave form of the 256x256 TN tile (see gemm_nt_w4_kernel for why four waves): 2 x 2 waves of 128x128, the same 4-stage
 // ring of 32-deep stages and transposing reads as gemm_tn_ring_kernel, 256 accumulator registers pinned in AGPRs, and the
@@ -1195,11 +1060,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
         // LEFT = stages after this one (capped at 3): >= 3 request stage si+3; >= 2: stage si+2 is in flight at the barrier
         auto stage = [&](int si, bf16x8_t (&aC)[TM][2], bf16x8_t (&bC)[TN][2], bf16x8_t (&aN)[TM][2], bf16x8_t (&bN)[TN][2], auto left_c) {
             constexpr int LEFT = decltype(left_c)::value;
-#ifdef MMSUM_DIAG_TNW4_DRAIN        // tools/ builds only: every request retired at every barrier
-            wait_vmcnt<0>();
-#else
             if constexpr (LEFT >= 2) wait_vmcnt<8>(); else if constexpr (LEFT == 1) wait_vmcnt<0>();     // stage si+1 has landed
-#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const char* nxt = smem + ((si + 1) & 3) * Cfg::STAGE;
@@ -1289,26 +1150,21 @@ inline int ring_grid(const GemmArgs& a, int bm, int bn) {
     return tiles > cus ? cus : tiles;
 }
 
-// WG_PER_CU = 2: four-wave workgroups with a 3-stage ring (72 KB), two resident per CU.  They drift out of phase, so one's
-// epilogue (per-CU store rate ~10 B/clk: 6-12 us per tile with nothing else to do) runs under the other's MFMA main loop.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int WG_PER_CU = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
-    constexpr int NST = WG_PER_CU == 2 ? 3 : 4;
-    using R = RingCfg<BM, BN, WAVES_M, WAVES_N, NST>;
+    using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
     const size_t lds = R::NSTAGE * R::STAGE;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NST, WG_PER_CU>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.splitk;
-    const int cap = cu_count() * WG_PER_CU;
-    gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, NST, WG_PER_CU><<<dim3(tiles > cap ? cap : tiles), dim3(R::THREADS), lds, stream>>>(a);
+    gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT><<<dim3(ring_grid(a, BM, BN)), dim3(R::THREADS), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int WG_PER_CU = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
-#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O, WG_PER_CU>(a, stream);
+#define FAST_CASE(E, O) if (epi == E && out == O) return launch_one<BM, BN, WAVES_M, WAVES_N, E, O>(a, stream);
     FAST_CASE(MMSUM_EPI_NONE, OUT_T) FAST_CASE(MMSUM_EPI_NONE, OUT_T_ACC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
     FAST_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) FAST_CASE(MMSUM_EPI_NONE, OUT_F32)
     FAST_CASE(MMSUM_EPI_GELU, OUT_T) FAST_CASE(MMSUM_EPI_GELU_BWD, OUT_T) FAST_CASE(MMSUM_EPI_RELU, OUT_T) FAST_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
@@ -1316,27 +1172,28 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return MMSUM_ERR_BAD_SHAPE;
 }
 
-template <int EPI, int OUT>
+template <int EPI, int OUT, bool CS = false>
 int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
     using C = K64Cfg<256, 256, 2, 2>;
     const size_t lds = 3 * C::A_BYTES + 2 * C::B_BYTES;             // 160 KB: the whole LDS of a CU
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w4_kernel<EPI, OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w4_kernel<EPI, OUT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
-    const int cap = cu_count();
-    gemm_nt_w4_kernel<EPI, OUT><<<dim3(tiles > cap ? cap : tiles), dim3(256), lds, stream>>>(a);
+    gemm_nt_w4_kernel<EPI, OUT, CS><<<dim3(ring_grid(a, 256, 256)), dim3(256), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 int launch_w4(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
+    if (a.flags & MMSUM_GEMM_COLSUM) {        // column sums of the stored bf16 tile in the epilogue (bias gradients)
+        if (epi == MMSUM_EPI_GELU_BWD && out == OUT_T) return launch_w4_one<MMSUM_EPI_GELU_BWD, OUT_T, true>(a, stream);
+        if (epi == MMSUM_EPI_NONE && out == OUT_T) return launch_w4_one<MMSUM_EPI_NONE, OUT_T, true>(a, stream);
+        return MMSUM_ERR_BAD_SHAPE;           // gemm_glds_eligible admits column sums for these two forms only
+    }
 #define W4_CASE(E, O) if (epi == E && out == O) return launch_w4_one<E, O>(a, stream);
     W4_CASE(MMSUM_EPI_NONE, OUT_T) W4_CASE(MMSUM_EPI_NONE, OUT_T_ACC) W4_CASE(MMSUM_EPI_NONE, OUT_F32_ACC)
     W4_CASE(MMSUM_EPI_NONE, OUT_F32_ATOMIC) W4_CASE(MMSUM_EPI_NONE, OUT_F32)
-    W4_CASE(MMSUM_EPI_GELU, OUT_T) W4_CASE(MMSUM_EPI_RELU, OUT_T)
+    W4_CASE(MMSUM_EPI_GELU, OUT_T) W4_CASE(MMSUM_EPI_RELU, OUT_T) W4_CASE(MMSUM_EPI_GELU_BWD, OUT_T) W4_CASE(MMSUM_EPI_RELU_BWD, OUT_T)
 #undef W4_CASE
-    // GELU' / ReLU' (the guarded epilogue with a saved operand: 512 threads write a tile back faster than 256; measured in the
-    // step: 549 us on the eight-wave ring against 585 us here) and anything else stay on the eight-wave ring kernel
-    return launch_cfg<256, 256, 2, 4>(a, stream);
+    return MMSUM_ERR_BAD_SHAPE;               // gemm_glds_eligible admits no other combination
 }
 
 // Tile shape that keeps the 256 CUs busiest for a problem: fraction of the last round of workgroups that is filled x
@@ -1416,11 +1273,7 @@ int launch_tn_w4(const GemmArgs& a, hipStream_t stream) {
 
 int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {
-#if MMSUM_GEMM_TN_W4
         case TILE_256x256: return launch_tn_w4(a, stream);
-#else
-        case TILE_256x256: return launch_tn_cfg<256, 256, 2, 4>(a, stream);
-#endif
         case TILE_256x128: return launch_tn_cfg<256, 128, 4, 2>(a, stream);
         default: return launch_tn_cfg<128, 128, 2, 2>(a, stream);
     }
@@ -1428,11 +1281,7 @@ int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {
-#if MMSUM_GEMM_W4K64
         case TILE_256x256: return launch_w4(a, stream);
-#else
-        case TILE_256x256: return launch_cfg<256, 256, 2, 4>(a, stream);
-#endif
         case TILE_256x128: return launch_cfg<256, 128, 4, 2>(a, stream);
         default: return launch_cfg<128, 128, 2, 2>(a, stream);
     }

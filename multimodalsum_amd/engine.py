@@ -106,6 +106,23 @@ def resnet_specs(embedding_dim, prefix="img_encoder."):
     return live, frozen, bufs
 
 
+def splitk_rule(M, N, Kred, bf16=True, deterministic=False):
+    """Split count of the weight-gradient product dW[M, N] = dy[Kred, M]^T x[Kred, N] (Engine.wgrad; the bench-shape parity tests
+    call this same function, so they run the step's real slice counts)."""
+    if deterministic:
+        return 1
+    ktiles = max(1, Kred // (64 if bf16 else 32))
+    # one 256x256 tile per CU and launch: the TN kernel is not persistent, so tiles x slices should come as close to the 256
+    # CUs as it can from below (tools/tn_sk_sweep.py at R = 64,512: dW[4096,1024] 521 us at 3 slices = 192 workgroups, 451 us
+    # at 4 = 256, 613 us at 5 = 320); few-tile outputs with a very long reduction (the ResNet layer3 convolutions: 4..9 tiles,
+    # 43,904 rows) keep gaining up to 32 slices (tools/wgrad_small.py: 77 -> 46 us)
+    if not bf16:                                           # f32 parity mode (generic kernel, 128x128 tiles): the round-1 rule
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        return max(1, min(32, -(-768 // max(tiles, 1)), ktiles // 4))
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    return max(1, min(32, 256 // tiles if tiles <= 256 else 1, ktiles // 4))
+
+
 class Engine:
     def __init__(self, cfg, device="cuda", compute_dtype=torch.bfloat16, multimodal=True, with_table=False, with_img=False,
                  bart_prefix="", deterministic=False):
@@ -275,19 +292,7 @@ class Engine:
         self._conv_dirty = "layer3"
 
     def splitk(self, M, N, Kred):
-        if self.deterministic:
-            return 1
-        ktiles = max(1, Kred // (64 if self.dtype == torch.bfloat16 else 32))
-        # one 256x256 tile per CU and launch: the TN kernel is not persistent, so tiles x slices should come as close to the 256
-        # CUs as it can from below (tools/tn_sk_sweep.py at R = 64,512: dW[4096,1024] 521 us at 3 slices = 192 workgroups, 451 us
-        # at 4 = 256, 613 us at 5 = 320); few-tile outputs with a very long reduction (the ResNet layer3 convolutions: 4..9 tiles,
-        # 43,904 rows) keep gaining up to 32 slices (tools/wgrad_small.py: 77 -> 46 us)
-        if self.dtype != torch.bfloat16:                       # f32 parity mode (generic kernel, 128x128 tiles): the round-1 rule
-            tiles = ((M + 127) // 128) * ((N + 127) // 128)
-            return max(1, min(32, -(-768 // max(tiles, 1)), ktiles // 4))
-        tiles = ((M + 255) // 256) * ((N + 255) // 256)
-        sk = max(1, min(32, 256 // tiles if tiles <= 256 else 1, ktiles // 4))
-        return sk
+        return splitk_rule(M, N, Kred, bf16=self.dtype == torch.bfloat16, deterministic=self.deterministic)
 
     def wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
         """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena (live: device count of the rows R)."""
@@ -548,18 +553,28 @@ class Engine:
         c.out = x
         return x, c
 
-    def decoder_bwd(self, c, dout):
-        """dout [Rq, D] (consumed) -> dmem [Rmem, D]; accumulates decoder parameter gradients."""
+    def decoder_bwd(self, c, dout, split=None):
+        """dout [Rq, D] (consumed) -> dmem [Rmem, D]; accumulates decoder parameter gradients.
+        split=(lo, hi, carry): run layers hi-1 .. lo only -- the fused step cuts the decoder backward into gradient segments of a
+        few layers each, so that the data-parallel exchange of a finished segment runs under the next one.  `carry` = (dx, dmem)
+        handed from the part above (None for the part that starts at the top); a part with lo > 0 returns it for the next."""
         cfg, a = self.cfg, self.arena
         b = self.bp + "model.decoder."
-        dmem = self.empty(c.mem_c.shape[0], cfg.d_model)              # compact rows when the K/V projections run padding-free
-        dx = dout
-        for i in reversed(range(cfg.decoder_layers)):
+        L = cfg.decoder_layers
+        lo, hi, carry = (0, L, None) if split is None else split
+        if carry is None:
+            dmem = self.empty(c.mem_c.shape[0], cfg.d_model)          # compact rows when the K/V projections run padding-free
+            dx = dout
+        else:
+            dx, dmem = carry
+        for i in reversed(range(lo, hi)):
             lb = b + "layers.%d." % i
             sc, cc, fc = c.layers[i]
             dx = self._ffn_block_bwd(lb, fc, dx)
-            dx = self._cross_block_bwd(lb, cc, c, dx, dmem, first=(i == cfg.decoder_layers - 1))
+            dx = self._cross_block_bwd(lb, cc, c, dx, dmem, first=(i == L - 1))
             dx = self._self_block_bwd(lb, sc, dx)
+        if lo > 0:
+            return dx, dmem
         has_r = c.rd is not None
         kn.embed_ln_bwd(dx, c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), c.rd,
                         a.w(b + "rating_embeddings") if has_r else None, a.f32(b + "layernorm_embedding.weight"), c.mean0, c.rstd0,

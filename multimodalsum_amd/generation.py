@@ -91,8 +91,8 @@ class DecodeSession:
 
     def __init__(self, engine, layout, num_beams, max_length, has_rating, min_length=0, ngram=0):
         e, cfg = engine, engine.cfg
-        if max_length > 224:
-            raise ValueError("max_length > 224 exceeds the attention kernel's key tile")
+        if max_length > 256:
+            raise ValueError("max_length > 256 exceeds the decode self-attention kernel's cache walk (mmsum_decode_self_attn: Tmax <= 256)")
         if num_beams > 8:
             raise ValueError("num_beams > 8: the candidate kernel keeps 2*num_beams <= 16 entries per thread")
         self.e, self.L, self.qpb, self.Tmax = e, layout, num_beams, max_length

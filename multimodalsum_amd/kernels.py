@@ -76,13 +76,15 @@ def _gemm_args(a, b, out_rows, out_cols, a_t, b_t, bias, epi, aux, accumulate, a
 
 
 def gemm_plan(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, a2=None, splitk=1,
-              slabs=False, colsum=None):
-    """What gemm(...) with the same arguments would launch: (kernel family, BM, BN, workgroups) -- see mmsum_gemm_plan."""
+              slabs=False, colsum=None, live=None, alpha_dev=None):
+    """What gemm(...) with the same arguments would launch: (kernel family, BM, BN, workgroups) -- see mmsum_gemm_plan.
+    live / alpha_dev take part in the kernel selection (whether they are given, not their values)."""
     dt, M, N, K, ksplit, flags, bias = _gemm_args(a, b, out.shape[0], out.shape[1], a_t, b_t, bias, epi, aux, accumulate, a2, splitk,
                                                    slabs, colsum, out.dtype == torch.float32)
     plan = (ctypes.c_int * 4)()
     check(lib.mmsum_gemm_plan(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(out), _ld(out),
-                              _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, flags, splitk, plan), "mmsum_gemm_plan")
+                              _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, flags, splitk, _live(live), _p(alpha_dev), plan),
+          "mmsum_gemm_plan")
     return tuple(plan)
 
 

@@ -552,6 +552,50 @@ def _compact(model):
     return bool(getattr(model, "compact_encoder", True)) and model._engine.training
 
 
+def _layer_chunks(L, per):
+    """[(lo, hi)] from the top layer down, `per` layers each (the last one takes what is left); one chunk when per is falsy."""
+    if not per or per >= L:
+        return [(0, L)]
+    out, hi = [], L
+    while hi > 0:
+        lo = max(0, hi - per)
+        out.append((lo, hi))
+        hi = lo
+    return out
+
+
+def _segment_layers(model):
+    """Layers per gradient segment of the fused step's backward (`model.grad_segment_layers`, default 3; 0 = one segment per
+    stack).  A segment is one captured graph and one notification to the data-parallel wrapper: with three layers per segment
+    (~150 MB of f32 gradients) the exchange of a segment hides under the next one and only the last -- the encoder's bottom
+    layers and the tied embedding, which the encoder's embedding backward finalises -- is exchanged in the open."""
+    return int(getattr(model, "grad_segment_layers", 3))
+
+
+def _decoder_segments(e, s, st, release, upstream, per):
+    """(callable, finished-parameter prefixes) of the LM head + decoder backward; leaves st["dmem"]."""
+    dec = e.bp + "model.decoder."
+    chunks = _layer_chunks(e.cfg.decoder_layers, per)
+    segs = []
+    for ci, (lo, hi) in enumerate(chunks):
+        def run(lo=lo, hi=hi, top=(ci == 0)):
+            if top:
+                st["dh"] = e.lm_head_bwd(s.hL, s.dlogits, upstream=upstream)
+                if release:
+                    s.dlogits = None
+            r = e.decoder_bwd(s.dec, st.get("dh"), split=(lo, hi, st.get("dec_carry")))
+            st["dh"] = None
+            if lo > 0:
+                st["dec_carry"] = r
+            else:
+                st["dec_carry"], st["dmem"] = None, r
+        prefixes = [dec + "layers.%d." % i for i in range(lo, hi)]
+        if lo == 0:
+            prefixes += [dec + "embed_positions", dec + "layernorm_embedding", dec + "rating_embeddings"]
+        segs.append((run, prefixes))
+    return segs
+
+
 def _run_segments(engine, segments):
     _begin_backward(engine)
     for fn, prefixes in segments:
@@ -676,41 +720,36 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
         e = self._engine
         o1, o2 = s.layout.offs[1], s.layout.offs[2]
         st = {}
-
-        def decoder():
-            dh = e.lm_head_bwd(s.hL, s.dlogits, upstream=upstream)
-            if release:
-                s.dlogits = None
-            st["dmem"] = e.decoder_bwd(s.dec, dh)
-
+        per = _segment_layers(self)
+        segs = _decoder_segments(e, s, st, release, upstream, per)
         L = e.cfg.encoder_layers
-        cut = L // 2 if L >= 4 else 0                   # two encoder segments: the all-reduce of the upper half overlaps the lower half
         enc = e.bp + "model.encoder."
-
-        def encoders_upper():
-            # image + table backward (layer3 and the projections only: small, sequential kernels) beside the text encoder's
-            main = torch.cuda.current_stream() if st["dmem"].is_cuda else None
-            side = e.side_stream() if main is not None else None
-            if side is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
+        for ci, (lo, hi) in enumerate(_layer_chunks(L, per)):
+            def run(lo=lo, hi=hi, top=(ci == 0)):
+                if not top:
+                    st["dx"] = e.encoder_bwd(s.enc, None, split=(lo, hi, st["dx"]))
+                    return
+                # image + table backward (layer3 and the projections only: small, sequential kernels) beside the text encoder's
+                main = torch.cuda.current_stream() if st["dmem"].is_cuda else None
+                side = e.side_stream() if main is not None else None
+                if side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        e.img_bwd(s.img, st["dmem"][o2:])
+                        e.table_bwd(s.tab, st["dmem"][o1:o2])
+                    st["dx"] = e.encoder_bwd(s.enc, st["dmem"][:o1], split=(lo, hi, None))
+                    main.wait_stream(side)
+                else:
                     e.img_bwd(s.img, st["dmem"][o2:])
                     e.table_bwd(s.tab, st["dmem"][o1:o2])
-                st["dx"] = e.encoder_bwd(s.enc, st["dmem"][:o1], split=(cut, L, None))
-                main.wait_stream(side)
-            else:
-                e.img_bwd(s.img, st["dmem"][o2:])
-                e.table_bwd(s.tab, st["dmem"][o1:o2])
-                st["dx"] = e.encoder_bwd(s.enc, st["dmem"][:o1], split=(cut, L, None))
-
-        def encoder_lower():
-            e.encoder_bwd(s.enc, None, split=(0, cut, st["dx"]))
-
-        upper = ["img_encoder.", "table_encoder."] + [enc + "layers.%d." % i for i in range(cut, L)]
-        lower = [enc + "layers.%d." % i for i in range(cut)] + [enc + "embed", enc + "layernorm_embedding", e.bp + "model.shared."]
-        if cut == 0:
-            return [(decoder, [e.bp + "model.decoder."]), (encoders_upper, upper + lower)]
-        return [(decoder, [e.bp + "model.decoder."]), (encoders_upper, upper), (encoder_lower, lower)]
+                    st["dx"] = e.encoder_bwd(s.enc, st["dmem"][:o1], split=(lo, hi, None))
+            prefixes = [enc + "layers.%d." % i for i in range(lo, hi)]
+            if ci == 0:
+                prefixes = ["img_encoder.", "table_encoder."] + prefixes
+            if lo == 0:       # the encoder's embedding backward is the last contribution to the tied embedding: final only here
+                prefixes += [enc + "embed", enc + "layernorm_embedding", e.bp + "model.shared."]
+            segs.append((run, prefixes))
+        return segs
 
     def _step_bwd(self, s, upstream=None):
         _run_segments(self._engine, self._step_bwd_segments(s, upstream=upstream))
@@ -766,17 +805,17 @@ class TextSupervised(_StepGraphMixin, nn.Module):
     def _step_bwd_segments(self, s, release=True, upstream=None):
         e = self._engine
         st = {}
-
-        def decoder():
-            dh = e.lm_head_bwd(s.hL, s.dlogits, upstream=upstream)
-            if release:
-                s.dlogits = None
-            st["dmem"] = e.decoder_bwd(s.dec, dh)
-
-        def text_encoder():
-            e.encoder_bwd(s.enc, st["dmem"])
-
-        return [(decoder, [e.bp + "model.decoder."]), (text_encoder, [e.bp + "model.encoder.", e.bp + "model.shared."])]
+        per = _segment_layers(self)
+        segs = _decoder_segments(e, s, st, release, upstream, per)
+        enc = e.bp + "model.encoder."
+        for ci, (lo, hi) in enumerate(_layer_chunks(e.cfg.encoder_layers, per)):
+            def run(lo=lo, hi=hi, top=(ci == 0)):
+                st["dx"] = e.encoder_bwd(s.enc, st["dmem"] if top else None, split=(lo, hi, None if top else st["dx"]))
+            prefixes = [enc + "layers.%d." % i for i in range(lo, hi)]
+            if lo == 0:
+                prefixes += [enc + "embed", enc + "layernorm_embedding", e.bp + "model.shared."]
+            segs.append((run, prefixes))
+        return segs
 
     def _step_bwd(self, s, upstream=None):
         _run_segments(self._engine, self._step_bwd_segments(s, upstream=upstream))

@@ -6,17 +6,27 @@ Replaces apex.parallel.DistributedDataParallel(model, delay_allreduce=True)
 
 The reference flattens every gradient into one buffer AFTER backward and all-reduces it with no
 overlap.  Here the gradients already live in one arena, so there is nothing to flatten, and the
-fused step tells us when a whole parameter segment (decoder / image+table encoders + upper text
-encoder layers / lower layers + tied embedding) is final: its arena ranges are all-reduced on a
-side stream in large buckets while the rest of the backward keeps the compute stream busy.
-Parameters that never receive a gradient (ResNet stem/layer1/layer2/layer4/fc) are simply absent
-from the ranges.
+fused step tells us when a parameter segment is final (modules._segment_layers: three decoder /
+encoder layers at a time, the image + table encoders with the encoder's top layers, the tied
+embedding with its bottom ones): its arena ranges are exchanged on a side stream in large buckets
+while the next segment's backward keeps the compute stream busy, so only the last segment (the
+encoder's bottom layers + the 206 MB tied embedding, which the encoder's embedding backward is the
+last to touch) is exchanged in the open.  Parameters that never receive a gradient (ResNet
+stem/layer1/layer2/layer4/fc) are simply absent from the ranges.
+
+`mode`: "all_reduce" (one collective per bucket) or "reduce_scatter" (reduce-scatter of the bucket into
+this rank's 1/N shard, then all-gather of the shards back: the two halves of a ring all-reduce as
+separate collectives -- xGMI is point-to-point, 7 links per GPU, and the two phases of consecutive
+buckets overlap on the links; it is also the hook for a sharded optimiser step between the phases).
+Both give every rank the same mean.
 
 The mean is taken by the collective itself (ReduceOp.AVG on RCCL: no extra pass over the 1.95 GB of
 gradients); backends without AVG (gloo) get SUM followed by one scaling pass.  `grad_dtype=torch.bfloat16`
 sends bf16 buckets (half the bytes on the xGMI links; the f32 arena stays the accumulator) -- off by
 default because the reference reduces in f32.
 """
+import collections
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -33,8 +43,11 @@ def reduce_tensor(tensor, world_size):
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, delay_allreduce=True, bucket_elems=64 * 1024 * 1024, overlap=True, process_group=None,
-                 always_reduce=False, grad_dtype=None, collect_stats=False):
+                 always_reduce=False, grad_dtype=None, collect_stats=False, mode="all_reduce", stats_window=64):
         super().__init__()
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError("mode must be 'all_reduce' or 'reduce_scatter'")
+        self.mode = mode
         self.module = module
         self.group = process_group
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -46,7 +59,7 @@ class DistributedDataParallel(nn.Module):
         self.grad_dtype = grad_dtype
         self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.collect_stats = bool(collect_stats) and self.arena.grad.is_cuda
-        self.stats = []                          # per step: (events of every bucket, bytes), read by comm_stats()
+        self.stats = collections.deque(maxlen=max(1, int(stats_window)))     # the last steps only: (bucket events, bytes, end events); comm_stats() reads them
         self._events, self._bytes = [], 0
         self._done = set()
         if self.world_size > 1 or (always_reduce and dist.is_initialized()):      # always_reduce: exercise the path at world size 1
@@ -68,11 +81,19 @@ class DistributedDataParallel(nn.Module):
         buf = chunk
         if self.grad_dtype is not None and self.grad_dtype != chunk.dtype:
             buf = chunk.to(self.grad_dtype)
-        if self.native_avg:
-            dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            buf.mul_(1.0 / self.world_size)
+        op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+        W = self.world_size
+        n = (buf.numel() // W) * W if self.mode == "reduce_scatter" else 0
+        if n:
+            # the bucket as W equal shards: this rank reduces shard `rank`, then every rank gathers all of them (in place)
+            head = buf[:n]
+            shard = head.view(W, n // W)[dist.get_rank(self.group)]
+            dist.reduce_scatter_tensor(shard, head, op=op, group=self.group)
+            dist.all_gather_into_tensor(head, shard.clone(), group=self.group)
+        if n < buf.numel():                       # all_reduce mode, or the few elements a bucket has beyond a multiple of W
+            dist.all_reduce(buf[n:], op=op, group=self.group)
+        if not self.native_avg:
+            buf.mul_(1.0 / W)
         if buf is not chunk:
             chunk.copy_(buf)
         return buf.numel() * buf.element_size()
@@ -128,7 +149,7 @@ class DistributedDataParallel(nn.Module):
         """Averages over the recorded steps (after a device synchronise): milliseconds inside the collectives per step,
         milliseconds of them left exposed after the backward's last kernel, bytes reduced per step, and the bus bandwidth
         2 (N-1)/N * bytes / time that a ring all-reduce's links saw."""
-        steps = self.stats[skip:]
+        steps = list(self.stats)[skip:]
         if not steps:
             return None
         comm = sum(sum(a.elapsed_time(b) for a, b in ev) for ev, _, _, _ in steps) / len(steps)
@@ -138,4 +159,4 @@ class DistributedDataParallel(nn.Module):
         bus = (2.0 * (n - 1) / n * nbytes / (comm * 1e-3) / 1e9) if (comm > 0 and n > 1) else 0.0
         return {"allreduce_ms": comm, "exposed_ms": exposed, "overlap_frac": (1.0 - exposed / comm) if comm > 0 else None,
                 "bytes_per_step": nbytes, "bus_gb_s": bus, "buckets_per_step": sum(len(ev) for ev, _, _, _ in steps) / len(steps),
-                "grad_dtype": str(self.grad_dtype or torch.float32)}
+                "grad_dtype": str(self.grad_dtype or torch.float32), "mode": self.mode}

@@ -70,8 +70,10 @@ def next_token_logits(sd, cfg, input_ids, hiddens, masks, rating_diff, multimoda
 
 
 def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max_length, min_length=0,
-                no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.0, decoder_start_token_id=None, prefix=""):
-    """hiddens/masks: list of [B,N,S,D] / [B,N,S] (multimodal) or single tensors.  Returns LongTensor [B, L]."""
+                no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.0, decoder_start_token_id=None, prefix="",
+                return_scores=False):
+    """hiddens/masks: list of [B,N,S,D] / [B,N,S] (multimodal) or single tensors.  Returns LongTensor [B, L] (return_scores: and the
+    best hypothesis' score per business, which the reference does not return; tests check sequence_score against it)."""
     pad, bos, eos, V = cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id, cfg.vocab_size
     start = bos if decoder_start_token_id is None else decoder_start_token_id
     first = hiddens[0] if multimodal else hiddens
@@ -143,6 +145,7 @@ def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max
             row = b * num_beams + beam
             hyps[b].add(input_ids[row], beam_scores[row].item())
     best = [sorted(h.items, key=lambda x: x[0])[-1][1] for h in hyps]
+    best_scores = [sorted(h.items, key=lambda x: x[0])[-1][0] for h in hyps]
     lens = [len(t) for t in best]
     if min(lens) != max(lens):
         L = min(max(lens) + 1, max_length)
@@ -151,5 +154,45 @@ def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max
             out[i, :lens[i]] = t
             if lens[i] < max_length:
                 out[i, lens[i]] = eos
-        return out
-    return torch.stack(best).long()
+    else:
+        out = torch.stack(best).long()
+    return (out, best_scores) if return_scores else out
+
+
+def sequence_score(sd, cfg, seq, hiddens, masks, rating_diff, multimodal, max_length, min_length=0, length_penalty=1.0, prefix=""):
+    """The score _generate_beam_search assigns to the finished hypothesis that `seq` (one returned row: start token, tokens,
+    optionally the appended EOS and pads, modeling_multimodalsum.py:3040-3067) stands for: the sum of the log-probabilities of
+    its tokens and of the closing EOS under the same logits adjustment (:3084-3102: BOS forced at length 1, EOS forced at
+    max_length - 1, EOS banned below min_length), divided by len(tokens) ** length_penalty (BeamHypotheses.add, :959-960).
+    Teacher-forced: one causal decoder pass over the hypothesis.  hiddens / masks hold ONE business."""
+    pad, bos, eos = cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id
+    toks = [int(t) for t in seq.tolist()]
+    while len(toks) > 1 and toks[-1] == pad:
+        toks.pop()
+    if len(toks) > 1 and toks[-1] == eos:
+        toks.pop()
+    ids = torch.tensor([toks], dtype=torch.long)
+    T = ids.shape[1]
+    causal = torch.triu(torch.full((T, T), float("-inf")), 1)
+    h = bo.bart_decoder(sd, cfg, ids, hiddens, masks, None, causal, rating_diff, multimodal, False, prefix)
+    logits = F.linear(h[0], sd[prefix + "model.shared.weight"])               # row t: the distribution of token t + 1
+    total = 0.0
+    for t in range(T):
+        cur_len = t + 1
+        row = logits[t].clone()
+        nxt = toks[t + 1] if t + 1 < T else eos
+        if cur_len == 1:
+            keep = row[bos].clone()
+            row.fill_(float("-inf"))
+            row[bos] = keep
+        if cur_len == max_length - 1:
+            keep = row[eos].clone()
+            row.fill_(float("-inf"))
+            row[eos] = keep
+        lp = F.log_softmax(row, dim=-1)
+        if cur_len < min_length:
+            lp[eos] = float("-inf")
+        if t + 1 == T and cur_len >= max_length:
+            break                                                            # an unfinished hypothesis of full length: no closing EOS
+        total += float(lp[nxt])
+    return total / (len(toks) ** length_penalty)

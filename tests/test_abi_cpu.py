@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(_lib.lib, s), "libmmsum_hip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_argument_validation_without_gpu():
@@ -45,11 +45,11 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
     plan = (ctypes.c_int * 4)()
     fake = 1 << 20                       # any 16-byte aligned non-NULL address: the plan never dereferences
 
-    def p(M, N, K, flags=0, splitk=1, lda=None, ldb=None):
+    def p(M, N, K, flags=0, splitk=1, lda=None, ldb=None, live=None, alpha_dev=None):
         at, bt = flags & _lib.GEMM_A_T, flags & _lib.GEMM_B_T
         lda = lda or (M if at else K)
         ldb = ldb or (N if bt else K)
-        rc = lib.mmsum_gemm_plan(_lib.BF16, fake, lda, None, 0, 0, fake, ldb, fake, N, None, None, 0, M, N, K, flags, splitk, plan)
+        rc = lib.mmsum_gemm_plan(_lib.BF16, fake, lda, None, 0, 0, fake, ldb, fake, N, None, None, 0, M, N, K, flags, splitk, live, alpha_dev, plan)
         assert rc == 0, rc
         return tuple(plan)
 
@@ -64,7 +64,9 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
     assert p(4096, 1024, 64512, tn, 8)[:3] == (_lib.PLAN_TN_RING, 256, 256)     # fc1 weight gradient, split-K slabs
     assert p(1000, 520, 128)[0] == _lib.PLAN_NT_RING and p(1000, 520, 128)[1:3] == (128, 128)
     assert p(32, 4096, 1024)[0] == _lib.PLAN_SKINNY                              # decode-step rows
-    assert lib.mmsum_gemm_plan(_lib.F32, fake, 1024, None, 0, 0, fake, 1024, fake, 512, None, None, 0, 512, 512, 1024, 0, 1, plan) == 0
+    # a live row count or a device-side scale takes the product off the weight-streaming kernel: the plan must say so
+    assert p(32, 4096, 1024, live=fake)[0] == _lib.PLAN_NT_RING and p(32, 4096, 1024, alpha_dev=fake)[0] == _lib.PLAN_NT_RING
+    assert lib.mmsum_gemm_plan(_lib.F32, fake, 1024, None, 0, 0, fake, 1024, fake, 512, None, None, 0, 512, 512, 1024, 0, 1, None, None, plan) == 0
     assert plan[0] == _lib.PLAN_GENERIC
 
 

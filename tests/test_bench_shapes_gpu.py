@@ -146,18 +146,28 @@ def test_nt_ring_a2_split_and_lm_head():
     check(g, want, "lm head wgrad", rel=1e-3, atol=2e-3)
 
 
-@pytest.mark.parametrize("R,No,Ki,tile", [(64512, 4096, 1024, (256, 256)), (64512, 1024, 4096, (256, 256)), (38912, 3072, 1024, (256, 256)),
-                                          (64512, 1024, 1024, (256, 128)), (111048, 2048, 1024, (256, 256))])
-def test_tn_ring_weight_gradients_at_bench_sizes(R, No, Ki, tile):
-    """gemm_tn_ring_kernel<256,256,2,4> / <256,128,4,2>: dW[No, Ki] = dy[R, No]^T x[R, Ki] straight from the reduction-major
-    activations, with the split-K the engine picks at these sizes (the chooser takes the 256x128 tile for the square D x D
-    products: 8 slices of 32 tiles fill the chip exactly), against an fp64 product."""
+# (reduction rows R, outputs No, inputs Ki, slices the engine must pick): the step's weight gradients at B = 56 -- FFN both ways, the
+# padding-free encoder's fused qkv, the square D x D products (16 tiles -> 16 slices), the cross-attention K/V projection over the
+# compact memory rows, and ResNet layer3's 3x3 / 1x1 convolutions (few tiles, 43,904 rows: up to 32 slices)
+TN_CASES = [(64512, 4096, 1024, 4, 256), (64512, 1024, 4096, 4, 256), (38912, 3072, 1024, 5, 256), (64512, 1024, 1024, 16, 256),
+            (64512, 3072, 1024, 5, 256), (111048, 2048, 1024, 8, 256), (43904, 256, 2304, 28, 256), (43904, 1024, 256, 32, 128)]
+
+
+@pytest.mark.parametrize("R,No,Ki,want_sk,bn", TN_CASES)
+def test_tn_w4_weight_gradients_at_bench_sizes(R, No, Ki, want_sk, bn):
+    """gemm_tn_w4_kernel (256x256 tile, four waves, named-AGPR accumulators; the last case: 4 output tiles x 32 slices, where the
+    chooser takes the eight-wave 256x128 ring kernel to fill the chip): dW[No, Ki] = dy[R, No]^T x[R, Ki] straight from the
+    reduction-major activations with the split count Engine.wgrad picks (engine.splitk_rule: the same function, not a copy),
+    one workgroup per (tile, slice) and at most 256 of them, against an fp64 product."""
+    from multimodalsum_amd.engine import splitk_rule
     dy, x = rnd(R, No, seed=21, std=0.1), rnd(R, Ki, seed=22, std=0.5)
-    tiles = ((No + 127) // 128) * ((Ki + 127) // 128)
-    sk = max(1, min(8, -(-768 // tiles), (R // 64) // 4))                      # engine.Engine.splitk
-    assert sk > 1
+    sk = splitk_rule(No, Ki, R)
+    assert sk == want_sk, (sk, want_sk)
+    tiles = ((No + 255) // 256) * ((Ki + bn - 1) // bn)
     ws = torch.full((sk * No, Ki), float("nan"), device=DEV)
-    assert_plan(kn.gemm_plan(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True), _lib.PLAN_TN_RING, *tile)
+    plan = kn.gemm_plan(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+    assert_plan(plan, _lib.PLAN_TN_RING, 256, bn)
+    assert plan[3] == tiles * sk and plan[3] <= 256, plan
     kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
     g = torch.zeros(No, Ki, device=DEV)
     kn.slab_reduce(ws, sk, g, accumulate=True)
@@ -186,7 +196,8 @@ def test_live_row_counts_at_bench_sizes():
         # weight gradient: reduction over the live rows only (the rest is NaN and must not be read)
         dy = rnd(cap, Fd, seed=34, std=0.1)
         dy[live_n:] = float("nan")
-        sk = 3
+        from multimodalsum_amd.engine import splitk_rule
+        sk = splitk_rule(Fd, D, cap)                      # the engine sizes the split for the capacity, whatever the live count
         ws = torch.full((sk * Fd, D), float("nan"), device=DEV)
         kn.gemm(dy, a, ws, a_t=True, b_t=True, splitk=sk, slabs=True, live=live)
         g = torch.zeros(Fd, D, device=DEV)

@@ -137,6 +137,17 @@ def test_g1_beam_search(golden_dir):
                            no_repeat_ngram_size=2, early_stopping=False, length_penalty=2.0, prefix="f2.")
     assert torch.equal(a, gg["gen_a"]), (a, gg["gen_a"])
     assert torch.equal(b, gg["gen_b"]), (b, gg["gen_b"])
+    # sequence_score (the yardstick of the bf16 generation test's tie rule) reproduces the score the search itself gave its best
+    # hypothesis, for both call shapes -- teacher-forced on the returned row, pads and the appended EOS stripped
+    with torch.no_grad():
+        for kw, rd in ((dict(num_beams=4, max_length=14, no_repeat_ngram_size=3, early_stopping=True, length_penalty=1.0), torch.zeros(Bz, 1)),
+                       (dict(num_beams=2, max_length=10, min_length=4, no_repeat_ngram_size=2, early_stopping=False, length_penalty=2.0),
+                        gg["rating_diff"])):
+            out, scores = go.beam_search(sd, cfg, hid, msk, rd, True, prefix="f2.", return_scores=True, **kw)
+            for i in range(Bz):
+                got = go.sequence_score(sd, cfg, out[i], [h[i:i + 1] for h in hid], [m[i:i + 1] for m in msk], rd[i:i + 1], True,
+                                        kw["max_length"], kw.get("min_length", 0), kw["length_penalty"], prefix="f2.")
+                assert abs(got - scores[i]) <= 1e-4 * abs(scores[i]) + 1e-5, (i, got, scores[i])
 
 
 def test_f2_text_only(golden_dir):
