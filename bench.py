@@ -460,6 +460,121 @@ def bench_generate(args):
 def timed_steps(args, model, runner, opt, sch, next_batch, steps, warmup, sync):
     """`warmup` un-timed and `steps` timed training steps (after two priming steps when the step graphs are on: one eager, one
     that captures).  Returns (seconds of the timed region, last loss, the timed steps' device-side live counts, priming steps)."""
+    priming = 0
+    if not args.no_graphs:
+        model.enable_step_graphs()
+        priming = 2
+        for _ in range(priming):
+            run_step(args, runner, opt, sch, next_batch())
+    for _ in range(warmup):
+        run_step(args, runner, opt, sch, next_batch())
+    live_rows = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b = next_batch()                   # generated on the device inside the timed step
+        loss = run_step(args, runner, opt, sch, b)
+        live_rows.append((b["reviews_mask"].sum(), b["img_mask"].sum() if args.workload == "multimodal" else None))   # device scalars, read after the region
+    sync()
+    return time.perf_counter() - t0, loss, live_rows, priming, b
+
+
+def also_configs(args, cfg, model, device):
+    """The other BASELINE configurations, measured in the same run so that the one driver-run line carries them (a few steps each):
+    the reference-style per-GPU batch of 8 (multimodal_train.py:420 default is 1 per GPU; SURVEY.md 8d C4: {1, 8}) and test.py's
+    beam-search generation on the headline's model; the text-only step (text_pretrain.py:66-113, BASELINE config 2) follows on a
+    TextSupervised model built after this one is released (also_text_only)."""
+    import copy
+    import torch
+    from multimodalsum_amd import optim
+    out = {}
+
+    def train_cfg(name, workload, batch, mdl, steps=4, warmup=1):
+        a = copy.copy(args)
+        a.workload, a.batch = workload, batch
+        opt = optim.get_optimizer(1e-5, NO_DECAY, mdl.named_parameters(), None)
+        sch = optim.get_linear_schedule_with_warmup(opt, 100, 100000)
+        dt, loss, _, _, _ = timed_steps(a, mdl, mdl, opt, sch, batch_source(a, cfg, device, 0), steps, warmup, torch.cuda.synchronize)
+        out[name] = {"value": batch * steps / dt, "unit": "businesses/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                     "per_gpu_batch": batch, "final_loss": float(loss.item()),
+                     "workload": ("multimodal_train.py full step" if workload == "multimodal" else "text_pretrain.py text-only step")
+                                 + " (fwd+bwd+clip+AdamW), 9 reviews x 128 tok, hip-graph replay"}
+    try:
+        train_cfg("multimodal_B8", "multimodal", 8, model)
+        g = run_generate(model, cfg, device, 8, 2, 1, args.dtype)
+        out["generate_B8"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "decode_steps", "ms_per_decode_step", "tokens_per_s")}
+        out["generate_B8"]["workload"] = g["config"]["workload"]
+    except Exception as exc:                   # the headline number must survive a failure here
+        out["error_multimodal"] = repr(exc)[:300]
+    return out
+
+
+def also_text_only(args, cfg, device):
+    """BASELINE config 2: BART-large text-only (8 source reviews x 128 tok per pass) bf16 on one GPU, at the headline batch."""
+    import copy
+    import torch
+    from multimodalsum_amd import optim
+    try:
+        a = copy.copy(args)
+        a.workload, a.batch = "text", 56
+        _, mdl = build(a, device)
+        opt = optim.get_optimizer(1e-5, NO_DECAY, mdl.named_parameters(), None)
+        sch = optim.get_linear_schedule_with_warmup(opt, 100, 100000)
+        steps, warmup = 4, 1
+        dt, loss, _, _, _ = timed_steps(a, mdl, mdl, opt, sch, batch_source(a, cfg, device, 0), steps, warmup, torch.cuda.synchronize)
+        fpb = flops_per_business(cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, 1, multimodal=False)
+        val = a.batch * steps / dt
+        return {"value": val, "unit": "businesses/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup, "per_gpu_batch": a.batch,
+                "final_loss": float(loss.item()), "step_roofline_frac": val * fpb / 1e12 / PEAK_BF16_TFLOPS,
+                "workload": "text_pretrain.py BART-large text-only step (fwd+bwd+clip+AdamW), 9 reviews x 128 tok, hip-graph replay"}
+    except Exception as exc:
+        return {"error": repr(exc)[:300]}
+
+
+def main():
+    args = parse()
+    if args.workload == "generate":
+        return bench_generate(args)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)                       # does not return
+    world = int(env_world or "1")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    force_ddp = os.environ.get("MMSUM_FORCE_DDP") == "1"          # debugging aid: run the RCCL gradient path at world size 1
+    dist = None
+    if world > 1 or force_ddp:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(args.master_port))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+    import multimodalsum_amd as mm
+    from multimodalsum_amd import optim
+    cfg, model = build(args, device)
+    ddp = None
+    if world > 1 or force_ddp:
+        ddp = mm.DistributedDataParallel(model, delay_allreduce=True, always_reduce=force_ddp, collect_stats=True, mode=args.ddp_mode,
+                                         grad_dtype=torch.bfloat16 if args.grad_dtype == "bf16" else None)
+    runner = ddp if ddp is not None else model
+    opt = optim.get_optimizer(1e-5, NO_DECAY, model.named_parameters(), None)
+    sch = optim.get_linear_schedule_with_warmup(opt, 100, 100000)
+    next_batch = batch_source(args, cfg, device, rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     stats_skip = None
     dt, loss, live_rows, priming, b = timed_steps(args, model, runner, opt, sch, next_batch, args.steps, args.warmup, sync)
     if ddp is not None:

@@ -46,9 +46,14 @@ enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_E
 #define MMSUM_GEMM_ACCUM   0x040  /* C += */
 #define MMSUM_GEMM_OUT_F32 0x080  /* C is f32 regardless of dtype */
 #define MMSUM_GEMM_SLABS   0x100  /* split-K without atomics: slice s writes its partial to C + s*M*ldc (f32) */
-#define MMSUM_GEMM_COLSUM  0x200  /* bf16 NT fast path, plain or GELU_BWD epilogue, bf16 store: `bias` is an OUTPUT,
-                                    bias[n] += sum_m C[m][n] of the stored result (the bias gradient of the layer that
-                                    produced the GEMM's input gradient) */
+#define MMSUM_GEMM_COLSUM  0x200  /* `bias` is an OUTPUT (f32 atomics: not bit-reproducible run to run).  bf16 NT fast path, plain
+                                    or GELU_BWD epilogue, bf16 store: bias[n] += sum_m C[m][n] of the stored result (the bias
+                                    gradient of the layer that produced the GEMM's input gradient).  Weight-gradient product
+                                    (A_T | B_T, bf16, SLABS, 256x256 tiles): bias[m] += alpha * sum_k A(m,k), the bias gradient
+                                    of the same Linear, summed from the operand tiles the kernel stages anyway */
+
+#define MMSUM_GEMM_COLSUM2 0x400  /* with COLSUM on the NT path: `bias` holds 2 N floats and bias[N + n] += sum_m C[m][n]^2 as well -- the
+                                    BatchNorm statistics of a convolution's output taken in the convolution's own epilogue */
 
 int mmsum_abi_version(void);
 /* First 16 hex digits of the SHA-256 over the library's sources (csrc/Makefile: HASH_SRCS): lets the host tell a stale
@@ -170,9 +175,12 @@ int mmsum_attn_bwd(int dtype, const mmsum_attn_desc* d, const void* dout, long l
 int mmsum_gate_fwd(int dtype, const void* pa, const void* pb, const void* yt, const void* ytab, const void* yimg,
                    const uint8_t* no_table, const uint8_t* no_img, void* out, int R, int D, int rows_per_b,
                    void* stream);
+/* Backward of the gate.  sum_dpa / sum_dpb (f32 [D], both or both NULL): += column sums of dpa and of dpb -- the bias
+ * gradients of alpha_proj and beta_proj (:738-739), taken while the rows are in registers instead of by two more passes over
+ * them (f32 atomics: not bit-reproducible run to run). */
 int mmsum_gate_bwd(int dtype, const void* dout, const void* pa, const void* pb, const void* ytab, const void* yimg,
                    const uint8_t* no_table, const uint8_t* no_img, void* dpa, void* dpb, void* dyt, void* dytab,
-                   void* dyimg, int R, int D, int rows_per_b, void* stream);
+                   void* dyimg, int R, int D, int rows_per_b, float* sum_dpa, float* sum_dpb, void* stream);
 
 /* K16: label-smoothing loss (/root/reference/src/utils.py:32-38), fused forward + backward:
  * row_loss[r] = -sum_v true_dist*log_softmax(logits[r,:V]); logits[r,:] <- gscale*(softmax - true_dist)
@@ -227,6 +235,12 @@ int mmsum_conv_weight_permute(int dtype, void* matrix, float* weight, int Cout, 
  * unbiased variance) when running_mean != NULL. */
 long mmsum_bn_workspace(int C);
 int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, void* stream);
+/* BatchNorm batch statistics from plain column sums: raw = {sum_r x[r][c], sum_r x[r][c]^2} (2 C floats, as the convolution's GEMM
+ * epilogue leaves them with MMSUM_GEMM_COLSUM | MMSUM_GEMM_COLSUM2) -> sums = {mean, biased variance}; running_mean / running_var
+ * (may be NULL) receive the momentum update with the unbiased variance (torchvision BatchNorm2d in train mode,
+ * /root/reference/src/img_encoder.py:21-41).  Pass running_mean = NULL to mmsum_bn_apply afterwards: the update is done here. */
+int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* sums, float* running_mean, float* running_var, float momentum,
+                             void* stream);
 int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gamma, const float* beta,
                    const void* residual, void* y, float* running_mean, float* running_var, int R, int C, float eps,
                    float momentum, int relu, int training, void* stream);

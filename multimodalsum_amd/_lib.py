@@ -17,7 +17,7 @@ ERRORS = {-1: "bad shape", -2: "bad dtype", -3: "bad alignment", -4: "workspace 
 
 GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
-GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM = 0x40, 0x80, 0x100, 0x200
+GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM, GEMM_COLSUM2 = 0x40, 0x80, 0x100, 0x200, 0x400
 PLAN_GENERIC, PLAN_NT_RING, PLAN_TN_RING, PLAN_SKINNY = 0, 1, 2, 3
 ABI_VERSION = 4
 
@@ -63,7 +63,7 @@ SIGNATURES = {
     "mmsum_gate_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_void_p]),
     "mmsum_gate_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+                               c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mmsum_ls_loss": (c_int, [c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "mmsum_segment_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mmsum_l2_workspace": (c_long, []),
@@ -81,6 +81,7 @@ SIGNATURES = {
     "mmsum_conv_weight_permute": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_bn_workspace": (c_long, [c_int]),
     "mmsum_bn_reduce": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mmsum_bn_stats_from_sums": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "mmsum_bn_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_float, c_float, c_int, c_int, c_void_p]),
     "mmsum_bn_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p,

@@ -184,12 +184,15 @@ static int gemm_check(int dtype, const void* A, long lda, const void* A2, long l
     if (at && ((lda * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
     if (bt && ((ldb * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
     if (live_rows && at && !bt) return MMSUM_ERR_BAD_SHAPE;     // a live row count needs a row-streamed operand
-    if (flags & MMSUM_GEMM_COLSUM) {      // epilogue column sums exist on the LDS-DMA NT path with a bf16 result only
+    if (flags & MMSUM_GEMM_COLSUM) {
         GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, live_rows, nullptr};
         const int epi = (flags >> 3) & 7;
-        if (!gemm_glds_eligible(dtype, a) || (flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS | MMSUM_GEMM_ACCUM)) || splitk != 1 ||
-            !bias || !(epi == MMSUM_EPI_NONE || epi == MMSUM_EPI_GELU_BWD))
-            return MMSUM_ERR_BAD_SHAPE;
+        if (at && bt) {                   // weight-gradient product: column sums of A (the bias gradient) inside the four-wave TN kernel
+            if ((flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_ACCUM)) || epi != MMSUM_EPI_NONE || !gemm_tn_colsum_ok(dtype, a)) return MMSUM_ERR_BAD_SHAPE;
+        } else if (!gemm_glds_eligible(dtype, a) || (flags & (MMSUM_GEMM_BIAS | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS | MMSUM_GEMM_ACCUM)) || splitk != 1 ||
+                   !bias || !(epi == MMSUM_EPI_NONE || epi == MMSUM_EPI_GELU_BWD)) {
+            return MMSUM_ERR_BAD_SHAPE;   // epilogue column sums exist on the LDS-DMA NT path with a bf16 result only
+        }
     }
     return MMSUM_OK;
 }

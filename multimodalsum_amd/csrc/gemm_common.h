@@ -105,8 +105,10 @@ inline int out_mode_of(const GemmArgs& a) {
     return acc ? OUT_T_ACC : OUT_T;
 }
 
-// Grouped rasterisation: logical tile ids walk GROUP_M tile-rows at a time so that the tiles an
-// XCD works on concurrently share both A and B panels in its 4 MiB L2.
+// Grouped rasterisation: logical tile ids walk GROUP_M tile-rows at a time, so that the 32 workgroups of an XCD (32 consecutive
+// logical tiles: xcd_remap below) run an 8 x 4 block of tiles and share its 8 A and 4 B panels in the XCD's 4 MiB L2.
+// (Measured and not kept, round 3: walking groups of four tile COLUMNS down the rows instead, so that the four B panels stay
+// L2-resident -- within +-1 % on every shape of the step at M = 64,512)
 __device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& tm, int& tn) {
     constexpr int GROUP_M = 8;
     const int per_group = GROUP_M * tiles_n;
@@ -133,3 +135,4 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);   // gemm_skinny.
 bool gemm_skinny_eligible(int dtype, const GemmArgs& a);
 int launch_gemm_tn(const GemmArgs& a, hipStream_t stream);     // gemm_fast.hip: A [K,M], B [K,N] (weight gradients)
 bool gemm_tn_eligible(int dtype, const GemmArgs& a);
+bool gemm_tn_colsum_ok(int dtype, const GemmArgs& a);          // MMSUM_GEMM_COLSUM on the weight-gradient product: column sums of A

@@ -88,8 +88,9 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
     static_assert(LDS_BYTES >= WAVES_M * BAND * 4, "epilogue staging does not fit the kernel's LDS");
     float* stage0 = reinterpret_cast<float*>(smem);
     const bool do_colsum = (p.flags & MMSUM_GEMM_COLSUM) != 0;     // bias slot = f32 output: += column sums of the stored tile
+    const bool do_colsq = (p.flags & MMSUM_GEMM_COLSUM2) != 0;     // ... and, N floats further, += column sums of its squares
     static_assert(THREADS % CPR == 0, "a thread must own one 8-column chunk for the column sums");
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bf16_t* Ct = static_cast<bf16_t*>(p.C);
     float* Cf = static_cast<float*>(p.C);
     bf16_t* aux = static_cast<bf16_t*>(p.aux);
@@ -196,7 +197,11 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
             }
             if (do_colsum) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) csum[e] += (e < nvalid) ? (float)(bf16_t)v[e] : 0.f;     // what a separate pass over the bf16 result would add
+                for (int e = 0; e < 8; ++e) {
+                    const float t = (e < nvalid) ? (float)(bf16_t)v[e] : 0.f;     // what a separate pass over the bf16 result would add
+                    csum[e] += t;
+                    csq[e] = fmaf(t, t, csq[e]);
+                }
             }
             if constexpr (OUT == OUT_T_ACC) {
                 bf16_t t[8];
@@ -235,17 +240,19 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
     }
     if (do_colsum) {
         // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
-        lds_barrier();
         float* red = reinterpret_cast<float*>(smem);
         constexpr int NPART = THREADS / CPR;
+        for (int w = 0; w < (do_colsq ? 2 : 1); ++w) {
+            lds_barrier();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = csum[e];
-        lds_barrier();
-        for (int c = tid; c < BN; c += THREADS) {
-            float t = 0.f;
+            for (int e = 0; e < 8; ++e) red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = w ? csq[e] : csum[e];
+            lds_barrier();
+            for (int c = tid; c < BN; c += THREADS) {
+                float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < NPART; ++k) t += red[k * BN + c];
-            if (n0 + c < p.N) atomicAdd(const_cast<float*>(p.bias) + n0 + c, t);
+                for (int k = 0; k < NPART; ++k) t += red[k * BN + c];
+                if (n0 + c < p.N) atomicAdd(const_cast<float*>(p.bias) + (long)w * p.N + n0 + c, t);
+            }
         }
     }
 }
@@ -255,7 +262,7 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
 // guards, index arithmetic and run-time flags (measured at M = 64,512, N = 4096, K = 1024: 232 us of a 696 us launch with the
 // global stores REMOVED, against 386 us for the main loop alone).  Here a thread's rows are base + compile-time constants,
 // the LDS addresses are immediates, and bias / alpha / activation / accumulate / column sums are compile-time forms.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, bool CS, int LDS_BYTES, bool MF16 = false, typename AccSrc = AccArray>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int CS, int LDS_BYTES, bool MF16 = false, typename AccSrc = AccArray>
 __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                   char* smem, int m0, int n0, int wm, int wn, int tid, int lane, const float (&bv)[8], AccSrc src = AccSrc{}) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
@@ -278,7 +285,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
     float* Cf = static_cast<float*>(p.C);
     bf16_t* aux = static_cast<bf16_t*>(p.aux);
     const float alpha = p.alpha;
-    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // CS: 1 = column sums, 2 = + sums of squares
     // ONE register set: an iteration consumes its operand and at once requests the same iteration's operand of the NEXT pass,
     // before its own store is issued (vmcnt retires in issue order: a load issued behind stores would wait for their
     // acknowledgement; issued in front of them it only waits for the stores of a pass ago).
@@ -367,9 +374,13 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
-                if constexpr (CS) {
+                if constexpr (CS != 0) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) csum[e] += (float)t[e];                     // what a separate pass over the bf16 result would add
+                    for (int e = 0; e < 8; ++e) {
+                        const float tf = (float)t[e];                                       // what a separate pass over the bf16 result would add
+                        csum[e] += tf;
+                        if constexpr (CS == 2) csq[e] = fmaf(tf, tf, csq[e]);
+                    }
                 }
                 u32x4_t w;
                 __builtin_memcpy(&w, t, 16);
@@ -377,19 +388,23 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
             }
         }
     }
-    if constexpr (CS) {
+    if constexpr (CS != 0) {
         // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
-        lds_barrier();
         float* red = reinterpret_cast<float*>(smem);
         constexpr int NPART = THREADS / CPR;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = csum[e];
         lds_barrier();
-        for (int c = tid; c < BN; c += THREADS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = csum[e];
+            if constexpr (CS == 2) red[NPART * BN + (tid / CPR) * BN + (tid % CPR) * 8 + e] = csq[e];
+        }
+        lds_barrier();
+        for (int c = tid; c < CS * BN; c += THREADS) {
+            const int w = c / BN, cc = c % BN;
             float t = 0.f;
 #pragma unroll
-            for (int k = 0; k < NPART; ++k) t += red[k * BN + c];
-            atomicAdd(const_cast<float*>(p.bias) + n0 + c, t);
+            for (int k = 0; k < NPART; ++k) t += red[w * NPART * BN + k * BN + cc];
+            atomicAdd(const_cast<float*>(p.bias) + (long)w * p.N + n0 + cc, t);
         }
     }
 }
@@ -400,7 +415,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
 // out of the tile loop inside the register file.  On the eight-wave kernels (128 registers beside the accumulators) the
 // derivative arithmetic of a pass spilled 167 registers in the lean form: they keep the guarded one, with column sums by flag.
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false, typename AccSrc = AccArray,
-          bool WIDE = false, bool CS = false>
+          bool WIDE = false, int CS = 0>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                 char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, AccSrc src = AccSrc{}) {
     float bv[8];
@@ -412,7 +427,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     const bool interior = m0 + BM <= p.M && n0 + BN <= p.N && aligned;        // workgroup-uniform
     if constexpr (OUT != OUT_F32_ATOMIC && (WIDE || !kAuxIn)) {
         if (interior && (WIDE || !(p.flags & MMSUM_GEMM_COLSUM))) {
-            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, WIDE && CS, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
+            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, WIDE ? CS : 0, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
             return;
         }
     }
@@ -623,7 +638,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
 // tile of a column): one stage ahead is enough.  A streams from HBM: its DMA runs two stages ahead, so at the barrier only
 // the 8 youngest pieces (A of stage s+2) may still be in flight -- s_waitcnt vmcnt(8), not 0.
 // ---------------------------------------------------------------------------------------------
-template <int EPI, int OUT, bool CS = false>
+template <int EPI, int OUT, int CS = 0>
 __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 2, TM = 4, TN = 4;
     using C = K64Cfg<BM, BN, WAVES_M, WAVES_N>;
@@ -772,10 +787,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = c[i][j][r >> 2][r & 3];
+    // The lane index the epilogue's addresses derive from is re-read here, opaquely: from the kernel's `lane` the compiler hoists
+    // every lane-constant part of those addresses to kernel entry and carries them across the main loop, which has no register to
+    // spare (it spilled them around -- and, for the variants with more epilogue state, inside -- the MFMA loop: 4 .. 133 VGPRs
+    // per variant; none now).
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     if constexpr (OUT == OUT_F32_ATOMIC) {
-        gemm_epilogue<bf16_t, TM, TN, EPI, OUT, true>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+        gemm_epilogue<bf16_t, TM, TN, EPI, OUT, true>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane_e);
     } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, 3 * C::A_BYTES + 2 * C::B_BYTES, true, AccArray, true, CS>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, 3 * C::A_BYTES + 2 * C::B_BYTES, true, AccArray, true, CS>(p, acc, smem, m0, n0, ks, wm, wn,
+                                                                                                                     wave * 64 + lane_e, lane_e);
     }
     lds_barrier();
     }
@@ -936,7 +958,11 @@ typedef __attribute__((ext_vector_type(4))) short tn_s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short tn_s16x8_t;
 typedef __attribute__((address_space(3))) tn_s16x4_t* tn_lds_s16x4_ptr;
 
-template <int OUT>
+// BS (column sums of A, i.e. the bias gradient of the Linear whose weight gradient this product is: MMSUM_GEMM_COLSUM): the waves
+// of the first tile column (tn == 0, wn == 0) add up the A fragments they hold for the MFMAs anyway -- four v_dot2c_f32_bf16 per
+// fragment against (1, 1), 32 per stage, in the shadow of the stage's 32 MFMAs -- and leave bias[m] += sum_k A[k][m] with one
+// f32 atomic per column and slice.  The separate column-sum passes over dq / dk / dv (983 MB per decoder layer) are gone.
+template <int OUT, bool BS = false>
 __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 2, TM = 4, TN = 4;
     using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N>;
@@ -965,6 +991,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
     const bf16_t* A = static_cast<const bf16_t*>(p.A);
     const bf16_t* B = static_cast<const bf16_t*>(p.B);
 
+    const bool do_bsum = BS && tn == 0 && wn == 0;                 // wave-uniform
+    float bsum[TM] = {0.f, 0.f, 0.f, 0.f};
     // accumulator (i, j) = a[16 (4 i + j) : +15]: all 256 AGPRs, addressed by name (gemm_tn_w4_acc.inc).  The compiler does not know
     // they are in use: nothing else in this kernel may need an AGPR (register pressure stays below 256 VGPRs; the epilogue takes
     // the accumulators one row band -- 64 registers -- at a time).
@@ -1090,6 +1118,25 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
                 }
             }
             if constexpr (LEFT >= 3) zero_tail(si + 3);
+            if constexpr (BS) {
+                if (do_bsum) {
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+                    const bf16x2_t ones = {(bf16_t)1.f, (bf16_t)1.f};
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int s16 = 0; s16 < 2; ++s16)
+                        {
+                            const bf16x8_t f = aC[i][s16];
+                            float t = bsum[i];
+                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, t, false);
+                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, t, false);
+                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, t, false);
+                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, t, false);
+                            bsum[i] = t;
+                        }
+                }
+            }
         };
 #define TNW4_XY(SI, L) stage(SI, aX, bX, aY, bY, std::integral_constant<int, L>{});
 #define TNW4_YX(SI, L) stage(SI, aY, bY, aX, bX, std::integral_constant<int, L>{});
@@ -1107,6 +1154,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
     }
 #undef TNW4_ISSUE_ALL
     asm volatile("s_nop 15\n s_nop 15" ::: "memory");          // MFMAs issued from inline asm: results may still be in the pipeline
+    if constexpr (BS) {
+        if (do_bsum) {      // lanes l and l + 32 hold the two k halves of column l & 31 of each A block
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float t = wave_half_sum(bsum[i]);
+                const int col = m0 + (wm * TM + i) * 32 + (lane & 31);
+                if (lane < 32 && col < p.M) atomicAdd(const_cast<float*>(p.bias) + col, t * p.alpha);
+            }
+        }
+    }
     struct NamedAcc {
         __device__ __forceinline__ void operator()(int i, const f32x16_t (*)[TN], f32x16_t (&band)[TN]) const {
 #pragma unroll
@@ -1172,7 +1229,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return MMSUM_ERR_BAD_SHAPE;
 }
 
-template <int EPI, int OUT, bool CS = false>
+template <int EPI, int OUT, int CS = 0>
 int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
     using C = K64Cfg<256, 256, 2, 2>;
     const size_t lds = 3 * C::A_BYTES + 2 * C::B_BYTES;             // 160 KB: the whole LDS of a CU
@@ -1184,8 +1241,9 @@ int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
 int launch_w4(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
     if (a.flags & MMSUM_GEMM_COLSUM) {        // column sums of the stored bf16 tile in the epilogue (bias gradients)
-        if (epi == MMSUM_EPI_GELU_BWD && out == OUT_T) return launch_w4_one<MMSUM_EPI_GELU_BWD, OUT_T, true>(a, stream);
-        if (epi == MMSUM_EPI_NONE && out == OUT_T) return launch_w4_one<MMSUM_EPI_NONE, OUT_T, true>(a, stream);
+        const bool sq = (a.flags & MMSUM_GEMM_COLSUM2) != 0;       // + sums of squares: the BatchNorm statistics of a convolution's output
+        if (epi == MMSUM_EPI_GELU_BWD && out == OUT_T && !sq) return launch_w4_one<MMSUM_EPI_GELU_BWD, OUT_T, 1>(a, stream);
+        if (epi == MMSUM_EPI_NONE && out == OUT_T) return sq ? launch_w4_one<MMSUM_EPI_NONE, OUT_T, 2>(a, stream) : launch_w4_one<MMSUM_EPI_NONE, OUT_T, 1>(a, stream);
         return MMSUM_ERR_BAD_SHAPE;           // gemm_glds_eligible admits column sums for these two forms only
     }
 #define W4_CASE(E, O) if (epi == E && out == O) return launch_w4_one<E, O>(a, stream);
@@ -1241,6 +1299,12 @@ bool gemm_glds_eligible(int dtype, const GemmArgs& a) {
     return epilogue_reads_vectorisable(a);
 }
 
+// Column sums of A in the weight-gradient product (MMSUM_GEMM_COLSUM with A_T | B_T): only the four-wave 256x256 kernel with
+// split-K slabs carries them
+bool gemm_tn_colsum_ok(int dtype, const GemmArgs& a) {
+    return gemm_tn_eligible(dtype, a) && choose_tile(a) == TILE_256x256 && out_mode_of(a) == OUT_F32 && a.bias != nullptr;
+}
+
 // A [K,M] and B [K,N] reduction-major bf16 (flags A_T | B_T): the weight-gradient layout
 bool gemm_tn_eligible(int dtype, const GemmArgs& a) {
     if (dtype != MMSUM_BF16) return false;
@@ -1252,17 +1316,18 @@ bool gemm_tn_eligible(int dtype, const GemmArgs& a) {
     return epilogue_reads_vectorisable(a);
 }
 
-template <int OUT>
+template <int OUT, bool BS = false>
 int launch_tn_w4_one(const GemmArgs& a, hipStream_t stream) {
     using R = RingCfg<256, 256, 2, 2>;
     const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256);
     const size_t lds = R::NSTAGE * R::STAGE;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_w4_kernel<OUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_w4_kernel<OUT, BS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    gemm_tn_w4_kernel<OUT><<<dim3(tiles * a.splitk), dim3(256), lds, stream>>>(a);
+    gemm_tn_w4_kernel<OUT, BS><<<dim3(tiles * a.splitk), dim3(256), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 int launch_tn_w4(const GemmArgs& a, hipStream_t stream) {
+    if (a.flags & MMSUM_GEMM_COLSUM) return out_mode_of(a) == OUT_F32 ? launch_tn_w4_one<OUT_F32, true>(a, stream) : MMSUM_ERR_BAD_SHAPE;
     switch (out_mode_of(a)) {
         case OUT_T: return launch_tn_w4_one<OUT_T>(a, stream);
         case OUT_F32_ACC: return launch_tn_w4_one<OUT_F32_ACC>(a, stream);

@@ -354,6 +354,64 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ dou
     }
 }
 
+// The same with the two bias gradients that are column sums of the gate's own outputs taken on the way (the separate
+// column-sum passes re-read 264 MB per decoder layer): sum_dpa += column sums of dpa (alpha_proj.bias), sum_dpb += of dpb
+// (beta_proj.bias).  (out_proj.bias is the column sum of dyt / dytab / dyimg only AFTER the alpha / beta input gradients have
+// been accumulated into them: it comes out of out_proj's weight-gradient kernel instead.)  A thread owns column groups
+// threadIdx.x + 256 v of D / 4 in every row it visits (rows blockIdx.x, + gridDim.x, ...), keeps its sums in registers -- of
+// the values as stored, i.e. rounded to T -- and issues one f32 atomic per column at the end (a few hundred blocks per launch).
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void gate_bwd_sums_kernel(const T* __restrict__ dout, const T* __restrict__ pa, const T* __restrict__ pb,
+                                                            const T* __restrict__ ytab, const T* __restrict__ yimg,
+                                                            const uint8_t* __restrict__ no_table, const uint8_t* __restrict__ no_img,
+                                                            T* __restrict__ dpa, T* __restrict__ dpb, T* __restrict__ dyt,
+                                                            T* __restrict__ dytab, T* __restrict__ dyimg, int R, int D, int rows_per_b,
+                                                            float* __restrict__ sum_dpa, float* __restrict__ sum_dpb) {
+    const int cg = D >> 2;
+    f32x4_t sa[VPL], sb[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) { sa[v] = f32x4_t{0, 0, 0, 0}; sb[v] = f32x4_t{0, 0, 0, 0}; }
+    auto rnd = [](float x) { return to_f32(from_f32<T>(x)); };
+    for (int row = blockIdx.x; row < R; row += gridDim.x) {
+        const int b = row / rows_per_b;
+        const float ma = no_table[b] ? 0.f : 1.f, mb = no_img[b] ? 0.f : 1.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = threadIdx.x + 256 * v;
+            if (c >= cg) break;
+            const long e = (long)row * D + 4 * c;
+            const f32x4_t g = load4<T>(dout + e), a = load4<T>(pa + e), bb = load4<T>(pb + e), tb = load4<T>(ytab + e), im = load4<T>(yimg + e);
+            f32x4_t oa, ob, otb, oim;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ta = tanhf(a[j]), tbv = tanhf(bb[j]);
+                const float al = ma * fmaxf(ta, 0.f), be = mb * fmaxf(tbv, 0.f);
+                otb[j] = g[j] * al;
+                oim[j] = g[j] * be;
+                oa[j] = (ta > 0.f) ? ma * g[j] * tb[j] * (1.f - ta * ta) : 0.f;
+                ob[j] = (tbv > 0.f) ? mb * g[j] * im[j] * (1.f - tbv * tbv) : 0.f;
+                sa[v][j] += rnd(oa[j]);
+                sb[v][j] += rnd(ob[j]);
+            }
+            store4<T>(dpa + e, oa);
+            store4<T>(dpb + e, ob);
+            store4<T>(dyt + e, g);
+            store4<T>(dytab + e, otb);
+            store4<T>(dyimg + e, oim);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int c = threadIdx.x + 256 * v;
+        if (c >= cg) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(sum_dpa + 4 * c + j, sa[v][j]);
+            atomicAdd(sum_dpb + 4 * c + j, sb[v][j]);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // Label-smoothing loss: one block per row, online max/sum in one sweep, second sweep writes the
 // gradient in place.
@@ -789,12 +847,31 @@ extern "C" int mmsum_gate_fwd(int dtype, const void* pa, const void* pb, const v
     return ok();
 }
 
+template <typename T>
+static int gate_bwd_sums_t(const void* dout, const void* pa, const void* pb, const void* ytab, const void* yimg, const uint8_t* no_table,
+                           const uint8_t* no_img, void* dpa, void* dpb, void* dyt, void* dytab, void* dyimg, int R, int D, int rows_per_b,
+                           float* s0, float* s1, hipStream_t s) {
+    const int grid = R < 512 ? R : 512;            // 512 blocks x 2 D atomics: the additions stay far below the kernel's own time
+    const int vpl = (D / 4 + 255) / 256;
+#define GATE_CASE(V) if (vpl == V) { hipLaunchKernelGGL((gate_bwd_sums_kernel<T, V>), dim3(grid), dim3(256), 0, s, (const T*)dout, (const T*)pa, (const T*)pb, \
+        (const T*)ytab, (const T*)yimg, no_table, no_img, (T*)dpa, (T*)dpb, (T*)dyt, (T*)dytab, (T*)dyimg, R, D, rows_per_b, s0, s1); return ok(); }
+    GATE_CASE(1) GATE_CASE(2) GATE_CASE(3) GATE_CASE(4)
+#undef GATE_CASE
+    return MMSUM_ERR_BAD_SHAPE;
+}
+
 extern "C" int mmsum_gate_bwd(int dtype, const void* dout, const void* pa, const void* pb, const void* ytab, const void* yimg,
                               const uint8_t* no_table, const uint8_t* no_img, void* dpa, void* dpb, void* dyt, void* dytab,
-                              void* dyimg, int R, int D, int rows_per_b, void* stream) {
+                              void* dyimg, int R, int D, int rows_per_b, float* sum_dpa, float* sum_dpb, void* stream) {
     if (R <= 0 || D % 4) return MMSUM_ERR_BAD_SHAPE;
     const long n4 = (long)R * D / 4;
     hipStream_t s = (hipStream_t)stream;
+    if (sum_dpa != nullptr || sum_dpb != nullptr) {
+        if (!(sum_dpa && sum_dpb) || D > 4096) return MMSUM_ERR_BAD_SHAPE;                 // both or none
+        if (dtype == MMSUM_BF16) return gate_bwd_sums_t<bf16_t>(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, R, D, rows_per_b, sum_dpa, sum_dpb, s);
+        if (dtype == MMSUM_F32) return gate_bwd_sums_t<float>(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, R, D, rows_per_b, sum_dpa, sum_dpb, s);
+        return MMSUM_ERR_BAD_DTYPE;
+    }
     const int grid = grid_for(n4, 256);
     if (dtype == MMSUM_BF16) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)dout, (const bf16_t*)pa, (const bf16_t*)pb, (const bf16_t*)ytab, (const bf16_t*)yimg, no_table, no_img, (bf16_t*)dpa, (bf16_t*)dpb, (bf16_t*)dyt, (bf16_t*)dytab, (bf16_t*)dyimg, n4, D, rows_per_b);
     else if (dtype == MMSUM_F32) hipLaunchKernelGGL((gate_bwd_kernel<float>), dim3(grid), dim3(256), 0, s, (const float*)dout, (const float*)pa, (const float*)pb, (const float*)ytab, (const float*)yimg, no_table, no_img, (float*)dpa, (float*)dpb, (float*)dyt, (float*)dytab, (float*)dyimg, n4, D, rows_per_b);

@@ -390,6 +390,23 @@ __global__ void bn_running_kernel(const float* __restrict__ sums, float* __restr
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
 }
 
+// Statistics that arrive as plain column sums (the convolution's GEMM epilogue leaves raw = {sum x, sum x^2} of the values it
+// stored: MMSUM_GEMM_COLSUM | MMSUM_GEMM_COLSUM2): -> {mean, biased variance} and the running-statistics update in one launch.
+__global__ void bn_stats_from_sums_kernel(const float* __restrict__ raw, int R, int C, float* __restrict__ sums, float* __restrict__ running_mean,
+                                          float* __restrict__ running_var, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = raw[c] / R;
+    const float var = fmaxf(raw[C + c] / R - mean * mean, 0.f);
+    sums[c] = mean;
+    sums[C + c] = var;
+    if (running_mean != nullptr && running_var != nullptr) {
+        const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
 // dx = gamma rstd (g - sum(g)/R - xhat sum(g xhat)/R) = k g + kx x + k0 with per-channel constants; dresidual = g
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
@@ -754,6 +771,13 @@ extern "C" int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* su
               (bn_partial_kernel<float, 0><<<grid, block, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, R, C, cgb, 0, part)));
     DT_SWITCH(dtype, (bn_stats_finish_kernel<bf16_t><<<dim3((C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, R, (const bf16_t*)x, sums)),
               (bn_stats_finish_kernel<float><<<dim3((C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, R, (const float*)x, sums)));
+    return ok();
+}
+
+extern "C" int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* sums, float* running_mean, float* running_var, float momentum,
+                                        void* stream) {
+    if (R <= 0 || C <= 0 || raw == nullptr || sums == nullptr) return MMSUM_ERR_BAD_SHAPE;
+    bn_stats_from_sums_kernel<<<dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(raw, R, C, sums, running_mean, running_var, momentum);
     return ok();
 }
 

@@ -193,6 +193,26 @@ class Engine:
             self._side_stream = None if os.environ.get("MMSUM_SIDE_STREAM") == "0" else torch.cuda.Stream(device=self.device)
         return self._side_stream
 
+    def wgrad_stream(self):
+        """Third HIP stream for the weight-gradient products of the fused step's backward (MMSUM_WGRAD_STREAM=1; None otherwise).
+        A weight gradient is a leaf of the backward graph: nothing waits for it before the gradient segment ends, while the
+        input-gradient chain it branches off is strictly sequential.  On their own stream (a parallel branch of the captured
+        backward graphs) the weight-gradient kernels run in the launch gaps and partly filled last rounds of that chain."""
+        if not hasattr(self, "_wgrad_stream"):
+            import os
+            on = os.environ.get("MMSUM_WGRAD_STREAM") == "1" and self.device.type == "cuda"
+            self._wgrad_stream = torch.cuda.Stream(device=self.device) if on else None
+            self._wgrad_keep = []
+        return self._wgrad_stream
+
+    def join_wgrads(self):
+        """The current stream waits for every weight gradient issued on the weight-gradient stream (end of a layer's backward and
+        of a gradient segment).  The operands of those products are kept referenced until here: the allocator may hand their
+        memory out again only after this wait."""
+        if getattr(self, "_wgrad_keep", None):
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
+            self._wgrad_keep = []
+
     def p_drop(self):
         return float(self.cfg.dropout) if self.training else 0.0
 
@@ -295,19 +315,32 @@ class Engine:
         return splitk_rule(M, N, Kred, bf16=self.dtype == torch.bfloat16, deterministic=self.deterministic)
 
     def wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
-        """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena (live: device count of the rows R)."""
+        """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena (live: device count of the rows R).
+        bias_g (f32 [N_out], optional) += column sums of dy, the bias gradient of the same Linear: inside the weight-gradient
+        kernel where it can carry them (bf16 four-wave TN kernel: the sums come from the operand tiles it stages anyway), by the
+        column-sum kernel otherwise (f32 / deterministic mode, small products)."""
         out = gview if gview is not None else self.arena.g(gname)
-        if bias_g is not None:
-            kn.colsum(dy, bias_g, accumulate=True, live=live)
+        side = self.wgrad_stream() if (dy.is_cuda and self.dtype == torch.bfloat16) else None
+        if side is not None and torch.cuda.current_stream() not in (side, getattr(self, "_side_stream", None)):      # (the image / table branch keeps its own)
+            side.wait_stream(torch.cuda.current_stream())               # dy and x are complete on the issuing stream
+            with torch.cuda.stream(side):
+                self.wgrad(dy, x, gname, gview, bias_g, live, alpha_dev)
+            self._wgrad_keep.append((dy, x, live, alpha_dev))
+            return
         R = dy.shape[0]
         sk = self.splitk(dy.shape[1], x.shape[1], R)
         if self.dtype == torch.bfloat16 and sk > 1 and x.shape[1] % 4 == 0:
             # reduction-major product straight from the activations (gemm_tn_ring_kernel: transposing LDS reads);
             # split-K partial slabs + a deterministic reduce: cheaper than f32 atomics (1.3 TB/s chip-wide)
             ws = self.empty(sk * dy.shape[1], x.shape[1], dtype=torch.float32)
-            kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True, live=live, alpha_dev=alpha_dev)
+            fuse = bias_g is not None and not self.deterministic and kn.gemm_tn_colsum_ok(dy, x, ws, sk, bias_g)
+            if bias_g is not None and not fuse:
+                kn.colsum(dy, bias_g, accumulate=True, live=live)
+            kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True, live=live, alpha_dev=alpha_dev, colsum=bias_g if fuse else None)
             kn.slab_reduce(ws, sk, out, accumulate=True)
             return
+        if bias_g is not None:
+            kn.colsum(dy, bias_g, accumulate=True, live=live)
         kn.gemm(dy, x, out, a_t=True, b_t=True, accumulate=True, splitk=sk, live=live, alpha_dev=alpha_dev)
 
     def bgrad(self, dy, gname=None, gview=None, live=None):
@@ -461,6 +494,7 @@ class Engine:
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias",
                    lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.bias", lb + "self_attn_layer_norm.weight",
                    lb + "self_attn_layer_norm.bias")
+        self.join_wgrads()                    # end of a layer's backward (no-op without the weight-gradient stream)
         return dx
 
     def _ffn_block_fwd(self, lb, x, out=None, maps=None):
@@ -653,10 +687,15 @@ class Engine:
             dyy = self.empty(3 * Rq, D)
             dyt, dytab, dyimg = dyy[:Rq], dyy[Rq:2 * Rq], dyy[2 * Rq:]
             dpa, dpb = self.empty(Rq, D), self.empty(Rq, D)
-            kn.gate_bwd(dcv, c.pa, c.pb, ytab, yimg, dc.no_table, dc.no_img, dpa, dpb, dyt, dytab, dyimg, dc.qpb * dc.T)
+            # the alpha / beta bias gradients (column sums of dpa / dpb) are taken inside the gate kernel (f32 atomics); the
+            # deterministic mode keeps the separate, order-fixed column-sum passes
+            fused_b = not self.deterministic
+            sums = (a.g(pre + "alpha_proj.bias"), a.g(pre + "beta_proj.bias")) if fused_b else None
+            kn.gate_bwd(dcv, c.pa, c.pb, ytab, yimg, dc.no_table, dc.no_img, dpa, dpb, dyt, dytab, dyimg, dc.qpb * dc.T, sums=sums)
             for name, dp, other, dother in ((pre + "alpha_proj", dpa, ytab, dytab), (pre + "beta_proj", dpb, yimg, dyimg)):
                 W, gW = a.w(name + ".weight"), a.g(name + ".weight")
-                self.bgrad(dp, name + ".bias")
+                if not fused_b:
+                    self.bgrad(dp, name + ".bias")
                 self.wgrad(dp, yt, gview=gW[:, :D])
                 self.wgrad(dp, other, gview=gW[:, D:])
                 self.dgrad(dp, name + ".weight", W[:, :D], dyt, accumulate=True, rows=slice(0, D))
@@ -792,18 +831,38 @@ class Engine:
                     self.conv_mats_t[name] = mt
                 kn.transpose(m, mt)
 
-    def _bn_fwd(self, name, x, relu, residual=None):
+    def _bn_fwd(self, name, x, relu, residual=None, raw=None):
+        """raw (f32 [2C], optional): {sum x, sum x^2} over the rows of x, left by the convolution's GEMM epilogue (_conv_gemm): the
+        statistics then cost one tiny launch instead of a pass over x."""
         a = self.arena
         R, C = x.shape
         c = NS(x=x, relu=relu, name=name)
         c.y = self.empty(R, C)
         c.sums = self.empty(2 * C, dtype=torch.float32)
         training = self.training
-        if training:
+        rm, rv = self.buffers[name + ".running_mean"], self.buffers[name + ".running_var"]
+        if training and raw is not None:
+            kn.bn_stats_from_sums(raw, R, c.sums, rm, rv, 0.1)
+            rm = rv = None                                   # updated above
+        elif training:
             kn.bn_reduce(x, c.sums)
-        kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, self.buffers[name + ".running_mean"],
-                    self.buffers[name + ".running_var"], 1e-5, 0.1, relu, training)
+        kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, rm, rv, 1e-5, 0.1, relu, training)
         return c.y, c
+
+    def _conv_gemm(self, x, w, bn_name=None):
+        """y = x w^T for a convolution lowered to a GEMM (1x1: x = the NHWC activations; KxK: x = the im2col matrix).  In the bf16
+        training step the BatchNorm statistics of y are taken in the GEMM's epilogue (column sums of y and y^2 of the values as
+        stored, f32 atomics): returns (y, raw) with raw = the 2C sums for _bn_fwd, or None where the separate reduction runs."""
+        y = self.empty(x.shape[0], w.shape[0])
+        raw = None
+        if (bn_name is not None and self.training and self.dtype == torch.bfloat16 and not self.deterministic and self._bn_raw is not None
+                and kn.gemm_colsum_fusable(x)):
+            n = 2 * w.shape[0]
+            raw = self._bn_raw[self._bn_raw_off:self._bn_raw_off + n]
+            self._bn_raw_off += (n + 63) // 64 * 64
+            assert self._bn_raw_off <= self._bn_raw.numel()
+        kn.gemm(x, w, y, colsum=raw, colsum_sq=raw is not None)
+        return y, raw
 
     def _bn_bwd(self, c, dy, dresidual=None):
         a = self.arena
@@ -816,11 +875,9 @@ class Engine:
         self.touch(c.name + ".weight", c.name + ".bias")
         return dx
 
-    def _conv1x1(self, x, name):
+    def _conv1x1(self, x, name, bn_name=None):
         w = self.arena.w(name)
-        y = self.empty(x.shape[0], w.shape[0])
-        kn.gemm(x, w.view(w.shape[0], w.shape[1]), y)
-        return y
+        return self._conv_gemm(x, w.view(w.shape[0], w.shape[1]), bn_name)
 
     def img_fwd(self, img, out=None):
         """img [n,3,H,W] f32 NCHW -> [n*196, D] (rows (n, h, w)); saves what layer3's backward needs."""
@@ -832,13 +889,16 @@ class Engine:
         kn.nchw_to_nhwc(img.contiguous(), x, n, 3, Hh, Ww)
         if self.training:
             self._nbt_all[:self._nbt_live] += 1          # BatchNorm num_batches_tracked of every layer this pass runs
+        # one zeroed buffer for the {sum, sum of squares} every convolution's epilogue accumulates (stages 1-3: 94 BatchNorm layers)
+        self._bn_raw, self._bn_raw_off = None, 0
+        if self.training and self.dtype == torch.bfloat16 and not self.deterministic:
+            self._bn_raw = self.zeros(2 * 64 * 1024, dtype=torch.float32)
         Ho, Wo = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
         wm = self.conv_mats[r + "conv1.weight"]
         col = self.empty(n * Ho * Wo, wm.shape[1])
         kn.im2col(x, col, n, Hh, Ww, 3, 7, 7, 2, 3, Ho, Wo, wm.shape[1])
-        y = self.empty(n * Ho * Wo, 64)
-        kn.gemm(col, wm, y)
-        y, _ = self._bn_fwd(r + "bn1", y, True)
+        y, raw = self._conv_gemm(col, wm, r + "bn1")
+        y, _ = self._bn_fwd(r + "bn1", y, True, raw=raw)
         Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         x = self.empty(n * Hp * Wp, 64)
         kn.maxpool3x3s2(y, x, n, Ho, Wo, 64, Hp, Wp)
@@ -848,17 +908,16 @@ class Engine:
                 break
             b = r + "layer%d.%d." % (li, bi)
             bc = NS(x=x, H=Hc, W=Wc, inp=inp, pl=pl, stride=stride, down=down, name=b, li=li)
-            c1 = self._conv1x1(x, b + "conv1.weight")
-            o1, bc.bn1 = self._bn_fwd(b + "bn1", c1, True)
+            c1, raw = self._conv1x1(x, b + "conv1.weight", b + "bn1")
+            o1, bc.bn1 = self._bn_fwd(b + "bn1", c1, True, raw=raw)
             Ho2, Wo2 = (Hc + 2 - 3) // stride + 1, (Wc + 2 - 3) // stride + 1
             wm = self.conv_mats[b + "conv2.weight"]
             bc.col = self.empty(n * Ho2 * Wo2, wm.shape[1])
             kn.im2col(o1, bc.col, n, Hc, Wc, pl, 3, 3, stride, 1, Ho2, Wo2, wm.shape[1])
-            c2 = self.empty(n * Ho2 * Wo2, pl)
-            kn.gemm(bc.col, wm, c2)
-            o2, bc.bn2 = self._bn_fwd(b + "bn2", c2, True)
+            c2, raw = self._conv_gemm(bc.col, wm, b + "bn2")
+            o2, bc.bn2 = self._bn_fwd(b + "bn2", c2, True, raw=raw)
             bc.o1, bc.o2 = o1, o2
-            c3 = self._conv1x1(o2, b + "conv3.weight")
+            c3, raw3 = self._conv1x1(o2, b + "conv3.weight", b + "bn3")
             if down:
                 if stride == 1:
                     xs = x
@@ -866,14 +925,15 @@ class Engine:
                     xs = self.empty(n * Ho2 * Wo2, inp)
                     kn.im2col(x, xs, n, Hc, Wc, inp, 1, 1, stride, 0, Ho2, Wo2, inp)
                 bc.xs = xs
-                cd = self._conv1x1(xs, b + "downsample.0.weight")
-                idt, bc.bnd = self._bn_fwd(b + "downsample.1", cd, False)
+                cd, rawd = self._conv1x1(xs, b + "downsample.0.weight", b + "downsample.1")
+                idt, bc.bnd = self._bn_fwd(b + "downsample.1", cd, False, raw=rawd)
             else:
                 idt = x
-            x, bc.bn3 = self._bn_fwd(b + "bn3", c3, True, residual=idt)
+            x, bc.bn3 = self._bn_fwd(b + "bn3", c3, True, residual=idt, raw=raw3)
             Hc, Wc = Ho2, Wo2
             if li == 3:
                 c.blocks.append(bc)
+        self._bn_raw = None
         c.feat = x                                   # [n*14*14, 1024] for 224x224 inputs
         y = out if out is not None else self.empty(x.shape[0], self.cfg.d_model)
         kn.gemm(x, a.w("img_encoder.linear.weight"), y)

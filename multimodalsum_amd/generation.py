@@ -178,7 +178,7 @@ class DecodeSession:
             if g is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool):
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
                     self._step(t)
                 if self.pool is None:
                     self.pool = g.pool()
@@ -282,8 +282,11 @@ def _session(engine, layout, num_beams, max_length, has_rating, min_length, ngra
 
 @torch.no_grad()
 def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size, early_stopping,
-                length_penalty, decoder_start_token_id):
-    """Greedy beam search (_generate_beam_search :2803-3067).  Returns LongTensor [B, L] on the engine's device."""
+                length_penalty, decoder_start_token_id, trace=None):
+    """Greedy beam search (_generate_beam_search :2803-3067).  Returns LongTensor [B, L] on the engine's device.
+    trace (a list, tests only): receives one dict per decode step -- the hypotheses the step scored, their beam scores, which
+    businesses were still open and the 2 * num_beams candidates the device returned -- so that a CPU oracle can re-score the
+    very same hypotheses (tests/test_timed_path_gpu.py holds the bf16 decode path to the fp32 oracle step by step)."""
     cfg = engine.cfg
     pad, bos, eos, V = cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id, cfg.vocab_size
     dev = engine.device
@@ -303,6 +306,9 @@ def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_lengt
         # one decode step + its tail on the device: forced BOS / EOS (:3084-3089), log_softmax (:2874), min-length and n-gram
         # bans, + beam scores, top 2*num_beams of every business (:2925)
         top_s, top_i = sess.step(last, parents, host_scores, hist, cur_len - 1)
+        if trace is not None:
+            trace.append({"cur_len": cur_len, "prefixes": hist[:, :cur_len].copy(), "beam_scores": host_scores.copy(), "open": [not d for d in done],
+                          "top_scores": top_s.copy(), "top_ids": top_i.copy()})
         top_beam, top_tok = top_i // V, top_i % V
         nxt_s = np.zeros(R, dtype=np.float32)
         nxt_t = np.full(R, pad, dtype=np.int32)

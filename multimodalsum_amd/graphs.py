@@ -7,10 +7,11 @@ over hipGraph) and replayed:
 
   forward  : one graph  (salt bump, text encoder with the table/image encoders on a parallel branch, leave-one-out
              decoder, LM head + loss)
-  backward : one graph per gradient segment (decoder | upper half of the text encoder with the image/table backward on
-             a parallel branch | lower half + embeddings), so the data-parallel all-reduce of a finished segment
-             (parallel.DistributedDataParallel) overlaps the next segment's kernels and only the last ~0.4 GB of
-             gradients is reduced in the open -- the collectives stay outside the graphs, on their own stream.
+  backward : one graph per gradient segment (modules._segment_layers: three decoder layers at a time, then three encoder
+             layers at a time -- the first of those with the image/table backward on a parallel branch, the last with the
+             embeddings), so the data-parallel exchange of a finished segment (parallel.DistributedDataParallel) overlaps
+             the next segment's kernels and only the last ~0.36 GB of gradients (the encoder's bottom layers + the tied
+             embedding) is reduced in the open -- the collectives stay outside the graphs, on their own stream.
 
 What stays eager: weight shadow refresh (engine.sync_weights), gradient-buffer preparation, clipping and the
 optimiser (a handful of launches whose scalars -- lr, bias corrections -- change every step).
@@ -145,7 +146,10 @@ class StepGraphs:
         e.salt = self.salt                       # the dropout kernels captured below mix this device counter into their seeds
         try:
             ent.fwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ent.fwd, pool=self.pool):
+            # thread_local: other threads keep their HIP calls while this one captures (the RCCL process group's watchdog thread
+            # polls its events every few hundred milliseconds; under the default global mode that poll fails the capture -- and
+            # kills the watchdog -- once capturing takes longer than its period)
+            with torch.cuda.graph(ent.fwd, pool=self.pool, capture_error_mode="thread_local"):
                 check(lib.mmsum_bump_u64(self.salt.data_ptr(), 1, kn._stream()), "mmsum_bump_u64")
                 ent.saved = m._step_fwd(*_unflatten(ent.static, spec), compact=_compact(m))
             if self.pool is None:
@@ -156,8 +160,9 @@ class StepGraphs:
             for fn, prefixes in m._step_bwd_segments(ent.saved, release=False, upstream=ent.upstream):
                 e.touched = set()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool):
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
                     fn()
+                    e.join_wgrads()           # the weight-gradient stream is a branch of this graph: join it before the capture ends
                 ent.bwd.append((g, frozenset(e.touched), prefixes))
             e.touched = keep_touched
         finally:

@@ -43,6 +43,18 @@ def gemm_colsum_fusable(a, a_t=False, b_t=False, a2=None):
     return a.dtype == torch.bfloat16 and not a_t and not b_t and a2 is None and a.shape[1] % 64 == 0
 
 
+def gemm_tn_colsum_ok(dy, x, ws, splitk, colsum):
+    """True when the weight-gradient product gemm(dy, x, ws, a_t=True, b_t=True, splitk, slabs=True) can also leave the column sums
+    of dy (the bias gradient) in `colsum`: the four-wave 256x256 TN kernel (asks mmsum_gemm_plan, which validates the call)."""
+    if dy.dtype != torch.bfloat16 or splitk < 2:
+        return False
+    try:
+        plan = gemm_plan(dy, x, ws, a_t=True, b_t=True, splitk=splitk, slabs=True, colsum=colsum)
+    except RuntimeError:
+        return False
+    return plan[0] == _lib.PLAN_TN_RING and (plan[1], plan[2]) == (256, 256)
+
+
 def _live(t):
     """Device int32 scalar holding a live row count (or None)."""
     if t is None:
@@ -51,7 +63,7 @@ def _live(t):
     return _p(t)
 
 
-def _gemm_args(a, b, out_rows, out_cols, a_t, b_t, bias, epi, aux, accumulate, a2, splitk, slabs, colsum, out_f32):
+def _gemm_args(a, b, out_rows, out_cols, a_t, b_t, bias, epi, aux, accumulate, a2, splitk, slabs, colsum, out_f32, colsum_sq=False):
     dt = _dt(a)
     assert _dt(b) == dt
     M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
@@ -64,9 +76,12 @@ def _gemm_args(a, b, out_rows, out_cols, a_t, b_t, bias, epi, aux, accumulate, a
     assert out_rows == (M * splitk if slabs else M) and out_cols == N, (out_rows, out_cols, M, N)
     flags = (_lib.GEMM_A_T if a_t else 0) | (_lib.GEMM_B_T if b_t else 0) | (_lib.GEMM_BIAS if bias is not None else 0)
     flags |= _lib.gemm_epi(epi) | (_lib.GEMM_ACCUM if accumulate else 0) | (_lib.GEMM_SLABS if slabs else 0)
-    if colsum is not None:            # f32 [N] += column sums of the stored result (bias slot becomes an output)
-        assert bias is None and colsum.dtype == torch.float32 and gemm_colsum_fusable(a, a_t, b_t, a2)
+    if colsum is not None:            # NT: f32 [N] += column sums of the stored result; weight-gradient product: f32 [M] += column sums of A
+        assert bias is None and colsum.dtype == torch.float32 and ((a_t and b_t) or gemm_colsum_fusable(a, a_t, b_t, a2))
         flags |= _lib.GEMM_COLSUM
+        if colsum_sq:                 # colsum holds 2 N floats: [N:] += column sums of the squares (BatchNorm statistics)
+            assert not (a_t and b_t) and colsum.numel() == 2 * N
+            flags |= _lib.GEMM_COLSUM2
         bias = colsum
     if out_f32:
         flags |= _lib.GEMM_OUT_F32
@@ -89,7 +104,7 @@ def gemm_plan(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None
 
 
 def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None,
-         splitk=1, slabs=False, colsum=None, live=None, alpha_dev=None):
+         splitk=1, slabs=False, colsum=None, live=None, alpha_dev=None, colsum_sq=False):
     """out[M,N] = epi(alpha * A.B^T + bias) (+ out).  a: [M,K] (or [K,M] when a_t); b: [N,K] (or [K,N] when b_t);
     a2: optional second half of the K range ([M,K2], natural layout).  out may be f32 while a/b are bf16.
     live: device int32 scalar, the live rows of the row-streamed operand (M, or K of the a_t & b_t product);
@@ -97,7 +112,7 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
     if out.dtype != torch.float32:
         assert _dt(out) == _dt(a)
     dt, M, N, K, ksplit, flags, bias = _gemm_args(a, b, out.shape[0], out.shape[1], a_t, b_t, bias, epi, aux, accumulate, a2, splitk,
-                                                   slabs, colsum, out.dtype == torch.float32)
+                                                   slabs, colsum, out.dtype == torch.float32, colsum_sq)
     check(lib.mmsum_gemm(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(out), _ld(out),
                          _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, float(alpha), _p(alpha_dev), flags, splitk, _live(live),
                          _stream()),
@@ -195,10 +210,12 @@ def gate_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, out, rows_per_b):
                              rows_per_b, _stream()), "mmsum_gate_fwd")
 
 
-def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, rows_per_b):
+def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, rows_per_b, sums=None):
+    """sums = (sum_dpa, sum_dpb), f32 [D] each: += column sums of dpa and dpb (the alpha_proj / beta_proj bias gradients)."""
     R, D = dout.shape
+    s0, s1 = sums if sums is not None else (None, None)
     check(lib.mmsum_gate_bwd(_dt(dout), _p(dout), _p(pa), _p(pb), _p(ytab), _p(yimg), _p(no_table), _p(no_img), _p(dpa), _p(dpb),
-                             _p(dyt), _p(dytab), _p(dyimg), R, D, rows_per_b, _stream()), "mmsum_gate_bwd")
+                             _p(dyt), _p(dytab), _p(dyimg), R, D, rows_per_b, _p(s0), _p(s1), _stream()), "mmsum_gate_bwd")
 
 
 def ls_loss(logits, target, row_loss, V, smoothing, gscale, write_grad=True):
@@ -266,6 +283,13 @@ def bn_reduce(x, sums):
     R, C = x.shape
     ws = _workspace(lib.mmsum_bn_workspace(C), x.device, "bn")
     check(lib.mmsum_bn_reduce(_dt(x), _p(x), R, C, _p(sums), _p(ws), _stream()), "mmsum_bn_reduce")
+
+
+def bn_stats_from_sums(raw, R, sums, running_mean, running_var, momentum):
+    """raw f32 [2C] = {sum x, sum x^2} (the conv GEMM's epilogue: gemm(..., colsum=raw, colsum_sq=True)) -> sums = {mean, var}, and the
+    running statistics' momentum update."""
+    C = sums.numel() // 2
+    check(lib.mmsum_bn_stats_from_sums(_p(raw), R, C, _p(sums), _p(running_mean), _p(running_var), momentum, _stream()), "mmsum_bn_stats_from_sums")
 
 
 def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training):

@@ -174,6 +174,7 @@ def _begin_backward(engine):
 
 
 def _end_backward(engine):
+    engine.join_wgrads()
     engine.arena.attach_grads(engine.touched)
 
 
@@ -382,7 +383,7 @@ class _BartBase(nn.Module):
     def _generate(self, hiddens, masks, rating_diff, input_ids=None, max_length=None, min_length=None, do_sample=None,
                   early_stopping=None, num_beams=None, temperature=None, top_k=None, top_p=None, repetition_penalty=None,
                   bad_words_ids=None, bos_token_id=None, pad_token_id=None, eos_token_id=None, length_penalty=None,
-                  no_repeat_ngram_size=None, num_return_sequences=None, decoder_start_token_id=None, use_cache=None, **unused):
+                  no_repeat_ngram_size=None, num_return_sequences=None, decoder_start_token_id=None, use_cache=None, trace=None, **unused):
         """generate() of the reference (modeling_multimodalsum.py:2295-2693 / :1398-1700): greedy beam search as
         test.py:156-158 calls it.  Sampling, repetition penalty, bad-word lists, prompts and num_beams == 1 are
         not part of the scoped path and raise."""
@@ -408,7 +409,7 @@ class _BartBase(nn.Module):
             layout = e.make_memory(B, [(h.shape[1], h.shape[2]) for h in hiddens])
             pads = [m.eq(0).to(torch.uint8).contiguous() for m in masks]
             return beam_search(e, hiddens, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size,
-                               bool(early_stopping), float(length_penalty), int(start))
+                               bool(early_stopping), float(length_penalty), int(start), trace=trace)
         finally:
             e.training = was_training
 

@@ -69,6 +69,30 @@ def next_token_logits(sd, cfg, input_ids, hiddens, masks, rating_diff, multimoda
     return F.linear(h[:, -1, :], sd[prefix + "model.shared.weight"])
 
 
+def step_scores(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, max_length, min_length=0, no_repeat_ngram_size=0, prefix=""):
+    """Log-probabilities of the next token for every hypothesis row `input_ids` [rows, cur_len], with the reference's adjustments:
+    BOS forced at length 1 and EOS at max_length - 1 on the logits (:3084-3102), log_softmax (:2874), EOS banned below min_length
+    (:2877-2879) and the n-gram ban (:2890-2899) on the scores.  hiddens / masks / rating_diff: one entry per row."""
+    bos, eos = cfg.bos_token_id, cfg.eos_token_id
+    cur_len = input_ids.shape[1]
+    logits = next_token_logits(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, prefix)
+    if cur_len == 1:
+        keep = logits[:, bos].clone()
+        logits.fill_(float("-inf"))
+        logits[:, bos] = keep
+    if cur_len == max_length - 1 and eos is not None:
+        keep = logits[:, eos].clone()
+        logits.fill_(float("-inf"))
+        logits[:, eos] = keep
+    scores = F.log_softmax(logits, dim=-1)
+    if eos is not None and cur_len < min_length:
+        scores[:, eos] = float("-inf")
+    if no_repeat_ngram_size > 0:
+        for i, banned in enumerate(banned_ngram_tokens(input_ids.tolist(), no_repeat_ngram_size, cur_len)):
+            scores[i, banned] = float("-inf")
+    return scores
+
+
 def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max_length, min_length=0,
                 no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.0, decoder_start_token_id=None, prefix="",
                 return_scores=False):
@@ -93,21 +117,7 @@ def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max
     cur_len = 1
     next_scores = next_tokens = None
     while cur_len < max_length:
-        logits = next_token_logits(sd, cfg, input_ids, hid, msk, rd, multimodal, prefix)
-        if cur_len == 1:                                                               # (:3084-3102)
-            keep = logits[:, bos].clone()
-            logits.fill_(float("-inf"))
-            logits[:, bos] = keep
-        if cur_len == max_length - 1 and eos is not None:
-            keep = logits[:, eos].clone()
-            logits.fill_(float("-inf"))
-            logits[:, eos] = keep
-        scores = F.log_softmax(logits, dim=-1)
-        if eos is not None and cur_len < min_length:
-            scores[:, eos] = float("-inf")
-        if no_repeat_ngram_size > 0:
-            for i, banned in enumerate(banned_ngram_tokens(input_ids.tolist(), no_repeat_ngram_size, cur_len)):
-                scores[i, banned] = float("-inf")
+        scores = step_scores(sd, cfg, input_ids, hid, msk, rd, multimodal, max_length, min_length, no_repeat_ngram_size, prefix)
         cand = (scores + beam_scores[:, None]).view(B, num_beams * V)
         next_scores, next_tokens = torch.topk(cand, 2 * num_beams, dim=1, largest=True, sorted=True)
         nxt = []

@@ -26,13 +26,17 @@ def gemm_colsum_fusable(a, a_t=False, b_t=False, a2=None):
     return a.dtype == torch.bfloat16 and not a_t and not b_t and a2 is None and a.shape[1] % 64 == 0
 
 
+def gemm_tn_colsum_ok(dy, x, ws, splitk, colsum):
+    return dy.dtype == torch.bfloat16 and splitk >= 2
+
+
 def _n(live, rows):
     """Live row count of a kernel call: the device scalar when given (clamped to the capacity), else every row."""
     return rows if live is None else max(0, min(rows, int(live.reshape(-1)[0])))
 
 
 def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None, splitk=1, slabs=False,
-         colsum=None, live=None, alpha_dev=None):
+         colsum=None, live=None, alpha_dev=None, colsum_sq=False):
     """`live` as in include/mmsum_hip.h: natural A -> only the first `live` rows of A / aux / out take part; a_t & b_t ->
     only the first `live` reduction rows; rows past it are neither read nor written."""
     if alpha_dev is not None:
@@ -40,11 +44,14 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
     if live is not None and a_t and b_t:
         n = _n(live, a.shape[0])
         a, b, live = a[:n], b[:n], None
+    if colsum is not None and a_t and b_t:       # weight-gradient product: column sums of A (the bias gradient of the same Linear)
+        colsum.add_(alpha * a.float().sum(0))
+        colsum = None
     if live is not None:
         assert not a_t and not slabs
         n = _n(live, a.shape[0])
         return gemm(a[:n], b, out[:n], False, b_t, bias, epi, None if aux is None else aux[:n], accumulate, alpha,
-                    None if a2 is None else a2[:n], splitk, False, colsum)
+                    None if a2 is None else a2[:n], splitk, False, colsum, colsum_sq=colsum_sq)
     A = a.float().t() if a_t else a.float()
     if a2 is not None:
         A = torch.cat([A, a2.float()], dim=1)
@@ -72,7 +79,10 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
     else:
         out.copy_(v)
     if colsum is not None:
-        colsum.add_(out.float().sum(0))
+        N = out.shape[1]
+        colsum[:N].add_(out.float().sum(0))
+        if colsum_sq:
+            colsum[N:2 * N].add_((out.float() ** 2).sum(0))
     return out
 
 
@@ -254,7 +264,7 @@ def gate_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, out, rows_per_b):
     out.copy_(yt.float() + ma * F.relu(torch.tanh(pa.float())) * ytab.float() + mb * F.relu(torch.tanh(pb.float())) * yimg.float())
 
 
-def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, rows_per_b):
+def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, rows_per_b, sums=None):
     ma = (1 - no_table.float()).repeat_interleave(rows_per_b)[:, None]
     mb = (1 - no_img.float()).repeat_interleave(rows_per_b)[:, None]
     g = dout.float()
@@ -264,6 +274,9 @@ def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, d
     dpa.copy_(torch.where(ta > 0, ma * g * ytab.float() * (1 - ta * ta), torch.zeros_like(g)))
     dpb.copy_(torch.where(tb > 0, mb * g * yimg.float() * (1 - tb * tb), torch.zeros_like(g)))
     dyt.copy_(g)
+    if sums is not None:
+        sums[0].add_(dpa.float().sum(0))
+        sums[1].add_(dpb.float().sum(0))
 
 
 def ls_loss(logits, target, row_loss, V, smoothing, gscale, write_grad=True):
@@ -359,6 +372,16 @@ def bn_reduce(x, sums):
     C = x.shape[1]
     sums[:C] = x.float().mean(0)
     sums[C:] = x.float().var(0, unbiased=False)
+
+
+def bn_stats_from_sums(raw, R, sums, running_mean, running_var, momentum):
+    C = sums.numel() // 2
+    mean = raw[:C] / R
+    var = (raw[C:2 * C] / R - mean * mean).clamp_min(0)
+    sums[:C], sums[C:] = mean, var
+    if running_mean is not None:
+        running_mean.mul_(1 - momentum).add_(momentum * mean)
+        running_var.mul_(1 - momentum).add_(momentum * var * (R / (R - 1) if R > 1 else 1.0))
 
 
 def _bn_stats(sums, R, C, eps):

@@ -88,6 +88,14 @@ def test_nt_ring_256_persistent_all_epilogues(M, N, K):
     want_cs = 1.0 + out.double().sum(0)
     assert ((cs.double() - want_cs).abs() <= 1e-3 * out.double().abs().sum(0) + 1e-2).all(), "column sums"
     del u, uf, gp
+    # BatchNorm statistics of a convolution's output in the GEMM's epilogue: column sums of the stored values and of their squares
+    cs2 = torch.full((2 * N,), 2.0, device=DEV)
+    kn.gemm(a, w, out, colsum=cs2, colsum_sq=True)
+    check(out, ref, "plain with statistics", atol=2e-2 * sc)
+    od = out.double()
+    assert ((cs2[:N].double() - 2.0 - od.sum(0)).abs() <= 1e-3 * od.abs().sum(0) + 1e-2).all(), "column sums"
+    assert ((cs2[N:].double() - 2.0 - (od * od).sum(0)).abs() <= 1e-3 * (od * od).sum(0) + 1e-2).all(), "column sums of squares"
+    del od, cs2
     # ReLU' (table encoder), += into bf16 (dq / dx accumulation), += into f32, plain f32 output
     r = rnd(M, N, seed=5)
     kn.gemm(a, w, out, epi=kn.EPI_RELU_BWD, aux=r)
@@ -168,11 +176,17 @@ def test_tn_w4_weight_gradients_at_bench_sizes(R, No, Ki, want_sk, bn):
     plan = kn.gemm_plan(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
     assert_plan(plan, _lib.PLAN_TN_RING, 256, bn)
     assert plan[3] == tiles * sk and plan[3] <= 256, plan
-    kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True)
+    # with the bias gradient (column sums of dy) taken from the operand tiles inside the four-wave kernel, as Engine.wgrad asks for it
+    cs = torch.full((No,), 0.25, device=DEV)
+    fused = kn.gemm_tn_colsum_ok(dy, x, ws, sk, cs)
+    assert fused == (bn == 256)
+    kn.gemm(dy, x, ws, a_t=True, b_t=True, splitk=sk, slabs=True, colsum=cs if fused else None)
     g = torch.zeros(No, Ki, device=DEV)
     kn.slab_reduce(ws, sk, g, accumulate=True)
     want = dy.double().t() @ x.double()
     check(g, want, "wgrad", rel=1e-3, atol=1e-3 * math.sqrt(R / 1024.0))
+    if fused:
+        check(cs, 0.25 + dy.double().sum(0), "bias gradient from the weight-gradient kernel", rel=1e-4, atol=1e-3 * math.sqrt(R / 1024.0))
 
 
 def test_live_row_counts_at_bench_sizes():
@@ -199,10 +213,12 @@ def test_live_row_counts_at_bench_sizes():
         from multimodalsum_amd.engine import splitk_rule
         sk = splitk_rule(Fd, D, cap)                      # the engine sizes the split for the capacity, whatever the live count
         ws = torch.full((sk * Fd, D), float("nan"), device=DEV)
-        kn.gemm(dy, a, ws, a_t=True, b_t=True, splitk=sk, slabs=True, live=live)
+        bsum = torch.zeros(Fd, device=DEV)
+        kn.gemm(dy, a, ws, a_t=True, b_t=True, splitk=sk, slabs=True, live=live, colsum=bsum)      # + the bias gradient, live rows only
         g = torch.zeros(Fd, D, device=DEV)
         kn.slab_reduce(ws, sk, g, accumulate=True)
         check(g, dy[:live_n].double().t() @ a[:live_n].double(), "live wgrad (%d)" % live_n, rel=1e-3, atol=1e-2)
+        check(bsum, dy[:live_n].double().sum(0), "live wgrad bias sums (%d)" % live_n, rel=1e-3, atol=1e-2)
         cs = torch.zeros(Fd, device=DEV)
         kn.colsum(dy, cs, live=live)
         check(cs, dy[:live_n].double().sum(0), "live colsum (%d)" % live_n, rel=1e-3, atol=1e-2)

@@ -507,6 +507,46 @@ def test_gate(dtype):
     kn.gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, *outs, rows)
     for o, f, nm in zip(outs, fl, ["dpa", "dpb", "dyt", "dytab", "dyimg"]):
         close(o, f.grad, dtype, what=nm)
+    # the form with the two bias gradients summed on the way (alpha_proj, beta_proj): same five outputs, sums of the values AS
+    # STORED, added to what the buffers held -- at the step's width too
+    for R2, D2 in ((R, D), (4 * 130, 1024)):
+        ts2 = [rnd(R2, D2, dtype=dtype, seed=10 + s_) for s_ in range(6)]
+        nt2 = torch.zeros(4, dtype=torch.uint8, device=DEV)
+        nt2[1] = 1
+        ni2 = torch.zeros(4, dtype=torch.uint8, device=DEV)
+        ni2[2] = 1
+        plain = [torch.empty_like(ts2[0]) for _ in range(5)]
+        kn.gate_bwd(ts2[5], ts2[0], ts2[1], ts2[3], ts2[4], nt2, ni2, *plain, R2 // 4)
+        fused = [torch.empty_like(ts2[0]) for _ in range(5)]
+        sums = [torch.full((D2,), 0.5, device=DEV) for _ in range(2)]
+        kn.gate_bwd(ts2[5], ts2[0], ts2[1], ts2[3], ts2[4], nt2, ni2, *fused, R2 // 4, sums=sums)
+        for a_, b_ in zip(plain, fused):           # two kernels, the same arithmetic: equal to the last bit or one FMA contraction apart
+            close(b_, a_.float(), dtype, what="gate bwd with sums")
+        want = [plain[0].double().sum(0), plain[1].double().sum(0)]
+        for got, w_, nm in zip(sums, want, ["sum dpa", "sum dpb"]):
+            assert float((got.double() - 0.5 - w_).abs().max()) <= 1e-4 * float(w_.abs().max()) + 1e-4, nm
+
+
+def test_gemm_epilogue_statistics_small_tiles():
+    """Column sums and sums of squares of the stored result in the GEMM epilogue (MMSUM_GEMM_COLSUM | COLSUM2: the BatchNorm
+    statistics of a convolution's output) on the smaller-tile ring kernels and on ragged edges: N = 64 / 128 (256 x 128 tiles,
+    the early ResNet stages), rows that end inside a tile, and the statistics -> {mean, variance} + running-statistics kernel."""
+    for M, N, K in ((1000, 64, 192), (5000, 128, 576), (3000, 256, 64), (700, 1024, 256)):
+        a, w = rnd(M, K, dtype=torch.bfloat16, seed=1, std=0.5), rnd(N, K, dtype=torch.bfloat16, seed=2, std=0.5)
+        out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        raw = torch.zeros(2 * N, device=DEV)
+        kn.gemm(a, w, out, colsum=raw, colsum_sq=True)
+        od = out.double()
+        close(out, a.float() @ w.float().t(), torch.bfloat16, what="gemm with statistics")
+        assert float((raw[:N].double() - od.sum(0)).abs().max()) <= 1e-4 * float(od.abs().sum(0).max()) + 1e-3, (M, N, K)
+        assert float((raw[N:].double() - (od * od).sum(0)).abs().max()) <= 1e-4 * float((od * od).sum(0).max()) + 1e-3, (M, N, K)
+        sums = torch.empty(2 * N, device=DEV)
+        rm, rv = torch.full((N,), 0.5, device=DEV), torch.full((N,), 2.0, device=DEV)
+        kn.bn_stats_from_sums(raw, M, sums, rm, rv, 0.1)
+        mean, var = od.mean(0), od.var(0, unbiased=False)
+        assert float((sums[:N].double() - mean).abs().max()) <= 1e-4 * float(mean.abs().max()) + 1e-5
+        assert float((sums[N:].double() - var).abs().max()) <= 1e-3 * float(var.max()) + 1e-5
+        assert float((rm.double() - (0.45 + 0.1 * mean)).abs().max()) <= 1e-4 and float((rv.double() - (1.8 + 0.1 * var * M / (M - 1))).abs().max()) <= 1e-3 * float(var.max()) + 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

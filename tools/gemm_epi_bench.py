@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """mmsum_gemm with the epilogues of the training step (bias, GELU + saved pre-activation, GELU', column sums), HIP-event
-timed on rotating buffers so that the operands come from HBM as they do in the step.  A/B switches: MMSUM_GEMM_PREFETCH=0."""
+timed on rotating buffers so that the operands come from HBM as they do in the step.  A/B: MMSUM_LIB=/path/to/another/libmmsum_hip.so."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,7 +12,8 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 20480
 ONLY = sys.argv[2].split(",") if len(sys.argv) > 2 else None
 CASES = [("fc1+bias", 4096, 1024, "bias"), ("proj+bias", 1024, 1024, "bias"), ("qkv+bias", 3072, 1024, "bias"), ("fc1+bias+gelu", 4096, 1024, "gelu"),
          ("fc2+bias", 1024, 4096, "bias"), ("dgrad plain", 1024, 1024, "none"), ("dgrad fc2 gelu'", 4096, 1024, "gelu_bwd"),
-         ("dgrad fc1", 1024, 4096, "none"), ("dgrad accumulate", 1024, 1024, "acc"), ("dgrad fc1 accum", 1024, 4096, "acc")]
+         ("dgrad fc1", 1024, 4096, "none"), ("dgrad accumulate", 1024, 1024, "acc"), ("dgrad fc1 accum", 1024, 4096, "acc"),
+         ("kv+bias", 2048, 1024, "bias"), ("dgrad qkv accum", 1024, 3072, "acc")]
 
 
 def main():
