@@ -19,7 +19,8 @@ dense bf16 MFMA peak with the canonical algorithmic FLOP count of SURVEY.md sect
 once per step) and, beside it, with the FLOPs actually executed (valid rows only).  `cpu_baseline` times the CPU
 oracle (the restated reference algorithm, literal) on the host cores: whole B=1 steps of the same configuration
 (forward, backward, clip, AdamW), no extrapolation.  `also` carries the other BASELINE configurations measured in
-the same run (text-only step, the reference-style per-GPU batch of 8, beam-search generation), a few steps each.
+the same run (text-only step, per-GPU batches of 56 -- the headline of rounds 1-2 -- and 8, beam-search generation), a few
+steps each.
 """
 import argparse
 import json
@@ -69,9 +70,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None,
-                    help="businesses per GPU per step; default 56 for the training workloads (9*56*128 decoder rows = 252 x 256-row GEMM "
-                         "tiles; ~105 GB of the 288 GB; 28 is 4 %% slower per business, 8 is BASELINE C4's reference-style batch) and 8 "
-                         "for --workload generate (test.py:176)")
+                    help="businesses per GPU per step; default 112 for the training workloads (9*112*128 decoder rows = 504 x 256-row GEMM "
+                         "tiles: 7.9 rounds of the 256 CUs per N=1024 product; ~200 GB of the 288 GB.  Measured on one box: 112 -> 233, "
+                         "56 -> 223 businesses/s, 28 is 4 %% below 56; 8 is BASELINE C4's reference-style batch) and 8 for --workload "
+                         "generate (test.py:176)")
     ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text", "generate"],
                     help="multimodal / text: the training step (BASELINE configs 4 / 2); generate: test.py's beam search (BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -86,7 +88,7 @@ def parse(argv=None):
     ap.add_argument("--master-port", type=int, default=29517)
     args = ap.parse_args(argv)
     if args.batch is None:
-        args.batch = 8 if args.workload == "generate" else 56
+        args.batch = 8 if args.workload == "generate" else 112
     return args
 
 
@@ -485,9 +487,13 @@ def also_configs(args, cfg, model, device):
     beam-search generation on the headline's model; the text-only step (text_pretrain.py:66-113, BASELINE config 2) follows on a
     TextSupervised model built after this one is released (also_text_only)."""
     import copy
+    import gc
     import torch
     from multimodalsum_amd import optim
     out = {}
+    object.__setattr__(model, "_step_graphs", None)        # the headline's captured graph set pins its activations: release it first
+    gc.collect()
+    torch.cuda.empty_cache()
 
     def train_cfg(name, workload, batch, mdl, steps=4, warmup=1):
         a = copy.copy(args)
@@ -500,6 +506,11 @@ def also_configs(args, cfg, model, device):
                      "workload": ("multimodal_train.py full step" if workload == "multimodal" else "text_pretrain.py text-only step")
                                  + " (fwd+bwd+clip+AdamW), 9 reviews x 128 tok, hip-graph replay"}
     try:
+        if args.batch != 56:
+            train_cfg("multimodal_B56", "multimodal", 56, model)     # the batch of rounds 1-2's headline, for continuity
+            object.__setattr__(model, "_step_graphs", None)
+            gc.collect()
+            torch.cuda.empty_cache()
         train_cfg("multimodal_B8", "multimodal", 8, model)
         g = run_generate(model, cfg, device, 8, 2, 1, args.dtype)
         out["generate_B8"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "decode_steps", "ms_per_decode_step", "tokens_per_s")}
@@ -516,7 +527,7 @@ def also_text_only(args, cfg, device):
     from multimodalsum_amd import optim
     try:
         a = copy.copy(args)
-        a.workload, a.batch = "text", 56
+        a.workload = "text"                          # at the headline's batch
         _, mdl = build(a, device)
         opt = optim.get_optimizer(1e-5, NO_DECAY, mdl.named_parameters(), None)
         sch = optim.get_linear_schedule_with_warmup(opt, 100, 100000)
@@ -594,14 +605,14 @@ def main():
         probe, families = probe_step_kernels(args, model, runner, opt, sch, b, cfg)
     also = None
     if rank == 0 and world == 1 and not args.no_also and args.workload == "multimodal" and args.dtype == "bf16" and not args.no_graphs:
+        del runner, opt, sch, next_batch, b, loss, graphs
         also = also_configs(args, cfg, model, device)
         object.__setattr__(model, "_step_graphs", None)        # release the headline model before the text-only one is built
-        del runner, opt, sch, next_batch, b, loss, graphs
         model = None
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        also["text_only_B56"] = also_text_only(args, cfg, device)
+        also["text_only_B%d" % args.batch] = also_text_only(args, cfg, device)
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt

@@ -664,6 +664,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     const int a_frag0 = wm * (TM * 32) * C::ROWB + fo, b_frag0 = B_BASE + wn * (TN * 32) * C::ROWB + fo;
     const int ydelta = (fo ^ 64) - fo;
 
+    // Start-time skew.  All 256 workgroups run tiles of equal length, so they reach their write-backs together, every round: 33.5 MB
+    // (one bf16 tile per CU) hit the memory system at once and take ~6.7 us to drain, which the in-order vmcnt exposes (the next tile's
+    // first DMA wait also waits for those stores).  Starting the eight tile rows an XCD runs at a time an eighth of the window apart
+    // spreads the write-backs over the window: each one then drains at the CU's own rate.  The launch ends one window later; with
+    // several rounds per launch the rounds' savings outweigh it.  (Workgroups that share an A panel -- same tile row -- keep
+    // running in lockstep; the B panels are L2-resident across the skew.)
+    if (p.stagger > 0) {
+        const int level = (blockIdx.x >> 3) & 7;
+        for (int i = level * p.stagger / 8; i > 0; --i) __builtin_amdgcn_s_sleep(16);       // 16 x 64 cycles
+    }
     for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
     const int wg = xcd_remap(vid, total);
     const int ks = wg / tiles;
@@ -993,6 +1003,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
 
     const bool do_bsum = BS && tn == 0 && wn == 0;                 // wave-uniform
     float bsum[TM] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BS) p.flags &= ~MMSUM_GEMM_COLSUM;                 // here the flag means sums of A, not of the stored tile: the epilogue must not see it
     // accumulator (i, j) = a[16 (4 i + j) : +15]: all 256 AGPRs, addressed by name (gemm_tn_w4_acc.inc).  The compiler does not know
     // they are in use: nothing else in this kernel may need an AGPR (register pressure stays below 256 VGPRs; the epilogue takes
     // the accumulators one row band -- 64 registers -- at a time).
@@ -1235,7 +1246,11 @@ int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = 3 * C::A_BYTES + 2 * C::B_BYTES;             // 160 KB: the whole LDS of a CU
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w4_kernel<EPI, OUT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    gemm_nt_w4_kernel<EPI, OUT, CS><<<dim3(ring_grid(a, 256, 256)), dim3(256), lds, stream>>>(a);
+    GemmArgs b = a;
+    static const int stagger_us = [] { const char* e = getenv("MMSUM_W4_STAGGER_US"); return e ? atoi(e) : 0; }();      // A/B hook
+    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
+    b.stagger = tiles >= 3 * cu_count() ? stagger_us * 2 : 0;        // ~2 x 1024 cycles per microsecond; only launches of three rounds or more
+    gemm_nt_w4_kernel<EPI, OUT, CS><<<dim3(ring_grid(a, 256, 256)), dim3(256), lds, stream>>>(b);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 int launch_w4(const GemmArgs& a, hipStream_t stream) {

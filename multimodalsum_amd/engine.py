@@ -193,26 +193,6 @@ class Engine:
             self._side_stream = None if os.environ.get("MMSUM_SIDE_STREAM") == "0" else torch.cuda.Stream(device=self.device)
         return self._side_stream
 
-    def wgrad_stream(self):
-        """Third HIP stream for the weight-gradient products of the fused step's backward (MMSUM_WGRAD_STREAM=1; None otherwise).
-        A weight gradient is a leaf of the backward graph: nothing waits for it before the gradient segment ends, while the
-        input-gradient chain it branches off is strictly sequential.  On their own stream (a parallel branch of the captured
-        backward graphs) the weight-gradient kernels run in the launch gaps and partly filled last rounds of that chain."""
-        if not hasattr(self, "_wgrad_stream"):
-            import os
-            on = os.environ.get("MMSUM_WGRAD_STREAM") == "1" and self.device.type == "cuda"
-            self._wgrad_stream = torch.cuda.Stream(device=self.device) if on else None
-            self._wgrad_keep = []
-        return self._wgrad_stream
-
-    def join_wgrads(self):
-        """The current stream waits for every weight gradient issued on the weight-gradient stream (end of a layer's backward and
-        of a gradient segment).  The operands of those products are kept referenced until here: the allocator may hand their
-        memory out again only after this wait."""
-        if getattr(self, "_wgrad_keep", None):
-            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
-            self._wgrad_keep = []
-
     def p_drop(self):
         return float(self.cfg.dropout) if self.training else 0.0
 
@@ -320,13 +300,6 @@ class Engine:
         kernel where it can carry them (bf16 four-wave TN kernel: the sums come from the operand tiles it stages anyway), by the
         column-sum kernel otherwise (f32 / deterministic mode, small products)."""
         out = gview if gview is not None else self.arena.g(gname)
-        side = self.wgrad_stream() if (dy.is_cuda and self.dtype == torch.bfloat16) else None
-        if side is not None and torch.cuda.current_stream() not in (side, getattr(self, "_side_stream", None)):      # (the image / table branch keeps its own)
-            side.wait_stream(torch.cuda.current_stream())               # dy and x are complete on the issuing stream
-            with torch.cuda.stream(side):
-                self.wgrad(dy, x, gname, gview, bias_g, live, alpha_dev)
-            self._wgrad_keep.append((dy, x, live, alpha_dev))
-            return
         R = dy.shape[0]
         sk = self.splitk(dy.shape[1], x.shape[1], R)
         if self.dtype == torch.bfloat16 and sk > 1 and x.shape[1] % 4 == 0:
@@ -494,7 +467,6 @@ class Engine:
         self.touch(q + ".weight", k + ".weight", v + ".weight", q + ".bias", k + ".bias", v + ".bias",
                    lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.bias", lb + "self_attn_layer_norm.weight",
                    lb + "self_attn_layer_norm.bias")
-        self.join_wgrads()                    # end of a layer's backward (no-op without the weight-gradient stream)
         return dx
 
     def _ffn_block_fwd(self, lb, x, out=None, maps=None):

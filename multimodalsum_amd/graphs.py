@@ -162,7 +162,6 @@ class StepGraphs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
                     fn()
-                    e.join_wgrads()           # the weight-gradient stream is a branch of this graph: join it before the capture ends
                 ent.bwd.append((g, frozenset(e.touched), prefixes))
             e.touched = keep_touched
         finally:

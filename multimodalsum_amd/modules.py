@@ -174,7 +174,6 @@ def _begin_backward(engine):
 
 
 def _end_backward(engine):
-    engine.join_wgrads()
     engine.arena.attach_grads(engine.touched)
 
 

@@ -56,8 +56,11 @@ def yelp_table_encoder(sd, emb_weight, field, field_value, prefix="table_encoder
     names = field_name.unsqueeze(0).expand(B, -1, -1)
     values = torch.cat([name_e, cat_e, strcat_e, strbool_e, rating_e, hours_e], dim=1)   # [B,47,D]
     x = torch.cat([names, values], dim=-1)                                # [B,47,2D]
-    x = F.linear(x, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
-    x = F.linear(torch.relu(x), sd[prefix + "linear.weight"])
+    # through bart_oracle.linear: identical to F.linear unless the bf16 emulation is on (tests only), which then rounds these two
+    # Linears like every other one of the path
+    from oracle import bart_oracle as _bo
+    x = _bo.linear(x, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
+    x = _bo.linear(torch.relu(x), sd[prefix + "linear.weight"])
     ones = torch.ones(B, 1, dtype=torch.bool)
     mask = torch.cat([ones, category[:, :1, 0].ne(1), str_cat[:, :, 0].ne(1), str_bool[:, :, 0].ne(1),
                       ones, hours.sum(dim=-1) != 0], dim=1)
@@ -101,8 +104,11 @@ def amazon_table_encoder(sd, emb_weight, field, field_value, prefix="table_encod
     names = field_name.unsqueeze(0).expand(B, -1, -1)
     values = torch.cat([price_e, rating_e, brand_e, name_e, cat_e, desc_e], dim=1)       # [B,133,D]
     x = torch.cat([names, values], dim=-1)
-    x = F.linear(x, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
-    x = F.linear(torch.relu(x), sd[prefix + "linear.weight"])
+    # through bart_oracle.linear: identical to F.linear unless the bf16 emulation is on (tests only), which then rounds these two
+    # Linears like every other one of the path
+    from oracle import bart_oracle as _bo
+    x = _bo.linear(x, sd[prefix + "fc.weight"], sd[prefix + "fc.bias"])
+    x = _bo.linear(torch.relu(x), sd[prefix + "linear.weight"])
     ones = torch.ones(B, 1, dtype=torch.bool)
     mask = torch.cat([price.sum(dim=1, keepdim=True) != 0, ones, brand[:, :1].ne(1), name[:, :1].ne(1), ones, description.ne(1)], dim=1)
     return x, mask

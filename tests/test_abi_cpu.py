@@ -53,7 +53,7 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
         assert rc == 0, rc
         return tuple(plan)
 
-    for M in (38912, 64512):
+    for M in (38912, 64512, 76288, 129024):
         for N, K in ((1024, 1024), (3072, 1024), (4096, 1024), (1024, 4096), (2048, 1024)):
             k, bm, bn, grid = p(M, N, K)
             assert (k, bm, bn) == (_lib.PLAN_NT_RING, 256, 256), (M, N, K, k, bm, bn)

@@ -1,7 +1,8 @@
 """GPU: parity AT THE SIZES AND ON THE KERNELS THE BENCHMARK RUNS.
 
-The tile chooser sends small test shapes to the 128x128 kernels; the bench (B=56 per GPU: 64,512 decoder rows, ~38,900
-valid encoder rows, F=4096, V=50265) runs the persistent 256x256 ring kernels.  This file holds those kernels and sizes to
+The tile chooser sends small test shapes to the 128x128 kernels; the bench (B=112 per GPU: 129,024 decoder rows, ~76,300
+valid encoder rows; B=56, the headline batch of rounds 1-2: 64,512 / ~38,900; F=4096, V=50265) runs the persistent 256x256
+kernels.  This file holds those kernels and sizes to
 element-wise bounds against fp32 / fp64 matmuls (a wrong epilogue on a few tiles cannot hide behind a norm), asserts through
 mmsum_gemm_plan that each case really reaches the kernel it means to cover, checks the device-side live row counts at
 those sizes, and compares the HIP path with the reference's own outputs at the real cfg/bart-large.json (fixtures F8, F8b
@@ -56,13 +57,14 @@ def assert_plan(plan, family, bm=256, bn=256, persistent=None):
 
 # the step's NT products at the bench batch: (M rows) x (N, K) of qkv / out_proj / fc1 / fc2 / kv projections
 NT_SHAPES = [(64512, 4096, 1024), (64512, 1024, 4096), (64512, 3072, 1024), (64512, 1024, 1024), (38912, 4096, 1024),
-             (38912, 1024, 4096), (38912, 3072, 1024), (38912, 1024, 1024), (38912, 2048, 1024), (64512, 2048, 2048)]
+             (38912, 1024, 4096), (38912, 3072, 1024), (38912, 1024, 1024), (38912, 2048, 1024), (64512, 2048, 2048),
+             (129024, 4096, 1024), (129024, 1024, 4096), (129024, 3072, 1024), (129024, 1024, 1024), (76288, 4096, 1024), (76288, 1024, 1024)]
 
 
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_nt_ring_256_persistent_all_epilogues(M, N, K):
-    """gemm_nt_ring_kernel<256,256,2,4,*> with more tiles than CUs (persistent tile walk): every epilogue / output form the
-    step uses, against an fp32 matmul of the same bf16 operands."""
+    """gemm_nt_w4_kernel<EPI, OUT, CS> (256x256 tiles, four waves) with more tiles than CUs (persistent tile walk): every epilogue
+    / output form the step uses, against an fp32 matmul of the same bf16 operands."""
     a, w = rnd(M, K, seed=1, std=0.5), rnd(N, K, seed=2, std=0.5)
     bias = rnd(N, dtype=torch.float32, seed=3)
     ref = a.float() @ w.float().t()
@@ -158,7 +160,9 @@ def test_nt_ring_a2_split_and_lm_head():
 # padding-free encoder's fused qkv, the square D x D products (16 tiles -> 16 slices), the cross-attention K/V projection over the
 # compact memory rows, and ResNet layer3's 3x3 / 1x1 convolutions (few tiles, 43,904 rows: up to 32 slices)
 TN_CASES = [(64512, 4096, 1024, 4, 256), (64512, 1024, 4096, 4, 256), (38912, 3072, 1024, 5, 256), (64512, 1024, 1024, 16, 256),
-            (64512, 3072, 1024, 5, 256), (111048, 2048, 1024, 8, 256), (43904, 256, 2304, 28, 256), (43904, 1024, 256, 32, 128)]
+            (64512, 3072, 1024, 5, 256), (111048, 2048, 1024, 8, 256), (43904, 256, 2304, 28, 256), (43904, 1024, 256, 32, 128),
+            (129024, 4096, 1024, 4, 256), (129024, 1024, 1024, 16, 256), (76288, 3072, 1024, 5, 256), (222096, 2048, 1024, 8, 256),
+            (87808, 1024, 256, 32, 128)]
 
 
 @pytest.mark.parametrize("R,No,Ki,want_sk,bn", TN_CASES)
@@ -193,8 +197,8 @@ def test_live_row_counts_at_bench_sizes():
     """The device-side live row count on the big kernels: rows past it are neither read (they hold NaN) nor written (they keep
     their sentinel), rows below it match; one launch geometry (capacity 64,512) serves any count -- including 0 and ragged
     ones that end inside a tile."""
-    cap, D, Fd = 64512, 1024, 4096
-    for live_n in (38907, 256, 0, cap):
+    D, Fd = 1024, 4096
+    for cap, live_n in ((64512, 38907), (64512, 256), (64512, 0), (64512, 64512), (129024, 76301)):
         live = torch.tensor([live_n], device=DEV, dtype=torch.int32)
         a = rnd(cap, D, seed=31, std=0.5)
         a[live_n:] = float("nan")
