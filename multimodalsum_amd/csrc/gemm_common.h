@@ -8,7 +8,6 @@ struct GemmArgs {
     int M, N, K; long lda, lda2, ldb, ldc, ldaux; int ksplit; float alpha; int flags; int splitk;
     const int* live;     // device int32 or NULL: live rows of the row-streamed operand (M for natural A, K for the A_T|B_T product)
     const float* alpha_dev;   // device f32 or NULL: alpha is multiplied by it when the kernel runs (an upstream gradient scale)
-    int stagger;         // persistent NT kernel: start-time skew window in units of 1024 shader cycles (0 = none; set by the launcher)
 };
 
 // Live row count (device-resident, so one captured HIP graph serves every batch): rows at and past it are neither read

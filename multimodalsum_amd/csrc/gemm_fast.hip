@@ -664,16 +664,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     const int a_frag0 = wm * (TM * 32) * C::ROWB + fo, b_frag0 = B_BASE + wn * (TN * 32) * C::ROWB + fo;
     const int ydelta = (fo ^ 64) - fo;
 
-    // Start-time skew.  All 256 workgroups run tiles of equal length, so they reach their write-backs together, every round: 33.5 MB
-    // (one bf16 tile per CU) hit the memory system at once and take ~6.7 us to drain, which the in-order vmcnt exposes (the next tile's
-    // first DMA wait also waits for those stores).  Starting the eight tile rows an XCD runs at a time an eighth of the window apart
-    // spreads the write-backs over the window: each one then drains at the CU's own rate.  The launch ends one window later; with
-    // several rounds per launch the rounds' savings outweigh it.  (Workgroups that share an A panel -- same tile row -- keep
-    // running in lockstep; the B panels are L2-resident across the skew.)
-    if (p.stagger > 0) {
-        const int level = (blockIdx.x >> 3) & 7;
-        for (int i = level * p.stagger / 8; i > 0; --i) __builtin_amdgcn_s_sleep(16);       // 16 x 64 cycles
-    }
     for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
     const int wg = xcd_remap(vid, total);
     const int ks = wg / tiles;
@@ -969,9 +959,9 @@ typedef __attribute__((ext_vector_type(8))) short tn_s16x8_t;
 typedef __attribute__((address_space(3))) tn_s16x4_t* tn_lds_s16x4_ptr;
 
 // BS (column sums of A, i.e. the bias gradient of the Linear whose weight gradient this product is: MMSUM_GEMM_COLSUM): the waves
-// of the first tile column (tn == 0, wn == 0) add up the A fragments they hold for the MFMAs anyway -- four v_dot2c_f32_bf16 per
-// fragment against (1, 1), 32 per stage, in the shadow of the stage's 32 MFMAs -- and leave bias[m] += sum_k A[k][m] with one
-// f32 atomic per column and slice.  The separate column-sum passes over dq / dk / dv (983 MB per decoder layer) are gone.
+// of the first tile column (tn == 0) add up the A fragments they hold for the MFMAs anyway -- four v_dot2c_f32_bf16 per fragment
+// against (1, 1); the two waves of a wave row hold the same A blocks and take two each: 16 per wave and stage, in the shadow of
+// the stage's 32 MFMAs -- and leave bias[m] += sum_k A[k][m] with one f32 atomic per column and slice.  The separate column-sum passes over dq / dk / dv (983 MB per decoder layer) are gone.
 template <int OUT, bool BS = false>
 __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
     constexpr int BM = 256, BN = 256, WAVES_M = 2, WAVES_N = 2, TM = 4, TN = 4;
@@ -1001,8 +991,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
     const bf16_t* A = static_cast<const bf16_t*>(p.A);
     const bf16_t* B = static_cast<const bf16_t*>(p.B);
 
-    const bool do_bsum = BS && tn == 0 && wn == 0;                 // wave-uniform
-    float bsum[TM] = {0.f, 0.f, 0.f, 0.f};
+    const bool do_bsum = BS && tn == 0;                            // workgroup-uniform; wave (wm, wn) sums A blocks 2 wn, 2 wn + 1 of its row
+    float bsum[2] = {0.f, 0.f};
     if constexpr (BS) p.flags &= ~MMSUM_GEMM_COLSUM;                 // here the flag means sums of A, not of the stored tile: the epilogue must not see it
     // accumulator (i, j) = a[16 (4 i + j) : +15]: all 256 AGPRs, addressed by name (gemm_tn_w4_acc.inc).  The compiler does not know
     // they are in use: nothing else in this kernel may need an AGPR (register pressure stays below 256 VGPRs; the epilogue takes
@@ -1133,19 +1123,15 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
                 if (do_bsum) {
                     typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
                     const bf16x2_t ones = {(bf16_t)1.f, (bf16_t)1.f};
+                    auto add8 = [&](float t, const bf16x8_t f) {
+                        t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, t, false);
+                        t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, t, false);
+                        t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, t, false);
+                        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, t, false);
+                    };
 #pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int s16 = 0; s16 < 2; ++s16)
-                        {
-                            const bf16x8_t f = aC[i][s16];
-                            float t = bsum[i];
-                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), ones, t, false);
-                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), ones, t, false);
-                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), ones, t, false);
-                            t = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), ones, t, false);
-                            bsum[i] = t;
-                        }
+                    for (int i = 0; i < TM; ++i)    // scalar branches (selecting the fragments per register would cost as much as the sums)
+                        if ((i >> 1) == wn) bsum[i & 1] = add8(add8(bsum[i & 1], aC[i][0]), aC[i][1]);
                 }
             }
         };
@@ -1168,9 +1154,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
     if constexpr (BS) {
         if (do_bsum) {      // lanes l and l + 32 hold the two k halves of column l & 31 of each A block
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float t = wave_half_sum(bsum[i]);
-                const int col = m0 + (wm * TM + i) * 32 + (lane & 31);
+            for (int ii = 0; ii < 2; ++ii) {
+                const float t = wave_half_sum(bsum[ii]);
+                const int col = m0 + (wm * TM + 2 * wn + ii) * 32 + (lane & 31);
                 if (lane < 32 && col < p.M) atomicAdd(const_cast<float*>(p.bias) + col, t * p.alpha);
             }
         }
@@ -1246,11 +1232,7 @@ int launch_w4_one(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = 3 * C::A_BYTES + 2 * C::B_BYTES;             // 160 KB: the whole LDS of a CU
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_w4_kernel<EPI, OUT, CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    GemmArgs b = a;
-    static const int stagger_us = [] { const char* e = getenv("MMSUM_W4_STAGGER_US"); return e ? atoi(e) : 0; }();      // A/B hook
-    const int tiles = ((a.M + 255) / 256) * ((a.N + 255) / 256) * a.splitk;
-    b.stagger = tiles >= 3 * cu_count() ? stagger_us * 2 : 0;        // ~2 x 1024 cycles per microsecond; only launches of three rounds or more
-    gemm_nt_w4_kernel<EPI, OUT, CS><<<dim3(ring_grid(a, 256, 256)), dim3(256), lds, stream>>>(b);
+    gemm_nt_w4_kernel<EPI, OUT, CS><<<dim3(ring_grid(a, 256, 256)), dim3(256), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 int launch_w4(const GemmArgs& a, hipStream_t stream) {

@@ -114,6 +114,40 @@ def linear(x, w, b=None):
     return F.linear(x, w, b)
 
 
+def _unbroadcast(g, shape):
+    """Sum a gradient over the dimensions torch.matmul broadcast."""
+    while g.dim() > len(shape):
+        g = g.sum(0)
+    for i, (gs, ss) in enumerate(zip(g.shape, shape)):
+        if ss == 1 and gs != 1:
+            g = g.sum(i, keepdim=True)
+    return g
+
+
+class _QuantMatmul(torch.autograd.Function):
+    """The attention products (scores = q k^T, out = p v) as ANY bf16 matrix-core implementation runs them: both operands
+    rounded to bf16 (the probabilities and, in backward, the score gradients included), f32 accumulation, forward and backward."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        aq, bq = _q(a), _q(b)
+        ctx.save_for_backward(aq, bq)
+        return torch.matmul(aq, bq)
+
+    @staticmethod
+    def backward(ctx, g):
+        aq, bq = ctx.saved_tensors
+        gq = _q(g)
+        return _unbroadcast(torch.matmul(gq, bq.transpose(-1, -2)), aq.shape), _unbroadcast(torch.matmul(aq.transpose(-1, -2), gq), bq.shape)
+
+
+def attn_matmul(a, b):
+    """torch.matmul for the two products of an attention; with the bf16 emulation on (tests only), with bf16 operands."""
+    if EMULATE_BF16:
+        return _QuantMatmul.apply(a, b)
+    return torch.matmul(a, b)
+
+
 def _lin(sd, name, x):
     return linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
 
@@ -168,13 +202,13 @@ def self_attention(sd, pre, x, heads, key_pad=None, causal=None):
         return t.contiguous().view(T, B * heads, hd).transpose(0, 1)
 
     q, k, v = sh(q), sh(k), sh(v)
-    w = torch.bmm(q, k.transpose(1, 2))  # [B*H,T,T]
+    w = attn_matmul(q, k.transpose(1, 2))  # [B*H,T,T]   (torch.bmm, :819)
     if causal is not None:
         w = (w.view(B, heads, T, T) + causal).view(B * heads, T, T)
     if key_pad is not None:
         w = w.view(B, heads, T, T).masked_fill(key_pad[:, None, None, :], float("-inf")).view(B * heads, T, T)
     p = F.softmax(w, dim=-1)
-    o = torch.bmm(p, v)  # [B*H,T,hd]
+    o = attn_matmul(p, v)  # [B*H,T,hd]   (torch.bmm, :869)
     o = o.transpose(0, 1).contiguous().view(T, B, D)
     return _lin(sd, pre + ".out_proj", o)
 
@@ -193,11 +227,11 @@ def entity_cross_attention_heads(sd, pre, x, keys, pad, heads):
     qh = q.view(T, B, heads, hd).permute(1, 2, 0, 3)          # [B,H,T,hd]
     kh = k.view(S, N, B, heads, hd).permute(1, 2, 3, 0, 4)    # [N,B,H,S,hd]
     vh = v.view(S, N, B, heads, hd).permute(1, 2, 3, 0, 4)
-    a = torch.einsum("bhtd,nbhsd->nbhts", qh, kh)
+    a = attn_matmul(qh.unsqueeze(0), kh.transpose(-1, -2))      # [N,B,H,T,S] = einsum("bhtd,nbhsd->nbhts")
     if pad is not None:
         a = a.masked_fill(pad.transpose(0, 1)[:, :, None, None, :], NEG_FILL_CROSS)
     p = F.softmax(a, dim=-1)
-    o = torch.einsum("nbhts,nbhsd->nbhtd", p, vh)              # [N,B,H,T,hd]
+    o = attn_matmul(p, vh)                                     # [N,B,H,T,hd] = einsum("nbhts,nbhsd->nbhtd")
     if pad is not None:
         null = pad.all(dim=-1)                                 # [B,N]  (:858)
         valid = (~null).transpose(0, 1).to(o.dtype)            # [N,B]

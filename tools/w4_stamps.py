@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Where a tile of the four-wave NT GEMM kernel spends its time: in-kernel stamps (s_memtime), in a DIAGNOSTIC build.
+
+    python tools/w4_stamps.py build          # CPU: copies csrc/ to tools/build/stamps/, patches gemm_fast.hip, builds libmmsum_hip.so there
+    python tools/w4_stamps.py run [M N K]    # GPU: runs x W^T (+bias) through that library and prints the breakdown per tile
+
+The shipped kernel carries no stamp: the patch below adds, to a copy of the source, five stamps per tile taken by wave 0 --
+tile start, first fragments read (prologue done: the first DMA round trip), main loop done, epilogue done (all stores issued),
+tile end -- accumulated per workgroup in registers and written to a __device__ array at kernel exit (nothing the kernel computes
+reads them).  Cycles are shader cycles (s_memtime); microseconds use the clock measured over the kernel (s_memrealtime, 100 MHz).
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "multimodalsum_amd", "csrc")
+DST = os.path.join(ROOT, "tools", "build", "stamps")
+
+
+def patch(text):
+    def rep(old, new, count=1):
+        nonlocal text
+        assert text.count(old) >= count, old[:70]
+        text = text.replace(old, new, count)
+
+    # storage + accessor
+    rep("namespace {\n", "__device__ unsigned long long g_w4_stamps[256][8];\n"
+        "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps(unsigned long long* host256x8) {\n"
+        "    return hipMemcpyFromSymbol(host256x8, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps)) == hipSuccess ? 0 : -5;\n}\n"
+        "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps_clear(void) {\n"
+        "    static unsigned long long z[256][8];\n"
+        "    return hipMemcpyToSymbol(HIP_SYMBOL(g_w4_stamps), z, sizeof(z)) == hipSuccess ? 0 : -5;\n}\n"
+        "namespace {\n")
+    # per-workgroup accumulators, inside the w4 NT kernel only (anchors that occur once, in that kernel)
+    rep("    const int ydelta = (fo ^ 64) - fo;\n",
+        "    const int ydelta = (fo ^ 64) - fo;\n"
+        "    unsigned long long st_pro = 0, st_main = 0, st_epi = 0, st_end = 0, st_tiles = 0;\n"
+        "    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();\n")
+    rep("        // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)\n",
+        "        const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();\n"
+        "        // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)\n")
+    rep("        // four MFMAs: A block I x B block J (quarters q = 2 si + sj)\n",
+        "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
+        "        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();\n"
+        "        // four MFMAs: A block I x B block J (quarters q = 2 si + sj)\n")
+    rep("        stage(st, abuf, std::integral_constant<int, 0>{});\n        asm volatile(\"s_nop 15\\n s_nop 15\" ::: \"memory\");",
+        "        stage(st, abuf, std::integral_constant<int, 0>{});\n        asm volatile(\"s_nop 15\\n s_nop 15\" ::: \"memory\");\n"
+        "        const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();\n"
+        "        st_pro += st_t1 - st_t0; st_main += st_t2 - st_t1; st_epi -= st_t2; st_end -= st_t2; ++st_tiles;")
+    rep("                                                                                                                     wave * 64 + lane_e, lane_e);\n    }\n    lds_barrier();\n    }\n}\n",
+        "                                                                                                                     wave * 64 + lane_e, lane_e);\n    }\n"
+        "    { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); st_epi += t3; }\n"
+        "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");      // DIAGNOSTIC ONLY: how long the tile's stores take to be acknowledged\n"
+        "    { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); st_end += t4; }\n"
+        "    lds_barrier();\n    }\n"
+        "    if (threadIdx.x == 0 && blockIdx.x < 256) {\n"
+        "        unsigned long long* o = g_w4_stamps[blockIdx.x];\n"
+        "        o[0] = st_tiles; o[1] = st_pro; o[2] = st_main; o[3] = st_epi; o[4] = st_end;\n"
+        "        o[5] = __builtin_amdgcn_s_memtime() - st_k0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0;\n    }\n}\n")
+    return text
+
+
+def build():
+    if os.path.isdir(DST):
+        shutil.rmtree(DST)
+    os.makedirs(os.path.dirname(DST), exist_ok=True)
+    shutil.copytree(SRC, DST, ignore=shutil.ignore_patterns("*.o", "*.so", "*.txt"))
+    p = os.path.join(DST, "gemm_fast.hip")
+    patched = patch(open(p).read())
+    open(p, "w").write(patched)
+    mk = os.path.join(DST, "Makefile")
+    m = open(mk).read()
+    m = m.replace("../../include/mmsum_hip.h", os.path.join(ROOT, "include", "mmsum_hip.h"))
+    m = m.replace("\tpython3 check_resources.py gemm_fast.resources.txt || { rm -f $@; exit 1; }\n", "")       # the stamps cost registers: diagnostic build
+    open(mk, "w").write(m)
+    for f in os.listdir(DST):                               # includes of the public header by relative path
+        if f.endswith((".h", ".hip")):
+            q = os.path.join(DST, f)
+            t = open(q).read()
+            if "../../include/mmsum_hip.h" in t:
+                t = t.replace("../../include/mmsum_hip.h", os.path.join(ROOT, "include", "mmsum_hip.h"))
+                open(q, "w").write(t)
+    subprocess.check_call(["make", "-C", DST, "-j4"])
+    print("built", os.path.join(DST, "libmmsum_hip.so"))
+
+
+def run(M, N, K, variants=("plain", "bias", "gelu", "acc")):
+    os.environ["MMSUM_LIB"] = os.path.join(DST, "libmmsum_hip.so")
+    sys.path.insert(0, ROOT)
+    import torch
+    from multimodalsum_amd import kernels as kn, _lib
+    lib = _lib.lib
+    dt = torch.bfloat16
+    a = torch.randn(M, K, device="cuda").to(dt)
+    w = (torch.randn(N, K, device="cuda") * 0.03).to(dt)
+    out = torch.randn(M, N, device="cuda").to(dt)
+    aux = torch.empty(M, N, device="cuda", dtype=dt)
+    bias = torch.randn(N, device="cuda")
+    buf = (ctypes.c_ulonglong * (256 * 8))()
+    for var in variants:
+        def launch():
+            if var == "plain":
+                kn.gemm(a, w, out)
+            elif var == "bias":
+                kn.gemm(a, w, out, bias=bias)
+            elif var == "gelu":
+                kn.gemm(a, w, out, bias=bias, epi=kn.EPI_GELU, aux=aux)
+            else:
+                kn.gemm(a, w, out, accumulate=True)
+        for _ in range(3):
+            launch()
+        torch.cuda.synchronize()
+        lib.mmsum_w4_stamps_clear()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        torch.cuda.synchronize()
+        assert lib.mmsum_w4_stamps(buf) == 0
+        rows = [[buf[i * 8 + j] for j in range(8)] for i in range(256)]
+        rows = [r for r in rows if r[0] > 0]
+        tiles = sum(r[0] for r in rows)
+        ghz = sum(r[5] for r in rows) / (sum(r[6] for r in rows) * 10.0)       # cycles per 10 ns tick -> GHz
+        cyc = [sum(r[j] for r in rows) / tiles for j in (1, 2, 3, 4)]
+        us = [c / (ghz * 1e3) for c in cyc]
+        print("%-5s M=%d N=%d K=%d: %.1f us launch, %d tiles on %d workgroups, %.2f GHz in-kernel | per tile: prologue %.2f us, main loop %.2f us "
+              "(%d stages), epilogue issue %.2f us, + until its stores are acknowledged %.2f us  (sum %.2f us)"
+              % (var, M, N, K, e0.elapsed_time(e1) * 1e3, tiles, len(rows), ghz, us[0], us[1], K // 64, us[2], us[3] - us[2], us[0] + us[1] + us[3]), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "build":
+        build()
+    else:
+        args = [int(x) for x in sys.argv[2:5]] if len(sys.argv) >= 5 else None
+        shapes = [tuple(args)] if args else [(64512, 1024, 1024), (64512, 1024, 4096), (64512, 4096, 1024), (64512, 1024, 64)]
+        for M, N, K in shapes:
+            run(M, N, K)
