@@ -4,16 +4,19 @@ gemm_tn_w4_kernel keeps its 256 accumulators in AGPRs that it names in inline as
 know they are live between the zero-fill and the read-out, so it must never need an AGPR or a scratch slot of its own in that
 kernel: the build fails if the kernel spills, uses scratch, or asks for more than 256 architectural VGPRs (beyond that the
 allocator would take AGPRs).  The four-wave NT kernel binds its accumulators as "+a" operands (the compiler knows them), but a
-spill inside its main loop would put scratch traffic on the vmcnt counter the DMA pipeline is counted on: it must not spill
-either (it does not since its epilogue re-reads the lane index opaquely; tools/asm_scratch_report.py shows where spills sit)."""
+spill inside its main loop would put scratch traffic on the vmcnt counter the DMA pipeline is counted on: its allowance is a
+handful of registers, which the allocator parks around the main loop, never in it (its tile header and its epilogue re-read the
+lane index opaquely so that nothing lane-constant is carried across; tools/asm_scratch_report.py shows where spills sit)."""
 import re
 import sys
 
 LIMITS = {                    # kernel-name substring -> (max arch VGPRs, max scratch bytes / lane, max VGPR spills)
     "gemm_tn_w4_kernel": (256, 0, 0),
-    "gemm_nt_w4_kernel": (256, 0, 0),
+    # NT: a few registers may be parked in scratch AROUND the main loop (stored in the tile header, reloaded for the epilogue:
+    # two to four instructions per tile); tools/asm_scratch_report.py must show none between the first and the last MFMA of a tile
+    "gemm_nt_w4_kernel": (256, 48, 10),
     # the f32-atomic output form (split-K without slabs: not on the training step's path) stores element by element from the
-    # accumulator layout and spills a few registers in that epilogue; more specific entries win
+    # accumulator layout and spills a few more registers in that epilogue; more specific entries win
     "gemm_nt_w4_kernelILi0ELi3E": (256, 96, 24),
 }
 

@@ -47,18 +47,61 @@ __device__ __forceinline__ float gelu_grad_fast_f(float x) {
     return cdf + x * 0.39894228040143267794f * e;
 }
 
+// The same two functions on PAIRS of values, written on 2-vectors so that the polynomial, the squares and the products issue
+// as packed f32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of work per issue slot); |x| rides on the source
+// modifiers of the non-packed instructions.  Per element 7 + 2 transcendental instructions instead of 15 + 2: in the four-wave
+// GEMM a 256x256 tile's GELU cost 9.8 us of a 39 us tile (in-kernel stamps, tools/w4_stamps.py).
+//   gelu(x)  = max(x, 0) - |x| q(|x|),   gelu'(x) = 1/2 + copysign(1/2 - q, x) + x pdf(x),   q = Phi(-|x|) as above.
+typedef float gelu_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_q_e_pair(gelu_f32x2_t x, gelu_f32x2_t& q, gelu_f32x2_t& e) {
+    gelu_f32x2_t t;
+    t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), 0.23164189f, 1.f));
+    t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), 0.23164189f, 1.f));
+    const gelu_f32x2_t a = (x * x) * gelu_f32x2_t{-0.72134752044f, -0.72134752044f};            // -x^2/2 log2(e)
+    e.x = __builtin_amdgcn_exp2f(a.x);
+    e.y = __builtin_amdgcn_exp2f(a.y);
+    const gelu_f32x2_t c5 = {0.5307027145f, 0.5307027145f}, c4 = {-0.7265760135f, -0.7265760135f}, c3 = {0.7107068705f, 0.7107068705f},
+                       c2 = {-0.142248368f, -0.142248368f}, c1 = {0.127414796f, 0.127414796f};         // the A-S coefficients, halved
+    const gelu_f32x2_t poly = t * (c1 + t * (c2 + t * (c3 + t * (c4 + t * c5))));
+    q = poly * e;
+}
+__device__ __forceinline__ gelu_f32x2_t gelu_fast2(gelu_f32x2_t x) {
+    gelu_f32x2_t q, e, r;
+    gelu_q_e_pair(x, q, e);
+    r.x = fmaf(-fabsf(x.x), q.x, fmaxf(x.x, 0.f));
+    r.y = fmaf(-fabsf(x.y), q.y, fmaxf(x.y, 0.f));
+    return r;
+}
+__device__ __forceinline__ gelu_f32x2_t gelu_grad_fast2(gelu_f32x2_t x) {
+    gelu_f32x2_t q, e, h;
+    gelu_q_e_pair(x, q, e);
+    const gelu_f32x2_t d = gelu_f32x2_t{0.5f, 0.5f} - q;                                            // >= 0
+    h.x = __builtin_copysignf(d.x, x.x);
+    h.y = __builtin_copysignf(d.y, x.y);
+    return (h + gelu_f32x2_t{0.5f, 0.5f}) + (x * e) * gelu_f32x2_t{0.39894228040143267794f, 0.39894228040143267794f};
+}
+
 // Epilogue of one wave: acc[i][j] is the 32x32 tile at rows row0 + i*32, columns col0 + j*32.
 // OUT selects the store form at compile time (the runtime-flag version costs ~250 instructions per
 // element): 0 = store T, 1 = T += , 2 = f32 += , 3 = f32 atomic += , 4 = store f32.
 enum { OUT_T = 0, OUT_T_ACC = 1, OUT_F32_ACC = 2, OUT_F32_ATOMIC = 3, OUT_F32 = 4 };
 
-// Position of accumulator register r of a 32x32 block for this lane.  MF16 = false: the block is one 32x32x16 MFMA result
-// (column on the lane).  MF16 = true: the block is four 16x16x32 results, registers 4q..4q+3 = quarter q = 2 (row half) + (col half),
-// each with rows 4 (lane >> 4) + e and column lane & 15.
-template <bool MF16> __device__ __forceinline__ int blk_row(int r, int lane) { return MF16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : acc_row(r, lane); }
-template <bool MF16> __device__ __forceinline__ int blk_col(int r, int lane) { return MF16 ? 16 * ((r >> 2) & 1) + (lane & 15) : (lane & 31); }
+// Position of accumulator register r of a 32x32 block for this lane, by accumulator layout LAY:
+//   LAY_32   the block is one 32x32x16 MFMA result (column on the lane);
+//   LAY_16   four 16x16x32 results, registers 4q..4q+3 = quarter q = 2 (row half) + (col half), each with rows 4 (lane >> 4) + e
+//            and column lane & 15;
+//   LAY_16T  the same four quarters from MFMAs issued with the operand roles swapped (weights as the MFMA's A operand): row
+//            lane & 15 and the four CONSECUTIVE columns 4 (lane >> 4) + e -- what a lane holds of a quarter is 8 contiguous bytes of a
+//            bf16 output row.
+enum { LAY_32 = 0, LAY_16 = 1, LAY_16T = 2 };
+template <int LAY> __device__ __forceinline__ int blk_row(int r, int lane) {
+    return LAY == LAY_16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : LAY == LAY_16T ? 16 * (r >> 3) + (lane & 15) : acc_row(r, lane);
+}
+template <int LAY> __device__ __forceinline__ int blk_col(int r, int lane) {
+    return LAY == LAY_16 ? 16 * ((r >> 2) & 1) + (lane & 15) : LAY == LAY_16T ? 16 * ((r >> 2) & 1) + 4 * (lane >> 4) + (r & 3) : (lane & 31);
+}
 
-template <typename T, int TM, int TN, int EPI, int OUT, bool MF16 = false>
+template <typename T, int TM, int TN, int EPI, int OUT, int LAY = LAY_32>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x16_t (&acc)[TM][TN], int row0, int col0, int ks, int lane) {
     const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0);
     float* Cf = static_cast<float*>(p.C);
@@ -70,10 +113,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x16_t 
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int col = col0 + j * 32 + blk_col<MF16>(r, lane);
+                const int col = col0 + j * 32 + blk_col<LAY>(r, lane);
                 const bool col_ok = col < p.N;
                 const float bv = (has_bias && col_ok) ? p.bias[col] : 0.f;
-                const int row = row0 + i * 32 + blk_row<MF16>(r, lane);
+                const int row = row0 + i * 32 + blk_row<LAY>(r, lane);
                 if (!col_ok || row >= p.M) continue;
                 float v = acc[i][j][r] * p.alpha + bv;
                 if constexpr (EPI == MMSUM_EPI_GELU) {

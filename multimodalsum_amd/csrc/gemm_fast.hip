@@ -70,7 +70,7 @@ struct AccArray {
 };
 
 // Edge tiles (rows past M / columns past N inside the tile, unaligned C): every access guarded, scalar fallbacks.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false, typename AccSrc = AccArray>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, int LAY = LAY_32, typename AccSrc = AccArray>
 __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                            char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, const float (&bv)[8], AccSrc src = AccSrc{}) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
@@ -136,7 +136,7 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
             for (int j = 0; j < TN; ++j) {
                 const int col = wn * (TN * 32) + j * 32;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) stage[blk_row<MF16>(r, lane) * BN + col + blk_col<MF16>(r, lane)] = band[j][r];
+                for (int r = 0; r < 16; ++r) stage[blk_row<LAY>(r, lane) * BN + col + blk_col<LAY>(r, lane)] = band[j][r];
             }
         }
         lds_barrier();
@@ -262,7 +262,7 @@ __device__ __forceinline__ void epilogue_edge(const GemmArgs& p, const f32x16_t 
 // guards, index arithmetic and run-time flags (measured at M = 64,512, N = 4096, K = 1024: 232 us of a 696 us launch with the
 // global stores REMOVED, against 386 us for the main loop alone).  Here a thread's rows are base + compile-time constants,
 // the LDS addresses are immediates, and bias / alpha / activation / accumulate / column sums are compile-time forms.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int CS, int LDS_BYTES, bool MF16 = false, typename AccSrc = AccArray>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int CS, int LDS_BYTES, int LAY = LAY_32, typename AccSrc = AccArray>
 __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                   char* smem, int m0, int n0, int wm, int wn, int tid, int lane, const float (&bv)[8], AccSrc src = AccSrc{}) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
     for (int it = 0; it < NIT; ++it) prefetch1(0, it);
     lds_barrier();                                    // every wave is done reading the operand stages
     const float* rd0 = stage0 + trow * BN + cc;       // this thread's read position inside a band set (+ compile-time offsets)
-    float* wr0 = stage0 + wm * BAND + wn * (TN * 32) + (MF16 ? (4 * (lane >> 4)) * BN + (lane & 15) : (4 * (lane >> 5)) * BN + (lane & 31));
+    float* wr0 = stage0 + wm * BAND + wn * (TN * 32) + (LAY == LAY_16 ? (4 * (lane >> 4)) * BN + (lane & 15) : (4 * (lane >> 5)) * BN + (lane & 31));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         constexpr int SETF = WAVES_M * BAND;
@@ -318,7 +318,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                wr0[seto + (MF16 ? (16 * (r >> 3) + (r & 3)) * BN + 16 * ((r >> 2) & 1) : ((r & 3) + 8 * (r >> 2)) * BN) + j * 32] = band[j][r];
+                wr0[seto + (LAY == LAY_16 ? (16 * (r >> 3) + (r & 3)) * BN + 16 * ((r >> 2) & 1) : ((r & 3) + 8 * (r >> 2)) * BN) + j * 32] = band[j][r];
         lds_barrier();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -349,10 +349,16 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
             } else if constexpr (kAuxIn) {
                 bf16_t t[8];
                 __builtin_memcpy(t, &aux_now, 16);
+                if constexpr (EPI == MMSUM_EPI_GELU_BWD) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if constexpr (EPI == MMSUM_EPI_GELU_BWD) v[e] *= gelu_grad_fast_f((float)t[e]);
-                    else v[e] = ((float)t[e] > 0.f) ? v[e] : 0.f;
+                    for (int e = 0; e < 8; e += 2) {
+                        const gelu_f32x2_t g = gelu_grad_fast2(gelu_f32x2_t{(float)t[e], (float)t[e + 1]});
+                        v[e] *= g.x;
+                        v[e + 1] *= g.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((float)t[e] > 0.f) ? v[e] : 0.f;
                 }
             } else if constexpr (EPI == MMSUM_EPI_RELU) {
 #pragma unroll
@@ -409,29 +415,167 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
     }
 }
 
+// Interior tiles of a kernel whose accumulators are in the LAY_16T layout (a lane holds four consecutive columns of a row) and
+// whose epilogue reads nothing from global memory (plain / GELU / ReLU, bf16 output): alpha, bias and the activation are applied
+// on the registers, the result is converted to bf16 THERE and staged as bf16 -- one 8-byte LDS write per quarter (64 per wave and
+// tile, against 256 four-byte writes of the f32 staging) into rows padded by 16 bytes (the 16 rows x 4 column groups of a write
+// then fall in 64 different banks), half the LDS bytes both ways, and nothing but a 16-byte LDS read and a 16-byte global store
+// per 8 outputs on the way out.  The saved pre-activation of the GELU form is staged and stored the same way.  Column sums (CS)
+// are taken on the way out from the bf16 values, i.e. of exactly what a separate pass over the stored tile would read.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int CS, int LDS_BYTES, typename AccSrc = AccArray>
+__device__ __forceinline__ void epilogue_interior_packed(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
+                                                         char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, AccSrc src = AccSrc{}) {
+    static_assert(EPI == MMSUM_EPI_NONE || EPI == MMSUM_EPI_GELU || EPI == MMSUM_EPI_RELU, "epilogues that read global memory stage in f32");
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int THREADS = WAVES_M * WAVES_N * 64;
+    constexpr int PITCH = BN * 2 + 16;                  // bytes per staged row
+    constexpr int BANDB = 32 * PITCH, SETB = WAVES_M * BANDB;
+    constexpr int CPR = BN / 8, RPI = THREADS / CPR, NIT = WAVES_M * 32 / RPI;
+    constexpr bool kAux = EPI == MMSUM_EPI_GELU;
+    static_assert(THREADS % CPR == 0 && RPI <= 32 && 32 % RPI == 0 && NIT * RPI == WAVES_M * 32, "write-back geometry");
+    static_assert(LDS_BYTES >= (kAux ? 4 : 2) * SETB, "two sets of bands (+ two of the saved pre-activation)");
+    const bool has_aux = kAux && p.aux != nullptr;     // workgroup-uniform
+    bf16_t* Ct = static_cast<bf16_t*>(p.C);
+    bf16_t* aux = static_cast<bf16_t*>(p.aux);
+    const float alpha = p.alpha;
+    // bias of this lane's columns: 4 consecutive ones per 16-column quarter, 2 TN quarters per row.  Loaded once per tile and
+    // retired here (see epilogue_bias)
+    f32x4_t bq[TN][2];
+    {
+        const bool has_bias = (p.flags & MMSUM_GEMM_BIAS) && (ks == 0) && !(p.flags & MMSUM_GEMM_COLSUM);
+        const float* bsrc = p.bias + n0 + wn * (TN * 32) + 4 * (lane >> 4);
+        const bool vec = (((uintptr_t)p.bias) & 15) == 0 && (n0 & 3) == 0;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int sj = 0; sj < 2; ++sj) {
+                bq[j][sj] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (has_bias) {
+                    if (vec) bq[j][sj] = *reinterpret_cast<const f32x4_t*>(bsrc + j * 32 + 16 * sj);
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) bq[j][sj][e] = bsrc[j * 32 + 16 * sj + e];
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int sj = 0; sj < 2; ++sj) asm volatile("" : "+v"(bq[j][sj]));
+    }
+    const int trow = tid / CPR, cc = (tid % CPR) * 8;
+    auto row_of = [](int i, int it) { return ((it * RPI) / 32) * (TM * 32) + i * 32 + (it * RPI) % 32; };
+    const long cbase = (long)(m0 + trow) * p.ldc + n0 + cc;
+    const long abase = (long)(m0 + trow) * p.ldaux + n0 + cc;
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, csq[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    char* wr0 = smem + wm * BANDB + (lane & 15) * PITCH + (wn * (TN * 32) + 4 * (lane >> 4)) * 2;
+    const char* rd0 = smem + trow * PITCH + cc * 2;
+    auto pack4 = [](const float (&v)[4]) {
+        bf16_t t[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[e] = (bf16_t)v[e];
+        u32x2_t w;
+        __builtin_memcpy(&w, t, 8);
+        return w;
+    };
+    lds_barrier();                                    // every wave is done reading the operand stages
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int seto = (i & 1) * SETB;             // the readers of a set are two barriers behind its next writers
+        f32x16_t band[TN];
+        src(i, acc, band);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(band[j][4 * q + e], alpha, bq[j][q & 1][e]);
+                const int off = seto + (16 * (q >> 1)) * PITCH + (j * 32 + 16 * (q & 1)) * 2;
+                if constexpr (kAux) {
+                    if (has_aux) *reinterpret_cast<u32x2_t*>(wr0 + 2 * SETB + off) = pack4(v);
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const gelu_f32x2_t g = gelu_fast2(gelu_f32x2_t{v[e], v[e + 1]});
+                        v[e] = g.x;
+                        v[e + 1] = g.y;
+                    }
+                } else if constexpr (EPI == MMSUM_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *reinterpret_cast<u32x2_t*>(wr0 + off) = pack4(v);
+            }
+        lds_barrier();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int lo = seto + ((it * RPI) / 32) * BANDB + ((it * RPI) % 32) * PITCH;
+            const long r = row_of(i, it);
+            const u32x4_t w = *reinterpret_cast<const u32x4_t*>(rd0 + lo);
+            if constexpr (kAux) {
+                if (has_aux) *reinterpret_cast<u32x4_t*>(aux + abase + r * p.ldaux) = *reinterpret_cast<const u32x4_t*>(rd0 + 2 * SETB + lo);
+            }
+            if constexpr (CS != 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float tf = __builtin_bit_cast(float, (e & 1) ? (w[e >> 1] & 0xffff0000u) : (w[e >> 1] << 16));
+                    csum[e] += tf;
+                    if constexpr (CS == 2) csq[e] = fmaf(tf, tf, csq[e]);
+                }
+            }
+            *reinterpret_cast<u32x4_t*>(Ct + cbase + r * p.ldc) = w;
+        }
+    }
+    if constexpr (CS != 0) {
+        // every thread owns one 8-column chunk (tid % CPR) in all passes: fold the THREADS / CPR partials through LDS
+        float* red = reinterpret_cast<float*>(smem);
+        constexpr int NPART = THREADS / CPR;
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(tid / CPR) * BN + (tid % CPR) * 8 + e] = csum[e];
+            if constexpr (CS == 2) red[NPART * BN + (tid / CPR) * BN + (tid % CPR) * 8 + e] = csq[e];
+        }
+        lds_barrier();
+        for (int c = tid; c < CS * BN; c += THREADS) {
+            const int w = c / BN, col = c % BN;
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPART; ++k) t += red[w * NPART * BN + k * BN + col];
+            atomicAdd(const_cast<float*>(p.bias) + (long)w * p.N + n0 + col, t);
+        }
+    }
+}
+
 // WIDE = the workgroup has the whole 512-register file per wave (the four-wave kernels: accumulators in AGPRs, 256 VGPRs for the
 // epilogue): GELU' / ReLU' and the column sums then take the lean form too, and CS (column sums of the stored tile) is a
 // compile-time property of the kernel -- one lean body per instantiation keeps the lane-constant addresses the compiler hoists
 // out of the tile loop inside the register file.  On the eight-wave kernels (128 registers beside the accumulators) the
 // derivative arithmetic of a pass spilled 167 registers in the lean form: they keep the guarded one, with column sums by flag.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, bool MF16 = false, typename AccSrc = AccArray,
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, int LDS_BYTES = 4 * (BM + BN) * SLAB_BYTES, int LAY = LAY_32, typename AccSrc = AccArray,
           bool WIDE = false, int CS = 0>
 __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_t (&acc)[BM / WAVES_M / 32][BN / WAVES_N / 32],
                                                 char* smem, int m0, int n0, int ks, int wm, int wn, int tid, int lane, AccSrc src = AccSrc{}) {
-    float bv[8];
-    epilogue_bias<BN, WAVES_M * WAVES_N * 64>(p, n0, ks, tid, bv);
     constexpr bool kF32 = (OUT == OUT_F32_ACC || OUT == OUT_F32_ATOMIC || OUT == OUT_F32);
     constexpr bool kAuxIn = (EPI == MMSUM_EPI_GELU_BWD || EPI == MMSUM_EPI_RELU_BWD);
     const bool aligned = (((uintptr_t)p.C) & 15) == 0 && (p.ldc & (kF32 ? 3 : 7)) == 0 &&
                          (p.aux == nullptr || ((((uintptr_t)p.aux) & 15) == 0 && (p.ldaux & 7) == 0));
     const bool interior = m0 + BM <= p.M && n0 + BN <= p.N && aligned;        // workgroup-uniform
-    if constexpr (OUT != OUT_F32_ATOMIC && (WIDE || !kAuxIn)) {
-        if (interior && (WIDE || !(p.flags & MMSUM_GEMM_COLSUM))) {
-            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, WIDE ? CS : 0, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
+    if constexpr (LAY == LAY_16T) {
+        static_assert(WIDE && OUT == OUT_T && !kAuxIn, "the swapped-operand layout is the bf16 store without a global read");
+        if (interior) {
+            epilogue_interior_packed<BM, BN, WAVES_M, WAVES_N, EPI, CS, LDS_BYTES, AccSrc>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, src);
             return;
         }
     }
-    epilogue_edge<BM, BN, WAVES_M, WAVES_N, EPI, OUT, LDS_BYTES, MF16, AccSrc>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, bv, src);
+    float bv[8];
+    epilogue_bias<BN, WAVES_M * WAVES_N * 64>(p, n0, ks, tid, bv);
+    if constexpr (LAY != LAY_16T && OUT != OUT_F32_ATOMIC && (WIDE || !kAuxIn)) {
+        if (interior && (WIDE || !(p.flags & MMSUM_GEMM_COLSUM))) {
+            epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, WIDE ? CS : 0, LDS_BYTES, LAY, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
+            return;
+        }
+    }
+    epilogue_edge<BM, BN, WAVES_M, WAVES_N, EPI, OUT, LDS_BYTES, LAY, AccSrc>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, bv, src);
 }
 
 __device__ __forceinline__ void dma16(const bf16_t* gsrc, char* lds_dst) {
@@ -612,9 +756,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
     }
     if constexpr (OUT == OUT_F32_ATOMIC) {
         // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
-        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT, true>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
+        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT, LAY_16>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
     } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE, true>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE, LAY_16>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
     }
     lds_barrier();            // the staging reads are done before the next tile's DMA lands in the same LDS (stores stay in flight)
     }
@@ -644,6 +788,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     using C = K64Cfg<BM, BN, WAVES_M, WAVES_N>;
     static_assert(C::PAW == 8 && C::PBW == 8, "8 + 8 pieces per wave and stage: one behind each group of four MFMAs");
     constexpr int B_BASE = 3 * C::A_BYTES;                        // [A0 | A1 | A2 | B0 | B1]
+    // Epilogues that read nothing from global memory (bf16 store, plain / GELU / ReLU) issue their MFMAs with the operand roles
+    // swapped -- the weight fragment as the MFMA's A operand -- which hands every lane four consecutive COLUMNS of an output row
+    // per quarter (LAY_16T) instead of four consecutive rows of a column: the epilogue then converts on the registers and stages
+    // bf16 in 8-byte pieces (epilogue_interior_packed).  Same products, same order of summation.
+    constexpr bool SWAP = OUT == OUT_T && (EPI == MMSUM_EPI_NONE || EPI == MMSUM_EPI_GELU || EPI == MMSUM_EPI_RELU);
+    constexpr int LAYW = SWAP ? LAY_16T : LAY_16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -676,23 +826,24 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     const int per = ((nslab_total + p.splitk - 1) / p.splitk + 1) & ~1;
     const int s_beg = ks * per, s_end = min(nslab_total, s_beg + per);
     const int nst = (s_end - s_beg) / 2, k_beg = s_beg * 32;
+    if (nst <= 0) continue;      // never: gemm_glds_eligible admits this kernel only when every reduction slice holds a stage
 
     // 256 accumulator registers = all AGPRs of the wave: the MFMAs are issued from inline asm with "+a" operands so that the
     // accumulators never move (left to the compiler they were copied to VGPRs and back around every MFMA: 600 moves per 128)
+    // They are not zeroed per tile (256 v_accvgpr_write, which the compiler moreover emitted once per path: 512 per tile): the
+    // first 64 MFMAs of a tile take the constant 0 as their C operand (W4_MMA0).
     f32x4_t c[TM][TN][4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) c[i][j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // DMA sources: lane -> (row = lane >> 3 of the piece, chunk position lane & 7); rows past the edge re-read the last one
+    // (the lane index is re-read opaquely here, as it is for the epilogue below: from the kernel's `lane` the compiler hoists the
+    // lane-constant parts of these offsets to kernel entry and, with no register to carry them across the main loop, spills them)
+    int lane_t;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
     int offA[C::PAW], offA2[C::PAW], offB[C::PBW];
 #pragma unroll
     for (int i = 0; i < C::PAW; ++i) {
-        const int row = (i * C::NW + wave) * 8 + (lane >> 3);
-        const int ch = ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+        const int row = (i * C::NW + wave) * 8 + (lane_t >> 3);
+        const int ch = ((lane_t & 7) ^ ((row >> 1) & 7)) * 16;
         const int ra = m0 + row < p.M ? row : p.M - 1 - m0, rb = n0 + row < p.N ? row : p.N - 1 - n0;
         offA[i] = ra * (int)p.lda * 2 + ch;
         offA2[i] = ra * (int)p.lda2 * 2 + ch;
@@ -710,7 +861,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     }
 #define W4_B(I, ST) k64_piece<C, I>(smem + B_BASE + ((ST) & 1) * C::B_BYTES, baseB, offB[I], k_beg + (ST) * 64, wave);
 #define W4_ALL(M, ST) M(0, ST) M(1, ST) M(2, ST) M(3, ST) M(4, ST) M(5, ST) M(6, ST) M(7, ST)
-    if (nst > 0) {
+    {
         Frag aX[TM], bX[TN], aY[TM], bY[TN];
         // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)
         W4_ALL(W4_A, 0) W4_ALL(W4_B, 0)
@@ -727,15 +878,22 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
         // four MFMAs: A block I x B block J (quarters q = 2 si + sj)
 #define W4_MMA(FA, FB, I, J)                                                                                          \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                  \
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c[I][J][q]) : "v"(FA[I].c[q >> 1]), "v"(FB[J].c[q & 1]) : "memory");
+            if constexpr (SWAP) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %1, %0" : "+a"(c[I][J][q]) : "v"(FA[I].c[q >> 1]), "v"(FB[J].c[q & 1]) : "memory"); \
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c[I][J][q]) : "v"(FA[I].c[q >> 1]), "v"(FB[J].c[q & 1]) : "memory");
+        // the same with C = 0: the first MFMA into each accumulator of a tile
+#define W4_MMA0(FA, FB, I, J)                                                                                         \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                                  \
+            if constexpr (SWAP) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %1, 0" : "=a"(c[I][J][q]) : "v"(FA[I].c[q >> 1]), "v"(FB[J].c[q & 1]) : "memory"); \
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c[I][J][q]) : "v"(FA[I].c[q >> 1]), "v"(FB[J].c[q & 1]) : "memory");
         // LEFT = stages after this one: >= 2 steady state; 1: nothing left to request; 0: the last stage
-        auto stage = [&](int st, int abuf, auto left_c) {
+        auto stage = [&](int st, int abuf, auto left_c, auto first_c) {
             constexpr int LEFT = decltype(left_c)::value;
+            constexpr bool FIRST = decltype(first_c)::value;
             const char* As = smem + abuf * C::A_BYTES + a_frag0;
             const char* Bs = smem + (st & 1) * C::B_BYTES + b_frag0;
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                W4_MMA(aX, bX, g >> 2, g & 3)
+                if constexpr (FIRST) { W4_MMA0(aX, bX, g >> 2, g & 3) } else { W4_MMA(aX, bX, g >> 2, g & 3) }
                 if (g < 8) bY[g >> 1].c[g & 1] = *reinterpret_cast<const u32x4_t*>(Bs + ((g >> 1) * 32 + (g & 1) * 16) * C::ROWB + ydelta);
                 else aY[(g - 8) >> 1].c[g & 1] = *reinterpret_cast<const u32x4_t*>(As + (((g - 8) >> 1) * 32 + (g & 1) * 16) * C::ROWB + ydelta);
                 // A of stage st+2 into the A stage that stage st-1 left at the previous barrier (one piece behind every other group)
@@ -770,11 +928,16 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
                 }
             }
         };
-        int st = 0, abuf = 0;
-        for (; st + 2 < nst; ++st) { stage(st, abuf, std::integral_constant<int, 2>{}); abuf = abuf == 2 ? 0 : abuf + 1; }
-        if (st + 1 < nst) { stage(st, abuf, std::integral_constant<int, 1>{}); abuf = abuf == 2 ? 0 : abuf + 1; ++st; }
-        stage(st, abuf, std::integral_constant<int, 0>{});
+        // stage 0 defines the accumulators (C = 0 in its first 64 MFMAs), in whichever of the three forms the tile's length asks for
+        if (nst >= 3) stage(0, 0, std::integral_constant<int, 2>{}, std::true_type{});
+        else if (nst == 2) stage(0, 0, std::integral_constant<int, 1>{}, std::true_type{});
+        else stage(0, 0, std::integral_constant<int, 0>{}, std::true_type{});
+        int st = 1, abuf = 1;
+        for (; st + 2 < nst; ++st) { stage(st, abuf, std::integral_constant<int, 2>{}, std::false_type{}); abuf = abuf == 2 ? 0 : abuf + 1; }
+        if (st + 1 < nst) { stage(st, abuf, std::integral_constant<int, 1>{}, std::false_type{}); abuf = abuf == 2 ? 0 : abuf + 1; ++st; }
+        if (st < nst) stage(st, abuf, std::integral_constant<int, 0>{}, std::false_type{});
         asm volatile("s_nop 15\n s_nop 15" ::: "memory");      // MFMAs issued from inline asm: the compiler does not know results are still in the pipeline
+#undef W4_MMA0
 #undef W4_MMA
     }
 #undef W4_ALL
@@ -794,9 +957,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     int lane_e;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
     if constexpr (OUT == OUT_F32_ATOMIC) {
-        gemm_epilogue<bf16_t, TM, TN, EPI, OUT, true>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane_e);
+        gemm_epilogue<bf16_t, TM, TN, EPI, OUT, LAYW>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane_e);
     } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, 3 * C::A_BYTES + 2 * C::B_BYTES, true, AccArray, true, CS>(p, acc, smem, m0, n0, ks, wm, wn,
+        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, 3 * C::A_BYTES + 2 * C::B_BYTES, LAYW, AccArray, true, CS>(p, acc, smem, m0, n0, ks, wm, wn,
                                                                                                                      wave * 64 + lane_e, lane_e);
     }
     lds_barrier();
@@ -1289,8 +1452,12 @@ static bool epilogue_reads_vectorisable(const GemmArgs& a) {
 bool gemm_glds_eligible(int dtype, const GemmArgs& a) {
     if (dtype != MMSUM_BF16) return false;
     if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T)) return false;
-    if (a.K % 64) return false;
+    if (a.K < 64 || a.K % 64) return false;
     if (a.A2 && (a.ksplit % 64)) return false;
+    if (a.splitk > 1) {           // every reduction slice holds at least one 64-deep stage (the four-wave kernel's first stage defines its accumulators)
+        const int ns = a.K / 32, per = ((ns + a.splitk - 1) / a.splitk + 1) & ~1;
+        if ((a.splitk - 1) * per >= ns) return false;
+    }
     const int epi = (a.flags >> 3) & 7, out = out_mode_of(a);
     if (epi != MMSUM_EPI_NONE && out != OUT_T) return false;     // rare combinations stay on the generic kernel
     return epilogue_reads_vectorisable(a);

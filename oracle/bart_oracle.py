@@ -79,7 +79,9 @@ def bart_param_shapes(cfg, multimodal=True, prefix=""):
 
 
 # bf16 emulation (tests only): with EMULATE_BF16 on, every Linear of the path rounds its operands and its result to bf16
-# (f32 accumulation), forward and backward, the way ANY bf16 implementation of the same algorithm must.  The difference
+# (f32 accumulation), forward and backward, the way ANY bf16 implementation of the same algorithm must; so do the attention
+# products (attn_matmul), the LayerNorm outputs a bf16 model keeps in memory (store) and the gradient of a tensor with several
+# consumers, which such a model accumulates in bf16 (fan_out).  The difference
 # between the emulated and the plain f32 run is the yardstick the bf16 HIP path is held to (tests/test_bench_shapes_gpu.py):
 # its error against the f32 oracle may be a small multiple of this one, per tensor.  Off (None) = the reference's arithmetic.
 EMULATE_BF16 = False
@@ -141,6 +143,50 @@ class _QuantMatmul(torch.autograd.Function):
         return _unbroadcast(torch.matmul(gq, bq.transpose(-1, -2)), aq.shape), _unbroadcast(torch.matmul(aq.transpose(-1, -2), gq), bq.shape)
 
 
+class _QuantStore(torch.autograd.Function):
+    """An activation a bf16 model keeps in memory: rounded to bf16 when written (forward) and so is its gradient (backward)."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return _q(x) if fwd else x.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (_q(g) if ctx.bwd else g), None, None
+
+
+def store(x, fwd=True, bwd=True):
+    """Identity; with the bf16 emulation on (tests only), a tensor stored in bf16 (its gradient too)."""
+    if EMULATE_BF16:
+        return _QuantStore.apply(x, fwd, bwd)
+    return x
+
+
+class _QuantFanOut(torch.autograd.Function):
+    """A tensor read by n consumers (the encoder memories, read by every decoder layer): a bf16 model accumulates the consumers'
+    gradients in the tensor's own dtype, in the order the backward pass produces them (last consumer first)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.clone() for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        acc = None
+        for g in reversed(gs):
+            if g is None:
+                continue
+            acc = _q(g) if acc is None else _q(acc + g)
+        return acc, None
+
+
+def fan_out(x, n):
+    if EMULATE_BF16:
+        return list(_QuantFanOut.apply(x, n))
+    return [x] * n
+
+
 def attn_matmul(a, b):
     """torch.matmul for the two products of an attention; with the bf16 emulation on (tests only), with bf16 operands."""
     if EMULATE_BF16:
@@ -153,7 +199,8 @@ def _lin(sd, name, x):
 
 
 def _ln(sd, name, x):
-    return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5)
+    # emulation: the normalised rows are stored in bf16; so is the gradient of the sum they were computed from
+    return store(F.layer_norm(store(x, fwd=False), (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5))
 
 
 def _drop(x, p, training):
@@ -298,17 +345,18 @@ def bart_decoder(sd, cfg, dec_in, hiddens, masks, dec_pad, causal, rating_diff, 
         x = x + (rating_diff * sd[b + "rating_embeddings"]).unsqueeze(1)   # (:591-593)
     x = _ln(sd, b + "layernorm_embedding", x)
     x = _drop(x, cfg.dropout, training).transpose(0, 1)                    # [T,B,D]
+    nl = cfg.decoder_layers
     if multimodal:
-        keys = [h.transpose(0, -2) for h in hiddens]                        # [S,N,B,D]
+        keys = [fan_out(h.transpose(0, -2), nl) for h in hiddens]           # [S,N,B,D], one handle per layer (the same tensor)
         pads = [m.eq(0) for m in masks]
     else:
-        keys = hiddens.transpose(0, -2)
+        keys = fan_out(hiddens.transpose(0, -2), nl)
         pads = masks.eq(0) if masks is not None else None
     for i in range(cfg.decoder_layers):
         lb = b + "layers.%d" % i
         a = self_attention(sd, lb + ".self_attn", x, cfg.heads, key_pad=dec_pad, causal=causal)
         x = _ln(sd, lb + ".self_attn_layer_norm", x + _drop(a, cfg.dropout, training))
-        c = cross_attention(sd, lb + ".encoder_attn", x, keys, pads, cfg.heads, multimodal)
+        c = cross_attention(sd, lb + ".encoder_attn", x, [km[i] for km in keys] if multimodal else keys[i], pads, cfg.heads, multimodal)
         x = _ln(sd, lb + ".encoder_attn_layer_norm", x + _drop(c, cfg.dropout, training))
         h = F.gelu(_lin(sd, lb + ".fc1", x))
         h = _lin(sd, lb + ".fc2", h)

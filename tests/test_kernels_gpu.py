@@ -286,8 +286,10 @@ def test_embed_ln(dtype):
 
 
 # ------------------------------------------------------------------------------------------------
-def attn_reference(q, k, v, pad, nq, T, qpb, N, S, H, exclude, causal, scale):
-    """q [nq*T, H*64]; k/v [B*N*S, H*64]; pad [B,N,S] bool.  Returns out [nq*T, H*64] (fp32 autograd)."""
+def attn_reference(q, k, v, pad, nq, T, qpb, N, S, H, exclude, causal, scale, mm=None):
+    """q [nq*T, H*64]; k/v [B*N*S, H*64]; pad [B,N,S] bool.  Returns out [nq*T, H*64] (autograd, in the dtype of q).
+    mm: the two attention products (default torch.matmul; the bf16 yardstick passes the oracle's bf16-operand product)."""
+    mm = mm or torch.matmul
     B = nq // qpb
     qh = q.view(nq, T, H, 64).permute(0, 2, 1, 3)                       # [nq,H,T,64]
     kh = k.view(B, N, S, H, 64).permute(0, 1, 3, 2, 4)                   # [B,N,H,S,64]
@@ -301,15 +303,15 @@ def attn_reference(q, k, v, pad, nq, T, qpb, N, S, H, exclude, causal, scale):
                 continue
             if pad is not None and bool(pad[b, n].all()):
                 continue
-            s = torch.einsum("htd,hsd->hts", qh[qb], kh[b, n]) * scale
+            s = mm(qh[qb], kh[b, n].transpose(-1, -2)) * scale
             if pad is not None:
                 s = s.masked_fill(pad[b, n][None, None, :], float("-inf"))
             if causal:
-                s = s + torch.triu(torch.full((T, S), float("-inf"), device=s.device), 1)
-            acc = acc + torch.einsum("hts,hsd->htd", torch.softmax(s, -1), vh[b, n])
+                s = s + torch.triu(torch.full((T, S), float("-inf"), device=s.device, dtype=s.dtype), 1)
+            acc = acc + mm(torch.softmax(s, -1), vh[b, n])
             cnt += 1
         if cnt == 0:
-            outs.append(torch.zeros(H, T, 64, device=q.device) + 0 * qh[qb])
+            outs.append(torch.zeros(H, T, 64, device=q.device, dtype=q.dtype) + 0 * qh[qb])
         else:
             outs.append(acc / cnt)
     return torch.stack(outs).permute(0, 2, 1, 3).reshape(nq * T, H * 64)
@@ -399,6 +401,60 @@ def test_attention(dtype, case):
     dq_o.copy_(base)
     kn.attn_bwd(desc_o, dout, dq_o, True, dk_o, dv_o, stats)
     assert torch.equal(dq_o, dq2) and torch.equal(dk_o, dk) and torch.equal(dv_o, dv)
+
+
+@pytest.mark.parametrize("std", [1.0, 0.25], ids=["peaked", "flat"])
+@pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[0] in ("enc_self", "dec_self", "cross_text_full", "cross_img_one_entity")], ids=lambda c: c[0])
+def test_attention_bf16_error_against_the_bf16_yardstick(case, std):
+    """How far the bf16 attention kernels are from exact arithmetic, beside ANY bf16 matrix-core attention: the f64 attention of the
+    bf16 inputs is the truth; the yardstick is the same algorithm in f32 with both products on bf16 operands (probabilities and
+    score gradients rounded, oracle/bart_oracle._QuantMatmul).  Relative L2 error of out / dQ / dK / dV of the HIP kernels must
+    stay within 1.5x the yardstick's + 1e-3.  `flat` = small scores (nearly uniform probabilities: dS = P (dP - delta) is then a
+    difference of nearly equal numbers, the regime of a freshly initialised model), `peaked` = unit-variance q, k."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from oracle import bart_oracle as bo
+    name, B, qpb, N, S, T, H, exclude, causal, is_self = case
+    nq, D, dtype = B * qpb, H * 64, torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    pad = torch.zeros(B, N, S, dtype=torch.bool)
+    for b in range(B):
+        for n in range(N):
+            pad[b, n, int(torch.randint(max(1, S // 3), S + 1, (1,), generator=g)):] = True
+    pad = pad.to(DEV)
+    if is_self:
+        qkv = rnd(nq * T, 3 * D, dtype=dtype, seed=1, std=std)
+        q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    else:
+        q = rnd(nq * T, D, dtype=dtype, seed=1, std=std)
+        kv = rnd(B * N * S, 2 * D, dtype=dtype, seed=2, std=std)
+        k, v = kv[:, :D], kv[:, D:]
+    dout = rnd(nq * T, D, dtype=dtype, seed=3)
+
+    def run(ft, mm):
+        qf, kf, vf = (t.to(ft).contiguous().requires_grad_(True) for t in (q, k, v))
+        o = attn_reference(qf, kf, vf, pad, nq, T, qpb, N, S, H, exclude, causal, 0.125, mm=mm)
+        o.backward(dout.to(ft))
+        return [t.detach().double() for t in (o, qf.grad, kf.grad, vf.grad)]
+
+    truth = run(torch.float64, None)
+    emu = [t.to(torch.bfloat16).double() for t in run(torch.float32, bo._QuantMatmul.apply)]      # results stored in bf16, like the kernels'
+    pad_u8 = pad.to(torch.uint8).contiguous()
+    null = torch.empty(B * N, dtype=torch.uint8, device=DEV)
+    kn.entity_null(pad_u8, null, B * N, S)
+    out = torch.zeros(nq * T, D, device=DEV, dtype=dtype)
+    desc = kn.make_attn_desc(q, k, v, out, pad_u8, null, nq, T, qpb, N, S, H, exclude, causal, 0.125)
+    kn.attn_fwd(desc, q)
+    dq, dk, dv = torch.zeros_like(out), torch.zeros(B * N * S, D, device=DEV, dtype=dtype), torch.zeros(B * N * S, D, device=DEV, dtype=dtype)
+    stats = torch.empty(kn.attn_bwd_workspace(desc) // 4, device=DEV)
+    kn.attn_bwd(desc, dout, dq, False, dk, dv, stats)
+    rel = lambda a, t: float((a.double() - t).norm() / t.norm().clamp_min(1e-30))      # noqa: E731
+    rows = []
+    for what, h, e, t in zip(("out", "dq", "dk", "dv"), (out, dq, dk, dv), emu, truth):
+        rows.append((what, rel(h, t), rel(e, t)))
+    print(name, std, " ".join("%s hip %.2e yardstick %.2e" % r for r in rows))
+    for what, eh, ee in rows:
+        assert eh <= 1.5 * ee + 1e-3, (name, std, what, eh, ee, rows)
 
 
 MAPPED_CASES = [c for c in ATTN_CASES if c[0] in ("enc_self", "cross_text_loo", "cross_text_full", "cross_table_walk", "cross_img", "cross_text_holes")]

@@ -27,39 +27,41 @@ def patch(text):
         text = text.replace(old, new, count)
 
     # storage + accessor
-    rep("namespace {\n", "__device__ unsigned long long g_w4_stamps[256][8];\n"
-        "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps(unsigned long long* host256x8) {\n"
-        "    return hipMemcpyFromSymbol(host256x8, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps)) == hipSuccess ? 0 : -5;\n}\n"
+    rep("namespace {\n", "__device__ unsigned long long g_w4_stamps[256][10];\n"
+        "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps(unsigned long long* host256x10) {\n"
+        "    return hipMemcpyFromSymbol(host256x10, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps)) == hipSuccess ? 0 : -5;\n}\n"
         "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps_clear(void) {\n"
-        "    static unsigned long long z[256][8];\n"
+        "    static unsigned long long z[256][10];\n"
         "    return hipMemcpyToSymbol(HIP_SYMBOL(g_w4_stamps), z, sizeof(z)) == hipSuccess ? 0 : -5;\n}\n"
         "namespace {\n")
     # per-workgroup accumulators, inside the w4 NT kernel only (anchors that occur once, in that kernel)
     rep("    const int ydelta = (fo ^ 64) - fo;\n",
         "    const int ydelta = (fo ^ 64) - fo;\n"
-        "    unsigned long long st_pro = 0, st_main = 0, st_epi = 0, st_end = 0, st_tiles = 0;\n"
+        "    unsigned long long st_pro = 0, st_main = 0, st_epi = 0, st_end = 0, st_tiles = 0, st_gap = 0, st_prev = 0, st_head = 0;\n"
         "    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();\n")
     rep("        // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)\n",
         "        const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();\n"
+        "        if (st_prev != 0) st_gap += st_t0 - st_prev; else st_head = st_t0 - st_k0;\n"
         "        // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)\n")
     rep("        // four MFMAs: A block I x B block J (quarters q = 2 si + sj)\n",
         "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
         "        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();\n"
         "        // four MFMAs: A block I x B block J (quarters q = 2 si + sj)\n")
-    rep("        stage(st, abuf, std::integral_constant<int, 0>{});\n        asm volatile(\"s_nop 15\\n s_nop 15\" ::: \"memory\");",
-        "        stage(st, abuf, std::integral_constant<int, 0>{});\n        asm volatile(\"s_nop 15\\n s_nop 15\" ::: \"memory\");\n"
+    rep("        if (st < nst) stage(st, abuf, std::integral_constant<int, 0>{}, std::false_type{});\n        asm volatile(\"s_nop 15\\n s_nop 15\" ::: \"memory\");",
+        "        if (st < nst) stage(st, abuf, std::integral_constant<int, 0>{}, std::false_type{});\n        asm volatile(\"s_nop 15\\n s_nop 15\" ::: \"memory\");\n"
         "        const unsigned long long st_t2 = __builtin_amdgcn_s_memtime();\n"
         "        st_pro += st_t1 - st_t0; st_main += st_t2 - st_t1; st_epi -= st_t2; st_end -= st_t2; ++st_tiles;")
     rep("                                                                                                                     wave * 64 + lane_e, lane_e);\n    }\n    lds_barrier();\n    }\n}\n",
         "                                                                                                                     wave * 64 + lane_e, lane_e);\n    }\n"
         "    { const unsigned long long t3 = __builtin_amdgcn_s_memtime(); st_epi += t3; }\n"
         "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");      // DIAGNOSTIC ONLY: how long the tile's stores take to be acknowledged\n"
-        "    { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); st_end += t4; }\n"
+        "    { const unsigned long long t4 = __builtin_amdgcn_s_memtime(); st_end += t4; st_prev = t4; }\n"
         "    lds_barrier();\n    }\n"
         "    if (threadIdx.x == 0 && blockIdx.x < 256) {\n"
         "        unsigned long long* o = g_w4_stamps[blockIdx.x];\n"
         "        o[0] = st_tiles; o[1] = st_pro; o[2] = st_main; o[3] = st_epi; o[4] = st_end;\n"
-        "        o[5] = __builtin_amdgcn_s_memtime() - st_k0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0;\n    }\n}\n")
+        "        o[5] = __builtin_amdgcn_s_memtime() - st_k0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_gap;\n"
+        "        g_w4_stamps[blockIdx.x][8] = st_head; g_w4_stamps[blockIdx.x][9] = __builtin_amdgcn_s_memtime() - st_prev;\n    }\n}\n")
     return text
 
 
@@ -99,7 +101,7 @@ def run(M, N, K, variants=("plain", "bias", "gelu", "acc")):
     out = torch.randn(M, N, device="cuda").to(dt)
     aux = torch.empty(M, N, device="cuda", dtype=dt)
     bias = torch.randn(N, device="cuda")
-    buf = (ctypes.c_ulonglong * (256 * 8))()
+    buf = (ctypes.c_ulonglong * (256 * 10))()
     for var in variants:
         def launch():
             if var == "plain":
@@ -120,15 +122,21 @@ def run(M, N, K, variants=("plain", "bias", "gelu", "acc")):
         e1.record()
         torch.cuda.synchronize()
         assert lib.mmsum_w4_stamps(buf) == 0
-        rows = [[buf[i * 8 + j] for j in range(8)] for i in range(256)]
+        rows = [[buf[i * 10 + j] for j in range(10)] for i in range(256)]
         rows = [r for r in rows if r[0] > 0]
         tiles = sum(r[0] for r in rows)
         ghz = sum(r[5] for r in rows) / (sum(r[6] for r in rows) * 10.0)       # cycles per 10 ns tick -> GHz
         cyc = [sum(r[j] for r in rows) / tiles for j in (1, 2, 3, 4)]
         us = [c / (ghz * 1e3) for c in cyc]
-        print("%-5s M=%d N=%d K=%d: %.1f us launch, %d tiles on %d workgroups, %.2f GHz in-kernel | per tile: prologue %.2f us, main loop %.2f us "
-              "(%d stages), epilogue issue %.2f us, + until its stores are acknowledged %.2f us  (sum %.2f us)"
-              % (var, M, N, K, e0.elapsed_time(e1) * 1e3, tiles, len(rows), ghz, us[0], us[1], K // 64, us[2], us[3] - us[2], us[0] + us[1] + us[3]), flush=True)
+        gaps = sum(r[7] for r in rows) / max(1, tiles - len(rows)) / (ghz * 1e3)          # between a tile's end and the next one's first DMA
+        head = sum(r[8] for r in rows) / len(rows) / (ghz * 1e3)
+        tail = sum(r[9] for r in rows) / len(rows) / (ghz * 1e3)
+        inker = max(r[6] for r in rows) / 100.0                                          # the longest workgroup, in us (100 MHz ticks)
+        print("%-5s M=%d N=%d K=%d: %.1f us launch (longest workgroup %.1f us), %d tiles on %d workgroups, %.2f GHz in-kernel | per tile: prologue %.2f us, "
+              "main loop %.2f us (%d stages), epilogue issue %.2f us, + until its stores are acknowledged %.2f us, tile end -> next tile's first DMA %.2f us "
+              "(sum %.2f us) | per workgroup: kernel start -> first DMA %.2f us, last store -> exit %.2f us"
+              % (var, M, N, K, e0.elapsed_time(e1) * 1e3, inker, tiles, len(rows), ghz, us[0], us[1], K // 64, us[2], us[3] - us[2], gaps,
+                 us[0] + us[1] + us[3] + gaps, head, tail), flush=True)
 
 
 if __name__ == "__main__":
