@@ -1155,19 +1155,25 @@ __device__ __forceinline__ void scores_tr(f32x16_t (&sacc)[NKB], const char* kti
     }
     m = wave_half_max(fmaxf(m, mraw * c2));                  // scale > 0
     const float ms = (m == -INFINITY) ? 0.f : m;
-    float l = 0.f;
+    // exponent arguments and the row sum on register PAIRS (packed f32: one issue slot per two scores for the FMA and for the
+    // add; a single running sum is a serial chain the compiler may not re-associate into pairs by itself)
+    typedef float pair_t __attribute__((ext_vector_type(2)));
+    pair_t l2 = {0.f, 0.f};
+    const pair_t c2v = {c2, c2}, msv = {ms, ms};
 #pragma unroll
     for (int kb = 0; kb < NACT; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float pv = (kb < NFAST && !(CAUSAL && kb == NACT - 1)) ? __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -ms))
-                                                                         : __builtin_amdgcn_exp2f(sacc[kb][r] - ms);
-            sacc[kb][r] = pv;
-            l += pv;
+        for (int r = 0; r < 16; r += 2) {
+            const pair_t a = {sacc[kb][r], sacc[kb][r + 1]};
+            const pair_t t = (kb < NFAST && !(CAUSAL && kb == NACT - 1)) ? a * c2v - msv : a - msv;
+            const pair_t pv = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            sacc[kb][r] = pv.x;
+            sacc[kb][r + 1] = pv.y;
+            l2 += pv;
         }
     }
     m_out = ms;
-    l_out = wave_half_sum(l);
+    l_out = wave_half_sum(l2.x + l2.y);
 }
 
 // Calls body(integral_constant<NACT>, integral_constant<NFAST>) for the wave-uniform run-time counts: NACT in 1..NKB,
@@ -1397,7 +1403,8 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
             scores_tr<NKB, NACT, NFAST, CAUSAL>(p, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
             if (rem) commit(nx);
             const float invl = (l > 0.f) ? __builtin_amdgcn_rcpf(l) : 0.f;
-            float raw = 0.f;                                      // sum_k p * dP, un-normalised
+            typedef float pair_t __attribute__((ext_vector_type(2)));
+            pair_t raw2 = {0.f, 0.f};                             // sum_k p * dP, un-normalised, on register pairs (packed FMAs)
 #pragma unroll
             for (int kb = 0; kb < NACT; ++kb) {
                 f32x16_t dpk = zero_acc();
@@ -1407,9 +1414,9 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                     mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) raw = fmaf(p[kb][r], dpk[r], raw);
+                for (int r = 0; r < 16; r += 2) raw2 += pair_t{p[kb][r], p[kb][r + 1]} * pair_t{dpk[r], dpk[r + 1]};
             }
-            const float dprime = wave_half_sum(raw) * invl * d.scale;          // delta * count * scale
+            const float dprime = wave_half_sum(raw2.x + raw2.y) * invl * d.scale;          // delta * count * scale
             if (lane < 32 && qvalid) {
                 float* sp = stats + ((((long)qb * d.N + cur_n) * d.H + h) * d.T + qpos) * 2;
                 sp[0] = m + __log2f(l);
@@ -1599,7 +1606,8 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                 float m, l;
                 scores_tr<NKB, NACT, NFAST, false>(p, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
                 const float invl = (l > 0.f) ? __builtin_amdgcn_rcpf(l) : 0.f;
-                float raw = 0.f;
+                typedef float pair_t __attribute__((ext_vector_type(2)));
+                pair_t raw2 = {0.f, 0.f};
 #pragma unroll
                 for (int kb = 0; kb < NACT; ++kb) {
                     f32x16_t dpk = zero_acc();
@@ -1609,9 +1617,9 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                         mma_slab<T>(dpk, a, dof[sl]);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) raw = fmaf(p[kb][r], dpk[r], raw);
+                    for (int r = 0; r < 16; r += 2) raw2 += pair_t{p[kb][r], p[kb][r + 1]} * pair_t{dpk[r], dpk[r + 1]};
                 }
-                const float dprime = wave_half_sum(raw) * invl * d.scale;          // delta * count * scale, count = 1
+                const float dprime = wave_half_sum(raw2.x + raw2.y) * invl * d.scale;          // delta * count * scale, count = 1
                 if (lane < 32 && qvalid) {
                     float* sp = stats + (((long)qb * d.H + h) * d.T + qpos) * 2;   // N == 1
                     sp[0] = m + __log2f(l);

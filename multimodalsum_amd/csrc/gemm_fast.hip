@@ -267,7 +267,10 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
                                                   char* smem, int m0, int n0, int wm, int wn, int tid, int lane, const float (&bv)[8], AccSrc src = AccSrc{}) {
     constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
     constexpr int THREADS = WAVES_M * WAVES_N * 64;
-    constexpr int CPR = BN / 8, BAND = 32 * BN;
+    // LAY_16T: a lane holds four consecutive columns of a row per quarter -> one 16-byte LDS write per quarter (64 per wave and
+    // tile instead of 256 four-byte ones) into rows padded by four floats (the 16 rows of a write then start 4 banks apart)
+    constexpr int PITCH = LAY == LAY_16T ? BN + 4 : BN;
+    constexpr int CPR = BN / 8, BAND = 32 * PITCH;
     constexpr int RPI = THREADS / CPR;                 // rows one iteration of the write-back covers
     constexpr int NIT = WAVES_M * 32 / RPI;
     static_assert(THREADS % CPR == 0 && RPI <= 32 && 32 % RPI == 0 && NIT * RPI == WAVES_M * 32, "write-back geometry");
@@ -305,8 +308,9 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
 #pragma unroll
     for (int it = 0; it < NIT; ++it) prefetch1(0, it);
     lds_barrier();                                    // every wave is done reading the operand stages
-    const float* rd0 = stage0 + trow * BN + cc;       // this thread's read position inside a band set (+ compile-time offsets)
-    float* wr0 = stage0 + wm * BAND + wn * (TN * 32) + (LAY == LAY_16 ? (4 * (lane >> 4)) * BN + (lane & 15) : (4 * (lane >> 5)) * BN + (lane & 31));
+    const float* rd0 = stage0 + trow * PITCH + cc;    // this thread's read position inside a band set (+ compile-time offsets)
+    float* wr0 = stage0 + wm * BAND + wn * (TN * 32) +
+                 (LAY == LAY_16T ? (lane & 15) * PITCH + 4 * (lane >> 4) : LAY == LAY_16 ? (4 * (lane >> 4)) * BN + (lane & 15) : (4 * (lane >> 5)) * BN + (lane & 31));
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         constexpr int SETF = WAVES_M * BAND;
@@ -314,11 +318,20 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
         if (NSETS == 1 && i > 0) lds_barrier();
         f32x16_t band[TN];
         src(i, acc, band);
+        if constexpr (LAY == LAY_16T) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                wr0[seto + (LAY == LAY_16 ? (16 * (r >> 3) + (r & 3)) * BN + 16 * ((r >> 2) & 1) : ((r & 3) + 8 * (r >> 2)) * BN) + j * 32] = band[j][r];
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f32x4_t*>(wr0 + seto + (16 * (q >> 1)) * PITCH + j * 32 + 16 * (q & 1)) =
+                        f32x4_t{band[j][4 * q], band[j][4 * q + 1], band[j][4 * q + 2], band[j][4 * q + 3]};
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wr0[seto + (LAY == LAY_16 ? (16 * (r >> 3) + (r & 3)) * BN + 16 * ((r >> 2) & 1) : ((r & 3) + 8 * (r >> 2)) * BN) + j * 32] = band[j][r];
+        }
         lds_barrier();
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -328,7 +341,7 @@ __device__ __forceinline__ void epilogue_interior(const GemmArgs& p, const f32x1
             if constexpr (OUT == OUT_T_ACC) c_now = c_pre[it];
             if constexpr (OUT == OUT_F32_ACC) { cf_now[0] = cf_pre[it][0]; cf_now[1] = cf_pre[it][1]; }
             if (i + 1 < TM) prefetch1(i + 1, it);
-            const float* src = rd0 + seto + ((it * RPI) / 32) * BAND + ((it * RPI) % 32) * BN;
+            const float* src = rd0 + seto + ((it * RPI) / 32) * BAND + ((it * RPI) % 32) * PITCH;
             const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src);
             const f32x4_t b = *reinterpret_cast<const f32x4_t*>(src + 4);
             float v[8];
@@ -560,8 +573,8 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     const bool aligned = (((uintptr_t)p.C) & 15) == 0 && (p.ldc & (kF32 ? 3 : 7)) == 0 &&
                          (p.aux == nullptr || ((((uintptr_t)p.aux) & 15) == 0 && (p.ldaux & 7) == 0));
     const bool interior = m0 + BM <= p.M && n0 + BN <= p.N && aligned;        // workgroup-uniform
-    if constexpr (LAY == LAY_16T) {
-        static_assert(WIDE && OUT == OUT_T && !kAuxIn, "the swapped-operand layout is the bf16 store without a global read");
+    if constexpr (LAY == LAY_16T && OUT == OUT_T && !kAuxIn) {
+        static_assert(WIDE, "the packed epilogue is the four-wave kernels'");
         if (interior) {
             epilogue_interior_packed<BM, BN, WAVES_M, WAVES_N, EPI, CS, LDS_BYTES, AccSrc>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane, src);
             return;
@@ -569,7 +582,7 @@ __device__ __forceinline__ void epilogue_staged(const GemmArgs& p, const f32x16_
     }
     float bv[8];
     epilogue_bias<BN, WAVES_M * WAVES_N * 64>(p, n0, ks, tid, bv);
-    if constexpr (LAY != LAY_16T && OUT != OUT_F32_ATOMIC && (WIDE || !kAuxIn)) {
+    if constexpr (!(LAY == LAY_16T && OUT == OUT_T && !kAuxIn) && OUT != OUT_F32_ATOMIC && (WIDE || !kAuxIn)) {
         if (interior && (WIDE || !(p.flags & MMSUM_GEMM_COLSUM))) {
             epilogue_interior<BM, BN, WAVES_M, WAVES_N, EPI, OUT, WIDE ? CS : 0, LDS_BYTES, LAY, AccSrc>(p, acc, smem, m0, n0, wm, wn, tid, lane, bv, src);
             return;
@@ -788,11 +801,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     using C = K64Cfg<BM, BN, WAVES_M, WAVES_N>;
     static_assert(C::PAW == 8 && C::PBW == 8, "8 + 8 pieces per wave and stage: one behind each group of four MFMAs");
     constexpr int B_BASE = 3 * C::A_BYTES;                        // [A0 | A1 | A2 | B0 | B1]
-    // Epilogues that read nothing from global memory (bf16 store, plain / GELU / ReLU) issue their MFMAs with the operand roles
-    // swapped -- the weight fragment as the MFMA's A operand -- which hands every lane four consecutive COLUMNS of an output row
-    // per quarter (LAY_16T) instead of four consecutive rows of a column: the epilogue then converts on the registers and stages
-    // bf16 in 8-byte pieces (epilogue_interior_packed).  Same products, same order of summation.
-    constexpr bool SWAP = OUT == OUT_T && (EPI == MMSUM_EPI_NONE || EPI == MMSUM_EPI_GELU || EPI == MMSUM_EPI_RELU);
+    // The bf16-output forms issue their MFMAs with the operand roles swapped -- the weight fragment as the MFMA's A operand -- which
+    // hands every lane four consecutive COLUMNS of an output row per quarter (LAY_16T) instead of four consecutive rows of a column:
+    // the epilogues that read nothing from global memory (plain / GELU / ReLU) then convert on the registers and stage bf16 in
+    // 8-byte pieces (epilogue_interior_packed), the accumulating store stages f32 in 16-byte pieces.  Same products, same order of
+    // summation.  Columns stay on the lanes where the wider pieces cost registers the epilogue does not have (GELU' / ReLU' with
+    // their saved operand: 20 spills; the f32 accumulate with two vectors of C per chunk: 174) and for the f32-atomic form, which
+    // stores element-wise from the registers.
+    constexpr bool SWAP = OUT == OUT_T_ACC || (OUT == OUT_T && EPI != MMSUM_EPI_GELU_BWD && EPI != MMSUM_EPI_RELU_BWD);
     constexpr int LAYW = SWAP ? LAY_16T : LAY_16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
