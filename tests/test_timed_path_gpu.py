@@ -227,7 +227,8 @@ def test_generation_token_ids_bf16_at_bart_large_width():
     Equal token ids cannot be demanded of a bf16 path: a bf16 logit carries 8 significant bits, candidates whose exact scores
     differ by less than that rounding are ties it cannot break the reference's way, and one flipped tie sends the rest of the
     search elsewhere (measured here: ids equal for the first four tokens, then one of two businesses departs).  The rule
-    instead, with TIE = 0.25 nats (the bf16 hidden states of two decoder layers and the bf16 logits, |logit| <= ~12):
+    instead, with TIE = 0.4 nats (the bf16 hidden states of two decoder layers and the bf16 logits, |logit| <= ~12; measured worst
+    deviation over the search 0.23 .. 0.25 nats, depending on the summation order inside the kernels):
     every decode step of the HIP search is re-scored by the oracle ON THE SAME HYPOTHESES (generation.beam_search's trace),
       (1) each of the 2 * num_beams (score, beam, token) candidates the device returned carries the oracle's score for that
           beam and token -- log-softmax with the forced BOS / EOS, the n-gram bans, + the beam's running score -- within TIE;
@@ -238,7 +239,7 @@ def test_generation_token_ids_bf16_at_bart_large_width():
     mis-scored beam is an error of many nats on at least one candidate."""
     from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
     from oracle import generate_oracle as go
-    TIE = 0.25
+    TIE = 0.4
     cfg = _bart_large(layers=2)
     ocfg = bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim, encoder_layers=2, decoder_layers=2,
                       heads=cfg.heads, max_position_embeddings=cfg.max_position_embeddings, dropout=0.0)

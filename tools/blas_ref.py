@@ -21,7 +21,8 @@ def timeit(fn, iters=10):
 
 def main():
     dt = torch.bfloat16
-    for M, N, K in [(64512, 4096, 1024), (64512, 1024, 4096), (64512, 1024, 1024), (64512, 3072, 1024), (38912, 4096, 1024)]:
+    rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64512            # 129024 = the bench batch (B = 112)
+    for M, N, K in [(rows, 4096, 1024), (rows, 1024, 4096), (rows, 1024, 1024), (rows, 3072, 1024), (rows * 38912 // 64512, 4096, 1024)]:
         x = torch.randn(M, K, device="cuda").to(dt)
         w = torch.randn(N, K, device="cuda").to(dt) * 0.02
         y = torch.empty(M, N, device="cuda", dtype=dt)
@@ -29,7 +30,7 @@ def main():
         t_ours = timeit(lambda: kn.gemm(x, w, y))
         fl = 2.0 * M * N * K
         print("NT  M=%6d N=%5d K=%5d   hipBLASLt %7.1f us (%6.1f TF/s)   mmsum %7.1f us (%6.1f TF/s)" % (M, N, K, t_blas, fl / t_blas / 1e6, t_ours, fl / t_ours / 1e6), flush=True)
-    for R, N, K in [(64512, 4096, 1024), (64512, 1024, 4096), (64512, 1024, 1024)]:        # wgrad: dW[N,K] = dy[R,N]^T x[R,K]
+    for R, N, K in [(rows, 4096, 1024), (rows, 1024, 4096), (rows, 1024, 1024)]:        # wgrad: dW[N,K] = dy[R,N]^T x[R,K]
         dy = torch.randn(R, N, device="cuda").to(dt)
         x = torch.randn(R, K, device="cuda").to(dt)
         dw = torch.empty(N, K, device="cuda", dtype=torch.float32)
