@@ -27,22 +27,31 @@ def patch(text):
         text = text.replace(old, new, count)
 
     # storage + accessor
-    rep("namespace {\n", "__device__ unsigned long long g_w4_stamps[256][10];\n"
-        "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps(unsigned long long* host256x10) {\n"
-        "    return hipMemcpyFromSymbol(host256x10, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps)) == hipSuccess ? 0 : -5;\n}\n"
+    rep("namespace {\n", "__device__ unsigned long long g_w4_stamps[256][12];\n"
+        "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps(unsigned long long* host256x12) {\n"
+        "    return hipMemcpyFromSymbol(host256x12, HIP_SYMBOL(g_w4_stamps), sizeof(g_w4_stamps)) == hipSuccess ? 0 : -5;\n}\n"
         "extern \"C\" __attribute__((visibility(\"default\"))) int mmsum_w4_stamps_clear(void) {\n"
-        "    static unsigned long long z[256][10];\n"
+        "    static unsigned long long z[256][12];\n"
         "    return hipMemcpyToSymbol(HIP_SYMBOL(g_w4_stamps), z, sizeof(z)) == hipSuccess ? 0 : -5;\n}\n"
         "namespace {\n")
     # per-workgroup accumulators, inside the w4 NT kernel only (anchors that occur once, in that kernel)
     rep("    const int ydelta = (fo ^ 64) - fo;\n",
         "    const int ydelta = (fo ^ 64) - fo;\n"
-        "    unsigned long long st_pro = 0, st_main = 0, st_epi = 0, st_end = 0, st_tiles = 0, st_gap = 0, st_prev = 0, st_head = 0;\n"
+        "    unsigned long long st_pro = 0, st_main = 0, st_epi = 0, st_end = 0, st_tiles = 0, st_gap = 0, st_prev = 0, st_head = 0, st_sync = 0, st_vm = 0;\n"
         "    const unsigned long long st_k0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();\n")
     rep("        // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)\n",
         "        const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();\n"
         "        if (st_prev != 0) st_gap += st_t0 - st_prev; else st_head = st_t0 - st_k0;\n"
         "        // prologue, in the order the steady state issues: A(0) B(0) A(1) B(1) A(2)\n")
+    rep("            if constexpr (LEFT >= 2) wait_vmcnt<8>(); else if constexpr (LEFT == 1) wait_vmcnt<0>();     // stage st+1 has landed; A of st+2 may be in flight\n"
+        "            asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
+        "            __builtin_amdgcn_s_barrier();\n",
+        "            asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
+        "            const unsigned long long st_s0 = __builtin_amdgcn_s_memtime();\n"
+        "            if constexpr (LEFT >= 2) wait_vmcnt<8>(); else if constexpr (LEFT == 1) wait_vmcnt<0>();\n"
+        "            const unsigned long long st_s1 = __builtin_amdgcn_s_memtime();\n"
+        "            __builtin_amdgcn_s_barrier();\n"
+        "            { const unsigned long long st_s2 = __builtin_amdgcn_s_memtime(); st_vm += st_s1 - st_s0; st_sync += st_s2 - st_s1; }\n")
     rep("        // four MFMAs: A block I x B block J (quarters q = 2 si + sj)\n",
         "        asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
         "        const unsigned long long st_t1 = __builtin_amdgcn_s_memtime();\n"
@@ -61,7 +70,7 @@ def patch(text):
         "        unsigned long long* o = g_w4_stamps[blockIdx.x];\n"
         "        o[0] = st_tiles; o[1] = st_pro; o[2] = st_main; o[3] = st_epi; o[4] = st_end;\n"
         "        o[5] = __builtin_amdgcn_s_memtime() - st_k0; o[6] = __builtin_amdgcn_s_memrealtime() - st_r0; o[7] = st_gap;\n"
-        "        g_w4_stamps[blockIdx.x][8] = st_head; g_w4_stamps[blockIdx.x][9] = __builtin_amdgcn_s_memtime() - st_prev;\n    }\n}\n")
+        "        g_w4_stamps[blockIdx.x][8] = st_head; g_w4_stamps[blockIdx.x][9] = __builtin_amdgcn_s_memtime() - st_prev; g_w4_stamps[blockIdx.x][10] = st_vm; g_w4_stamps[blockIdx.x][11] = st_sync;\n    }\n}\n")
     return text
 
 
@@ -101,7 +110,7 @@ def run(M, N, K, variants=("plain", "bias", "gelu", "acc")):
     out = torch.randn(M, N, device="cuda").to(dt)
     aux = torch.empty(M, N, device="cuda", dtype=dt)
     bias = torch.randn(N, device="cuda")
-    buf = (ctypes.c_ulonglong * (256 * 10))()
+    buf = (ctypes.c_ulonglong * (256 * 12))()
     for var in variants:
         def launch():
             if var == "plain":
@@ -122,7 +131,7 @@ def run(M, N, K, variants=("plain", "bias", "gelu", "acc")):
         e1.record()
         torch.cuda.synchronize()
         assert lib.mmsum_w4_stamps(buf) == 0
-        rows = [[buf[i * 10 + j] for j in range(10)] for i in range(256)]
+        rows = [[buf[i * 12 + j] for j in range(12)] for i in range(256)]
         rows = [r for r in rows if r[0] > 0]
         tiles = sum(r[0] for r in rows)
         ghz = sum(r[5] for r in rows) / (sum(r[6] for r in rows) * 10.0)       # cycles per 10 ns tick -> GHz
@@ -134,9 +143,11 @@ def run(M, N, K, variants=("plain", "bias", "gelu", "acc")):
         inker = max(r[6] for r in rows) / 100.0                                          # the longest workgroup, in us (100 MHz ticks)
         print("%-5s M=%d N=%d K=%d: %.1f us launch (longest workgroup %.1f us), %d tiles on %d workgroups, %.2f GHz in-kernel | per tile: prologue %.2f us, "
               "main loop %.2f us (%d stages), epilogue issue %.2f us, + until its stores are acknowledged %.2f us, tile end -> next tile's first DMA %.2f us "
-              "(sum %.2f us) | per workgroup: kernel start -> first DMA %.2f us, last store -> exit %.2f us"
+              "(sum %.2f us) | per workgroup: kernel start -> first DMA %.2f us, last store -> exit %.2f us | inside the main loop, per stage: "
+              "waiting for the own DMA of the next stage (vmcnt) %.0f cycles, at the barrier %.0f cycles, of %.0f cycles per stage (2,048 = MFMA issue)"
               % (var, M, N, K, e0.elapsed_time(e1) * 1e3, inker, tiles, len(rows), ghz, us[0], us[1], K // 64, us[2], us[3] - us[2], gaps,
-                 us[0] + us[1] + us[3] + gaps, head, tail), flush=True)
+                 us[0] + us[1] + us[3] + gaps, head, tail, sum(r[10] for r in rows) / tiles / (K // 64), sum(r[11] for r in rows) / tiles / (K // 64),
+                 cyc[1] / (K // 64)), flush=True)
 
 
 if __name__ == "__main__":
