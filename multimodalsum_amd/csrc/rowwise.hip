@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const T* __restrict__
     f32x4_t ag[VPL], ab[VPL], ap[VPL], ar[VPL];
 #pragma unroll
     for (int i = 0; i < VPL; ++i) { ag[i] = ab[i] = ap[i] = ar[i] = f32x4_t{0, 0, 0, 0}; }
-    for (int seq = wave; seq < nseq; seq += wpb) {
+    // grid = (positions, sequence chunks): a position's sequences are shared out over gridDim.y blocks (one block per position left
+    // half the CUs idle and 252 rows in a row per wave); every per-position / per-column sum below leaves through atomics anyway
+    for (int seq = blockIdx.y * wpb + wave; seq < nseq; seq += wpb * gridDim.y) {
         const int row = seq * T_len + t;
         const long id = ids[row];
         const float r = rd ? rd[seq] : 0.f;
@@ -778,7 +780,8 @@ int embed_ln_bwd_t(const void* dy, const int64_t* ids, const void* E, const void
                    hipStream_t s) {
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
-        embed_ln_bwd_kernel<T, VPL><<<dim3(T_len), dim3(256), 0, s>>>((const T*)dy, ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
+        const int chunks = nseq >= 256 ? 8 : nseq >= 64 ? 4 : 1;
+        embed_ln_bwd_kernel<T, VPL><<<dim3(T_len, chunks), dim3(256), 0, s>>>((const T*)dy, ids, (const T*)E, (const T*)P, rd, (const T*)rvec,
                                                                      (const float*)gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta,
                                                                      nseq, T_len, D, pos_offset, pad_id, p_drop, seed, salt);
     });

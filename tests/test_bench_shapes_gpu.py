@@ -211,6 +211,28 @@ def test_live_row_counts_at_bench_sizes():
         check(out[:live_n], F.gelu(pre), "live gelu out (%d)" % live_n)
         check(aux[:live_n], pre, "live gelu aux (%d)" % live_n)
         assert bool((out[live_n:] == 3.0).all()) and bool((aux[live_n:] == 5.0).all()), "rows past the live count were written"
+        # the other two epilogue families on the same ragged count (their edge tiles: the tile the count ends in): GELU' on a saved
+        # pre-activation + column sums, and the accumulating bf16 store
+        u = rnd(cap, Fd, seed=41)
+        uf = u[:live_n].float()
+        gp = 0.5 * (1 + torch.erf(uf / math.sqrt(2))) + uf * torch.exp(-0.5 * uf * uf) / math.sqrt(2 * math.pi)
+        out.fill_(3.0)
+        cs = torch.zeros(Fd, device=DEV)
+        kn.gemm(a, w, out, epi=kn.EPI_GELU_BWD, aux=u, colsum=cs, live=live)
+        check(out[:live_n], (a[:live_n].float() @ w.float().t()) * gp, "live gelu' out (%d)" % live_n, rel=2.0 ** -6, atol=4e-2)
+        assert bool((out[live_n:] == 3.0).all()), "gelu': rows past the live count were written"
+        want_cs = out[:live_n].double().sum(0)
+        assert ((cs.double() - want_cs).abs() <= 1e-3 * out[:live_n].double().abs().sum(0) + 1e-2).all(), "live gelu' column sums"
+        del u, uf, gp
+        dyq = rnd(cap, Fd, seed=42, std=0.1)
+        dyq[live_n:] = float("nan")
+        w2 = rnd(D, Fd, seed=43, std=0.5)
+        base = rnd(cap, D, seed=44)
+        acc = base.clone()
+        kn.gemm(dyq, w2, acc, accumulate=True, live=live)
+        check(acc[:live_n], base[:live_n].float() + dyq[:live_n].float() @ w2.float().t(), "live accumulate (%d)" % live_n, atol=4e-2)
+        assert torch.equal(acc[live_n:], base[live_n:]), "accumulate: rows past the live count were touched"
+        del dyq, w2, base, acc
         # weight gradient: reduction over the live rows only (the rest is NaN and must not be read)
         dy = rnd(cap, Fd, seed=34, std=0.1)
         dy[live_n:] = float("nan")
