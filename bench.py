@@ -554,6 +554,13 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries the ONE JSON line and nothing else: while the ranks run, file descriptor 1 points at stderr (RCCL writes its
+    # library banner to the C stdout at init and at teardown); it is put back for the final print
+    saved_stdout = None
+    if world > 1 or os.environ.get("MMSUM_FORCE_DDP") == "1":
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
@@ -677,13 +684,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline_bounded(args)
     if dist is not None:
         dist.destroy_process_group()          # RCCL prints its library banner on teardown: keep the JSON line last
+    sys.stdout.flush()
+    try:                                       # RCCL's banner sits in the C stdio buffer until exit: push it out (to stderr) first
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     if rank == 0:
-        sys.stdout.flush()
-        try:                                   # RCCL's banner sits in the C stdio buffer until exit: push it out first
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
         print(json.dumps(out), flush=True)
 
 
