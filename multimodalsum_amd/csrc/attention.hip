@@ -1818,6 +1818,194 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SELF-attention backward in ONE kernel (N == 1 entity, qpb == 1 query block per entity, T and S <= 128: the encoder's and the
+// decoder's self-attention).  Nothing leaves the workgroup here -- every query of the (sequence, head) is in it and so is every key --
+// so S, the exponentials and dP are computed ONCE: 5 MFMA units (S, dP twice, dQ + dK + dV counted as 3... see below) instead of the
+// 8 of the dQ kernel followed by the dK/dV kernel, and half the v_exp.
+//   query phase  (wave w = queries 32 w ..): exactly the dQ kernel's body on the staged K / V tiles: scores, p, delta, dS, dQ += dS K.
+//                P' = p / l goes to LDS as bf16, transposed into a [key][query] image X (row = key, 264 bytes: the 32 lanes of a
+//                read then cover all 64 banks); dS stays packed in registers (32 VGPRs).
+//   key phase    (wave w = keys 32 w ..): after a barrier the K / V stage is overwritten by the Q and dO tiles (requested into
+//                registers at kernel start), and dV^T += dO^T P' with P' read from X as the MFMA's B operand (8 queries per lane in
+//                the permuted order the transposing A read uses); then X is rewritten with dS and dK^T += Q^T dS the same way.
+// LDS: stage 33 KB + X / output staging 34 KB = 67 KB: two workgroups per CU, as the two kernels it replaces.
+// Causal: wave w's P' exists for key blocks <= w and key block w reads query blocks >= w only.  grid = (H, sequences).
+// ---------------------------------------------------------------------------------------------
+template <int NKB, bool CAUSAL, bool MAPPED>
+__global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_self_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
+                                                                                        bf16_t* __restrict__ dQ, long lddq, int accumulate_dq,
+                                                                                        bf16_t* __restrict__ dK, long lddk, bf16_t* __restrict__ dV, long lddv) {
+    typedef bf16_t T;
+    static_assert(NKB <= 4, "one key block per wave");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32, TQ = 128, QT_TILE = TQ * HD * 2, XROW = 264;
+    typedef TrStage<NKB> Stage;
+    constexpr int XOFF = ((Stage::BYTES > 2 * QT_TILE ? Stage::BYTES : 2 * QT_TILE) + 15) & ~15;
+    const Stage st{smem};
+    char* X = smem + XOFF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FragOff fo = frag_off<T>(lane);
+    const TrOff tro = tr_off(lane);
+    const int h = blockIdx.x, qb = blockIdx.y;                  // qpb == 1: the sequence
+    const bool live_ent = valid_entities(d, qb, -1) != 0;
+    const float c2 = d.scale * LOG2E_F;
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+
+    const int qpos = wave * 32 + (lane & 31);
+    const bool qvalid = qpos < d.T;
+    Frag qf[2], dof[2];
+    {
+        const long qr = phys_row(d.q_rows, (long)qb * d.T + qpos, qvalid);
+        const T* qrow = Q + (qr >= 0 ? qr : 0) * d.ldq + h * HD;
+        const T* drow = dO + (qr >= 0 ? qr : 0) * lddo + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            qf[sl] = global_frag<T>(qrow + sl * 32, lane, qr >= 0);
+            dof[sl] = global_frag<T>(drow + sl * 32, lane, qr >= 0);
+        }
+    }
+    pin_frags(qf);
+    pin_frags(dof);
+    f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
+
+    BufTile<TQ> qreg, doreg;                                    // the key phase's A operands: requested now, committed after the query phase
+    {
+        BufTile<SPAD> kreg, vreg;
+        if (MAPPED && d.kv_rows != nullptr) {
+            RowIdx<SPAD> kvidx;
+            kvidx.load(d.kv_rows, (long)qb * d.S, d.S, tid);
+            kreg.load_mapped(K + h * HD, d.ldk, kvidx, tid);
+            vreg.load_mapped(V + h * HD, d.ldv, kvidx, tid);
+        } else {
+            kreg.load(K + h * HD, d.ldk, (long)qb * d.S, d.S, tid);
+            vreg.load(V + h * HD, d.ldv, (long)qb * d.S, d.S, tid);
+        }
+        const uint8_t mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[(long)qb * d.S + tid] : 0);
+        if (MAPPED && d.q_rows != nullptr) {
+            RowIdx<TQ> qidx;
+            qidx.load(d.q_rows, (long)qb * d.T, d.T, tid);
+            qreg.load_mapped(Q + h * HD, d.ldq, qidx, tid);
+            doreg.load_mapped(dO + h * HD, lddo, qidx, tid);
+        } else {
+            qreg.load(Q + h * HD, d.ldq, (long)qb * d.T, d.T, tid);
+            doreg.load(dO + h * HD, lddo, (long)qb * d.T, d.T, tid);
+        }
+        kreg.commit(st.k(), tid);
+        vreg.commit(st.v(), tid);
+        publish_key_mask(st.bias(), st.slots(), mreg, d.S, SPAD, tid);
+    }
+    __syncthreads();
+    int slen, fmask;
+    read_key_mask(st.slots(), slen, fmask);
+
+    // ---- query phase ----
+    bf16x8_t dspk[NKB][2];                                      // dS of this wave's 32 queries, packed as the dQ product's operand
+    int nact_w = 0;
+    if (live_ent) {
+        dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
+            constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
+            nact_w = NACT;
+            f32x16_t p[NKB];
+            float m, l;
+            scores_tr<NKB, NACT, NFAST, CAUSAL>(p, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
+            const float invl = (l > 0.f) ? __builtin_amdgcn_rcpf(l) : 0.f;
+            char* xq = X + qpos * 2;
+#pragma unroll
+            for (int kb = 0; kb < NACT; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    *reinterpret_cast<bf16_t*>(xq + (kb * 32 + acc_row(r, lane)) * XROW) = (bf16_t)(p[kb][r] * invl);
+            typedef float pair_t __attribute__((ext_vector_type(2)));
+            pair_t raw2 = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NACT; ++kb) {
+                f32x16_t dpk = zero_acc();
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    mma_slab<T>(dpk, a, dof[sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) raw2 += pair_t{p[kb][r], p[kb][r + 1]} * pair_t{dpk[r], dpk[r + 1]};
+            }
+            const float dprime = wave_half_sum(raw2.x + raw2.y) * invl * d.scale;          // delta * scale
+            const float ca = invl * d.scale, cb = invl * dprime;
+#pragma unroll
+            for (int kb = 0; kb < NACT; ++kb) {
+                f32x16_t dpk = zero_acc();
+#pragma unroll
+                for (int sl = 0; sl < 2; ++sl) {
+                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    mma_slab<T>(dpk, a, dof[sl]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dpk[r] = p[kb][r] * fmaf(dpk[r], ca, -cb);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dspk[kb][s2] = pack8(dpk, s2);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        mfma16(dqacc[db], tr_frag(st.k() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), dspk[kb][s2]);
+                }
+            }
+        });
+    }
+    __syncthreads();                                            // the K / V tiles are dead; X holds P'
+    qreg.commit(smem, tid);
+    doreg.commit(smem + QT_TILE, tid);
+    __syncthreads();
+
+    // ---- key phase ----
+    const int key = wave * 32 + (lane & 31);
+    bool masked = true;
+    if (wave < NKB && key < d.S) {
+        const long kr = phys_row(d.kv_rows, (long)qb * d.S + key, true);
+        masked = kr < 0 || (d.pad && d.pad[(long)qb * d.S + key]);
+    }
+    const bool alive = live_ent && wave < NKB && __ballot(!masked) != 0;          // wave-uniform
+    const int nqb = (d.T + 31) >> 5;
+    f32x16_t dvacc[2] = {zero_acc(), zero_acc()}, dkacc[2] = {zero_acc(), zero_acc()};
+    const char* xk = X + key * XROW + 8 * (lane >> 5);
+    auto sweep = [&](f32x16_t (&acc)[2], const char* tile) {
+        for (int qq = CAUSAL ? wave : 0; qq < nqb; ++qq) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x2_t lo = *reinterpret_cast<const u32x2_t*>(xk + (qq * 32 + 16 * s2) * 2);
+                const u32x2_t hi = *reinterpret_cast<const u32x2_t*>(xk + (qq * 32 + 16 * s2) * 2 + 16);
+                const u32x4_t w = {lo[0], lo[1], hi[0], hi[1]};
+                const bf16x8_t b = __builtin_bit_cast(bf16x8_t, w);
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+                    mfma16(acc[db], tr_frag(tile + db * (TQ * SLAB_BYTES) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), b);
+            }
+        }
+    };
+    if (alive) sweep(dvacc, smem + QT_TILE);
+    __syncthreads();                                            // every wave has read P': X takes dS
+    {
+        char* xq = X + qpos * 2;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            if (kb < nact_w) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) *reinterpret_cast<bf16_t*>(xq + (kb * 32 + acc_row(r, lane)) * XROW) = dspk[kb][r >> 3][r & 7];
+            }
+    }
+    __syncthreads();
+    if (alive) sweep(dkacc, smem);
+    __syncthreads();                                            // X is read: the output staging takes its place
+    float* stg = reinterpret_cast<float*>(smem + XOFF + wave * OUT_STAGE_BYTES);
+    flush_tile_t(stg, dqacc, dQ + h * HD, lddq, (long)qb * d.T + wave * 32, d.q_rows, d.T - wave * 32, accumulate_dq != 0, lane);
+    if (wave < NKB) {
+        flush_tile_t(stg, dkacc, dK + h * HD, lddk, (long)qb * d.S + wave * 32, d.kv_rows, d.S - wave * 32, false, lane);
+        flush_tile_t(stg, dvacc, dV + h * HD, lddv, (long)qb * d.S + wave * 32, d.kv_rows, d.S - wave * 32, false, lane);
+    }
+}
+
 __global__ void entity_null_kernel(const uint8_t* __restrict__ pad, uint8_t* __restrict__ null_entity, int S) {
     __shared__ int any_live;
     if (threadIdx.x == 0) any_live = 0;
@@ -1855,6 +2043,13 @@ template <typename T> size_t pipe_lds(int nkb, int ntiles) {
 }
 
 // One entity per business shared by its qpb > 1 query blocks (table / image memory of the decoder's cross-attention).
+// Self-attention: one entity per sequence, attended by that sequence's one query block (the merged backward kernel)
+inline bool self_attention(const mmsum_attn_desc& d) { return d.N == 1 && d.qpb == 1 && !d.exclude_self && d.S <= 128 && d.T <= 128; }
+inline size_t self_lds(int nkb) {
+    const size_t stage = (size_t)2 * nkb * 32 * HD * 2 + nkb * 32 * sizeof(float) + 32, tiles = 2 * (size_t)128 * HD * 2;
+    const size_t xoff = ((stage > tiles ? stage : tiles) + 15) & ~(size_t)15, x = (size_t)nkb * 32 * 264;
+    return xoff + (x > 4 * (size_t)OUT_STAGE_BYTES ? x : 4 * (size_t)OUT_STAGE_BYTES);
+}
 inline bool shared_entity(const mmsum_attn_desc& d) { return d.N == 1 && d.qpb > 1 && !d.exclude_self && !d.causal; }
 inline int shared_splits(const mmsum_attn_desc& d) { return d.qpb % 3 == 0 ? 3 : 1; }
 template <typename T> size_t shared_lds(int nkb) { return (size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 32 + 4 * (size_t)OUT_STAGE_BYTES; }
@@ -1910,6 +2105,18 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
                void* dv, long lddv, void* stats, hipStream_t s) {
     const int nkb = nkb_for(d.S);
     if constexpr (sizeof(T) == 2) {
+        if (self_attention(d)) {          // one entity, one query block per entity: one kernel for dQ, dK and dV
+            const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
+            const size_t lds = self_lds(nkb);
+            const bool mapped = d.q_rows != nullptr || d.kv_rows != nullptr;
+#define SELF_CASE(N, C, M) LAUNCH_LDS((attn_tr_bwd_self_kernel<N, C, M>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (T*)dk, lddk, (T*)dv, lddv)
+#define SELF_NKB(N) do { if (d.causal) { if (mapped) SELF_CASE(N, true, true); else SELF_CASE(N, true, false); } \
+                         else { if (mapped) SELF_CASE(N, false, true); else SELF_CASE(N, false, false); } } while (0)
+            if (nkb == 2) SELF_NKB(2); else SELF_NKB(4);
+#undef SELF_NKB
+#undef SELF_CASE
+            return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+        }
         if (shared_entity(d)) {
             const dim3 sgrid(d.H, d.n_qblocks / d.qpb, shared_splits(d)), block(ATT_THREADS);
             const size_t lds = shared_lds<T>(nkb);
