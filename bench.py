@@ -70,10 +70,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None,
-                    help="businesses per GPU per step; default 112 for the training workloads (9*112*128 decoder rows = 504 x 256-row GEMM "
-                         "tiles: 7.9 rounds of the 256 CUs per N=1024 product; ~200 GB of the 288 GB.  Measured on one box: 112 -> 233, "
-                         "56 -> 223 businesses/s, 28 is 4 %% below 56; 8 is BASELINE C4's reference-style batch) and 8 for --workload "
-                         "generate (test.py:176)")
+                    help="businesses per GPU per step; default 128 for the training workloads (9*128*128 decoder rows = 576 x 256-row GEMM "
+                         "tiles: exactly 9 rounds of the 256 CUs per N=1024 product; 228 GB of the 288 GB.  Measured on one box: 128 -> 239.2, "
+                         "112 -> 235.8, 56 -> 225.7 businesses/s, 28 is 4 %% below 56; 8 is BASELINE C4's reference-style batch) and 8 for "
+                         "--workload generate (test.py:176)")
     ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text", "generate"],
                     help="multimodal / text: the training step (BASELINE configs 4 / 2); generate: test.py's beam search (BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -88,7 +88,7 @@ def parse(argv=None):
     ap.add_argument("--master-port", type=int, default=29517)
     args = ap.parse_args(argv)
     if args.batch is None:
-        args.batch = 8 if args.workload == "generate" else 112
+        args.batch = 8 if args.workload == "generate" else 128
     return args
 
 

@@ -58,7 +58,8 @@ def assert_plan(plan, family, bm=256, bn=256, persistent=None):
 # the step's NT products at the bench batch: (M rows) x (N, K) of qkv / out_proj / fc1 / fc2 / kv projections
 NT_SHAPES = [(64512, 4096, 1024), (64512, 1024, 4096), (64512, 3072, 1024), (64512, 1024, 1024), (38912, 4096, 1024),
              (38912, 1024, 4096), (38912, 3072, 1024), (38912, 1024, 1024), (38912, 2048, 1024), (64512, 2048, 2048),
-             (129024, 4096, 1024), (129024, 1024, 4096), (129024, 3072, 1024), (129024, 1024, 1024), (76288, 4096, 1024), (76288, 1024, 1024)]
+             (129024, 4096, 1024), (129024, 1024, 4096), (129024, 3072, 1024), (129024, 1024, 1024), (76288, 4096, 1024), (76288, 1024, 1024),
+             (147456, 4096, 1024), (147456, 1024, 4096), (147456, 1024, 1024), (87296, 3072, 1024)]          # 147,456 rows = the bench batch (B = 128)
 
 
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
@@ -162,7 +163,7 @@ def test_nt_ring_a2_split_and_lm_head():
 TN_CASES = [(64512, 4096, 1024, 4, 256), (64512, 1024, 4096, 4, 256), (38912, 3072, 1024, 5, 256), (64512, 1024, 1024, 16, 256),
             (64512, 3072, 1024, 5, 256), (111048, 2048, 1024, 8, 256), (43904, 256, 2304, 28, 256), (43904, 1024, 256, 32, 128),
             (129024, 4096, 1024, 4, 256), (129024, 1024, 1024, 16, 256), (76288, 3072, 1024, 5, 256), (222096, 2048, 1024, 8, 256),
-            (87808, 1024, 256, 32, 128)]
+            (87808, 1024, 256, 32, 128), (147456, 4096, 1024, 4, 256), (147456, 1024, 1024, 16, 256), (87296, 3072, 1024, 5, 256)]
 
 
 @pytest.mark.parametrize("R,No,Ki,want_sk,bn", TN_CASES)
@@ -198,7 +199,7 @@ def test_live_row_counts_at_bench_sizes():
     their sentinel), rows below it match; one launch geometry (capacity 64,512) serves any count -- including 0 and ragged
     ones that end inside a tile."""
     D, Fd = 1024, 4096
-    for cap, live_n in ((64512, 38907), (64512, 256), (64512, 0), (64512, 64512), (129024, 76301)):
+    for cap, live_n in ((64512, 38907), (64512, 256), (64512, 0), (64512, 64512), (129024, 76301), (147456, 87211)):
         live = torch.tensor([live_n], device=DEV, dtype=torch.int32)
         a = rnd(cap, D, seed=31, std=0.5)
         a[live_n:] = float("nan")
