@@ -37,6 +37,118 @@ PEAK_F32_TFLOPS = 157.3
 NO_DECAY = ('bias', 'bn1.weight', 'bn2.weight', 'bn3.weight', 'layer_norm.weight', 'layernorm_embedding.weight')
 
 
+TELEMETRY_CODE = r"""
+import glob, os, re, subprocess, sys, time
+path = sys.argv[1]
+def cards():
+    out = []
+    for h in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+        p = [os.path.join(h, n) for n in ('power1_average', 'power1_input') if os.path.exists(os.path.join(h, n))]
+        f = os.path.join(h, 'freq1_input')
+        if p and os.path.exists(f):
+            bdf = os.path.basename(os.path.realpath(os.path.join(h, '..', '..')))
+            out.append((bdf, p[0], f, os.path.join(h, 'power1_cap')))
+    return out
+def rd(p):
+    with open(p) as f:
+        return float(f.read().strip())
+src = cards()
+with open(path, 'w') as f:
+    if src:
+        for i, (bdf, p, fr, cap) in enumerate(src):
+            try:
+                c = rd(cap) / 1e6
+            except Exception:
+                c = None
+            f.write('# card %d %s cap %s\n' % (i, bdf, c))
+    else:
+        cap = None
+        try:
+            out = subprocess.run(['rocm-smi', '--showmaxpower'], capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r'Power \(W\): ([\d.]+)', out)
+            cap = float(m.group(1)) if m else None
+        except Exception:
+            pass
+        f.write('# card 0 rocm-smi cap %s\n' % cap)
+    f.flush()
+    while True:
+        try:
+            if src:
+                t = time.time()
+                for i, (bdf, p, fr, cap) in enumerate(src):
+                    f.write('%.3f %d %.1f %.0f\n' % (t, i, rd(p) / 1e6, rd(fr) / 1e6))
+                f.flush()
+                time.sleep(0.05)
+            else:
+                out = subprocess.run(['rocm-smi', '--showpower', '--showclocks'], capture_output=True, text=True, timeout=10).stdout
+                p = re.search(r'Power \(W\): ([\d.]+)', out)
+                c = re.search(r'sclk clock level: \d+: \((\d+)Mhz\)', out)
+                if p and c:
+                    f.write('%.3f 0 %.1f %.0f\n' % (time.time(), float(p.group(1)), float(c.group(1))))
+                    f.flush()
+                time.sleep(0.1)
+        except Exception:
+            time.sleep(0.2)
+"""
+
+
+def start_telemetry():
+    """Socket power and shader clock, sampled by a CHILD process started before this process touches a GPU (read-only: the amdgpu
+    hwmon files of every card the node shows, or rocm-smi where they are absent).  Returns (process, sample file) or (None, None)."""
+    import tempfile
+    try:
+        fd, path = tempfile.mkstemp(prefix="mmsum_telemetry_", suffix=".txt")
+        os.close(fd)
+        proc = subprocess.Popen([sys.executable, "-c", TELEMETRY_CODE, path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        return proc, path
+    except Exception:
+        return None, None
+
+
+def read_telemetry(proc, path, t0, t1, bdf=None):
+    """Mean / extreme power and clock of the samples taken inside [t0, t1] (the timed region; wall clock) on the card whose PCI address
+    is `bdf` (this process's device; the node may show other GPUs, idle or busy with somebody else's work).  Without a match: the
+    card that drew the most power inside the window, and the line says so."""
+    if proc is None:
+        return None
+    try:
+        proc.terminate()
+        proc.wait(timeout=5)
+    except Exception:
+        pass
+    try:
+        with open(path) as f:
+            lines = f.read().splitlines()
+        os.unlink(path)
+        cards = {}
+        for ln in lines:
+            if ln.startswith("# card"):
+                _, _, idx, name, _, cap = ln.split()
+                cards[int(idx)] = (name, None if cap == "None" else float(cap))
+        rows = [tuple(float(x) for x in ln.split()) for ln in lines if ln and not ln.startswith("#")]
+        mine = [r for r in rows if t0 <= r[0] <= t1]
+        if not mine:
+            return {"samples": 0, "cards": len(cards), "note": "no sample fell inside the timed region"}
+        pick, how = None, "pci address of the process's device"
+        if bdf is not None:
+            pick = next((i for i, (name, _) in cards.items() if name.lower() == bdf.lower()), None)
+        if pick is None:
+            means = {}
+            for r in mine:
+                means.setdefault(int(r[1]), []).append(r[2])
+            pick = max(means, key=lambda i: sum(means[i]) / len(means[i]))
+            how = "the card with the highest mean power inside the window (no PCI address match)" if len(cards) > 1 else "the only card shown"
+        sel = [r for r in mine if int(r[1]) == pick]
+        pw, ck = [r[2] for r in sel], [r[3] for r in sel]
+        name, cap = cards.get(pick, (None, None))
+        return {"power_w_mean": sum(pw) / len(pw), "power_w_max": max(pw), "sclk_mhz_mean": sum(ck) / len(ck), "sclk_mhz_min": min(ck),
+                "sclk_mhz_max": max(ck), "power_cap_w": cap, "samples": len(sel), "card": name, "cards_shown": len(cards), "selected_by": how,
+                "window": "the timed region (barrier to barrier), sampled by a child process started before the first GPU call"}
+    except Exception as exc:
+        return {"samples": 0, "error": repr(exc)[:200]}
+
+
 def flops_per_business(D, F, V, L_enc, L_dec, NR, S, T, I, P=196, Ft=47, multimodal=True, with_resnet=True, enc_rows=None,
                        mem_rows=None):
     """Algorithmic FLOPs (2*MAC) of ONE training step for ONE business, de-duplicated count of
@@ -74,8 +186,9 @@ def parse(argv=None):
                          "tiles: exactly 9 rounds of the 256 CUs per N=1024 product; 228 GB of the 288 GB.  Measured on one box: 128 -> 239.2, "
                          "112 -> 235.8, 56 -> 225.7 businesses/s, 28 is 4 %% below 56; 8 is BASELINE C4's reference-style batch) and 8 for "
                          "--workload generate (test.py:176)")
-    ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text", "generate"],
-                    help="multimodal / text: the training step (BASELINE configs 4 / 2); generate: test.py's beam search (BASELINE config 5)")
+    ap.add_argument("--workload", default="multimodal", choices=["multimodal", "text", "text_table", "generate"],
+                    help="multimodal / text / text_table: the training step (BASELINE configs 4 / 2 / 3: text + table, one all-zero image slot per "
+                         "business with img_mask False everywhere, multimodal_train.py:165-193); generate: test.py's beam search (BASELINE config 5)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true")
@@ -85,6 +198,9 @@ def parse(argv=None):
     ap.add_argument("--ddp-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
     ap.add_argument("--no-also", action="store_true", help="skip the extra configurations (text-only step, batch 8, generation)")
+    ap.add_argument("--diag-stub-resnet", action="store_true",
+                    help="DIAGNOSTIC (the line is marked invalid): the image encoder's forward / backward are replaced by a zero fill, to "
+                         "measure how much of the step's wall time the ResNet branch is responsible for")
     ap.add_argument("--master-port", type=int, default=29517)
     args = ap.parse_args(argv)
     if args.batch is None:
@@ -117,11 +233,19 @@ def build(args, device):
     import multimodalsum_amd as mm
     cfg = mm.BartConfig.from_json_file(os.path.join(ROOT, "cfg", "bart-large.json"))
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if args.workload == "multimodal":
+    if args.workload in ("multimodal", "text_table"):
         model = mm.MultimodalSum(config=cfg, label_smoothing=0.1, device=device, dtype=dtype)
     else:
         model = mm.TextSupervised(config=cfg, label_smoothing=None, device=device, dtype=dtype)
     model.train()
+    if getattr(args, "diag_stub_resnet", False) and args.workload in ("multimodal", "text_table"):
+        e = model._engine
+
+        def img_fwd(img, out=None):
+            y = out if out is not None else e.empty(img.shape[0] * 196, cfg.d_model)
+            y.zero_()
+            return y, None
+        e.img_fwd, e.img_bwd = img_fwd, (lambda c, dy: None)
     return cfg, model
 
 
@@ -129,7 +253,10 @@ def batch_source(args, cfg, device, rank):
     """A callable returning the next step's inputs (device tensors)."""
     from multimodalsum_amd import synthetic as syn
     multimodal = args.workload == "multimodal"
-    I, hw = (4, 224) if multimodal else (1, 8)
+    I, hw = (4, 224) if multimodal else ((1, 224) if args.workload == "text_table" else (1, 8))
+    if args.workload == "text_table":      # BASELINE config 3: the reference cannot run with I = 0 (multimodal_train.py:189), so one zero image, masked out
+        gen = syn.DeviceBatches(args.batch, 9, 128, 1, cfg.vocab_size, device, seed=1234 + rank, img_hw=224, no_images=True)
+        return gen.next
     if args.fixed_batches:
         fixed = [syn.batch_to(syn.yelp_batch(args.batch, 9, 128, I, cfg.vocab_size, seed=1234 + 1000 * rank + i, img_hw=hw), device)
                  for i in range(2)]
@@ -145,7 +272,7 @@ def batch_source(args, cfg, device, rank):
 
 def run_step(args, model, opt, sch, b):
     from multimodalsum_amd import optim
-    if args.workload == "multimodal":
+    if args.workload in ("multimodal", "text_table"):
         loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
     else:
         loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0]
@@ -226,16 +353,23 @@ def probe_step_kernels(args, model, runner, opt, sch, b, cfg):
         else:
             del e._side_stream
     fam = {k: {"launches": 0, "ms": 0.0, "flops": 0.0} for k in ("gemm_nt", "gemm_tn", "attention")}
+    shapes = {"gemm_nt": {}, "gemm_tn": {}}          # per launch shape [M, N, K] as called (row CAPACITY; live rows go into the FLOPs)
     dec, enc = [], []
     for e0, e1, M, N, K, tn, live, dominant in gemms:
         ms = e0.elapsed_time(e1)
+        cap = (M, N, K)
         lv = int(live.item()) if live is not None else None
         if lv is not None:
             M, K = (M, min(K, lv)) if tn else (min(M, lv), K)
-        f = fam["gemm_tn" if tn else "gemm_nt"]
+        name = "gemm_tn" if tn else "gemm_nt"
+        f = fam[name]
         f["launches"] += 1
         f["ms"] += ms
         f["flops"] += 2.0 * M * N * K
+        sh = shapes[name].setdefault(cap + (lv is not None,), [0, 0.0, 0.0])
+        sh[0] += 1
+        sh[1] += ms
+        sh[2] += 2.0 * M * N * K
         if dominant:
             (dec if lv is None else enc).append((ms, M))
     for e0, e1, fl in attns:
@@ -244,6 +378,10 @@ def probe_step_kernels(args, model, runner, opt, sch, b, cfg):
         f["ms"] += e0.elapsed_time(e1)
         f["flops"] += fl
     fam["gemm"] = {k: fam["gemm_nt"][k] + fam["gemm_tn"][k] for k in ("launches", "ms", "flops")}
+    for name, table in shapes.items():        # the ten shapes that take the most time, per family
+        rows = sorted(table.items(), key=lambda kv: -kv[1][1])[:10]
+        fam[name]["by_shape"] = [{"MNK": list(k[:3]), "live_rows": k[3], "launches": v[0], "ms": round(v[1], 3),
+                                  "tflops": round(v[2] / v[1] / 1e9, 1) if v[1] > 0 else None} for k, v in rows]
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
     for f in fam.values():
         f["achieved"] = f["flops"] / f["ms"] / 1e9 if f["ms"] > 0 else None
@@ -438,12 +576,21 @@ def run_generate(model, cfg, device, B, steps, warmup, dtype_name):
     dt = (time.perf_counter() - t0) / steps
     model.train(was_training)
     nsteps = out.shape[1] - 1
+    # algorithmic HBM bytes of ONE decode step: the decoder's weights once (per layer 3 + 1 self-attention, 1 + 1
+    # cross-attention q / out, 2 + 2 alpha / beta, 4 + 4 FFN = 18 D^2; + the tied LM head V D), the cached cross-attention K / V of the
+    # un-expanded memory (B businesses x (8 x 128 + 47 + 4 x 196) rows x 2 D per layer), the self-attention caches of the rows so far
+    # (mean length max_length / 2); bf16 = 2 bytes, f32 = 4
+    es = 2 if dtype_name == "bf16" else 4
+    D, Ld, V = cfg.d_model, cfg.decoder_layers, cfg.vocab_size
+    step_bytes = es * (Ld * 18 * D * D + V * D + Ld * B * (8 * 128 + 47 + 4 * 196) * 2 * D + Ld * B * beams * (max_length // 2) * 2 * D)
+    step_s = dt / max(nsteps, 1)
     return {"metric": "generated summaries/sec (4-beam search, max_length 128) BART-large multimodal", "value": B / dt, "unit": "summaries/s",
             "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype_name, "data": "synthetic Yelp-shaped test batch (seeded), formula-initialised weights",
             "config": {"workload": "test.py beam-search generation (beam=4, max_len=128, no_repeat_ngram_size=3, early_stopping) full multimodal: "
                                    "8 reviews x 128 tok + table + 4 images per business", "per_gpu_batch": B, "num_beams": beams},
-            "decode_steps": nsteps, "ms_per_decode_step": dt * 1e3 / max(nsteps, 1), "tokens_per_s": B * nsteps / dt}
+            "decode_steps": nsteps, "ms_per_decode_step": dt * 1e3 / max(nsteps, 1), "tokens_per_s": B * nsteps / dt,
+            "decode_step_bytes": step_bytes, "decode_hbm_frac": step_bytes / step_s / 8e12}
 
 
 def bench_generate(args):
@@ -472,13 +619,16 @@ def timed_steps(args, model, runner, opt, sch, next_batch, steps, warmup, sync):
         run_step(args, runner, opt, sch, next_batch())
     live_rows = []
     sync()
+    w0 = time.time()
     t0 = time.perf_counter()
     for _ in range(steps):
         b = next_batch()                   # generated on the device inside the timed step
         loss = run_step(args, runner, opt, sch, b)
-        live_rows.append((b["reviews_mask"].sum(), b["img_mask"].sum() if args.workload == "multimodal" else None))   # device scalars, read after the region
+        live_rows.append((b["reviews_mask"].sum(), b["img_mask"].sum() if args.workload in ("multimodal", "text_table") else None))   # device scalars, read after the region
     sync()
-    return time.perf_counter() - t0, loss, live_rows, priming, b
+    dt = time.perf_counter() - t0
+    args.timed_window = (w0, time.time())          # wall-clock bounds of the timed region (the telemetry child's samples are cut to it)
+    return dt, loss, live_rows, priming, b
 
 
 def also_configs(args, cfg, model, device):
@@ -503,8 +653,13 @@ def also_configs(args, cfg, model, device):
         dt, loss, _, _, _ = timed_steps(a, mdl, mdl, opt, sch, batch_source(a, cfg, device, 0), steps, warmup, torch.cuda.synchronize)
         out[name] = {"value": batch * steps / dt, "unit": "businesses/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                      "per_gpu_batch": batch, "final_loss": float(loss.item()),
-                     "workload": ("multimodal_train.py full step" if workload == "multimodal" else "text_pretrain.py text-only step")
+                     "workload": {"multimodal": "multimodal_train.py full step", "text": "text_pretrain.py text-only step",
+                                  "text_table": "multimodal_train.py text + table step (BASELINE config 3: one all-zero image slot per business, "
+                                                "img_mask False everywhere; the ResNet still runs on it, as in the reference)"}[workload]
                                  + " (fwd+bwd+clip+AdamW), 9 reviews x 128 tok, hip-graph replay"}
+        if workload == "text_table":
+            fpb = flops_per_business(cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, 1)
+            out[name]["step_roofline_frac"] = out[name]["value"] * fpb / 1e12 / PEAK_BF16_TFLOPS
     try:
         if args.batch != 56:
             train_cfg("multimodal_B56", "multimodal", 56, model)     # the batch of rounds 1-2's headline, for continuity
@@ -512,12 +667,34 @@ def also_configs(args, cfg, model, device):
             gc.collect()
             torch.cuda.empty_cache()
         train_cfg("multimodal_B8", "multimodal", 8, model)
+        out["multimodal_B8"]["step_roofline_frac"] = out["multimodal_B8"]["value"] * flops_per_business(
+            cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, 4) / 1e12 / PEAK_BF16_TFLOPS
         g = run_generate(model, cfg, device, 8, 2, 1, args.dtype)
-        out["generate_B8"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "decode_steps", "ms_per_decode_step", "tokens_per_s")}
+        out["generate_B8"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "decode_steps", "ms_per_decode_step", "tokens_per_s",
+                                                "decode_step_bytes", "decode_hbm_frac")}
         out["generate_B8"]["workload"] = g["config"]["workload"]
+        object.__setattr__(model, "_step_graphs", None)
+        gc.collect()
+        torch.cuda.empty_cache()
+        train_cfg("text_table_B%d" % args.batch, "text_table", args.batch, model)     # BASELINE config 3 at the headline batch
     except Exception as exc:                   # the headline number must survive a failure here
         out["error_multimodal"] = repr(exc)[:300]
     return out
+
+
+def also_generate_f32(cfg, device):
+    """BASELINE config 5 in the compute mode whose token ids are held to the oracle's (tests/test_generation_gpu.py): f32 weights and
+    kernels (v_mfma_f32_32x32x2_f32), the same 8 businesses x 4 beams x max_length 128, beside the bf16 line."""
+    import torch
+    import multimodalsum_amd as mm
+    try:
+        mdl = mm.MultimodalSum(config=cfg, label_smoothing=0.1, device=device, dtype=torch.float32, deterministic=True)
+        g = run_generate(mdl, cfg, device, 8, 1, 1, "f32")
+        out = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "decode_steps", "ms_per_decode_step", "tokens_per_s")}
+        out["workload"] = g["config"]["workload"] + " -- f32 compute mode (deterministic kernels): the mode of the id-exact generation tests"
+        return out
+    except Exception as exc:
+        return {"error": repr(exc)[:300]}
 
 
 def also_text_only(args, cfg, device):
@@ -554,6 +731,7 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    tele_proc, tele_path = start_telemetry() if rank == 0 else (None, None)      # a child process, before this one touches a GPU
     # stdout carries the ONE JSON line and nothing else: while the ranks run, file descriptor 1 points at stderr (RCCL writes its
     # library banner to the C stdout at init and at teardown); it is put back for the final print
     saved_stdout = None
@@ -602,8 +780,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(loss.item())
+    telemetry = None
+    if rank == 0:
+        bdf = None
+        try:
+            pr = torch.cuda.get_device_properties(device)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        telemetry = read_telemetry(tele_proc, tele_path, *args.timed_window, bdf=bdf)
     live_rows = [(float(t), float(im) if im is not None else 0.0) for t, im in live_rows]      # the device scalars, now that the region is over
     comm = ddp.comm_stats(skip=stats_skip) if ddp is not None else None
+    if world > 1:                       # every rank: the exchange's two forms on the wrapper's bucket sizes, outside the step
+        try:
+            from multimodalsum_amd.parallel import bus_microbench
+            mb = bus_microbench(device, iters=3)
+            if comm is not None:
+                comm["microbench"] = mb
+                comm["xgmi_links"] = "7 links x ~153 GB/s per GPU (point-to-point)"
+        except Exception as exc:
+            sys.stderr.write("bench.py: bus microbench failed: %r\n" % (exc,))
     graphs = getattr(model, "_step_graphs", None)
     captures = graphs.captures if graphs is not None else 0
     peak_gb = round(torch.cuda.max_memory_reserved() / 2**30, 1)
@@ -633,13 +829,16 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             also["text_only_B%d" % args.batch] = also_text_only(args, cfg, device)
+            gc.collect()
+            torch.cuda.empty_cache()
+            also["generate_B8_f32"] = also_generate_f32(cfg, device)
         except Exception as exc:
             sys.stderr.write("bench.py: extra configurations failed: %r\n" % (exc,))
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
-        multimodal = args.workload == "multimodal"
-        I = 4 if multimodal else 1
+        multimodal = args.workload in ("multimodal", "text_table")
+        I = 4 if args.workload == "multimodal" else 1
         dims = (cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, I)
         fpb = flops_per_business(*dims, multimodal=multimodal)
         text_rows = sum(t for t, _ in live_rows) / len(live_rows) / args.batch
@@ -669,13 +868,18 @@ def main():
                "data": "synthetic Yelp-shaped batches generated on the device inside every timed step (fresh review lengths and image counts "
                        "per step), formula-initialised BART-large/ResNet101 weights" if not args.fixed_batches else
                        "two fixed synthetic Yelp-shaped batches (seeded), formula-initialised BART-large/ResNet101 weights",
-               "config": {"workload": "multimodal_train.py full text+img(4x224^2)+table step (fwd+bwd+clip+AdamW), 9 reviews x 128 tok"
-                          if multimodal else "text_pretrain.py BART-large text-only step, 9 reviews x 128 tok",
+               "config": {"workload": {"multimodal": "multimodal_train.py full text+img(4x224^2)+table step (fwd+bwd+clip+AdamW), 9 reviews x 128 tok",
+                                       "text_table": "multimodal_train.py text+table step (one all-zero image slot per business, img_mask False), 9 reviews x 128 tok",
+                                       "text": "text_pretrain.py BART-large text-only step, 9 reviews x 128 tok"}[args.workload],
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                           "dropout": cfg.dropout},
                "launch": "eager" if args.no_graphs else "hip-graph replay (1 forward graph + 1 graph per backward gradient segment, ONE set for all "
                          "batches: row counts are device-side), %d priming steps before warmup, %d capture(s) in the whole run" % (priming, captures),
                "graph_captures": captures, "final_loss": loss_val, "peak_hbm_gb": peak_gb, "roofline": roof}
+        if telemetry is not None:
+            out["telemetry"] = telemetry
+        if args.diag_stub_resnet:
+            out["diagnostic"] = "INVALID as a benchmark: ResNet forward / backward stubbed (--diag-stub-resnet)"
         if comm is not None:
             out["comm"] = comm
         if also is not None:

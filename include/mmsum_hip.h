@@ -27,7 +27,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define MMSUM_ABI_VERSION 4
+#define MMSUM_ABI_VERSION 5
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -54,6 +54,10 @@ enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_E
 
 #define MMSUM_GEMM_COLSUM2 0x400  /* with COLSUM on the NT path: `bias` holds 2 N floats and bias[N + n] += sum_m C[m][n]^2 as well -- the
                                     BatchNorm statistics of a convolution's output taken in the convolution's own epilogue */
+
+#define MMSUM_GEMM_A_F32   0x800  /* dtype BF16, weight-streaming kernel only (M <= 64, plain epilogue, with OUT_F32): A is f32 (lda in f32
+                                    elements); the kernel multiplies its bf16 hi and lo parts separately, so the product carries 16
+                                    significant bits of A.  The decode step's LM head: final LayerNorm output and logits stay f32 */
 
 int mmsum_abi_version(void);
 /* First 16 hex digits of the SHA-256 over the library's sources (csrc/Makefile: HASH_SRCS): lets the host tell a stale
@@ -127,9 +131,11 @@ int mmsum_rows_gather(const void* src, long src_pitch, int src_rows, void* dst, 
 
 /* K4/K6/K21: y = LN(res + dropout(x))  (modeling_multimodalsum.py:294-297,305-308,458-461,474-477,486-489;
  * apex FusedLayerNorm :972-980). */
+/* y_f32 (may be NULL): the same result as un-rounded f32 [R, D] beside y (bf16 mode: the decode step's last LayerNorm feeds the LM
+ * head in f32). */
 int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,
                      float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, const void* salt,
-                     const int* live_rows, void* stream);
+                     const int* live_rows, float* y_f32, void* stream);
 /* dres <- dz (or += if accumulate_dres), dx <- dz * dropmask/(1-p); dgamma/dbeta += (f32);
  * dxsum (f32 [D], may be NULL) += column sums of dx = the bias gradient of the Linear that produced x (:302,304,885). */
 int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, const void* gamma, const float* mean,

@@ -17,9 +17,9 @@ ERRORS = {-1: "bad shape", -2: "bad dtype", -3: "bad alignment", -4: "workspace 
 
 GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
-GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM, GEMM_COLSUM2 = 0x40, 0x80, 0x100, 0x200, 0x400
+GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM, GEMM_COLSUM2, GEMM_A_F32 = 0x40, 0x80, 0x100, 0x200, 0x400, 0x800
 PLAN_GENERIC, PLAN_NT_RING, PLAN_TN_RING, PLAN_SKINNY = 0, 1, 2, 3
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def gemm_epi(e):
@@ -52,7 +52,7 @@ SIGNATURES = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                    c_int, c_float, c_uint64, c_void_p, c_void_p]),
     "mmsum_add_ln_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                 c_float, c_float, c_uint64, c_void_p, c_void_p, c_void_p]),
+                                 c_float, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmsum_add_ln_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_int, c_int, c_float, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmsum_entity_null": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -179,6 +179,11 @@ static int gemm_check(int dtype, const void* A, long lda, const void* A2, long l
     if ((flags & MMSUM_GEMM_SLABS) && (flags & (MMSUM_GEMM_ACCUM | MMSUM_GEMM_BIAS))) return MMSUM_ERR_BAD_SHAPE;
     const size_t es = (dtype == MMSUM_BF16) ? 2 : 4;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)A2) & 15) return MMSUM_ERR_BAD_ALIGN;
+    if (flags & MMSUM_GEMM_A_F32) {        // f32 A beside bf16 weights: the weight-streaming kernel only (checked again by the caller)
+        if (dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
+        if (at || A2 || (K % 8)) return MMSUM_ERR_BAD_SHAPE;
+        if ((lda * 4) & 15) return MMSUM_ERR_BAD_ALIGN;
+    } else
     if (!at && ((lda * es) & 15)) return MMSUM_ERR_BAD_ALIGN;
     if (!bt && ((ldb * es) & 15)) return MMSUM_ERR_BAD_ALIGN;
     if (at && ((lda * es) & (es == 2 ? 7 : 15))) return MMSUM_ERR_BAD_ALIGN;
@@ -205,6 +210,7 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk, live_rows, alpha_dev};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (gemm_skinny_eligible(dtype, a)) return launch_gemm_skinny(a, s);
+    if (flags & MMSUM_GEMM_A_F32) return MMSUM_ERR_BAD_DTYPE;          // no other kernel reads an f32 A beside bf16 weights
     if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
     if (gemm_tn_eligible(dtype, a)) return launch_gemm_tn(a, s);
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
@@ -221,6 +227,7 @@ extern "C" int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A
     GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, live_rows, alpha_dev};
     GemmPlan g;
     if (gemm_skinny_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 32, (a.N + 31) / 32};
+    else if (flags & MMSUM_GEMM_A_F32) return MMSUM_ERR_BAD_DTYPE;
     else if (gemm_glds_eligible(dtype, a)) g = plan_gemm_glds(a);
     else if (gemm_tn_eligible(dtype, a)) g = plan_gemm_tn(a);
     else g = GemmPlan{MMSUM_PLAN_GENERIC, BM, BN, ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * a.splitk};

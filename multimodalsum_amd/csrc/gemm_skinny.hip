@@ -14,7 +14,28 @@ namespace {
 // longer reduction or more than 32 rows take eight waves (K = 4096: two batches of 8 slabs per wave instead of four; 96 rows: a third of
 // the fragment loads and MFMAs per wave).  The partial accumulators of ALL waves meet in LDS and every wave finishes its share of the
 // accumulator registers (sum, bias / GELU, store), instead of one wave adding up seven others.
-template <int MT, int EPI, int NW>
+//
+// AF32 (MMSUM_GEMM_A_F32): x is f32 while W is bf16 -- the LM head of the decode step takes the final LayerNorm's output un-rounded.
+// A lane splits its eight f32 values of a chunk into hi = bf16(x) and lo = bf16(x - hi) and issues the slab's MFMAs twice: the
+// product carries 16 significant bits of x (the weights are the model's bf16 weights either way) and accumulates in f32.
+// CF32 (MMSUM_GEMM_OUT_F32): the result is stored as f32 (decode logits: the quantity that is ranked keeps its f32 accumulator).
+__device__ __forceinline__ void split_hi_lo(const float* src, bool valid, u32x4_t& hi, u32x4_t& lo) {
+    bf16_t h[8], l[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        f32x4_t v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (valid) v = *reinterpret_cast<const f32x4_t*>(src + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            h[4 * q + e] = (bf16_t)v[e];
+            l[4 * q + e] = (bf16_t)(v[e] - (float)h[4 * q + e]);
+        }
+    }
+    __builtin_memcpy(&hi, h, 16);
+    __builtin_memcpy(&lo, l, 16);
+}
+
+template <int MT, int EPI, int NW, bool AF32 = false, bool CF32 = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float (*red)[MT][16][64] = reinterpret_cast<float (*)[MT][16][64]>(smem_raw);      // [NW][MT][16][64]
@@ -41,8 +62,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int m = mt * 32 + ln;
-            const Frag a = global_frag<bf16_t>(Ab + (long)(m < p.M ? m : 0) * lda + k0, lane, m < p.M);
-            mma_slab<bf16_t>(acc[mt], a, b);
+            if constexpr (AF32) {
+                const float* arow = static_cast<const float*>(p.A) + (long)(m < p.M ? m : 0) * p.lda + k0;
+                Frag hi, lo;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) split_hi_lo(arow + lane_chunk<bf16_t>(lane >> 5, i) * 8, m < p.M, hi.c[i], lo.c[i]);
+                mma_slab<bf16_t>(acc[mt], hi, b);
+                mma_slab<bf16_t>(acc[mt], lo, b);
+            } else {
+                const Frag a = global_frag<bf16_t>(Ab + (long)(m < p.M ? m : 0) * lda + k0, lane, m < p.M);
+                mma_slab<bf16_t>(acc[mt], a, b);
+            }
         }
     }
 #pragma unroll
@@ -62,7 +92,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
         v = v * p.alpha + bv;
         if constexpr (EPI == MMSUM_EPI_GELU) v = gelu_fast_f(v);
         const int m = mt * 32 + acc_row(r, lane);
-        if (col_ok && m < p.M) C[(long)m * p.ldc + nrow] = (bf16_t)v;
+        if (col_ok && m < p.M) {
+            if constexpr (CF32) static_cast<float*>(p.C)[(long)m * p.ldc + nrow] = v;
+            else C[(long)m * p.ldc + nrow] = (bf16_t)v;
+        }
     }
 }
 
@@ -126,21 +159,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs p) {
 
 bool gemm_skinny_eligible(int dtype, const GemmArgs& a) {
     if (dtype != MMSUM_BF16 || a.M > 128 || a.splitk != 1 || a.live != nullptr || a.alpha_dev != nullptr) return false;
-    if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_ACCUM | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_SLABS | MMSUM_GEMM_COLSUM)) return false;
+    if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_ACCUM | MMSUM_GEMM_SLABS | MMSUM_GEMM_COLSUM)) return false;
     const int epi = (a.flags >> 3) & 7;
     if (!(epi == MMSUM_EPI_NONE || (epi == MMSUM_EPI_GELU && a.aux == nullptr))) return false;
+    // f32 result / f32 x: the decode LM head only (32-column workgroups, plain epilogue, one operand tensor)
+    if ((a.flags & (MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_A_F32)) && (epi != MMSUM_EPI_NONE || a.A2 != nullptr || a.M > 64)) return false;
+    if ((a.flags & MMSUM_GEMM_A_F32) && !(a.flags & MMSUM_GEMM_OUT_F32)) return false;
     if (a.K % 128 || (a.A2 && a.ksplit % 32)) return false;
     if (a.N < 256) return false;                 // tiny outputs: nothing to gain
     return true;
 }
 
-template <int MT, int EPI, int NW>
+template <int MT, int EPI, int NW, bool AF32 = false, bool CF32 = false>
 int launch_skinny_one(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = (size_t)NW * MT * 16 * 64 * sizeof(float);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<MT, EPI, NW>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_skinny_kernel<MT, EPI, NW, AF32, CF32>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
-    gemm_skinny_kernel<MT, EPI, NW><<<dim3((a.N + 31) / 32), dim3(NW * 64), lds, stream>>>(a);
+    gemm_skinny_kernel<MT, EPI, NW, AF32, CF32><<<dim3((a.N + 31) / 32), dim3(NW * 64), lds, stream>>>(a);
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
@@ -153,6 +189,11 @@ int launch_skinny16_one(const GemmArgs& a, hipStream_t stream) {
 
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     const int epi = (a.flags >> 3) & 7;
+    if (a.flags & MMSUM_GEMM_OUT_F32) {                        // decode logits (eligibility: plain epilogue, M <= 64)
+        const bool af = a.flags & MMSUM_GEMM_A_F32;
+        if (a.M <= 32) return af ? launch_skinny_one<1, MMSUM_EPI_NONE, 4, true, true>(a, stream) : launch_skinny_one<1, MMSUM_EPI_NONE, 4, false, true>(a, stream);
+        return af ? launch_skinny_one<2, MMSUM_EPI_NONE, 8, true, true>(a, stream) : launch_skinny_one<2, MMSUM_EPI_NONE, 8, false, true>(a, stream);
+    }
     if (a.N <= 4096 && a.M <= 96 && a.K % 256 == 0) {          // 16-column workgroups: more CUs on the weight stream
         const bool w8 = a.K >= 2048 || a.M > 32;
 #define SK16(MB)                                                                                                          \

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
                                                          T* __restrict__ y, float* __restrict__ mean_out,
                                                          float* __restrict__ rstd_out, int R, int D, float eps,
                                                          float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
-                                                         const int* __restrict__ live) {
+                                                         const int* __restrict__ live, float* __restrict__ y32) {
     seed = salted_seed(seed, salt);
     R = live_rows_of(R, live);
     const int lane = threadIdx.x & 63;
@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = (z[i][j] - mean) * rstd * g[j] + b[j];
             store4<T>(y + (long)row * D + c, o);
+            if (y32 != nullptr) store4<float>(y32 + (long)row * D + c, o);
         }
         if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
     }
@@ -740,12 +741,12 @@ int dispatch_vpl(int D, F&& f) {
 
 template <typename T>
 int add_ln_fwd_t(const void* x, const void* res, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int R,
-                 int D, float eps, float p_drop, uint64_t seed, const uint64_t* salt, const int* live, hipStream_t s) {
+                 int D, float eps, float p_drop, uint64_t seed, const uint64_t* salt, const int* live, float* y32, hipStream_t s) {
     const int grid = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
     return dispatch_vpl(D, [&](auto vpl) {
         constexpr int VPL = decltype(vpl)::value;
         add_ln_fwd_kernel<T, VPL><<<dim3(grid), dim3(256), 0, s>>>((const T*)x, (const T*)res, (const float*)gamma, (const float*)beta,
-                                                                  (T*)y, mean, rstd, R, D, eps, p_drop, seed, salt, live);
+                                                                  (T*)y, mean, rstd, R, D, eps, p_drop, seed, salt, live, y32);
     });
 }
 template <typename T>
@@ -793,12 +794,12 @@ extern "C" int mmsum_abi_version(void) { return MMSUM_ABI_VERSION; }
 
 extern "C" int mmsum_add_ln_fwd(int dtype, const void* x, const void* res, const void* gamma, const void* beta, void* y,
                                 float* mean, float* rstd, int R, int D, float eps, float p_drop, uint64_t seed, const void* salt,
-                                const int* live_rows, void* stream) {
+                                const int* live_rows, float* y_f32, void* stream) {
     if (R <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const uint64_t* sp = static_cast<const uint64_t*>(salt);
-    if (dtype == MMSUM_BF16) return add_ln_fwd_t<bf16_t>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, sp, live_rows, s);
-    if (dtype == MMSUM_F32) return add_ln_fwd_t<float>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, sp, live_rows, s);
+    if (dtype == MMSUM_BF16) return add_ln_fwd_t<bf16_t>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, sp, live_rows, y_f32, s);
+    if (dtype == MMSUM_F32) return add_ln_fwd_t<float>(x, res, gamma, beta, y, mean, rstd, R, D, eps, p_drop, seed, sp, live_rows, y_f32, s);
     return MMSUM_ERR_BAD_DTYPE;
 }
 

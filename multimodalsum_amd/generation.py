@@ -123,7 +123,11 @@ class DecodeSession:
         self.d_int = torch.zeros(R * (2 + self.nban), dtype=torch.int32, device=dev)
         self.beam_scores = torch.zeros(R, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(R, 1, dtype=torch.long, device=dev)
-        self.logits = e.empty(R, e.Vpad)
+        # the quantity that is ranked stays f32 in either compute mode: f32 logits [rows, Vpad] (6 MB), and in bf16 mode the last
+        # LayerNorm also leaves its un-rounded f32 result for the LM head (mmsum_gemm's MMSUM_GEMM_A_F32 form: bf16 weights, the
+        # f32 activations multiplied as bf16 hi + lo parts, f32 accumulation and f32 store)
+        self.logits = e.empty(R, e.Vpad, dtype=torch.float32)
+        self.x32 = e.empty(R, D, dtype=torch.float32) if e.dtype == torch.bfloat16 else None
         K = 2 * num_beams
         self.out_scores = torch.zeros(layout.B, K, dtype=torch.float32, device=dev)
         self.out_ids = torch.zeros(layout.B, K, dtype=torch.int64, device=dev)
@@ -255,11 +259,12 @@ class DecodeSession:
             f = e.empty(R, D)
             kn.gemm(h, a.w(lb + "fc2.weight"), f, bias=a.f32(lb + "fc2.bias"))
             y = e.empty(R, D)
+            last = i == cfg.decoder_layers - 1
             kn.add_ln_fwd(f, x, a.f32(lb + "final_layer_norm.weight"), a.f32(lb + "final_layer_norm.bias"), y, self.mean, self.rstd, 1e-5,
-                          0.0, 0)
+                          0.0, 0, y_f32=self.x32 if last else None)
             x = y
         V = cfg.vocab_size
-        kn.gemm(x, a.w(e.bp + "model.shared.weight"), self.logits[:, :V],
+        kn.gemm(self.x32 if self.x32 is not None else x, a.w(e.bp + "model.shared.weight"), self.logits[:, :V],
                 bias=e.buffers[e.bp + "final_logits_bias"].reshape(-1))                                      # :2281
         # ---- tail: forced BOS / EOS, log-softmax, min-length and n-gram bans, + beam scores, top 2*beams per business
         cur_len = t + 1

@@ -64,8 +64,9 @@ def _live(t):
 
 
 def _gemm_args(a, b, out_rows, out_cols, a_t, b_t, bias, epi, aux, accumulate, a2, splitk, slabs, colsum, out_f32, colsum_sq=False):
-    dt = _dt(a)
-    assert _dt(b) == dt
+    dt = _dt(b)
+    a_f32 = a.dtype == torch.float32 and dt == BF16       # f32 x beside bf16 weights: the decode LM head (MMSUM_GEMM_A_F32)
+    assert a_f32 or _dt(a) == dt
     M, K = (a.shape[1], a.shape[0]) if a_t else (a.shape[0], a.shape[1])
     N, Kb = (b.shape[1], b.shape[0]) if b_t else (b.shape[0], b.shape[1])
     ksplit = 0
@@ -85,6 +86,9 @@ def _gemm_args(a, b, out_rows, out_cols, a_t, b_t, bias, epi, aux, accumulate, a
         bias = colsum
     if out_f32:
         flags |= _lib.GEMM_OUT_F32
+    if a_f32:
+        assert out_f32 and not a_t and a2 is None
+        flags |= _lib.GEMM_A_F32
     if bias is not None:
         assert bias.dtype == torch.float32
     return dt, M, N, K, ksplit, flags, bias
@@ -159,10 +163,13 @@ def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, dr
                                  p_drop, seed, _p(salt), _stream()), "mmsum_embed_ln_bwd")
 
 
-def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None, live=None):
+def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None, live=None, y_f32=None):
+    """y_f32 (f32 [R, D], optional): the same result un-rounded, beside y (the decode step's last LayerNorm in bf16 mode)."""
     R, D = x.shape
+    if y_f32 is not None:
+        assert y_f32.dtype == torch.float32 and y_f32.shape == (R, D) and y_f32.is_contiguous()
     check(lib.mmsum_add_ln_fwd(_dt(x), _p(x), _p(res), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), R, D, eps, p_drop, seed,
-                               _p(salt), _live(live), _stream()), "mmsum_add_ln_fwd")
+                               _p(salt), _live(live), _p(y_f32), _stream()), "mmsum_add_ln_fwd")
 
 
 def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None, salt=None, live=None):

@@ -925,11 +925,15 @@ def init_formula(module, std=0.02, prefix=None):
     e = module._engine
     pre = prefix
     names = {n: e.arena.shapes[n] for n in e.arena.params}
+    # the closed form is integer hashing + f64 arithmetic: evaluated ON THE DEVICE it gives bit-identical values (exact integer ops,
+    # IEEE f64 multiply / add) in milliseconds -- on the host it is ~50 s for the 505 M parameters, and `bench.py --gpus 8` would run
+    # it eight times on the node's cores although rank 0 broadcasts its parameters anyway
+    dev = e.device
     if pre is not None:
-        sd = formula_state_dict({pre + n[len(e.bp):] if n.startswith(e.bp) else n: s for n, s in names.items()}, std=std)
+        sd = formula_state_dict({pre + n[len(e.bp):] if n.startswith(e.bp) else n: s for n, s in names.items()}, std=std, device=dev)
         sd = {(e.bp + k[len(pre):]) if k.startswith(pre) else k: v for k, v in sd.items()}
     else:
-        sd = formula_state_dict(names, std=std)
+        sd = formula_state_dict(names, std=std, device=dev)
     with torch.no_grad():
         for n, v in sd.items():
             e.arena.params[n].copy_(v.to(e.device))

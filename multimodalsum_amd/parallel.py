@@ -62,6 +62,15 @@ class DistributedDataParallel(nn.Module):
         self.stats = collections.deque(maxlen=max(1, int(stats_window)))     # the last steps only: (bucket events, bytes, end events); comm_stats() reads them
         self._events, self._bytes = [], 0
         self._done = set()
+        # persistent staging (collectives of one rank run in order on ONE stream, so one buffer serves every bucket): the bucket in
+        # the wire dtype when that is not the arena's f32, and this rank's shard between the two phases of reduce_scatter mode
+        self._wire = None
+        if grad_dtype is not None and grad_dtype != self.arena.grad.dtype:
+            self._wire = torch.empty(self.bucket_elems, dtype=grad_dtype, device=self.arena.grad.device)
+        self._shard = None
+        if mode == "reduce_scatter":
+            self._shard = torch.empty(-(-self.bucket_elems // max(1, self.world_size)), dtype=grad_dtype or self.arena.grad.dtype,
+                                      device=self.arena.grad.device)
         if self.world_size > 1 or (always_reduce and dist.is_initialized()):      # always_reduce: exercise the path at world size 1
             dist.broadcast(self.arena.data, 0, group=self.group)          # C2: parameters from rank 0
             for b in self.engine.buffers.values():
@@ -79,17 +88,20 @@ class DistributedDataParallel(nn.Module):
     # ---- gradient all-reduce ----------------------------------------------------------------------
     def _all_reduce_mean(self, chunk):
         buf = chunk
-        if self.grad_dtype is not None and self.grad_dtype != chunk.dtype:
-            buf = chunk.to(self.grad_dtype)
+        if self._wire is not None:
+            buf = self._wire[:chunk.numel()]
+            buf.copy_(chunk)                     # f32 -> wire dtype into the persistent staging buffer (no allocation per bucket)
         op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
         W = self.world_size
         n = (buf.numel() // W) * W if self.mode == "reduce_scatter" else 0
         if n:
-            # the bucket as W equal shards: this rank reduces shard `rank`, then every rank gathers all of them (in place)
+            # the bucket as W equal shards: this rank reduces shard `rank` into the persistent shard buffer, then every rank gathers
+            # all of them back into the bucket.  (An in-place all-gather whose input aliases its own slice of the output is legal on
+            # RCCL but not on every backend this class runs on -- gloo in the CPU tests --, and the copy it saves is 1/W of a bucket.)
             head = buf[:n]
-            shard = head.view(W, n // W)[dist.get_rank(self.group)]
+            shard = self._shard[:n // W]
             dist.reduce_scatter_tensor(shard, head, op=op, group=self.group)
-            dist.all_gather_into_tensor(head, shard.clone(), group=self.group)
+            dist.all_gather_into_tensor(head, shard, group=self.group)
         if n < buf.numel():                       # all_reduce mode, or the few elements a bucket has beyond a multiple of W
             dist.all_reduce(buf[n:], op=op, group=self.group)
         if not self.native_avg:
@@ -132,7 +144,12 @@ class DistributedDataParallel(nn.Module):
         rest = [p for n, p in self.arena.params.items() if p.grad is not None and n not in self._done]
         if rest:
             self._done.update(p._mmsum_name for p in rest)
-            self._reduce_ranges(_ranges(self.arena, rest))
+            if self.overlap:          # on the communication stream like every other bucket: the staging buffers are ordered by that ONE stream
+                self.comm_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.comm_stream):
+                    self._reduce_ranges(_ranges(self.arena, rest))
+            else:
+                self._reduce_ranges(_ranges(self.arena, rest))
         if self.overlap:
             if self.collect_stats:
                 bwd_done = torch.cuda.Event(enable_timing=True)
@@ -160,3 +177,47 @@ class DistributedDataParallel(nn.Module):
         return {"allreduce_ms": comm, "exposed_ms": exposed, "overlap_frac": (1.0 - exposed / comm) if comm > 0 else None,
                 "bytes_per_step": nbytes, "bus_gb_s": bus, "buckets_per_step": sum(len(ev) for ev, _, _, _ in steps) / len(steps),
                 "grad_dtype": str(self.grad_dtype or torch.float32), "mode": self.mode}
+
+
+def bus_microbench(device, sizes_elems=(64 * 1024 * 1024, 16 * 1024 * 1024), dtypes=(torch.float32, torch.bfloat16), iters=5, group=None):
+    """Times the two exchange forms of DistributedDataParallel on its own bucket sizes, outside any training step: all_reduce against
+    reduce_scatter + all_gather, f32 and bf16 buckets.  Bus bandwidth = 2 (N-1)/N * bytes / time (what a ring's links carry), to be
+    read against the 7 x ~153 GB/s of xGMI links a MI355X has.  Every rank calls it; returns a list of dicts (identical on all ranks
+    up to timing).  `python bench.py --gpus N` attaches it to the JSON line as comm.microbench; tools/rccl_bus_bench.py prints it."""
+    import time
+    W = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    cuda = torch.device(device).type == "cuda"
+    avg = dist.get_backend(group) == "nccl"
+    op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+    out = []
+    for dt in dtypes:
+        for n in sizes_elems:
+            n = (n // W) * W
+            buf = torch.ones(n, dtype=dt, device=device)
+            shard = torch.empty(n // W, dtype=dt, device=device)
+
+            def ar():
+                dist.all_reduce(buf, op=op, group=group)
+
+            def rs_ag():
+                dist.reduce_scatter_tensor(shard, buf, op=op, group=group)
+                dist.all_gather_into_tensor(buf, shard, group=group)
+            row = {"elements": n, "dtype": str(dt).replace("torch.", ""), "bytes": n * buf.element_size()}
+            for name, fn in (("all_reduce", ar), ("reduce_scatter_all_gather", rs_ag)):
+                fn()
+                if cuda:
+                    torch.cuda.synchronize()
+                dist.barrier(group=group)
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    fn()
+                if cuda:
+                    torch.cuda.synchronize()
+                dt_s = torch.tensor([(time.perf_counter() - t0) / iters], dtype=torch.float64, device=device)
+                dist.all_reduce(dt_s, op=dist.ReduceOp.MAX, group=group)
+                sec = float(dt_s.item())
+                row[name + "_ms"] = sec * 1e3
+                row[name + "_bus_gb_s"] = (2.0 * (W - 1) / W * row["bytes"] / sec / 1e9) if W > 1 else 0.0
+            out.append(row)
+    return out

@@ -116,8 +116,10 @@ class DeviceBatches:
     exercises the device-side live row counts of the fused step).  Same distributions as `yelp_batch`; the values differ
     (device generator), which is irrelevant for a throughput run.  The constant `field` tensor is made once."""
 
-    def __init__(self, B, NR, S, I, vocab, device, seed, img_hw=224):
+    def __init__(self, B, NR, S, I, vocab, device, seed, img_hw=224, no_images=False):
+        """no_images: BASELINE config 3 (text + table): every image slot is zeros and img_mask is False everywhere."""
         self.B, self.NR, self.S, self.I, self.vocab, self.img_hw = B, NR, S, I, vocab, img_hw
+        self.no_images = no_images
         self.device = torch.device(device)
         self.g = torch.Generator(device=self.device)
         self.g.manual_seed(int(seed))
@@ -158,6 +160,8 @@ class DeviceBatches:
         hours = torch.where((self._rand(B, 7) < 0.2).unsqueeze(-1), torch.zeros_like(hours), hours)
         img = torch.randn(B, I, 3, self.img_hw, self.img_hw, generator=self.g, device=dev)
         n_valid = torch.randint(0, I + 1, (B,), generator=self.g, device=dev)
+        if self.no_images:
+            n_valid = torch.zeros_like(n_valid)
         img_mask = torch.arange(I, device=dev).unsqueeze(0) < n_valid.unsqueeze(1)
         img = img * img_mask[:, :, None, None, None].float()
         return {"reviews": reviews, "reviews_mask": reviews.ne(PAD).long(), "reviews_rating": rating, "field": self.field,

@@ -95,9 +95,18 @@ def step_scores(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, max
 
 def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max_length, min_length=0,
                 no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.0, decoder_start_token_id=None, prefix="",
-                return_scores=False):
+                return_scores=False, margins=None, guide=None, return_all=False):
     """hiddens/masks: list of [B,N,S,D] / [B,N,S] (multimodal) or single tensors.  Returns LongTensor [B, L] (return_scores: and the
-    best hypothesis' score per business, which the reference does not return; tests check sequence_score against it)."""
+    best hypothesis' score per business, which the reference does not return; tests check sequence_score against it).
+    margins (a list, tests only): receives per decode step the smallest gap between two consecutive candidates among the best
+    2 * num_beams + 1 of any open business -- how far the step's ranking is from a tie (an id-exact comparison with another
+    implementation is only meaningful where this is well above that implementation's rounding).
+    guide (tests only): guide(step, input_ids, beam_scores, cand [B, num_beams * V]) -> (scores [B, 2 * num_beams], ids [B, 2 * num_beams]) or
+    None; when it returns a pair, that pair takes the place of torch.topk's (:2925) for the step.  torch.topk leaves the order of
+    candidates with (nearly) equal scores unspecified; a test that holds another implementation to this search passes a guide that
+    checks the other implementation's choice against `cand` and, where it is a valid top 2 * num_beams up to a stated tolerance,
+    adopts its ORDER with this search's own scores -- every later step then sees the same hypotheses and the final ids must agree.
+    return_all: also return, per business, the finished hypotheses [(score, tokens)] the final choice was made from."""
     pad, bos, eos, V = cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id, cfg.vocab_size
     start = bos if decoder_start_token_id is None else decoder_start_token_id
     first = hiddens[0] if multimodal else hiddens
@@ -116,10 +125,29 @@ def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max
     done = [False] * B
     cur_len = 1
     next_scores = next_tokens = None
+
+    def _scores(ids):
+        # cross-attention K / V of the (fixed) memory: projected once per generate() call like the reference's cache (:804-815)
+        prev, bo.KV_MEMO = bo.KV_MEMO, memo_store
+        try:
+            return step_scores(sd, cfg, ids, hid, msk, rd, multimodal, max_length, min_length, no_repeat_ngram_size, prefix)
+        finally:
+            bo.KV_MEMO = prev
+    memo_store = {}
     while cur_len < max_length:
-        scores = step_scores(sd, cfg, input_ids, hid, msk, rd, multimodal, max_length, min_length, no_repeat_ngram_size, prefix)
+        scores = _scores(input_ids)
         cand = (scores + beam_scores[:, None]).view(B, num_beams * V)
         next_scores, next_tokens = torch.topk(cand, 2 * num_beams, dim=1, largest=True, sorted=True)
+        if guide is not None:
+            g = guide(cur_len - 1, input_ids, beam_scores, cand)
+            if g is not None:
+                next_scores, next_tokens = g
+        if margins is not None:
+            top = torch.topk(cand, 2 * num_beams + 1, dim=1, largest=True, sorted=True)[0]
+            gaps = (top[:, :-1] - top[:, 1:])
+            gaps = torch.where(torch.isfinite(gaps) & (top[:, 1:] > -1e8), gaps, torch.full_like(gaps, float("inf")))   # (dead beams carry -1e9)
+            open_rows = [b for b in range(B) if not done[b]]
+            margins.append(float(gaps[open_rows].min()) if open_rows else float("inf"))
         nxt = []
         for b in range(B):
             if done[b]:
@@ -166,6 +194,8 @@ def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max
                 out[i, lens[i]] = eos
     else:
         out = torch.stack(best).long()
+    if return_all:
+        return out, [[(float(sc), [int(t) for t in toks]) for sc, toks in h.items] for h in hyps]
     return (out, best_scores) if return_scores else out
 
 

@@ -136,7 +136,7 @@ def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, dr
         drvec.add_((dz.view(nseq, T, D) * rating_diff.view(nseq, 1, 1)).sum((0, 1)))
 
 
-def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None, live=None):
+def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None, live=None, y_f32=None):
     if live is not None:
         n = _n(live, x.shape[0])
         assert p_drop == 0, "the emulator's dropout mask is keyed by the full shape"
@@ -147,6 +147,8 @@ def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None,
     mean.copy_(mu)
     rstd.copy_(rs)
     y.copy_((z - mu[:, None]) * rs[:, None] * gamma + beta)
+    if y_f32 is not None:
+        y_f32.copy_((z - mu[:, None]) * rs[:, None] * gamma + beta)
 
 
 def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None, salt=None, live=None):

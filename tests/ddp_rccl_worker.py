@@ -34,6 +34,9 @@ def step(model, b):
 
 def main():
     out_dir, dtype_name, graphs = sys.argv[1], sys.argv[2], sys.argv[3] == "1"
+    mode = sys.argv[4] if len(sys.argv) > 4 else "all_reduce"
+    wire = torch.bfloat16 if (len(sys.argv) > 5 and sys.argv[5] == "bf16") else None
+    bucket = int(sys.argv[6]) if len(sys.argv) > 6 else 1 << 20
     dtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(local)
@@ -45,7 +48,8 @@ def main():
         with torch.no_grad():
             model._engine.arena.data.add_(0.25)
     from multimodalsum_amd.parallel import DistributedDataParallel, reduce_tensor
-    ddp = DistributedDataParallel(model, delay_allreduce=True, always_reduce=True, collect_stats=True, bucket_elems=1 << 20)
+    ddp = DistributedDataParallel(model, delay_allreduce=True, always_reduce=True, collect_stats=True, bucket_elems=bucket, mode=mode,
+                                  grad_dtype=wire)
     if graphs:
         model.enable_step_graphs()
     b = batch(cfg, rank, device)

@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(_lib.lib, s), "libmmsum_hip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_argument_validation_without_gpu():
@@ -34,7 +34,7 @@ def test_argument_validation_without_gpu():
     d = _lib.AttnDesc()
     d.T, d.S, d.N, d.H, d.qpb, d.n_qblocks = 200, 10, 1, 1, 1, 1
     assert lib.mmsum_attn_fwd(_lib.BF16, ctypes.byref(d), None) == -1  # T > 128
-    assert lib.mmsum_add_ln_fwd(_lib.F32, None, None, None, None, None, None, None, 4, 100, 1e-5, 0.0, 0, None, None, None) == -1  # D unsupported
+    assert lib.mmsum_add_ln_fwd(_lib.F32, None, None, None, None, None, None, None, 4, 100, 1e-5, 0.0, 0, None, None, None, None) == -1  # D unsupported
 
 
 def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
@@ -64,6 +64,11 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
     assert p(4096, 1024, 64512, tn, 8)[:3] == (_lib.PLAN_TN_RING, 256, 256)     # fc1 weight gradient, split-K slabs
     assert p(1000, 520, 128)[0] == _lib.PLAN_NT_RING and p(1000, 520, 128)[1:3] == (128, 128)
     assert p(32, 4096, 1024)[0] == _lib.PLAN_SKINNY                              # decode-step rows
+    # the decode LM head: f32 logits, and (bf16 mode) the final LayerNorm's f32 output as the A operand -- weight-streaming kernel only
+    assert p(32, 50265, 1024, _lib.GEMM_OUT_F32, ldb=1024)[0] == _lib.PLAN_SKINNY
+    assert p(32, 50265, 1024, _lib.GEMM_OUT_F32 | _lib.GEMM_A_F32, ldb=1024)[0] == _lib.PLAN_SKINNY
+    assert lib.mmsum_gemm_plan(_lib.BF16, fake, 1024, None, 0, 0, fake, 1024, fake, 4096, None, None, 0, 4096, 4096, 1024,
+                               _lib.GEMM_OUT_F32 | _lib.GEMM_A_F32, 1, None, None, plan) == -2      # no tiled kernel reads an f32 A
     # a live row count or a device-side scale takes the product off the weight-streaming kernel: the plan must say so
     assert p(32, 4096, 1024, live=fake)[0] == _lib.PLAN_NT_RING and p(32, 4096, 1024, alpha_dev=fake)[0] == _lib.PLAN_NT_RING
     assert lib.mmsum_gemm_plan(_lib.F32, fake, 1024, None, 0, 0, fake, 1024, fake, 512, None, None, 0, 512, 512, 1024, 0, 1, None, None, plan) == 0

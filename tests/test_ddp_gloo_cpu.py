@@ -74,6 +74,10 @@ def _worker(rank, world, port, out_dir):
         mean_loss = reduce_tensor(loss.detach().reshape(1), world)
         torch.save({"grad": model._engine.arena.grad.clone(), "data": model._engine.arena.data.clone(), "loss": mean_loss, "segments": seen,
                     "has_grad": [n for n, p in model.named_parameters() if p.grad is not None]}, os.path.join(out_dir, "%s_r%d.pt" % (name, rank)))
+    from multimodalsum_amd.parallel import bus_microbench          # the table bench.py --gpus N attaches as comm.microbench
+    mb = bus_microbench("cpu", sizes_elems=(4099,), dtypes=(torch.float32, torch.bfloat16), iters=1)
+    if rank == 0:
+        torch.save(mb, os.path.join(out_dir, "microbench.pt"))
     dist.destroy_process_group()
 
 
@@ -82,6 +86,8 @@ def test_ddp_two_ranks_gloo(tmp_path):
     that do not divide by the world size included), f32 and bf16 buckets, one and several gradient segments per stack."""
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mb = torch.load(tmp_path / "microbench.pt")
+    assert len(mb) == 2 and all(r["elements"] == 4098 and r["all_reduce_ms"] > 0 and r["reduce_scatter_all_gather_bus_gb_s"] > 0 for r in mb)
     for name, kw, layers, per in CASES:
         r0, r1 = torch.load(tmp_path / ("%s_r0.pt" % name)), torch.load(tmp_path / ("%s_r1.pt" % name))
         assert torch.equal(r0["data"], r1["data"]), "parameters were not broadcast from rank 0"

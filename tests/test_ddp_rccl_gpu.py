@@ -18,19 +18,24 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(n, out_dir, dtype, graphs, port):
+def _launch(n, out_dir, dtype, graphs, port, mode="all_reduce", wire="f32", bucket=1 << 20):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_rccl_worker.py"), str(out_dir), dtype, "1" if graphs else "0"]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "ddp_rccl_worker.py"), str(out_dir), dtype, "1" if graphs else "0",
+           mode, wire, str(bucket)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), PYTHONPATH=ROOT)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, "ranks failed:\n" + r.stdout[-2000:] + "\n" + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("dtype,graphs", [("f32", False), ("bf16", True)])
-def test_ddp_rccl_gradient_mean(tmp_path, dtype, graphs):
+@pytest.mark.parametrize("dtype,graphs,mode,wire,bucket", [
+    ("f32", False, "all_reduce", "f32", 1 << 20), ("bf16", True, "all_reduce", "f32", 1 << 20),
+    # the reduce-scatter + all-gather form through RCCL (ReduceOp.AVG into the persistent shard buffer), with a bucket size that no
+    # world size divides (1,000,003 elements: the remainder goes through all_reduce) and, once, bf16 buckets on the wire
+    ("f32", False, "reduce_scatter", "f32", 1000003), ("bf16", True, "reduce_scatter", "bf16", 1000003)])
+def test_ddp_rccl_gradient_mean(tmp_path, dtype, graphs, mode, wire, bucket):
     n = torch.cuda.device_count()
     assert n >= 1
-    _launch(n, tmp_path, dtype, graphs, 29611 + (1 if graphs else 0))
+    _launch(n, tmp_path, dtype, graphs, 29611 + (1 if graphs else 0) + (2 if mode == "reduce_scatter" else 0), mode, wire, bucket)
     ranks = [torch.load(tmp_path / ("r%d.pt" % r), weights_only=False) for r in range(n)]
     for r in ranks[1:]:
         assert torch.equal(ranks[0]["data"], r["data"]), "parameters were not broadcast from rank 0"
@@ -57,6 +62,8 @@ def test_ddp_rccl_gradient_mean(tmp_path, dtype, graphs):
     ref = sum(grads) / n
     err = (ranks[0]["grad"].double() - ref).abs().max().item()
     tol = (1e-6 + 1e-5 * ref.abs().max().item()) if dtype == "f32" else (1e-5 + 2e-3 * ref.abs().max().item())
+    if wire == "bf16":
+        tol += 2.0 ** -8 * ref.abs().max().item()              # the buckets are rounded to bf16 for the exchange
     assert err <= tol, (err, ref.abs().max().item())
     assert abs(float(ranks[0]["loss"]) - sum(losses) / n) <= 1e-5 + 1e-3 * abs(sum(losses) / n)
 

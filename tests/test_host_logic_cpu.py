@@ -425,6 +425,47 @@ def test_beam_search_host_logic(monkeypatch, case):
         model.generate(*([enc, text_m, table_h, table_m, img_h, img_m] if multimodal else [enc, text_m]), num_beams=1, max_length=5)
 
 
+def test_beam_search_long_run_guided_check(monkeypatch):
+    """A 255-step search (max_length 256: the decode self-attention kernel's limit, four cache positions per lane; bans over 250-token
+    prefixes; the ancestor table's last columns) through the kernel emulator, held to the oracle by tests/gen_check.py's guided
+    search -- the check the GPU generation tests apply at BART-large width.  EOS is banned until length 250 (min_length), so the
+    search cannot end early; 2 beams."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
+    from tests.gen_check import guided_check
+    cfg = tiny_cfg(vocab=400, d=256, ffn=128, layers=1, heads=4, maxpos=300)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
+    model = BartForMultiEncConditionalGeneration(cfg, device="cpu", dtype=torch.float32)
+    model.load_state_dict(sd)
+    model.eval()
+    Bz, N, S = 2, 3, 8
+    ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
+    text_m = ids.ne(1).clone()
+    table_h = formula_tensor("t.table_h", (Bz, 1, 6, cfg.d_model), std=1.0)
+    img_h = formula_tensor("t.img_h", (Bz, 2, 4, cfg.d_model), std=1.0)
+    table_m = torch.ones(Bz, 1, 6, dtype=torch.bool)
+    img_m = torch.ones(Bz, 2, 4, dtype=torch.bool)
+    img_m[1, 1] = False
+    kw = dict(num_beams=2, max_length=256, min_length=250, no_repeat_ngram_size=3, early_stopping=True, length_penalty=1.0)
+    rd = torch.zeros(Bz, 1)
+    trace = []
+    with torch.no_grad():
+        enc = model.model.encoder(input_ids=ids.view(-1, S), attention_mask=ids.view(-1, S).ne(1))[0].view(Bz, N, S, -1)
+        oenc = bo.bart_encoder(sd, ocfg, ids.view(-1, S), ids.view(-1, S).ne(1)).view(Bz, N, S, -1)
+        out = model.generate(enc, text_m, table_h, table_m, img_h, img_m, rating_diff=rd, decoder_start_token_id=cfg.bos_token_id, trace=trace, **kw)
+        assert len(trace) >= 249
+        st = guided_check(out, trace, sd, ocfg, [oenc, table_h, img_h], [text_m, table_m, img_m], rd, True, kw, tie=1e-3, start_token=cfg.bos_token_id)
+    assert st["steps"] == len(trace)
+    # the check has teeth: one wrong candidate score in the trace is refused
+    bad = [dict(t) for t in trace]
+    bad[200]["top_scores"] = bad[200]["top_scores"].copy()
+    bad[200]["top_scores"][0, 0] += 0.5
+    with torch.no_grad(), pytest.raises(AssertionError):
+        guided_check(out, bad, sd, ocfg, [oenc, table_h, img_h], [text_m, table_m, img_m], rd, True, kw, tie=1e-3, start_token=cfg.bos_token_id)
+
+
+
 def test_amazon_table_encoder_module(monkeypatch):
     """AmazonTableEncoder drop-in (table_encoder.py:86-167) through TableSupervised(TableEncoder=AmazonTableEncoder):
     133-position gather, fc/relu/linear, unimodal decoder branch, loss and every gradient against the oracle."""

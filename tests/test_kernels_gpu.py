@@ -404,13 +404,15 @@ def test_attention(dtype, case):
 
 
 @pytest.mark.parametrize("std", [1.0, 0.25], ids=["peaked", "flat"])
-@pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[0] in ("enc_self", "dec_self", "cross_text_full", "cross_img_one_entity")], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", [c for c in ATTN_CASES if c[0] in ("enc_self", "dec_self", "cross_text_full", "cross_img_one_entity", "cross_img")], ids=lambda c: c[0])
 def test_attention_bf16_error_against_the_bf16_yardstick(case, std):
     """How far the bf16 attention kernels are from exact arithmetic, beside ANY bf16 matrix-core attention: the f64 attention of the
     bf16 inputs is the truth; the yardstick is the same algorithm in f32 with both products on bf16 operands (probabilities and
     score gradients rounded, oracle/bart_oracle._QuantMatmul).  Relative L2 error of out / dQ / dK / dV of the HIP kernels must
     stay within 1.5x the yardstick's + 1e-3.  `flat` = small scores (nearly uniform probabilities: dS = P (dP - delta) is then a
-    difference of nearly equal numbers, the regime of a freshly initialised model), `peaked` = unit-variance q, k."""
+    difference of nearly equal numbers, the regime of a freshly initialised model), `peaked` = unit-variance q, k.
+    `cross_img` (several 196-key entities per business) runs the chunked kernels: running softmax over two chunks of keys in the
+    forward, two walks in dQ (attn_tr_fwd_chunk_kernel / attn_tr_bwd_dq_chunk_kernel)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from oracle import bart_oracle as bo
