@@ -92,6 +92,18 @@ int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda
                     const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
                     int splitk, const int* live_rows, const float* alpha_dev, int* plan);
 
+/* The decode step's products (generation.py; modeling_multimodalsum.py:783-792,885,738-739,302-304,2281 at one token per hypothesis):
+ *   out[M <= 96, N] = gelu?(x[M,K] . W[N,K]^T + bias) (+ residual),  bf16 x / W (x f32 with MMSUM_GEMM_A_F32), bf16 or f32 (OUT_F32) out.
+ * The REDUCTION is split over one-wave workgroups ((N / 16) x splitk of them: every CU pulls weights, every load of a slice in
+ * flight at once); a column tile's slices meet through f32 slabs + an arrival ticket in `workspace` and the last arriver adds
+ * them and runs the epilogue (agent-scope release / acquire: correct for any placement).  x2 / ksplit as in mmsum_gemm (K split
+ * over two tensors), K and ksplit multiples of 256.  flags: MMSUM_GEMM_EPI(MMSUM_EPI_GELU), MMSUM_GEMM_OUT_F32, MMSUM_GEMM_A_F32.
+ * workspace: mmsum_dec_gemm_workspace(M, N, K) bytes, ZERO before its first use; the kernel leaves the ticket words zero, so one
+ * workspace serves every product of a stream in turn. */
+long mmsum_dec_gemm_workspace(int M, int N, int K);
+int mmsum_dec_gemm(const void* x, long ldx, const void* x2, long ldx2, int ksplit, const void* W, long ldw, const float* bias,
+                   const void* residual, long ldres, void* out, long ldo, int M, int N, int K, int flags, void* workspace, void* stream);
+
 /* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
 int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
 
@@ -176,11 +188,28 @@ long mmsum_attn_bwd_workspace(const mmsum_attn_desc* d);
 int mmsum_attn_bwd(int dtype, const mmsum_attn_desc* d, const void* dout, long lddo, void* dq, long lddq,
                    int accumulate_dq, void* dk, long lddk, void* dv, long lddv, void* stats, void* stream);
 
+/* The decode step's cross-attention over the CACHED K / V of every modality in one launch (generation.py; reference: the cached branch
+ * of SelfAttention.get_head_output, modeling_multimodalsum.py:794-815,819-869, at one query per hypothesis).  q [B * qpb, H*64] bf16:
+ * the qpb hypotheses of business b are rows b*qpb ..; modality m: k / v [B * N * S rows, pitch ldkv] bf16 (entity (b, n) at row
+ * (b*N + n)*S), pad [B*N*S] uint8 (1 = masked key, filled with -2^16 like the reference) or NULL, null_entity [B*N] uint8 or NULL.
+ * out [nmod * B*qpb, H*64] bf16: row m * B*qpb + r = the entity MEAN of modality m for hypothesis r (null entities dropped, zeros
+ * when all are null).  One workgroup per (entity, head); the mean crosses workgroups through `workspace`
+ * (mmsum_decode_cross_attn_workspace bytes, ZERO before its first use; the kernel leaves its ticket words zero). */
+typedef struct { const void* k; const void* v; const uint8_t* pad; const uint8_t* null_entity; int N, S; } mmsum_xattn_memory;
+long mmsum_decode_cross_attn_workspace(int n_entities, int H, int qpb, int B, int nmod);
+int mmsum_decode_cross_attn(const void* q, long ldq, const mmsum_xattn_memory* mods, int nmod, long ldkv, void* out, long ldo,
+                            int B, int qpb, int H, float scale, void* workspace, void* stream);
+
 /* K13 elementwise part (modeling_multimodalsum.py:732-744): given pre-activations pa, pb,
  * out = yt + relu(tanh(pa))*[!no_table[b]]*ytab + relu(tanh(pb))*[!no_img[b]]*yimg; row r -> b = r / rows_per_b. */
 int mmsum_gate_fwd(int dtype, const void* pa, const void* pb, const void* yt, const void* ytab, const void* yimg,
                    const uint8_t* no_table, const uint8_t* no_img, void* out, int R, int D, int rows_per_b,
                    void* stream);
+/* The decode step's form of the two lines above and the LayerNorm behind them in one launch (generation: nothing saved):
+ * y = LN(res + yt + relu(tanh(pa)) [table] ytab + relu(tanh(pb)) [image] yimg)  (:732-744 then :474-477); D in {256, 512, 768, 1024}. */
+int mmsum_gate_add_ln_fwd(int dtype, const void* pa, const void* pb, const void* yt, const void* ytab, const void* yimg,
+                          const uint8_t* no_table, const uint8_t* no_img, const void* res, const void* gamma, const void* beta,
+                          void* y, int R, int D, int rows_per_b, float eps, void* stream);
 /* Backward of the gate.  sum_dpa / sum_dpb (f32 [D], both or both NULL): += column sums of dpa and of dpb -- the bias
  * gradients of alpha_proj and beta_proj (:738-739), taken while the rows are in registers instead of by two more passes over
  * them (f32 atomics: not bit-reproducible run to run). */
@@ -289,7 +318,7 @@ int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* pr
  * mmsum_beam_topk: the tail of one step on the [rows, V] logits (rows = businesses * num_beams, hypotheses of a business
  * consecutive): forced token (adjust_logits_during_generation :3084-3089: BOS at cur_len 1, EOS at max_length - 1; -1 =
  * none), log_softmax (:2874), then -- AFTER the normalisation, as the reference does -- ban_token (EOS while cur_len <
- * min_length; -1 = none) and the no-repeat-n-gram bans (`banned` [rows, nban] int32, -1 padded, may be NULL), + beam_scores
+ * min_length; -1 = none) and the no-repeat-n-gram bans (`banned` [rows, nban] int32: a row's list is filled from the front and its first -1 ends it; may be NULL), + beam_scores
  * [rows], and the top 2*num_beams of each business's num_beams * V candidates (:2925): out_scores / out_ids
  * [rows / num_beams, 2 * num_beams], best first, id = beam * V + token, ties by lower id.  The banned positions of `logits`
  * are overwritten with -inf.  workspace: mmsum_beam_topk_workspace() bytes (per-chunk statistics and candidates: the logits are

@@ -26,6 +26,10 @@ def gemm_epi(e):
     return e << 3
 
 
+class XattnMemory(ctypes.Structure):
+    _fields_ = [("k", c_void_p), ("v", c_void_p), ("pad", c_void_p), ("null_entity", c_void_p), ("N", c_int), ("S", c_int)]
+
+
 class AttnDesc(ctypes.Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p),
                 ("ldq", c_long), ("ldk", c_long), ("ldv", c_long), ("ldo", c_long),
@@ -43,6 +47,12 @@ SIGNATURES = {
                            c_void_p, c_long, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mmsum_gemm_plan": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                 c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
+    "mmsum_decode_cross_attn_workspace": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "mmsum_decode_cross_attn": (c_int, [c_void_p, c_long, ctypes.POINTER(XattnMemory), c_int, c_long, c_void_p, c_long, c_int, c_int, c_int,
+                                        c_float, c_void_p, c_void_p]),
+    "mmsum_dec_gemm_workspace": (c_long, [c_int, c_int, c_int]),
+    "mmsum_dec_gemm": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long,
+                               c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmsum_slab_reduce": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_long, c_int, c_void_p]),
     "mmsum_colsum_workspace": (c_long, [c_int]),
     "mmsum_colsum": (c_int, [c_int, c_void_p, c_long, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
@@ -62,6 +72,7 @@ SIGNATURES = {
                                c_void_p, c_long, c_void_p, c_void_p]),
     "mmsum_gate_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_int, c_void_p]),
+    "mmsum_gate_add_ln_fwd": (c_int, [c_int] + [c_void_p] * 11 + [c_int, c_int, c_int, c_float, c_void_p]),
     "mmsum_gate_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mmsum_ls_loss": (c_int, [c_int, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p]),

@@ -1604,223 +1604,6 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                  d.T - wave * 32, accumulate_dq != 0, lane);
 }
 
-// dQ of entities of more than 128 keys, in chunks like attn_tr_fwd_chunk_kernel (two workgroups per CU).  dS needs the entity's
-// log-sum-exp and delta before its first key can be finished, so an entity's chunks are walked TWICE:
-//   walk 0: scores against the running maximum, p~ = 2^(t - m), dP^T = V dO^T, running l and raw = sum_k p~ dP (both rescaled when the
-//           maximum moves); at the end lse = m + log2 l and delta' = scale raw / l go to `stats` (the dK/dV kernel reads them);
-//   walk 1: p = 2^(t - lse) directly (no maximum, no sum), dP again, dS^T = p (dP scale - delta') / count, dQ^T += K^T dS^T.
-// Five MFMA products per key block against the four of attn_tr_bwd_dq_kernel (which forms dP twice as well, but S once), and every
-// chunk is staged twice (from L2): the price of two workgroups per CU instead of one.
-// S^T = K Q^T for NACT key blocks and p = 2^(s c2 + bias - lse): probabilities normalised by a KNOWN log-sum-exp (log2 domain).
-template <int NKB, int NACT, int NFAST>
-__device__ __forceinline__ void probs_tr(f32x16_t (&sacc)[NKB], const char* ktile, const Frag* qf, const float* biasf, float c2, float lse,
-                                         int lane, const FragOff& fo) {
-    constexpr int SPAD = NKB * 32;
-    const int h = lane >> 5;
-#pragma unroll
-    for (int kb = 0; kb < NACT; ++kb) {
-        sacc[kb] = zero_acc();
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const Frag a = lds_frag_o(ktile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-            mma_slab<bf16_t>(sacc[kb], a, qf[sl]);
-        }
-    }
-#pragma unroll
-    for (int kb = 0; kb < NACT; ++kb) {
-        if (kb < NFAST) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], c2, -lse));
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(biasf + kb * 32 + 8 * g + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sacc[kb][4 * g + j] = __builtin_amdgcn_exp2f(fmaf(sacc[kb][4 * g + j], c2, bias[j]) - lse);
-            }
-        }
-    }
-}
-
-template <bool KVMAP>
-__global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dq_chunk_kernel(mmsum_attn_desc d, const bf16_t* __restrict__ dO, long lddo,
-                                                                                    bf16_t* __restrict__ dQ, long lddq, int accumulate_dq,
-                                                                                    float* __restrict__ stats) {
-    typedef bf16_t T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NKB = 4, SPAD = NKB * 32;
-    typedef TrStage<NKB> Stage;
-    // the entities' statistics between the two walks: [entity][{lse, delta'}][128 queries] behind the two stages
-    float* const est = reinterpret_cast<float*>(smem + 2 * Stage::BYTES);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const FragOff fo = frag_off<T>(lane);
-    const TrOff tro = tr_off(lane);
-    const int h = blockIdx.x, qb = blockIdx.y;
-    const int b = qb / d.qpb;
-    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
-    const uint32_t rem0 = valid_entities(d, b, excl);
-    const int cnt = __popc(rem0);
-    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
-    const float c2 = d.scale * LOG2E_F;
-    const int nch = (d.S + SPAD - 1) / SPAD;
-
-    const T* Q = static_cast<const T*>(d.q);
-    const T* K = static_cast<const T*>(d.k);
-    const T* V = static_cast<const T*>(d.v);
-
-    const int qpos = wave * 32 + (lane & 31);
-    const bool qvalid = qpos < d.T;
-    Frag qf[2], dof[2];
-    {
-        const long qr = phys_row(d.q_rows, (long)qb * d.T + qpos, qvalid);
-        const T* qrow = Q + (qr >= 0 ? qr : 0) * d.ldq + h * HD;
-        const T* drow = dO + (qr >= 0 ? qr : 0) * lddo + h * HD;
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            qf[sl] = global_frag<T>(qrow + sl * 32, lane, qr >= 0);
-            dof[sl] = global_frag<T>(drow + sl * 32, lane, qr >= 0);
-        }
-    }
-    pin_frags(qf);
-    pin_frags(dof);
-
-    BufTile<SPAD> kreg, vreg;
-    RowIdx<SPAD> kvidx;
-    uint8_t mreg = 1;
-    auto lookup = [&](const ChunkUnit& u) {
-        const int k0 = u.c * SPAD;
-        kvidx.load(d.kv_rows, ((long)b * d.N + u.n) * d.S + k0, min(SPAD, d.S - k0), tid);
-    };
-    auto prefetch = [&](const ChunkUnit& u) {
-        const long ent = (long)b * d.N + u.n;
-        const int k0 = u.c * SPAD, len = min(SPAD, d.S - k0);
-        if constexpr (KVMAP) {
-            kreg.load_mapped(K + h * HD, d.ldk, kvidx, tid);
-            vreg.load_mapped(V + h * HD, d.ldv, kvidx, tid);
-        } else {
-            kreg.load(K + h * HD, d.ldk, ent * d.S + k0, len, tid);
-            vreg.load(V + h * HD, d.ldv, ent * d.S + k0, len, tid);
-        }
-        mreg = (tid >= len) ? 1 : (d.pad ? d.pad[ent * d.S + k0 + tid] : 0);
-    };
-    auto commit = [&](const Stage& st, const ChunkUnit& u) {
-        kreg.commit(st.k(), tid);
-        vreg.commit(st.v(), tid);
-        publish_key_mask(st.bias(), st.slots(), mreg, min(SPAD, d.S - u.c * SPAD), SPAD, tid);
-    };
-    typedef float pair_t __attribute__((ext_vector_type(2)));
-    // One walk over the (entity, chunk) units with the staging scheme of the kernels above; body(unit, stage, NACT, NFAST, commit_next)
-    // must call commit_next() once (in the middle of its work: the next unit's rows have landed by then).
-    auto walk = [&](auto&& body, auto&& unit_done) {
-        ChunkUnit cu = chunk_first(rem0);
-        int cur = 0;
-        if (cu.ok) {
-            if constexpr (KVMAP) lookup(cu);
-            prefetch(cu);
-            const ChunkUnit n1 = chunk_next(cu, nch);
-            if constexpr (KVMAP) if (n1.ok) lookup(n1);
-            commit(Stage{smem}, cu);
-        }
-        __syncthreads();
-        while (cu.ok) {
-            const ChunkUnit nx1 = chunk_next(cu, nch), nx2 = chunk_next(nx1, nch);
-            const Stage st{smem + cur * Stage::BYTES}, nx{smem + (cur ^ 1) * Stage::BYTES};
-            int slen, fmask;
-            read_key_mask(st.slots(), slen, fmask);
-            if (nx1.ok) {
-                prefetch(nx1);
-                if constexpr (KVMAP) if (nx2.ok) lookup(nx2);
-            }
-            bool committed = false;
-            auto commit_next = [&]() { if (nx1.ok) commit(nx, nx1); committed = true; };
-            dispatch_blocks<NKB>(active_blocks<false>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) { body(cu, st, nact, nfast, commit_next); });
-            if (!committed) commit_next();                     // a chunk without an unmasked key
-            unit_done(cu);
-            __syncthreads();
-            cur ^= 1;
-            cu = nx1;
-        }
-    };
-
-    // ---- walk 0: log-sum-exp and delta' of every entity
-    {
-        float m_run = 0.f, l_run = 0.f, raw_run = 0.f;        // running maximum / sum / sum_k p~ dP of the entity (this lane's query)
-        walk([&](const ChunkUnit& cu, const Stage& st, auto nact, auto nfast, auto& commit_next) {
-            constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
-            if (cu.c == 0) { l_run = 0.f; m_run = 0.f; raw_run = 0.f; }
-            f32x16_t p[NKB];
-            float m, l;
-            scores_tr<NKB, NACT, NFAST, false>(p, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l, l_run > 0.f ? m_run : -INFINITY);
-            commit_next();
-            pair_t raw2 = {0.f, 0.f};
-#pragma unroll
-            for (int kb = 0; kb < NACT; ++kb) {
-                f32x16_t dpk = zero_acc();
-#pragma unroll
-                for (int sl = 0; sl < 2; ++sl) {
-                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-                    mma_slab<T>(dpk, a, dof[sl]);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) raw2 += pair_t{p[kb][r], p[kb][r + 1]} * pair_t{dpk[r], dpk[r + 1]};
-            }
-            const float raw = wave_half_sum(raw2.x + raw2.y);
-            const float alpha = l_run > 0.f ? __builtin_amdgcn_exp2f(m_run - m) : 0.f;          // m >= m_run: the maximum only grows
-            l_run = fmaf(l_run, alpha, l);
-            raw_run = fmaf(raw_run, alpha, raw);
-            m_run = m;
-        }, [&](const ChunkUnit& cu) {
-            if (cu.c != nch - 1) return;                       // the entity is complete
-            if (cu.c == 0 && l_run == 0.f) { m_run = 0.f; raw_run = 0.f; }
-            const float invl = (l_run > 0.f) ? __builtin_amdgcn_rcpf(l_run) : 0.f;
-            const float lse = (l_run > 0.f) ? m_run + __log2f(l_run) : INFINITY;
-            const float dprime = raw_run * invl * d.scale;     // delta * count * scale
-            if (lane < 32) {
-                est[(cu.n * 2 + 0) * 128 + qpos] = lse;
-                est[(cu.n * 2 + 1) * 128 + qpos] = dprime;
-                if (qvalid) {
-                    float* sp = stats + ((((long)qb * d.N + cu.n) * d.H + h) * d.T + qpos) * 2;
-                    sp[0] = lse;
-                    sp[1] = dprime;
-                }
-            }
-            l_run = 0.f;
-        });
-    }
-    // (the walk's last barrier orders the statistics before their readers)
-    // ---- walk 1: dS and dQ
-    f32x16_t dqacc[2] = {zero_acc(), zero_acc()};
-    walk([&](const ChunkUnit& cu, const Stage& st, auto nact, auto nfast, auto& commit_next) {
-        constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
-        const float lse = est[(cu.n * 2 + 0) * 128 + qpos], dprime = est[(cu.n * 2 + 1) * 128 + qpos];
-        f32x16_t p[NKB];
-        probs_tr<NKB, NACT, NFAST>(p, st.k(), qf, st.bias(), c2, lse, lane, fo);
-        commit_next();
-        const float ca = inv_cnt * d.scale, cb = inv_cnt * dprime;         // dS^T = p (dP scale - delta') / count
-#pragma unroll
-        for (int kb = 0; kb < NACT; ++kb) {
-            f32x16_t dpk = zero_acc();
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl) {
-                const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
-                mma_slab<T>(dpk, a, dof[sl]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dpk[r] = p[kb][r] * fmaf(dpk[r], ca, -cb);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8_t sb = pack8(dpk, s2);
-#pragma unroll
-                for (int db = 0; db < 2; ++db)
-                    mfma16(dqacc[db], tr_frag(st.k() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
-            }
-        }
-    }, [&](const ChunkUnit&) {});
-    flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), dqacc, dQ + h * HD, lddq, (long)qb * d.T + wave * 32, d.q_rows,
-                 d.T - wave * 32, accumulate_dq != 0, lane);
-}
-
 // ---------------------------------------------------------------------------------------------
 // One entity per business, attended by all qpb query blocks of the business (table and image memory: N == 1, no
 // leave-one-out): a workgroup stages the entity's K and V ONCE and walks its share of the query blocks, the next block's
@@ -2502,14 +2285,11 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
             else LAUNCH_LDS((attn_tr_bwd_dq_shared_kernel<7>), sgrid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
         } else {
             const dim3 grid(d.H, d.n_qblocks), block(ATT_THREADS);
-            if (nkb > 4 && !d.causal) {      // more than 128 keys per entity: chunks of four key blocks, two passes, two workgroups per CU
-                const size_t lds = tr_lds<T>(4) + (size_t)d.N * 2 * 128 * sizeof(float);     // + the entities' statistics between the two walks
-                if (d.kv_rows != nullptr) LAUNCH_LDS((attn_tr_bwd_dq_chunk_kernel<true>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
-                else LAUNCH_LDS((attn_tr_bwd_dq_chunk_kernel<false>), grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
-            } else {
+            // (entities of more than 128 keys keep the seven-block stages here: the chunked form of dQ needs the entity's log-sum-exp
+            // and delta before its first key can be finished, i.e. two walks over the chunks = five MFMA products per key block against
+            // four and every chunk staged twice -- measured 8 % SLOWER than this kernel at one workgroup per CU, profiles/NOTES_r04.md)
             const size_t lds = tr_lds<T>(nkb);
             LAUNCH_TR(attn_tr_bwd_dq_kernel, nkb, d.causal, d.kv_rows != nullptr, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dq, lddq, accumulate_dq, (float*)stats);
-            }
         }
         {
             const int n_ent = (d.n_qblocks / d.qpb) * d.N;

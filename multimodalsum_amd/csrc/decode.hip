@@ -82,11 +82,15 @@ __global__ __launch_bounds__(TK_THREADS) void beam_topk_chunk_kernel(T* __restri
         }
     };
     if (ban_token >= 0) ban(ban_token);
-    if (banned != nullptr)
+    if (banned != nullptr) {
+        // the list is filled from the front and -1 padded (generation._banned_ngram_table): stop at the first -1.  Each entry is a
+        // uniform, dependent load -- walking all nban (= max_length) slots cost ~0.3 us apiece, most of this kernel's 37 us
         for (int i = 0; i < nban; ++i) {
             const int t = banned[(long)row * nban + i];             // uniform load: every thread looks at every ban, the owner acts
-            if (t >= 0 && t < V) ban(t);
+            if (t < 0) break;
+            if (t < V) ban(t);
         }
+    }
     // ---- K rounds of block-wide arg-best over the values in registers (higher value first, lower token among equals)
     for (int r = 0; r < K; ++r) {
         float bv = -INFINITY;
@@ -128,6 +132,10 @@ __global__ __launch_bounds__(TK_THREADS) void beam_topk_chunk_kernel(T* __restri
 // as in next_scores.view(batch, num_beams * vocab) (:2920-2925).  force_token >= 0 (adjust_logits_during_generation :3084-3089: every
 // other logit is -inf, so log_softmax is 0 at the forced token): the candidates are built here and stage 1 is not launched.
 constexpr int TK_MAXC = 16;           // candidates per lane: num_beams * TK_CHUNKS * K / 64 <= 8 * 8 * 16 / 64
+// (flat index = beam * V + token < 8 * 65,536: 32 bits carry it; every lane keeps its candidates SORTED, best first, so a round is one
+// wave-wide arg-best over the lanes' heads -- two dwords through six exchange steps -- and a pop on the winning lane)
+__device__ __forceinline__ bool cand_better(float v, int id, float v2, int id2) { return v > v2 || (v == v2 && id < id2); }
+template <int MAXC>
 __global__ __launch_bounds__(64) void beam_topk_merge_kernel(const float* __restrict__ part_ms, const float* __restrict__ part_v,
                                                              const int* __restrict__ part_t, const float* __restrict__ beam_scores, int num_beams, int K,
                                                              int V, int force_token, float* __restrict__ out_scores, long long* __restrict__ out_ids) {
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(64) void beam_topk_merge_kernel(const float* __rest
     if (force_token < 0 && lane < num_beams) {
         const long row = (long)b * num_beams + lane;
         float mm = -INFINITY, ss = 0.f;
+#pragma unroll
         for (int c = 0; c < TK_CHUNKS; ++c) {
             const float m2 = part_ms[(row * TK_CHUNKS + c) * 2], s2 = part_ms[(row * TK_CHUNKS + c) * 2 + 1];
             const float mx = fmaxf(mm, m2);
@@ -147,49 +156,59 @@ __global__ __launch_bounds__(64) void beam_topk_merge_kernel(const float* __rest
     __syncthreads();
     const int per_beam = force_token >= 0 ? K : TK_CHUNKS * K;
     const int n = num_beams * per_beam;
-    float v[TK_MAXC];
-    long long id[TK_MAXC];
+    constexpr int NONE = 0x7fffffff;
+    float v[MAXC];
+    int id[MAXC];
 #pragma unroll
-    for (int j = 0; j < TK_MAXC; ++j) {
+    for (int j = 0; j < MAXC; ++j) {
         const int c = lane + 64 * j;
         v[j] = -INFINITY;
-        id[j] = 0x7fffffffffffffffLL;
+        id[j] = NONE;
         if (c < n) {
             const int beam = c / per_beam, k = c % per_beam;
             const long row = (long)b * num_beams + beam;
             if (force_token >= 0) {            // the row's K candidates: the forced token at 0 + beam score, then the lowest other tokens at -inf
                 const int tok = k == 0 ? force_token : (k - 1 < force_token ? k - 1 : k);
                 v[j] = k == 0 ? beam_scores[row] : -INFINITY;
-                id[j] = (long long)beam * V + tok;
+                id[j] = beam * V + tok;
             } else {
                 const int tok = part_t[row * TK_CHUNKS * K + k];
-                if (tok != 0x7fffffff) {
+                if (tok != NONE) {
                     v[j] = (part_v[row * TK_CHUNKS * K + k] - lse[beam]) + beam_scores[row];      // log_softmax, then + beam score (:2874, :2917)
-                    id[j] = (long long)beam * V + tok;
+                    id[j] = beam * V + tok;
                 }
             }
         }
     }
+    // sort this lane's candidates, best first (insertion sort on registers: MAXC is 4 for the usual 4 beams)
+#pragma unroll
+    for (int i = 1; i < MAXC; ++i)
+#pragma unroll
+        for (int j = i; j > 0; --j) {
+            const bool sw = cand_better(v[j], id[j], v[j - 1], id[j - 1]);
+            const float tv = sw ? v[j - 1] : v[j];
+            const int ti = sw ? id[j - 1] : id[j];
+            v[j - 1] = sw ? v[j] : v[j - 1];
+            id[j - 1] = sw ? id[j] : id[j - 1];
+            v[j] = tv;
+            id[j] = ti;
+        }
     for (int r = 0; r < K; ++r) {
-        int pick = 0;
-#pragma unroll
-        for (int j = 1; j < TK_MAXC; ++j) if (v[j] > v[pick] || (v[j] == v[pick] && id[j] < id[pick])) pick = j;
-        float bv = -INFINITY;
-        long long bi = 0x7fffffffffffffffLL;
-#pragma unroll
-        for (int j = 0; j < TK_MAXC; ++j) if (j == pick) { bv = v[j]; bi = id[j]; }
-        const long long mine = bi;
+        float bv = v[0];
+        int bi = id[0];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float v2 = __shfl_xor(bv, o);
-            const long long i2 = __shfl_xor(bi, o);
-            if (v2 > bv || (v2 == bv && i2 < bi)) { bv = v2; bi = i2; }
+            const int i2 = __shfl_xor(bi, o);
+            if (cand_better(v2, i2, bv, bi)) { bv = v2; bi = i2; }
         }
-        if (mine == bi && bi != 0x7fffffffffffffffLL) {                     // the owner retires the winner
+        if (bi != NONE && id[0] == bi) {                          // the owner pops its head (ids are unique: one lane matches)
 #pragma unroll
-            for (int j = 0; j < TK_MAXC; ++j) if (j == pick) { v[j] = -INFINITY; id[j] = 0x7fffffffffffffffLL; }
+            for (int j = 0; j + 1 < MAXC; ++j) { v[j] = v[j + 1]; id[j] = id[j + 1]; }
+            v[MAXC - 1] = -INFINITY;
+            id[MAXC - 1] = NONE;
         }
-        if (lane == 0) { out_scores[(long)b * K + r] = bv; out_ids[(long)b * K + r] = bi == 0x7fffffffffffffffLL ? 0 : bi; }
+        if (lane == 0) { out_scores[(long)b * K + r] = bv; out_ids[(long)b * K + r] = bi == NONE ? 0 : (long long)bi; }
     }
 }
 
@@ -292,7 +311,302 @@ extern "C" int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const fl
     } else if (dtype != MMSUM_BF16 && dtype != MMSUM_F32) {
         return MMSUM_ERR_BAD_DTYPE;
     }
-    beam_topk_merge_kernel<<<dim3(rows / num_beams), dim3(64), 0, s>>>(part_ms, part_v, part_t, beam_scores, num_beams, K, V, force_token, out_scores, out_ids);
+    if ((long)num_beams * V >= 0x7fffffffL) return MMSUM_ERR_BAD_SHAPE;
+    if (num_beams * TK_CHUNKS * K <= 4 * 64)
+        beam_topk_merge_kernel<4><<<dim3(rows / num_beams), dim3(64), 0, s>>>(part_ms, part_v, part_t, beam_scores, num_beams, K, V, force_token, out_scores, out_ids);
+    else
+        beam_topk_merge_kernel<TK_MAXC><<<dim3(rows / num_beams), dim3(64), 0, s>>>(part_ms, part_v, part_t, beam_scores, num_beams, K, V, force_token, out_scores, out_ids);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mmsum_decode_cross_attn: the decode step's per-entity cross-attention + entity mean over the cached K / V of ALL modalities in
+// one launch (modeling_multimodalsum.py:819-869 with T = 1 per hypothesis; the hypotheses of a business share its memory).
+//
+// The training kernel this replaces in the decode step runs one workgroup per (business, head) that walks the business's entities
+// one after the other with 4 live query rows in a 128-row tile: 128 workgroups, 19 + 15 + 5 us per layer for 61 MB of K / V (three
+// launches).  The step is a pure stream of the cached K / V -- 4 queries per business cost nothing -- so here ONE workgroup takes
+// ONE (entity, head): 8 x (8 + 1 + 4) x 16 = 1,664 workgroups, every row of an entity's K and V requested up front (eight lanes
+// fetch one 128-byte row: one full line per 8 lanes), scores by VALU dot products reduced over the eight lanes of a row, softmax per
+// query by one wave each, P V per lane over its rows and a tree over the row slots.  The entity mean crosses workgroups: each
+// leaves its normalised [beams, 64] output as f32 and takes a ticket on its (modality, business, head); the last arriver adds the
+// valid entities' outputs (in entity order), divides by their count and writes the bf16 head slice (write-through hand-off as in
+// mmsum_dec_gemm).
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int XA_THREADS = 256;
+constexpr int XA_MAXQ = 8;            // hypotheses per business (num_beams <= 8)
+constexpr int XA_MAXROWS = 7;         // key rows per thread: S <= 224
+struct XaMod { const bf16_t* k; const bf16_t* v; const uint8_t* pad; const uint8_t* null_entity; int N, S, ent0; };   // ent0: first global entity index of the modality
+struct XaArgs {
+    XaMod mod[3];
+    const bf16_t* q; bf16_t* out; float* part; unsigned* tickets;
+    long ldq, ldkv, ldo;
+    int nmod, B, H, qpb, R;          // R = B * qpb rows of q; out rows: modality * R + row
+    float scale;
+};
+
+// Sum over the 8 lanes that share a key row (lane & 7 = the 8-dim chunk): DPP adds, no LDS crossbar (ds_bpermute) on the way.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row8_sum(float v) {
+    v = dpp_add<0xB1>(v);            // quad_perm [1,0,3,2]: lane ^ 1
+    v = dpp_add<0x4E>(v);            // quad_perm [2,3,0,1]: lane ^ 2
+    return dpp_add<0x141>(v);        // row_half_mirror: lane i <-> 7 - i of each 8 (the other quad's sum)
+}
+
+// Layout of a workgroup's work (256 threads = 32 key-row slots x 8 chunks of 16 bytes):
+//   K  : row s = 32 i + slot, chunk c -> registers (one 16-byte load per row; eight lanes fetch one 128-byte row);
+//   V  : the same rows by LDS-DMA (global_load_lds, 16 bytes per lane: a wave's instruction lands as 8 rows x 128 bytes, contiguous)
+//        -- no registers, the tile [S][64] bf16 sits in LDS for the P V pass;
+//   scores: per lane 8 dims x QPB queries, summed over the 8 lanes of a row by DPP; softmax: one wave per query;
+//   P V: thread = (query, dim): walks the S keys with p broadcast from LDS and V read conflict-free (64 lanes x 2 bytes of one row).
+template <int QPB>
+__global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_kernel(XaArgs a) {
+    __shared__ __attribute__((aligned(16))) char vl[XA_MAXROWS * 32 * 128];     // V tile
+    __shared__ float sc[QPB][XA_MAXROWS * 32];                                  // scores, then probabilities, [query][key]
+    __shared__ unsigned last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x;
+    int e = blockIdx.y, m = 0;                                 // global entity index -> (modality, business, entity)
+    while (m + 1 < a.nmod && e >= a.mod[m + 1].ent0) ++m;
+    const XaMod M = a.mod[m];
+    const int le = e - M.ent0, b = le / M.N;
+    const int S = M.S;
+    float* mypart = a.part + ((long)e * a.H + h) * (QPB * 64);
+    unsigned* ticket = a.tickets + ((long)m * a.B + b) * a.H + h;
+    const bool is_null = M.null_entity != nullptr && M.null_entity[le] != 0;
+    if (!is_null) {
+        const int kslot = tid >> 3, dch = tid & 7;             // key row slot 0..31, 8-dim chunk of the head
+        const long row0 = (long)le * S;
+        const bf16_t* kb = M.k + row0 * a.ldkv + h * 64 + dch * 8;
+        const bf16_t* vb = M.v + row0 * a.ldkv + h * 64 + dch * 8;
+        const int nrow = (S + 31) >> 5;                        // rows per slot (<= XA_MAXROWS)
+        u32x4_t kreg[XA_MAXROWS];
+#pragma unroll
+        for (int i = 0; i < XA_MAXROWS; ++i) {
+            const int s = i * 32 + kslot;
+            kreg[i] = u32x4_t{0, 0, 0, 0};
+            if (i < nrow && s < S) {
+                kreg[i] = *reinterpret_cast<const u32x4_t*>(kb + (long)s * a.ldkv);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + (long)s * a.ldkv),
+                                                 (__attribute__((address_space(3))) void*)(vl + (i * 32 + wave * 8) * 128), 16, 0, 0);
+            }
+        }
+        float qv[QPB][8];
+#pragma unroll
+        for (int qi = 0; qi < QPB; ++qi) {
+            const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(a.q + (long)(b * QPB + qi) * a.ldq + h * 64 + dch * 8);
+            bf16_t qq[8];
+            __builtin_memcpy(qq, &raw, 16);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qv[qi][j] = to_f32(qq[j]) * a.scale;
+        }
+        // ---- scores
+#pragma unroll
+        for (int i = 0; i < XA_MAXROWS; ++i) {
+            if (i >= nrow) break;
+            bf16_t kk[8];
+            __builtin_memcpy(kk, &kreg[i], 16);
+            float part[QPB];
+#pragma unroll
+            for (int qi = 0; qi < QPB; ++qi) {
+                float x = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x = fmaf(qv[qi][j], to_f32(kk[j]), x);
+                part[qi] = row8_sum(x);
+            }
+            const int key = i * 32 + kslot;
+            if (dch == 0 && key < S) {
+                const bool masked = M.pad != nullptr && M.pad[row0 + key] != 0;
+#pragma unroll
+                for (int qi = 0; qi < QPB; ++qi) sc[qi][key] = masked ? -65536.0f : part[qi];      // masked_fill(-2^16), :841-845
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's V rows have landed in LDS
+        __syncthreads();
+        // ---- softmax: one wave per query
+        for (int qi = wave; qi < QPB; qi += XA_THREADS / 64) {
+            float mx = -INFINITY;
+            for (int s = lane; s < S; s += 64) mx = fmaxf(mx, sc[qi][s]);
+            mx = warp_max(mx);
+            float l = 0.f;
+            for (int s = lane; s < S; s += 64) { const float p = __expf(sc[qi][s] - mx); sc[qi][s] = p; l += p; }
+            l = warp_sum(l);
+            const float inv = 1.f / l;
+            for (int s = lane; s < S; s += 64) sc[qi][s] *= inv;
+        }
+        __syncthreads();
+        // ---- P V: thread = (query, dim)
+        for (int idx = tid; idx < QPB * 64; idx += XA_THREADS) {
+            const int qi = idx >> 6, dd = idx & 63;
+            const bf16_t* vcol = reinterpret_cast<const bf16_t*>(vl) + dd;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            int s = 0;
+            for (; s + 3 < S; s += 4) {
+                o0 = fmaf(sc[qi][s], to_f32(vcol[s * 64]), o0);
+                o1 = fmaf(sc[qi][s + 1], to_f32(vcol[(s + 1) * 64]), o1);
+                o2 = fmaf(sc[qi][s + 2], to_f32(vcol[(s + 2) * 64]), o2);
+                o3 = fmaf(sc[qi][s + 3], to_f32(vcol[(s + 3) * 64]), o3);
+            }
+            for (; s < S; ++s) o0 = fmaf(sc[qi][s], to_f32(vcol[s * 64]), o0);
+            __hip_atomic_store(mypart + qi * 64 + dd, (o0 + o1) + (o2 + o3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: write-through past the XCD's L2
+        }
+    }
+    // ---- the entity mean across workgroups: ticket on (modality, business, head); the last arriver adds the valid entities.
+    // Write-through hand-off (guide, Guideline 16): sc1 payload stores, every storing wave drains them, the workgroup's barrier, one
+    // lane's relaxed agent-scope ticket; the reducer reads every payload word with an sc1 load.  No release / acquire fence: an
+    // agent-scope release writes back the whole L2's dirty lines, and 1,664 workgroups of a launch would each pay it.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (unsigned)(M.N - 1)) ? 1u : 0u;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next layer's launch
+    }
+    __syncthreads();
+    if (!last) return;
+    for (int idx = tid; idx < QPB * 64; idx += XA_THREADS) {
+        const int qi = idx >> 6, dd = idx & 63;
+        float x = 0.f;
+        int cnt = 0;
+        for (int nn = 0; nn < M.N; ++nn) {
+            if (M.null_entity != nullptr && M.null_entity[b * M.N + nn] != 0) continue;      // null entities are dropped from the mean (:856-866)
+            x += __hip_atomic_load(a.part + ((long)(M.ent0 + b * M.N + nn) * a.H + h) * (QPB * 64) + qi * 64 + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++cnt;
+        }
+        x = cnt > 0 ? x / (float)cnt : 0.f;                    // every entity null: zeros (the out_proj bias still enters, :884-885)
+        a.out[((long)m * a.R + b * QPB + qi) * a.ldo + h * 64 + dd] = (bf16_t)x;
+    }
+}
+
+// Single-query self-attention over the caches through the ancestor table, bf16, in the layout of the cross-attention kernel above:
+// 256 threads = 32 key slots x 8 chunks; every K row of the hypothesis requested at once into registers and every V row by LDS-DMA
+// (the one-wave kernel further up walks the V rows eight at a time: up to 16 dependent round trips at 128 keys, 13 us per layer).
+// grid = (rows, H).  Key s of row r lives at cache row anc[r][s] * Tmax + s; position len - 1 comes from k_new / v_new and is
+// appended to the caches by the threads that hold it.
+__global__ __launch_bounds__(XA_THREADS) void decode_self_attn_bf16_kernel(const bf16_t* __restrict__ q, long ldq, bf16_t* __restrict__ kc, bf16_t* __restrict__ vc,
+                                                                           long ldc, const int* __restrict__ anc, bf16_t* __restrict__ out, long ldo, int len,
+                                                                           int Tmax, float scale, const bf16_t* __restrict__ k_new,
+                                                                           const bf16_t* __restrict__ v_new, long ldn) {
+    constexpr int MAXROWS = 8;                                  // Tmax <= 256
+    __shared__ __attribute__((aligned(16))) char vl[MAXROWS * 32 * 128];
+    __shared__ float sc[MAXROWS * 32];
+    __shared__ float red[XA_THREADS / 64][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = blockIdx.x, h = blockIdx.y;
+    const int kslot = tid >> 3, dch = tid & 7;
+    const bool fresh = k_new != nullptr;
+    const int nrow = (len + 31) >> 5;
+    const long col = h * 64 + dch * 8;
+    u32x4_t kreg[MAXROWS];
+#pragma unroll
+    for (int i = 0; i < MAXROWS; ++i) {
+        const int s = i * 32 + kslot;
+        kreg[i] = u32x4_t{0, 0, 0, 0};
+        if (i < nrow && s < len) {
+            const bool isnew = fresh && s == len - 1;
+            const long crow = ((long)anc[(long)r * Tmax + s] * Tmax + s) * ldc + col;
+            const bf16_t* ksrc = isnew ? k_new + (long)r * ldn + col : kc + crow;
+            const bf16_t* vsrc = isnew ? v_new + (long)r * ldn + col : vc + crow;
+            kreg[i] = *reinterpret_cast<const u32x4_t*>(ksrc);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
+                                             (__attribute__((address_space(3))) void*)(vl + (i * 32 + wave * 8) * 128), 16, 0, 0);
+            if (isnew) {                                        // append this step's K / V to the caches (row r itself: anc[r][len - 1] == r)
+                const long nrow_off = ((long)r * Tmax + s) * ldc + col;
+                *reinterpret_cast<u32x4_t*>(kc + nrow_off) = kreg[i];
+                *reinterpret_cast<u32x4_t*>(vc + nrow_off) = *reinterpret_cast<const u32x4_t*>(vsrc);
+            }
+        }
+    }
+    float qv[8];
+    {
+        const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(q + (long)r * ldq + col);
+        bf16_t qq[8];
+        __builtin_memcpy(qq, &raw, 16);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = to_f32(qq[j]) * scale;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXROWS; ++i) {
+        if (i >= nrow) break;
+        bf16_t kk[8];
+        __builtin_memcpy(kk, &kreg[i], 16);
+        float x = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x = fmaf(qv[j], to_f32(kk[j]), x);
+        x = row8_sum(x);
+        const int key = i * 32 + kslot;
+        if (dch == 0 && key < len) sc[key] = x;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {
+        float mx = -INFINITY;
+        for (int s = lane; s < len; s += 64) mx = fmaxf(mx, sc[s]);
+        mx = warp_max(mx);
+        float l = 0.f;
+        for (int s = lane; s < len; s += 64) { const float p = __expf(sc[s] - mx); sc[s] = p; l += p; }
+        l = warp_sum(l);
+        const float inv = 1.f / l;
+        for (int s = lane; s < len; s += 64) sc[s] *= inv;
+    }
+    __syncthreads();
+    // P V: thread = (key quarter, dim)
+    {
+        const bf16_t* vcol = reinterpret_cast<const bf16_t*>(vl) + lane;
+        float o = 0.f;
+        for (int s = wave; s < len; s += XA_THREADS / 64) o = fmaf(sc[s], to_f32(vcol[s * 64]), o);
+        red[wave][lane] = o;
+    }
+    __syncthreads();
+    if (tid < 64) out[(long)r * ldo + h * 64 + tid] = (bf16_t)((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+}
+
+}  // namespace
+
+extern "C" long mmsum_decode_cross_attn_workspace(int n_entities, int H, int qpb, int B, int nmod) {
+    if (n_entities <= 0 || H <= 0 || qpb <= 0 || B <= 0 || nmod <= 0) return 0;
+    // [tickets: nmod * B * H words, padded to 256 bytes][per-entity outputs: n_entities * H * qpb * 64 floats]
+    return (((long)nmod * B * H * 4 + 255) / 256) * 256 + (long)n_entities * H * qpb * 64 * (long)sizeof(float);
+}
+
+extern "C" int mmsum_decode_cross_attn(const void* q, long ldq, const mmsum_xattn_memory* mods, int nmod, long ldkv, void* out, long ldo,
+                                       int B, int qpb, int H, float scale, void* workspace, void* stream) {
+    if (nmod < 1 || nmod > 3 || B <= 0 || H <= 0 || qpb < 1 || qpb > XA_MAXQ || !mods) return MMSUM_ERR_BAD_SHAPE;
+    if (workspace == nullptr) return MMSUM_ERR_WORKSPACE;
+    if ((((uintptr_t)q) & 1) || ((ldkv * 2) & 15)) return MMSUM_ERR_BAD_ALIGN;
+    XaArgs a;
+    int ent = 0;
+    for (int m = 0; m < 3; ++m) {
+        if (m < nmod) {
+            if (mods[m].N <= 0 || mods[m].N > 32 || mods[m].S <= 0 || mods[m].S > XA_MAXROWS * 32) return MMSUM_ERR_BAD_SHAPE;
+            if ((((uintptr_t)mods[m].k | (uintptr_t)mods[m].v) & 15)) return MMSUM_ERR_BAD_ALIGN;
+            a.mod[m] = XaMod{static_cast<const bf16_t*>(mods[m].k), static_cast<const bf16_t*>(mods[m].v), mods[m].pad, mods[m].null_entity, mods[m].N, mods[m].S, ent};
+            ent += B * mods[m].N;
+        } else {
+            a.mod[m] = XaMod{nullptr, nullptr, nullptr, nullptr, 1, 1, 1 << 30};
+        }
+    }
+    a.q = static_cast<const bf16_t*>(q); a.out = static_cast<bf16_t*>(out);
+    a.tickets = static_cast<unsigned*>(workspace);
+    a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + (((long)nmod * B * H * 4 + 255) / 256) * 256);
+    a.ldq = ldq; a.ldkv = ldkv; a.ldo = ldo;
+    a.nmod = nmod; a.B = B; a.H = H; a.qpb = qpb; a.R = B * qpb; a.scale = scale;
+    const dim3 grid(H, ent), block(XA_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    switch (qpb) {
+        case 1: decode_cross_attn_kernel<1><<<grid, block, 0, s>>>(a); break;
+        case 2: decode_cross_attn_kernel<2><<<grid, block, 0, s>>>(a); break;
+        case 3: decode_cross_attn_kernel<3><<<grid, block, 0, s>>>(a); break;
+        case 4: decode_cross_attn_kernel<4><<<grid, block, 0, s>>>(a); break;
+        case 5: decode_cross_attn_kernel<5><<<grid, block, 0, s>>>(a); break;
+        case 6: decode_cross_attn_kernel<6><<<grid, block, 0, s>>>(a); break;
+        case 7: decode_cross_attn_kernel<7><<<grid, block, 0, s>>>(a); break;
+        default: decode_cross_attn_kernel<8><<<grid, block, 0, s>>>(a); break;
+    }
     return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
 }
 
@@ -303,7 +617,11 @@ extern "C" int mmsum_decode_self_attn(int dtype, const void* q, long ldq, void* 
     if ((k_new == nullptr) != (v_new == nullptr)) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(rows, H);
-    if (dtype == MMSUM_BF16)
+    const bool al16 = !((((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)k_new | (uintptr_t)v_new) & 15) || ((ldq | ld_cache | ld_new) & 7));
+    if (dtype == MMSUM_BF16 && al16)        // 16-byte rows: the 256-thread kernel (every K / V row of the hypothesis in flight at once)
+        decode_self_attn_bf16_kernel<<<grid, dim3(XA_THREADS), 0, s>>>((const bf16_t*)q, ldq, (bf16_t*)k_cache, (bf16_t*)v_cache, ld_cache, ancestors,
+                                                                       (bf16_t*)out, ldo, len, Tmax, scale, (const bf16_t*)k_new, (const bf16_t*)v_new, ld_new);
+    else if (dtype == MMSUM_BF16)
         decode_self_attn_kernel<bf16_t><<<grid, dim3(64), 0, s>>>((const bf16_t*)q, ldq, (bf16_t*)k_cache, (bf16_t*)v_cache, ld_cache, ancestors,
                                                                   (bf16_t*)out, ldo, len, Tmax, scale, (const bf16_t*)k_new, (const bf16_t*)v_new, ld_new);
     else if (dtype == MMSUM_F32)

@@ -228,3 +228,194 @@ int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream) {
     else SKINNY(4);
 #undef SKINNY
 }
+
+// ---------------------------------------------------------------------------------------------
+// mmsum_dec_gemm: the decode step's products with the REDUCTION split over workgroups.
+//
+// The kernels above put one workgroup on 16 or 32 output columns and split K over its waves: an N = 1024 product is 32 .. 64
+// workgroups, and a workgroup streams its weights at ~16 GB/s whatever its loads in flight (latency-bound), so the product takes
+// 7 .. 17 us for 2 .. 8 MB.  Here a workgroup is ONE wave = (16 output columns) x (one K slice of 256 .. 1024): 256 .. 512 workgroups,
+// every CU pulling weights, every load of a wave in flight at once (16 bytes per lane and 32-deep step straight into the
+// v_mfma_f32_16x16x32_bf16 operand layout), i.e. the whole matrix is requested within one memory round trip.  The slices of a column
+// tile meet through an f32 slab each + an arrival ticket; the LAST arriver adds the slabs (in slice order: bit-reproducible) and runs
+// the epilogue (bias, GELU, residual add, f32 or bf16 store) -- the guide's in-launch split-K reduction in its write-through form
+// (sc1 slab stores, vmcnt(0), relaxed agent-scope ticket; sc1 loads in the reducer): correct for any placement of the slices.  The
+// reducer puts the ticket word back to 0, so the workspace serves every product of a stream in turn (kernels of one stream do not
+// overlap) and a captured graph needs no memset node per product.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct DecGemmArgs {
+    const void* x; const void* x2; const bf16_t* W; const float* bias; const bf16_t* res; void* out;
+    float* slabs; unsigned* tickets;
+    long ldx, ldx2, ldw, ldres, ldo;
+    int M, N, K, ksplit, sk, ksl, ns16_ok;
+};
+
+// NS = 32-deep steps per batch: a batch's loads (NS of the weights, MB x NS of x) are all issued before its first MFMA, so a wave
+// that is alone on its SIMD (the small products: 256 .. 512 one-wave workgroups on 256 CUs) still has its whole slice in flight.
+template <int MB, int EPI, bool AF32, bool CF32, int NS>
+__global__ __launch_bounds__(64) void dec_gemm_kernel(DecGemmArgs p) {
+    const int lane = threadIdx.x;
+    const int total = gridDim.x;
+    const int id = xcd_remap(blockIdx.x, total);               // the slices of a tile get consecutive ids: one XCD (speed only)
+    const int tile = id / p.sk, slice = id % p.sk;
+    const int lr = lane & 15, kg = (lane >> 4) * 8;
+    const int col = tile * 16 + lr;
+    const bf16_t* wrow = p.W + (long)(col < p.N ? col : p.N - 1) * p.ldw + kg;
+    const int k_beg = slice * p.ksl, nbatch = p.ksl / (32 * NS);
+    f32x4_t acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int bt = 0; bt < nbatch; ++bt) {
+        int k0 = k_beg + bt * (32 * NS);
+        u32x4_t b[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const u32x4_t*>(wrow + k0 + s * 32);
+        const void* xb = p.x;
+        long ldx = p.ldx;
+        if (p.x2 != nullptr && k0 >= p.ksplit) { xb = p.x2; ldx = p.ldx2; k0 -= p.ksplit; }      // (a batch lies in one of the two tensors: the host checks)
+        if constexpr (AF32) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int m = mb * 16 + lr;
+                    u32x4_t hi, lo;
+                    split_hi_lo(static_cast<const float*>(xb) + (long)(m < p.M ? m : 0) * ldx + k0 + s * 32 + kg, m < p.M, hi, lo);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, hi), __builtin_bit_cast(bf16x8_t, b[s]), acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, lo), __builtin_bit_cast(bf16x8_t, b[s]), acc[mb], 0, 0, 0);
+                }
+        } else {
+            u32x4_t a[MB][NS];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mb * 16 + lr;
+                const bf16_t* xr = static_cast<const bf16_t*>(xb) + (long)(m < p.M ? m : 0) * ldx + k0 + kg;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) a[mb][s] = (m < p.M) ? *reinterpret_cast<const u32x4_t*>(xr + s * 32) : u32x4_t{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[mb][s]), __builtin_bit_cast(bf16x8_t, b[s]), acc[mb], 0, 0, 0);
+        }
+    }
+    if (p.sk > 1) {
+        // this slice's slab: [MB][4][64 lanes] f32, lane-contiguous (256-byte rows).  The hand-off is the guide's write-through form:
+        // every slab word is stored sc1 (a relaxed agent-scope atomic store IS a write-through store: it reaches memory past the XCD's
+        // L2, so no release fence -- an agent-scope release writes the whole L2's dirty lines back, microseconds per workgroup with
+        // 256 .. 512 of them at it), the wave drains its stores (vmcnt(0)), one lane takes the ticket with a relaxed agent-scope add,
+        // and the last arriver reads EVERY slab word with an sc1 load (relaxed agent-scope atomic load: it bypasses this CU's L1, which
+        // no other CU's store refreshes), so no acquire either.  Placement-independent.
+        float* mine = p.slabs + ((long)tile * p.sk + slice) * (MB * 4 * 64);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) __hip_atomic_store(mine + (mb * 4 + e) * 64 + lane, acc[mb][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(p.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket != (unsigned)(p.sk - 1)) return;            // not the last slice of this tile to arrive
+        asm volatile("" ::: "memory");
+        // the slabs are added in SLICE order whichever slice arrived last (its own partial takes its place in the order): the result
+        // does not depend on the arrival order, i.e. it is bit-reproducible run to run
+        const float* base = p.slabs + (long)tile * p.sk * (MB * 4 * 64);
+        f32x4_t own[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { own[mb] = acc[mb]; acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        for (int s = 0; s < p.sk; ++s) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float other = (s == slice) ? 0.f : __hip_atomic_load(base + ((long)s * MB * 4 + mb * 4 + e) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    acc[mb][e] += (s == slice) ? own[mb][e] : other;
+                }
+        }
+        if (lane == 0) __hip_atomic_store(p.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the stream's next product
+    }
+    const bool col_ok = col < p.N;
+    const float bv = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = mb * 16 + 4 * (lane >> 4) + e;        // 16x16 result: row 4 (l >> 4) + e, column l & 15
+            if (!col_ok || m >= p.M) continue;
+            float v = acc[mb][e] + bv;
+            if constexpr (EPI == MMSUM_EPI_GELU) v = gelu_fast_f(v);
+            if (p.res != nullptr) v += to_f32(p.res[(long)m * p.ldres + col]);
+            if constexpr (CF32) static_cast<float*>(p.out)[(long)m * p.ldo + col] = v;
+            else static_cast<bf16_t*>(p.out)[(long)m * p.ldo + col] = (bf16_t)v;
+        }
+}
+
+// How many ways the reduction is split: enough (column tiles x slices) workgroups to cover the CUs about twice, slices of at
+// least 256 k (8 loads per lane and operand) that divide K into whole 32-deep steps.
+inline int dec_gemm_splitk(int N, int K) {
+    const int tiles = (N + 15) / 16;
+    int sk = 1;
+    while (tiles * sk < 512 && K % (sk * 2 * 256) == 0) sk *= 2;
+    return sk;
+}
+
+template <int MB, int EPI>
+int launch_dec_gemm(const DecGemmArgs& a, bool af32, bool cf32, hipStream_t s) {
+    const dim3 grid(((a.N + 15) / 16) * a.sk), block(64);
+    // 16 steps per batch where the slice is a multiple of 512 k and the x fragments fit the registers beside them (MB <= 2), else 8
+    const bool ns16 = MB <= 2 && a.ksl % 512 == 0 && a.ns16_ok;
+    if (af32) { if (ns16) dec_gemm_kernel<MB, EPI, true, true, 16><<<grid, block, 0, s>>>(a); else dec_gemm_kernel<MB, EPI, true, true, 8><<<grid, block, 0, s>>>(a); }
+    else if (cf32) { if (ns16) dec_gemm_kernel<MB, EPI, false, true, 16><<<grid, block, 0, s>>>(a); else dec_gemm_kernel<MB, EPI, false, true, 8><<<grid, block, 0, s>>>(a); }
+    else { if (ns16) dec_gemm_kernel<MB, EPI, false, false, 16><<<grid, block, 0, s>>>(a); else dec_gemm_kernel<MB, EPI, false, false, 8><<<grid, block, 0, s>>>(a); }
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+}  // namespace
+
+// Workspace: [tickets: one word per column tile, a FIXED 16 KB region -- products of different N share the workspace one after the other,
+// and the slabs of one must never land on the ticket words of another][slabs: tiles x sk x (MB x 4 x 64) floats]
+constexpr long DEC_TICKET_BYTES = 16384;             // 4,096 column tiles: N <= 65,536
+
+extern "C" long mmsum_dec_gemm_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const long tiles = (N + 15) / 16, mb = (M + 15) / 16;
+    const long sk = dec_gemm_splitk(N, K);
+    return DEC_TICKET_BYTES + tiles * sk * mb * 4 * 64 * (long)sizeof(float);
+}
+
+extern "C" int mmsum_dec_gemm(const void* x, long ldx, const void* x2, long ldx2, int ksplit, const void* W, long ldw, const float* bias,
+                              const void* residual, long ldres, void* out, long ldo, int M, int N, int K, int flags, void* workspace,
+                              void* stream) {
+    if (M <= 0 || M > 96 || N <= 0 || K <= 0 || K % 256) return MMSUM_ERR_BAD_SHAPE;          // slices are whole batches of eight 32-deep steps
+    const bool af32 = flags & MMSUM_GEMM_A_F32, cf32 = flags & MMSUM_GEMM_OUT_F32;
+    const int epi = (flags >> 3) & 7;
+    if (flags & ~(MMSUM_GEMM_A_F32 | MMSUM_GEMM_OUT_F32 | MMSUM_GEMM_EPI(7))) return MMSUM_ERR_BAD_SHAPE;
+    if (!(epi == MMSUM_EPI_NONE || epi == MMSUM_EPI_GELU)) return MMSUM_ERR_BAD_SHAPE;
+    if (af32 && (!cf32 || x2 != nullptr || epi != MMSUM_EPI_NONE)) return MMSUM_ERR_BAD_SHAPE;
+    if (x2 != nullptr && (ksplit <= 0 || ksplit >= K || ksplit % 256)) return MMSUM_ERR_BAD_SHAPE;
+    const long esx = af32 ? 4 : 2;
+    if ((((uintptr_t)x | (uintptr_t)x2 | (uintptr_t)W) & 15) || ((ldx * esx) & 15) || ((ldx2 * esx) & 15) || ((ldw * 2) & 15)) return MMSUM_ERR_BAD_ALIGN;
+    if (workspace == nullptr || ((uintptr_t)workspace & 15)) return MMSUM_ERR_WORKSPACE;
+    const int tiles = (N + 15) / 16;
+    if ((long)tiles * 4 > DEC_TICKET_BYTES) return MMSUM_ERR_BAD_SHAPE;
+    DecGemmArgs a;
+    a.x = x; a.x2 = x2; a.W = static_cast<const bf16_t*>(W); a.bias = bias; a.res = static_cast<const bf16_t*>(residual); a.out = out;
+    a.tickets = static_cast<unsigned*>(workspace);
+    a.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + DEC_TICKET_BYTES);
+    a.ldx = ldx; a.ldx2 = ldx2; a.ldw = ldw; a.ldres = ldres; a.ldo = ldo;
+    a.M = M; a.N = N; a.K = K; a.ksplit = ksplit;
+    a.sk = dec_gemm_splitk(N, K);
+    a.ksl = K / a.sk;                        // a multiple of 256
+    a.ns16_ok = (x2 == nullptr || ksplit % 512 == 0) ? 1 : 0;       // a batch of steps must lie in ONE of the two operand tensors
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int mb = (M + 15) / 16;
+#define DEC_CASE(MBV)                                                                                              \
+    if (mb == MBV) return epi == MMSUM_EPI_GELU ? launch_dec_gemm<MBV, MMSUM_EPI_GELU>(a, af32, cf32, s)           \
+                                                : launch_dec_gemm<MBV, MMSUM_EPI_NONE>(a, af32, cf32, s);
+    DEC_CASE(1) DEC_CASE(2) DEC_CASE(3) DEC_CASE(4) DEC_CASE(5) DEC_CASE(6)
+#undef DEC_CASE
+    return MMSUM_ERR_BAD_SHAPE;
+}

@@ -99,6 +99,43 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const T* __restrict__ x
     }
 }
 
+// The decode step's gated fusion + residual + LayerNorm in one pass (generation only: nothing is saved for a backward):
+//   y = LN(res + yt + relu(tanh(pa)) [table present] ytab + relu(tanh(pb)) [image present] yimg)      (:732-744, :474-477)
+// One row per wave.  The gated sum is not rounded to the compute dtype on the way (the two-kernel form stores it).
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void gate_add_ln_fwd_kernel(const T* __restrict__ pa, const T* __restrict__ pb, const T* __restrict__ yt,
+                                                              const T* __restrict__ ytab, const T* __restrict__ yimg,
+                                                              const uint8_t* __restrict__ no_table, const uint8_t* __restrict__ no_img,
+                                                              const T* __restrict__ res, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, T* __restrict__ y, int R, int D, int rows_per_b, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wpb = blockDim.x >> 6;
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < R; row += gridDim.x * wpb) {
+        const int b = row / rows_per_b;
+        const float ma = no_table[b] ? 0.f : 1.f, mb = no_img[b] ? 0.f : 1.f;
+        f32x4_t z[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const long o = (long)row * D + (i * 64 + lane) * 4;
+            const f32x4_t a = load4<T>(pa + o), bb = load4<T>(pb + o), t = load4<T>(yt + o), tb = load4<T>(ytab + o), im = load4<T>(yimg + o);
+            const f32x4_t rv = load4<T>(res + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) z[i][j] = rv[j] + t[j] + ma * fmaxf(tanhf(a[j]), 0.f) * tb[j] + mb * fmaxf(tanhf(bb[j]), 0.f) * im[j];
+        }
+        float mean, rstd;
+        ln_stats<VPL>(z, D, eps, mean, rstd);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const f32x4_t g = load4<float>(gamma + c), be = load4<float>(beta + c);
+            f32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (z[i][j] - mean) * rstd * g[j] + be[j];
+            store4<T>(y + (long)row * D + c, o);
+        }
+    }
+}
+
 // dz = rstd * (g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); block accumulates dgamma/dbeta over its rows
 // in registers, reduces across its waves through LDS and issues one f32 atomic per column.
 template <typename T, int VPL>
@@ -837,6 +874,24 @@ extern "C" int mmsum_embed_ln_bwd(int dtype, const void* dy, const int64_t* ids,
     if (dtype == MMSUM_BF16) return embed_ln_bwd_t<bf16_t>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, sp, s);
     if (dtype == MMSUM_F32) return embed_ln_bwd_t<float>(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, D, pos_offset, pad_id, p_drop, seed, sp, s);
     return MMSUM_ERR_BAD_DTYPE;
+}
+
+extern "C" int mmsum_gate_add_ln_fwd(int dtype, const void* pa, const void* pb, const void* yt, const void* ytab, const void* yimg,
+                                     const uint8_t* no_table, const uint8_t* no_img, const void* res, const void* gamma, const void* beta,
+                                     void* y, int R, int D, int rows_per_b, float eps, void* stream) {
+    if (R <= 0 || rows_per_b <= 0) return MMSUM_ERR_BAD_SHAPE;
+    if (dtype != MMSUM_BF16 && dtype != MMSUM_F32) return MMSUM_ERR_BAD_DTYPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int grid = (R + 3) / 4 > 2048 ? 2048 : (R + 3) / 4;
+    return dispatch_vpl(D, [&](auto vpl) {
+        constexpr int VPL = decltype(vpl)::value;
+        if (dtype == MMSUM_BF16)
+            gate_add_ln_fwd_kernel<bf16_t, VPL><<<dim3(grid), dim3(256), 0, s>>>((const bf16_t*)pa, (const bf16_t*)pb, (const bf16_t*)yt, (const bf16_t*)ytab,
+                (const bf16_t*)yimg, no_table, no_img, (const bf16_t*)res, (const float*)gamma, (const float*)beta, (bf16_t*)y, R, D, rows_per_b, eps);
+        else
+            gate_add_ln_fwd_kernel<float, VPL><<<dim3(grid), dim3(256), 0, s>>>((const float*)pa, (const float*)pb, (const float*)yt, (const float*)ytab,
+                (const float*)yimg, no_table, no_img, (const float*)res, (const float*)gamma, (const float*)beta, (float*)y, R, D, rows_per_b, eps);
+    });
 }
 
 extern "C" int mmsum_gate_fwd(int dtype, const void* pa, const void* pb, const void* yt, const void* ytab, const void* yimg,

@@ -133,6 +133,20 @@ class DecodeSession:
         self.out_ids = torch.zeros(layout.B, K, dtype=torch.int64, device=dev)
         self.h_out_scores = torch.zeros(layout.B, K, dtype=torch.float32, pin_memory=pin)
         self.h_out_ids = torch.zeros(layout.B, K, dtype=torch.int64, pin_memory=pin)
+        # bf16 on the device: the decode step's own kernels (round 4) -- every product through mmsum_dec_gemm (the reduction split over
+        # one-wave workgroups so that every CU pulls weights; the slices meet in the product's last arriver) and the three modalities'
+        # cross-attention + entity mean over the cached K / V in ONE launch of one workgroup per (entity, head)
+        # (mmsum_decode_cross_attn).  f32 (the parity mode) and shapes outside those kernels keep the generic path below.
+        nm = len(layout.mods)
+        self.fast = (dev.type == "cuda" and e.dtype == torch.bfloat16 and nm * R <= 96 and num_beams <= 8 and D % 256 == 0
+                     and all(S <= 224 and N <= 32 for (N, S) in layout.mods) and __import__("os").environ.get("MMSUM_DECODE_FAST") != "0")
+        if self.fast:
+            Fd = cfg.decoder_ffn_dim
+            shapes = [(R, 3 * D, D), (R, D, D), (nm * R, D, D), (R, D, 2 * D), (R, Fd, D), (R, D, Fd), (R, cfg.vocab_size, D)]
+            nbytes = max(kn.lib.mmsum_dec_gemm_workspace(M_, N_, K_) for (M_, N_, K_) in shapes if K_ % 256 == 0)
+            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            n_ent = sum(layout.B * N for (N, S) in layout.mods)
+            self.xws = kn.decode_cross_attn_workspace(n_ent, cfg.heads, num_beams, layout.B, nm, dev)
         self.use_graphs = dev.type == "cuda" and __import__("os").environ.get("MMSUM_DECODE_GRAPHS") != "0"
         self.graphs, self.pool, self.warm = {}, None, False
 
@@ -180,10 +194,20 @@ class DecodeSession:
                 self.warm = True
             g = self.graphs.get(t)
             if g is None:
+                import gc
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
-                    self._step(t)
+                # no garbage collection while the stream captures: collecting a CUDAGraph of an EARLIER session (a model that went out
+                # of scope) destroys it through the HIP API, which is not permitted during capture and aborts the process
+                gc_was = gc.isenabled()
+                gc.collect()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                        self._step(t)
+                finally:
+                    if gc_was:
+                        gc.enable()
                 if self.pool is None:
                     self.pool = g.pool()
                 self.graphs[t] = g
@@ -194,7 +218,99 @@ class DecodeSession:
             torch.cuda.current_stream().synchronize()             # the step's one host<->device round trip
         return self.h_out_scores.numpy(), self.h_out_ids.numpy()
 
+    def _mm(self, x, w, out, bias=None, epi=kn.EPI_NONE, x2=None):
+        """One product of the fast step: mmsum_dec_gemm where its shape rules hold (K, and the split point of a two-tensor x, multiples
+        of 256), the general entry point otherwise (tiny test configurations)."""
+        K = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+        # Measured per launch inside a graph (tools/decode_kernels_bench.py, 32 rows): the cross-workgroup split wins where the reduction is
+        # long -- fc2, K = 4096: 12.0 against 14.5 us -- and loses 1 .. 2 us where K <= 2048 (qkv 9.1 / 6.9, out 7.6 / 6.7, alpha 10.4 / 8.4,
+        # fc1 9.0 / 7.2): a product of a few MB sits on a ~7 us floor of launch + one memory round trip + epilogue either way, and the
+        # hand-off adds to it.  So: K >= 4096 here, everything else on mmsum_gemm's weight-streaming kernels.
+        if K >= 4096 and K % 256 == 0 and x2 is None and x.shape[0] <= 96 and w.shape[0] <= 8192:
+            return kn.dec_gemm(x, w, out, self.ws, bias=bias, epi=epi, x2=x2)
+        return kn.gemm(x, w, out, bias=bias, epi=epi, a2=x2)
+
+    def _step_fast(self, t):
+        """The decode step with its own kernels (bf16): per layer the weight-streaming products (the long-K one with its reduction split
+        over workgroups), the cache-walking self-attention, ONE cross-attention launch over the cached K / V of every modality (one
+        workgroup per entity and head), the gate and three LayerNorms: 14 launches (16 before)."""
+        e, cfg, a = self.e, self.e.cfg, self.e.arena
+        D, H, R, Tm = cfg.d_model, cfg.heads, self.rows, self.Tmax
+        b = e.bp + "model.decoder."
+        scale = 64 ** -0.5
+        cur, prev = t & 1, (t - 1) & 1
+        self.tokens.copy_(self.d_int[:R].view(R, 1))
+        anc = self.anc[cur]
+        if t > 0:
+            torch.index_select(self.anc[prev], 0, self.d_int[R:2 * R], out=anc)
+        anc[:, t] = self.arange
+        x = e.empty(R, D)
+        kn.embed_ln_fwd(self.tokens, a.w(e.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), self.rd,
+                        a.w(b + "rating_embeddings") if self.rd is not None else None, a.f32(b + "layernorm_embedding.weight"),
+                        a.f32(b + "layernorm_embedding.bias"), x, self.mean, self.rstd, R, 1, cfg.extra_pos_embeddings + t, 1e-5, 0.0, 0)
+        L = self.L
+        nm = len(L.mods)
+        for i in range(cfg.decoder_layers):
+            lb = b + "layers.%d." % i
+            q, k, v = e._attn_names(lb, "self_attn")
+            qkv = e.empty(R, 3 * D)
+            self._mm(x, a.wspan(q + ".weight", v + ".weight", (3 * D, D)), qkv, bias=a.span(a.data, q + ".bias", v + ".bias", (3 * D,)))
+            att = e.empty(R, D)
+            kn.decode_self_attn(qkv[:, :D], self.kc[i], self.vc[i], anc, att, H, t + 1, Tm, scale, k_new=qkv[:, D:2 * D], v_new=qkv[:, 2 * D:])
+            o = e.empty(R, D)
+            self._mm(att, a.w(lb + "self_attn.out_proj.weight"), o, bias=a.f32(lb + "self_attn.out_proj.bias"))
+            y = e.empty(R, D)
+            kn.add_ln_fwd(o, x, a.f32(lb + "self_attn_layer_norm.weight"), a.f32(lb + "self_attn_layer_norm.bias"), y, self.mean, self.rstd,
+                          1e-5, 0.0, 0)
+            x = y
+            # ---- cross-attention over the cached K / V of every modality + entity mean: one launch (:711-750, :794-869)
+            q, _, _ = e._attn_names(lb, "encoder_attn")
+            pre = lb + "encoder_attn."
+            cq = e.empty(R, D)
+            self._mm(x, a.w(q + ".weight"), cq, bias=a.f32(q + ".bias"))
+            heads = e.empty(nm * R, D)
+            mods = []
+            for m, ((N, S), pad) in enumerate(zip(L.mods, self.pads)):
+                rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
+                mods.append((self.kv[i][rows, :D], self.kv[i][rows, D:], pad, self.nulls[m], N, S))
+            kn.decode_cross_attn(cq, mods, heads, self.xws, L.B, self.qpb, H, scale)
+            yy = e.empty(nm * R, D)
+            self._mm(heads, a.w(pre + "out_proj.weight"), yy, bias=a.f32(pre + "out_proj.bias"))
+            if e.multimodal:
+                yt, ytab, yimg = yy[:R], yy[R:2 * R], yy[2 * R:]
+                pa, pb = e.empty(R, D), e.empty(R, D)
+                self._mm(yt, a.w(pre + "alpha_proj.weight"), pa, bias=a.f32(pre + "alpha_proj.bias"), x2=ytab)
+                self._mm(yt, a.w(pre + "beta_proj.weight"), pb, bias=a.f32(pre + "beta_proj.bias"), x2=yimg)
+                y = e.empty(R, D)                     # gate + residual + LayerNorm in one launch
+                kn.gate_add_ln_fwd(pa, pb, yt, ytab, yimg, self.no_table, self.no_img, x, a.f32(lb + "encoder_attn_layer_norm.weight"),
+                                   a.f32(lb + "encoder_attn_layer_norm.bias"), y, self.qpb, 1e-5)
+            else:
+                y = e.empty(R, D)
+                kn.add_ln_fwd(yy, x, a.f32(lb + "encoder_attn_layer_norm.weight"), a.f32(lb + "encoder_attn_layer_norm.bias"), y, self.mean,
+                              self.rstd, 1e-5, 0.0, 0)
+            x = y
+            Fd = a.shapes[lb + "fc1.weight"][0]
+            h = e.empty(R, Fd)
+            self._mm(x, a.w(lb + "fc1.weight"), h, bias=a.f32(lb + "fc1.bias"), epi=kn.EPI_GELU)
+            f = e.empty(R, D)
+            self._mm(h, a.w(lb + "fc2.weight"), f, bias=a.f32(lb + "fc2.bias"))
+            y = e.empty(R, D)
+            last = i == cfg.decoder_layers - 1
+            kn.add_ln_fwd(f, x, a.f32(lb + "final_layer_norm.weight"), a.f32(lb + "final_layer_norm.bias"), y, self.mean, self.rstd, 1e-5,
+                          0.0, 0, y_f32=self.x32 if last else None)
+            x = y
+        V = cfg.vocab_size
+        self._mm(self.x32, a.w(e.bp + "model.shared.weight"), self.logits[:, :V], bias=e.buffers[e.bp + "final_logits_bias"].reshape(-1))
+        cur_len = t + 1
+        eos = cfg.eos_token_id
+        force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)
+        ban = eos if (eos is not None and cur_len < self.min_length) else -1
+        banned = self.d_int[2 * R:].view(R, self.nban) if self.nban else None
+        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids)
+
     def _step(self, t):
+        if self.fast:
+            return self._step_fast(t)
         e, cfg, a = self.e, self.e.cfg, self.e.arena
         D, H, R, Tm = cfg.d_model, cfg.heads, self.rows, self.Tmax
         b = e.bp + "model.decoder."

@@ -124,6 +124,32 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
     return out
 
 
+def dec_gemm_workspace(M, N, K, device):
+    """A zeroed workspace for dec_gemm products up to this size (tickets + f32 slabs); one serves every product of a stream in turn."""
+    return torch.zeros(max(16, lib.mmsum_dec_gemm_workspace(M, N, K)), dtype=torch.uint8, device=device)
+
+
+def dec_gemm(x, w, out, ws, bias=None, epi=EPI_NONE, x2=None, residual=None):
+    """out[M, N] = gelu?(x . w^T + bias) (+ residual): the decode step's weight-streaming product with the reduction split over
+    workgroups (mmsum_dec_gemm).  x bf16 [M, K] (or f32: the LM head on the un-rounded final LayerNorm output, out f32); x2: the second
+    half of the K range ([M, K2]); w bf16 [N, K]; out bf16 or f32."""
+    M, K = x.shape
+    N = w.shape[0]
+    ksplit = 0
+    if x2 is not None:
+        ksplit, K = K, K + x2.shape[1]
+    assert w.shape[1] == K and out.shape == (M, N) and w.dtype == torch.bfloat16
+    flags = _lib.gemm_epi(epi)
+    if out.dtype == torch.float32:
+        flags |= _lib.GEMM_OUT_F32
+    if x.dtype == torch.float32:
+        flags |= _lib.GEMM_A_F32
+    assert ws.numel() >= lib.mmsum_dec_gemm_workspace(M, N, K), "dec_gemm workspace too small"
+    check(lib.mmsum_dec_gemm(_p(x), _ld(x), _p(x2), _ld(x2) if x2 is not None else 0, ksplit, _p(w), _ld(w), _p(bias), _p(residual),
+                             _ld(residual) if residual is not None else 0, _p(out), _ld(out), M, N, K, flags, _p(ws), _stream()), "mmsum_dec_gemm")
+    return out
+
+
 def slab_reduce(ws, nslabs, out, accumulate=True):
     """out[rows, cols] (+)= sum of the nslabs f32 slabs stacked in ws [nslabs*rows, cols]."""
     rows, cols = out.shape
@@ -215,6 +241,13 @@ def gate_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, out, rows_per_b):
     R, D = yt.shape
     check(lib.mmsum_gate_fwd(_dt(yt), _p(pa), _p(pb), _p(yt), _p(ytab), _p(yimg), _p(no_table), _p(no_img), _p(out), R, D,
                              rows_per_b, _stream()), "mmsum_gate_fwd")
+
+
+def gate_add_ln_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, res, gamma, beta, y, rows_per_b, eps):
+    """y = LN(res + yt + relu(tanh(pa)) ytab + relu(tanh(pb)) yimg) in one launch (the decode step: nothing saved for a backward)."""
+    R, D = yt.shape
+    check(lib.mmsum_gate_add_ln_fwd(_dt(yt), _p(pa), _p(pb), _p(yt), _p(ytab), _p(yimg), _p(no_table), _p(no_img), _p(res), _p(gamma), _p(beta),
+                                    _p(y), R, D, rows_per_b, eps, _stream()), "mmsum_gate_add_ln_fwd")
 
 
 def gate_bwd(dout, pa, pb, ytab, yimg, no_table, no_img, dpa, dpb, dyt, dytab, dyimg, rows_per_b, sums=None):
@@ -362,7 +395,7 @@ def rows_gather(src, dst, row_map, live=None):
 
 def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids):
     """Tail of one beam-search step (see mmsum_beam_topk): logits [rows, >=V] (banned entries are overwritten with -inf),
-    beam_scores [rows] f32, banned [rows, nban] int32 (-1 padded) or None -> out_scores f32 / out_ids int64 [B, 2*num_beams]."""
+    beam_scores [rows] f32, banned [rows, nban] int32 (filled from the front, the first -1 ends a row's list) or None -> out_scores f32 / out_ids int64 [B, 2*num_beams]."""
     rows = logits.shape[0]
     assert beam_scores.dtype == torch.float32 and out_scores.dtype == torch.float32 and out_ids.dtype == torch.int64
     nban = 0 if banned is None else banned.shape[1]
@@ -384,3 +417,22 @@ def decode_self_attn(q, k_cache, v_cache, ancestors, out, H, length, Tmax, scale
     check(lib.mmsum_decode_self_attn(_dt(q), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _ld(k_cache), _p(ancestors), _p(out), out.stride(0),
                                      q.shape[0], H, int(length), Tmax, float(scale), _p(k_new), _p(v_new),
                                      k_new.stride(0) if k_new is not None else 0, _stream()), "mmsum_decode_self_attn")
+
+
+def decode_cross_attn_workspace(n_entities, H, qpb, B, nmod, device):
+    return torch.zeros(max(16, lib.mmsum_decode_cross_attn_workspace(n_entities, H, qpb, B, nmod)), dtype=torch.uint8, device=device)
+
+
+def decode_cross_attn(q, mods, out, ws, B, qpb, H, scale):
+    """The decode step's cross-attention + entity mean over the cached K / V of every modality in one launch (mmsum_decode_cross_attn).
+    q bf16 [B*qpb, H*64]; mods: list of (k, v, pad uint8 [B,N,S] or None, null_entity uint8 [B*N] or None, N, S) with k / v bf16
+    [B*N*S, H*64] views of one pitch; out bf16 [len(mods) * B*qpb, H*64]."""
+    arr = (_lib.XattnMemory * len(mods))()
+    ldkv = mods[0][0].stride(0)
+    for i, (k, v, pad, nul, N, S) in enumerate(mods):
+        assert k.dtype == torch.bfloat16 and k.stride(0) == ldkv and v.stride(0) == ldkv and k.shape[0] == B * N * S
+        arr[i].k, arr[i].v, arr[i].pad, arr[i].null_entity, arr[i].N, arr[i].S = _p(k), _p(v), _p(pad), _p(nul), N, S
+    assert q.dtype == torch.bfloat16 and out.shape[0] == len(mods) * B * qpb
+    check(lib.mmsum_decode_cross_attn(_p(q), q.stride(0), arr, len(mods), ldkv, _p(out), out.stride(0), B, qpb, H, float(scale), _p(ws), _stream()),
+          "mmsum_decode_cross_attn")
+    return out

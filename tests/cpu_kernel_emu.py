@@ -513,8 +513,9 @@ def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams,
     if banned is not None:
         for r in range(banned.shape[0]):
             for t in banned[r].tolist():
-                if t >= 0:
-                    sc[r, t] = float("-inf")
+                if t < 0:
+                    break                      # the contract: a row's list is filled from the front, its first -1 ends it
+                sc[r, t] = float("-inf")
     B = logits.shape[0] // num_beams
     cand = (sc + beam_scores[:, None]).view(B, num_beams * V)
     K = 2 * num_beams

@@ -8,10 +8,12 @@ is not a property either of them has.  The property that IS checkable, and that 
 cache row or a mis-scored beam breaks by many nats:
 
   the oracle's search, run with a guide that at every step (a) requires its hypotheses to equal the hypotheses the other search holds,
-  (b) requires every (score, beam, token) candidate the other search returned to carry the oracle's own score for that beam and token
-  within `tie`, -inf candidates (forced tokens, bans) to agree on being -inf, and no candidate the other search passed over to beat its
-  worst pick by more than 2 * tie, and then (c) adopts the other search's ORDER with the oracle's scores, ends on the same hypotheses;
-  and the ids the other search returned are, per business, the oracle's best finished hypothesis or one within `tie` per token of it.
+  (b) re-scores the step ON THE OTHER SEARCH'S running beam scores (oracle log-probabilities of the step + the beam scores the other
+  search carried into it: the step is judged, not the rounding it has accumulated so far) and requires every (score, beam, token)
+  candidate the other search returned to carry that score within `tie`, -inf candidates (forced tokens, bans) to agree on being
+  -inf, and no candidate the other search passed over to beat its worst pick by more than 2 * tie, and then (c) adopts the other
+  search's ORDER with the oracle's own running scores, ends on the same hypotheses; and the ids the other search returned are, per
+  business, the oracle's best finished hypothesis or one whose score is within `tie` per token of it.
 """
 import torch
 
@@ -33,6 +35,9 @@ def guided_check(out_ids, trace, sd, ocfg, hiddens, masks, rd, multimodal, kw, t
         assert st["cur_len"] == input_ids.shape[1]
         pre = torch.from_numpy(st["prefixes"]).long()
         top_s, top_i = torch.topk(cand, 2 * beams, dim=1, largest=True, sorted=True)
+        # the step's log-probabilities on the other search's running scores
+        step_lp = cand.view(B * beams, V) - beam_scores[:, None]
+        cand_h = (step_lp + torch.from_numpy(st["beam_scores"]).float()[:, None]).view(B, beams * V)
         for b in range(B):
             if not st["open"][b]:
                 continue                                  # finished business: padded rows on both sides, the step's pick is never used
@@ -40,19 +45,19 @@ def guided_check(out_ids, trace, sd, ocfg, hiddens, masks, rd, multimodal, kw, t
             assert torch.equal(pre[rows], input_ids[rows]), ("hypotheses differ at step %d, business %d" % (i, b), pre[rows], input_ids[rows])
             got_ids = torch.from_numpy(st["top_ids"][b]).long()
             got_sc = torch.from_numpy(st["top_scores"][b]).float()
-            want = cand[b, got_ids]
+            want = cand_h[b, got_ids]
             assert len(set(got_ids.tolist())) == got_ids.numel() or not bool(torch.isfinite(want).all()), ("duplicate candidates", i, b, got_ids)
             fin_w, fin_g = want > -1e8, got_sc > -1e8
             assert bool((fin_w == fin_g).all()), ("forced / banned / dead candidates disagree at step %d, business %d" % (i, b), got_sc, want)
             if fin_w.any():
                 dev = float((got_sc[fin_w] - want[fin_w]).abs().max())
                 assert dev <= tie, ("a candidate's score is not the oracle's: step %d business %d, off by %.3e" % (i, b, dev), got_sc, want)
-                rest = cand[b].clone()
+                rest = cand_h[b].clone()
                 rest[got_ids] = float("-inf")
                 over = float(rest.max() - want[fin_w].min())
                 assert over <= 2 * tie, ("a better candidate was passed over: step %d business %d, by %.3e" % (i, b, over))
                 stat["worst_score"], stat["worst_rank"] = max(stat["worst_score"], dev), max(stat["worst_rank"], over)
-            top_s[b], top_i[b] = want, got_ids              # the other search's order, the oracle's scores
+            top_s[b], top_i[b] = cand[b, got_ids], got_ids   # the other search's order, the oracle's own running scores
         return top_s, top_i
 
     ref, hyps = go.beam_search(sd, ocfg, hiddens, masks, rd, multimodal, decoder_start_token_id=start_token, guide=guide, return_all=True, **kw)
@@ -67,7 +72,7 @@ def guided_check(out_ids, trace, sd, ocfg, hiddens, masks, rd, multimodal, kw, t
         ok = False
         for s, toks in hyps[b]:
             cand_row = toks + ([eos] if len(toks) < max_length else [])
-            if row[:len(cand_row)] == cand_row and all(t == pad for t in row[len(cand_row):]) and best - s <= tie:
+            if row[:len(cand_row)] == cand_row and all(t == pad for t in row[len(cand_row):]) and best - s <= tie * len(toks):
                 ok = True
         assert ok, ("business %d: the returned ids are not the oracle's best hypothesis nor one that ties with it" % b, row[:16], ref[b][:16])
     return stat

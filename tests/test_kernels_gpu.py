@@ -411,8 +411,8 @@ def test_attention_bf16_error_against_the_bf16_yardstick(case, std):
     score gradients rounded, oracle/bart_oracle._QuantMatmul).  Relative L2 error of out / dQ / dK / dV of the HIP kernels must
     stay within 1.5x the yardstick's + 1e-3.  `flat` = small scores (nearly uniform probabilities: dS = P (dP - delta) is then a
     difference of nearly equal numbers, the regime of a freshly initialised model), `peaked` = unit-variance q, k.
-    `cross_img` (several 196-key entities per business) runs the chunked kernels: running softmax over two chunks of keys in the
-    forward, two walks in dQ (attn_tr_fwd_chunk_kernel / attn_tr_bwd_dq_chunk_kernel)."""
+    `cross_img` (several 196-key entities per business) runs the chunked forward: running softmax over two chunks of keys
+    (attn_tr_fwd_chunk_kernel)."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     from oracle import bart_oracle as bo
@@ -878,7 +878,7 @@ def test_beam_topk(dtype, num_beams, V):
             top_tok = logits[:, :V].float().argmax(-1).cpu()
             for r in range(R):
                 banned[r, 0] = int(top_tok[r])                    # ban each row's best token: the winner must change
-                banned[r, 3] = (r * 13 + 5) % V
+                banned[r, 1] = (r * 13 + 5) % V                   # (the list is filled from the front: the first -1 ends it)
             banned = banned.to(DEV)
         ref = logits[:, :V].float().clone()
         if force >= 0:
@@ -919,10 +919,11 @@ def test_beam_topk(dtype, num_beams, V):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_decode_self_attn_through_ancestor_table(dtype):
     """mmsum_decode_self_attn: one query per hypothesis over cache rows reached through the ancestor table == softmax(q K^T) V
-    over the gathered rows (what the reference gets after index_select-ing its caches, modeling_multimodalsum.py:3104-3115)."""
-    R, H, Tmax, D = 12, 16, 40, 1024
+    over the gathered rows (what the reference gets after index_select-ing its caches, modeling_multimodalsum.py:3104-3115).
+    bf16 takes the 256-thread kernel (every K row in registers, V rows by LDS-DMA): lengths across its 32-row slots up to Tmax = 256."""
+    R, H, Tmax, D = 12, 16, 256, 1024
     g = torch.Generator().manual_seed(11)
-    for length in (1, 7, 40):
+    for length in (1, 7, 40, 65, 130, 256):
         q = torch.randn(R, 3 * D, generator=g).to(DEV).to(dtype)               # a [R, 3D] qkv buffer: the query is a strided view
         kc = torch.randn(R * Tmax, D, generator=g).to(DEV).to(dtype)
         vc = torch.randn(R * Tmax, D, generator=g).to(DEV).to(dtype)
@@ -952,3 +953,121 @@ def test_decode_self_attn_through_ancestor_table(dtype):
         out3 = torch.full((R, D), float("nan"), device=DEV, dtype=dtype)
         kn.decode_self_attn(q[:, :D], kc3, vc3, anc2, out3, H, length, Tmax, 0.125)
         assert torch.equal(out2, out3)
+
+
+# ------------------------------------------------------------------------------------------------
+# the decode step's own kernels (round 4)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,epi,k2,f32", [
+    (32, 1024, 1024, 0, 0, False), (96, 1024, 1024, 0, 0, False), (32, 3072, 1024, 0, 0, False), (32, 4096, 1024, 1, 0, False),
+    (32, 1024, 4096, 0, 0, False), (32, 1024, 2048, 0, 1024, False), (12, 1024, 1024, 0, 0, False), (8, 264, 256, 0, 0, False),
+    (8, 256, 512, 0, 256, False), (32, 5001, 1024, 0, 0, True), (7, 4999, 1024, 0, 0, True)],
+    ids=["out", "out3R", "qkv", "fc1_gelu", "fc2", "alpha_two_tensors", "R12", "tiny_ragged_N", "tiny_two_tensors", "lm_head_f32", "lm_head_f32_R7"])
+def test_dec_gemm(M, N, K, epi, k2, f32):
+    """mmsum_dec_gemm (the reduction split over one-wave workgroups, the tile's last arriver reduces and runs the epilogue) against an
+    f64 product of the same bf16 operands; the same workspace serves two different products one after the other and a REPEAT of the
+    first (the ticket words are back at zero after every launch); rows past M and columns past N of a padded output stay untouched."""
+    bf = torch.bfloat16
+    x = rnd(M, K, dtype=torch.float32 if f32 else bf, seed=1)
+    w = rnd(N, K, dtype=bf, seed=2, std=0.05)
+    bias = rnd(N, seed=3)
+    ws = kn.dec_gemm_workspace(96, max(N, 4096), 4096, DEV)
+    out = torch.full((M + 1, N + 3), float("nan"), device=DEV, dtype=torch.float32 if f32 else bf)
+    x1, x2 = (x[:, :k2].contiguous(), x[:, k2:].contiguous()) if k2 else (x, None)
+
+    def run():
+        kn.dec_gemm(x1, w, out[:M, :N], ws, bias=bias, epi=epi, x2=x2)
+    run()
+    ref = x.double() @ w.double().t() + bias.double()
+    if epi:
+        ref = torch.nn.functional.gelu(ref)
+    first = out.clone()
+    assert torch.isnan(out[M]).all() and torch.isnan(out[:, N:]).all()
+    tol_ = 1e-5 + (1e-5 if f32 else 1e-2) * float(ref.abs().max())        # f32 x: bf16 hi + lo parts carry 16 bits of x; the weights are bf16
+    assert float((out[:M, :N].double() - ref).abs().max()) <= tol_, float((out[:M, :N].double() - ref).abs().max())
+    # another product through the same workspace, then the first one again: bit-identical
+    y = rnd(16, 1024, dtype=bf, seed=5)
+    wy = rnd(2048, 1024, dtype=bf, seed=6, std=0.05)
+    oy = torch.empty(16, 2048, device=DEV, dtype=bf)
+    kn.dec_gemm(y, wy, oy, ws)
+    assert float((oy.double() - y.double() @ wy.double().t()).abs().max()) <= 1e-2 * float((y.double() @ wy.double().t()).abs().max()) + 1e-5
+    out.fill_(float("nan"))
+    run()
+    assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(first, nan=7.0))
+
+
+@pytest.mark.parametrize("qpb", [4, 2])
+def test_decode_cross_attn(qpb):
+    """mmsum_decode_cross_attn -- one workgroup per (entity, head) over the cached K / V of the three modalities, the entity mean through
+    the last arriver -- against the per-entity softmax + entity mean of modeling_multimodalsum.py:819-869 in f64: trailing pads and a
+    hole in the text keys (masked_fill -2^16), a null review, a business without a table, one with a null image; called twice (the
+    tickets return to zero)."""
+    bf = torch.bfloat16
+    B, H = 3, 4
+    D = H * 64
+    mods_shape = [(3, 128), (1, 47), (2, 196)]
+    g = torch.Generator().manual_seed(3)
+    R = B * qpb
+    q = rnd(R, D, dtype=bf, seed=1)
+    rows = sum(B * N * S for N, S in mods_shape)
+    kv = rnd(rows, 2 * D, dtype=bf, seed=2)
+    pads, nulls, mods, off = [], [], [], 0
+    for mi, (N, S) in enumerate(mods_shape):
+        pad = torch.zeros(B, N, S, dtype=torch.bool)
+        for b in range(B):
+            for n in range(N):
+                pad[b, n, int(torch.randint(S // 3, S + 1, (1,), generator=g)):] = True
+        if mi == 0:
+            pad[0, 1, 5] = True                    # a hole
+            pad[1, 2] = True                       # a null review
+        if mi == 1:
+            pad[2, 0] = True                       # no table
+        if mi == 2:
+            pad[0, 1] = True                       # one null image
+            pad[1] = False                         # whole images are attended
+        pad_u8 = pad.to(torch.uint8).to(DEV).contiguous()
+        nul = torch.empty(B * N, dtype=torch.uint8, device=DEV)
+        kn.entity_null(pad_u8, nul, B * N, S)
+        sl = slice(off, off + B * N * S)
+        mods.append((kv[sl, :D], kv[sl, D:], pad_u8, nul, N, S))
+        pads.append(pad)
+        off += B * N * S
+    out = torch.full((3 * R, D), float("nan"), device=DEV, dtype=bf)
+    n_ent = sum(B * N for N, S in mods_shape)
+    ws = kn.decode_cross_attn_workspace(n_ent, H, qpb, B, 3, DEV)
+    for _ in range(2):
+        out.fill_(float("nan"))
+        kn.decode_cross_attn(q, mods, out, ws, B, qpb, H, 0.125)
+        off = 0
+        for mi, ((N, S), pad) in enumerate(zip(mods_shape, pads)):
+            k = kv[off:off + B * N * S, :D].double().cpu().view(B, N, S, H, 64)
+            v = kv[off:off + B * N * S, D:].double().cpu().view(B, N, S, H, 64)
+            off += B * N * S
+            qh = q.double().cpu().view(B, qpb, H, 64) * 0.125
+            s = torch.einsum("bqhd,bnshd->bnhqs", qh, k)
+            s = s.masked_fill(pad[:, :, None, None, :], -65536.0)
+            p = torch.softmax(s, dim=-1)
+            o = torch.einsum("bnhqs,bnshd->bnqhd", p, v)                    # [B,N,qpb,H,64]
+            valid = (~pad.all(dim=-1)).double()                              # [B,N]
+            cnt = valid.sum(1).clamp_min(1.0)
+            ref = (o * valid[:, :, None, None, None]).sum(1) / cnt[:, None, None, None]
+            got = out[mi * R:(mi + 1) * R].double().cpu().view(B, qpb, H, 64)
+            err = float((got - ref).abs().max())
+            assert err <= 1e-2 * float(ref.abs().max()) + 1e-3, (mi, err)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gate_add_ln_fwd(dtype):
+    """mmsum_gate_add_ln_fwd == the gate (:732-744) followed by LN(res + .) (:474-477) in f64, rows of businesses without table / image included."""
+    R, D, rpb = 12, 1024, 4
+    pa, pb, yt, ytab, yimg, res = (rnd(R, D, dtype=dtype, seed=i) for i in range(6))
+    gamma, beta = 1 + 0.1 * rnd(D, seed=7), 0.1 * rnd(D, seed=8)
+    no_table = torch.tensor([0, 1, 0], dtype=torch.uint8, device=DEV)
+    no_img = torch.tensor([1, 0, 0], dtype=torch.uint8, device=DEV)
+    y = torch.empty(R, D, device=DEV, dtype=dtype)
+    kn.gate_add_ln_fwd(pa, pb, yt, ytab, yimg, no_table, no_img, res, gamma, beta, y, rpb, 1e-5)
+    ma = (1 - no_table.double()).repeat_interleave(rpb)[:, None]
+    mb = (1 - no_img.double()).repeat_interleave(rpb)[:, None]
+    z = res.double() + yt.double() + ma * torch.relu(torch.tanh(pa.double())) * ytab.double() + mb * torch.relu(torch.tanh(pb.double())) * yimg.double()
+    ref = torch.nn.functional.layer_norm(z, (D,), gamma.double(), beta.double(), 1e-5)
+    close(y, ref, dtype, what="gate + add + LayerNorm")

@@ -8,7 +8,9 @@ from multimodalsum_amd import kernels as kn
 
 NB = int(os.environ.get("ATTN_BENCH_B", "8"))
 CASES = [("cross_text", NB, 9, 9, 128, 128, True, False), ("self_causal", 9 * NB, 1, 1, 128, 128, False, True),
-         ("cross_img", NB, 9, 1, 196, 128, False, False), ("cross_table", NB, 9, 1, 47, 128, False, False)]
+         ("cross_img", NB, 9, 1, 196, 128, False, False), ("cross_table", NB, 9, 1, 47, 128, False, False),
+         # the step's image memory: 4 image slots per business, U{0..4} of them filled (the others are null entities: skipped)
+         ("cross_img4", NB, 9, 4, 196, 128, False, False)]
 
 
 def timeit(fn, iters=5):
@@ -39,6 +41,14 @@ def main():
             lens = (torch.randn(B * N, generator=g) * 20 + 75).round().clamp(32, S).long()
             pad = (torch.arange(S).unsqueeze(0) >= lens.unsqueeze(1)).to(torch.uint8).reshape(-1).cuda()
         null = torch.zeros(B * N, dtype=torch.uint8, device="cuda")
+        live_frac = 1.0
+        if name == "cross_img4":
+            g = torch.Generator().manual_seed(1)
+            nv = torch.randint(0, N + 1, (B,), generator=g)
+            gone = (torch.arange(N).unsqueeze(0) >= nv.unsqueeze(1))                       # [B, N]
+            pad = gone.unsqueeze(-1).expand(B, N, S).reshape(-1).to(torch.uint8).cuda().contiguous()
+            null = gone.reshape(-1).to(torch.uint8).cuda().contiguous()
+            live_frac = float((~gone).float().mean())
         kv_rows = None
         if os.environ.get("ATTN_BENCH_MAPS") == "1" and not causal:     # compacted memory: K / V hold the unmasked rows only, read through a row map
             keep = pad.eq(0)
@@ -57,7 +67,8 @@ def main():
         tf = timeit(lambda: kn.attn_fwd(desc, q))
         tb = timeit(lambda: kn.attn_bwd(desc, dout, dq, False, dkv[:, :D], dkv[:, D:], stats))
         ta = timeit(lambda: kn.attn_bwd(desc, dout, dq, True, dkv[:, :D], dkv[:, D:], stats))
-        print("%-12s fwd %7.0f us (%6.1f TF/s)   bwd %7.0f us (%6.1f TF/s)   bwd+ %7.0f us" % (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6, ta), flush=True)
+        print("%-12s fwd %7.0f us (%6.1f TF/s)   bwd %7.0f us (%6.1f TF/s)   bwd+ %7.0f us%s" % (name, tf, fl / tf / 1e6, tb, 2.5 * fl / tb / 1e6, ta,
+              "   (%.0f %% of the entities live: TF/s at the canonical count of ALL entities)" % (100 * live_frac) if live_frac < 1 else ""), flush=True)
 
 
 if __name__ == "__main__":

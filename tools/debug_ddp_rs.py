@@ -1,0 +1,25 @@
+import os, sys, torch, torch.distributed as dist
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29578"); os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+import ddp_rccl_worker as w
+from multimodalsum_amd.parallel import DistributedDataParallel
+res = {}
+for mode, bucket in (("none", 0), ("all_reduce", 1 << 20), ("reduce_scatter", 1 << 20), ("reduce_scatter", 1000003)):
+    cfg, model = w.build(torch.float32, dev)
+    runner = model if mode == "none" else DistributedDataParallel(model, delay_allreduce=True, always_reduce=True, collect_stats=True, bucket_elems=bucket, mode=mode)
+    for p in model.parameters():
+        p.grad = None
+    loss = w.step(runner, w.batch(cfg, 0, dev))
+    torch.cuda.synchronize()
+    res[(mode, bucket)] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+base = res[("none", 0)]
+for key, g in res.items():
+    if key[0] == "none":
+        continue
+    bad = sorted(((float((g[n] - base[n]).abs().max()), n) for n in base), reverse=True)[:6]
+    print(key, "worst:", [(round(e, 6), n) for e, n in bad if e > 0] or "identical")
+dist.destroy_process_group()
