@@ -92,6 +92,12 @@ int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda
                     const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
                     int splitk, const int* live_rows, const float* alpha_dev, int* plan);
 
+/* Two INDEPENDENT bf16 products of one shape in one launch (the decode step's alpha and beta projections, :738-739: each alone is 64
+ * workgroups on a per-launch floor): C_i[M <= 64, N <= 4096] = A_i[M, ksplit] | A2_i[M, K - ksplit] . B_i[N, K]^T + bias_i, i = 0, 1.
+ * K a multiple of 256, ksplit a multiple of 32 (0 = no second tensor).  Leading dimensions in elements. */
+typedef struct { const void* A; const void* A2; const void* B; void* C; const float* bias; long lda, lda2, ldb, ldc; } mmsum_gemm_operands;
+int mmsum_gemm_pair(const mmsum_gemm_operands* ops, int M, int N, int K, int ksplit, void* stream);
+
 /* The decode step's products (generation.py; modeling_multimodalsum.py:783-792,885,738-739,302-304,2281 at one token per hypothesis):
  *   out[M <= 96, N] = gelu?(x[M,K] . W[N,K]^T + bias) (+ residual),  bf16 x / W (x f32 with MMSUM_GEMM_A_F32), bf16 or f32 (OUT_F32) out.
  * The REDUCTION is split over one-wave workgroups ((N / 16) x splitk of them: every CU pulls weights, every load of a slice in
@@ -103,6 +109,15 @@ int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda
 long mmsum_dec_gemm_workspace(int M, int N, int K);
 int mmsum_dec_gemm(const void* x, long ldx, const void* x2, long ldx2, int ksplit, const void* W, long ldw, const float* bias,
                    const void* residual, long ldres, void* out, long ldo, int M, int N, int K, int flags, void* workspace, void* stream);
+
+/* 3x3 convolution, stride 1, padding 1, bf16, as an IMPLICIT GEMM (ResNet101's conv2 of every bottleneck but the two strided ones,
+ * torchvision resnet101 as used by img_encoder.py:21-24,31-35): y[(n,y,x)][co] = sum_{ky,kx,c} xp[n][y+ky][x+kx][c] w[co][(3 ky + kx) C + c].
+ *   xp : the input in the PADDED NHWC layout [n, H+2, W+2, C] with ZERO borders (mmsum_bn_apply writes it: pad_H / pad_W);
+ *   w  : [Cout, ldw >= 9 C] in (ky, kx, c) column order (mmsum_conv_weight_permute);  y : [n*H*W, Cout], compact rows.
+ *   stats (f32 [2 Cout], may be NULL) += column sums of y and of y^2 as stored (the BatchNorm statistics, as MMSUM_GEMM_COLSUM2).
+ * The LDS-DMA pieces of the NT kernels read C-contiguous runs of one tap straight from xp: no im2col matrix.  C a power of two >= 64. */
+int mmsum_conv3x3_gemm(const void* xp, const void* w, long ldw, void* y, long ldy, float* stats, int n, int H, int W, int C,
+                       int Cout, void* stream);
 
 /* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
 int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
@@ -276,16 +291,20 @@ int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* w
  * /root/reference/src/img_encoder.py:21-41).  Pass running_mean = NULL to mmsum_bn_apply afterwards: the update is done here. */
 int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* sums, float* running_mean, float* running_var, float momentum,
                              void* stream);
+/* pad_H, pad_W (0, 0 = no): y is written in the zero-bordered PADDED layout [n, pad_H + 2, pad_W + 2, C] of an [n, pad_H, pad_W] image
+ * (R = n pad_H pad_W): pixel (n, y, x) lands at row n (pad_H+2)(pad_W+2) + (y+1)(pad_W+2) + x + 1 -- the operand layout of
+ * mmsum_conv3x3_gemm.  The borders are NOT written: the caller zeroes the buffer once.  x and residual stay compact. */
 int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gamma, const float* beta,
                    const void* residual, void* y, float* running_mean, float* running_var, int R, int C, float eps,
-                   float momentum, int relu, int training, void* stream);
+                   float momentum, int relu, int training, int pad_H, int pad_W, void* stream);
 /* BN backward, two launches: bn_reduce over (dy', dy'*xhat) via mmsum_bn_bwd_reduce, then bn_bwd_apply.
- * dy' = dy * (y > 0) when relu (y = forward output).  dsums[2*C] = {sum dy', sum dy'*xhat}. */
+ * dy' = dy * (y > 0) when relu (y = forward output; pad_H / pad_W: y is in the padded layout mmsum_bn_apply wrote).
+ * dsums[2*C] = {sum dy', sum dy'*xhat}. */
 int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* sums, int R, int C,
-                        float eps, int relu, float* dsums, void* workspace, void* stream);
+                        float eps, int relu, float* dsums, void* workspace, int pad_H, int pad_W, void* stream);
 int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
                        const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C,
-                       float eps, int relu, void* stream);
+                       float eps, int relu, int pad_H, int pad_W, void* stream);
 int mmsum_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 /* NCHW f32 image -> NHWC dtype. */
 int mmsum_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, void* stream);

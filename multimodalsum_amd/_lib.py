@@ -26,6 +26,11 @@ def gemm_epi(e):
     return e << 3
 
 
+class GemmOperands(ctypes.Structure):
+    _fields_ = [("A", c_void_p), ("A2", c_void_p), ("B", c_void_p), ("C", c_void_p), ("bias", c_void_p),
+                ("lda", c_long), ("lda2", c_long), ("ldb", c_long), ("ldc", c_long)]
+
+
 class XattnMemory(ctypes.Structure):
     _fields_ = [("k", c_void_p), ("v", c_void_p), ("pad", c_void_p), ("null_entity", c_void_p), ("N", c_int), ("S", c_int)]
 
@@ -50,6 +55,7 @@ SIGNATURES = {
     "mmsum_decode_cross_attn_workspace": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "mmsum_decode_cross_attn": (c_int, [c_void_p, c_long, ctypes.POINTER(XattnMemory), c_int, c_long, c_void_p, c_long, c_int, c_int, c_int,
                                         c_float, c_void_p, c_void_p]),
+    "mmsum_gemm_pair": (c_int, [ctypes.POINTER(GemmOperands), c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_dec_gemm_workspace": (c_long, [c_int, c_int, c_int]),
     "mmsum_dec_gemm": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long,
                                c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
@@ -94,11 +100,12 @@ SIGNATURES = {
     "mmsum_bn_reduce": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mmsum_bn_stats_from_sums": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "mmsum_bn_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                               c_int, c_float, c_float, c_int, c_int, c_void_p]),
+                               c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_bn_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p,
-                                    c_void_p, c_void_p]),
+                                    c_void_p, c_int, c_int, c_void_p]),
     "mmsum_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p]),
+    "mmsum_conv3x3_gemm": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_maxpool3x3s2": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_table_gather": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p]),

@@ -216,6 +216,23 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     return dtype == MMSUM_BF16 ? launch_gemm<bf16_t>(a, s) : launch_gemm<float>(a, s);
 }
 
+// 3x3 convolution, stride 1, padding 1, as an IMPLICIT GEMM on the LDS-DMA NT kernels: the operand rows are read from the activations
+// in the zero-bordered padded NHWC layout (gemm_common.h: conv_row / conv_koff); no im2col matrix exists.
+extern "C" int mmsum_conv3x3_gemm(const void* xp, const void* w, long ldw, void* y, long ldy, float* stats, int n, int H, int W, int C,
+                                  int Cout, void* stream) {
+    if (n <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C < 64 || (C & (C - 1))) return MMSUM_ERR_BAD_SHAPE;      // C: a power of two >= 64 (stages of one tap)
+    if ((long)n * (H + 2) * (W + 2) * C * 2 >= 0x7fffffffL || (long)n * H * W >= 0x7fffffffL) return MMSUM_ERR_BAD_SHAPE;   // 32-bit buffer offsets
+    if ((((uintptr_t)xp | (uintptr_t)w | (uintptr_t)y) & 15) || ((ldw * 2) & 15) || ((ldy * 2) & 15)) return MMSUM_ERR_BAD_ALIGN;
+    if (ldw < 9L * C) return MMSUM_ERR_BAD_SHAPE;
+    GemmArgs a{xp, nullptr, w, y, stats, nullptr, n * H * W, Cout, 9 * C, (long)C, 0, ldw, ldy, 0, 0, 1.f,
+               stats ? (MMSUM_GEMM_COLSUM | MMSUM_GEMM_COLSUM2) : 0, 1, nullptr, nullptr};
+    a.conv_wp = W + 2; a.conv_w = W; a.conv_hw = H * W; a.conv_hpwp = (H + 2) * (W + 2);
+    a.conv_cshift = 0;
+    while ((1 << a.conv_cshift) < C) ++a.conv_cshift;
+    if (!gemm_glds_eligible(MMSUM_BF16, a)) return MMSUM_ERR_BAD_SHAPE;
+    return launch_gemm_glds(a, static_cast<hipStream_t>(stream));
+}
+
 // Which kernel, tile and grid mmsum_gemm would launch for these arguments (no device work, no pointers dereferenced):
 // plan[0] = MMSUM_PLAN_* kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (< tiles * splitk
 // means persistent workgroups walking the tile list).  Lets tests assert that a shape reaches the kernel they mean to cover.

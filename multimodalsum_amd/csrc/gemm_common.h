@@ -8,7 +8,25 @@ struct GemmArgs {
     int M, N, K; long lda, lda2, ldb, ldc, ldaux; int ksplit; float alpha; int flags; int splitk;
     const int* live;     // device int32 or NULL: live rows of the row-streamed operand (M for natural A, K for the A_T|B_T product)
     const float* alpha_dev;   // device f32 or NULL: alpha is multiplied by it when the kernel runs (an upstream gradient scale)
+    // Implicit 3x3 convolution (stride 1, padding 1) as the NT product y[(n,y,x), co] = sum_{tap, c} A[pixel + tap][c] W[co][tap * C + c]
+    // (mmsum_conv3x3_gemm; conv_wp == 0: an ordinary product).  A = the activations in the PADDED NHWC layout [(n, H + 2, W + 2), C]
+    // with zero borders: the operand row of output pixel m for tap (ky, kx) is row conv_row(m) + ky * Wp + kx -- the im2col matrix is
+    // never materialised: the LDS-DMA pieces of a 64-deep (32-deep) stage read C-contiguous runs of one tap.  C is a power of two >= 64.
+    int conv_wp, conv_w, conv_hw, conv_hpwp, conv_cshift;
 };
+
+// Padded-layout row of output pixel m = (n, y, x) for tap (0, 0): n * Hp * Wp + y * Wp + x.
+__device__ __forceinline__ int conv_row(const GemmArgs& p, int m) {
+    const int n = m / p.conv_hw, rem = m - n * p.conv_hw;
+    const int y = rem / p.conv_w, x = rem - y * p.conv_w;
+    return n * p.conv_hpwp + y * p.conv_wp + x;
+}
+// Element offset (to add to the row's address) of reduction index k0 = tap * C + c0, k0 a multiple of 32 (scalar arithmetic).
+__device__ __forceinline__ int conv_koff(const GemmArgs& p, int k0) {
+    const int tap = k0 >> p.conv_cshift, c0 = k0 & ((1 << p.conv_cshift) - 1);
+    const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;            // tap / 3, tap % 3 for tap <= 8
+    return (ky * p.conv_wp + kx) * (int)p.lda + c0;
+}
 
 // Live row count (device-resident, so one captured HIP graph serves every batch): rows at and past it are neither read
 // nor written.  Natural A: limits M.  Reduction-major product (A_T | B_T, the weight gradient): limits K.

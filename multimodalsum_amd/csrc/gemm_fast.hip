@@ -717,7 +717,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
         int grow = (isA ? m0 : n0) + row;
         const int lim = isA ? p.M : p.N;
         grow = grow < lim ? grow : lim - 1;
-        offA[i] = (long)grow * (isA ? p.lda : p.ldb) + c * 8;
+        offA[i] = (long)((isA && p.conv_wp) ? conv_row(p, grow) : grow) * (isA ? p.lda : p.ldb) + c * 8;      // implicit convolution: the pixel's padded row
         offA2[i] = isA ? (long)grow * p.lda2 + c * 8 : 0;
     }
     auto issue = [&](int si) {          // si: slab index relative to s_beg
@@ -728,6 +728,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
         const bool second = A2 != nullptr && k0 >= p.ksplit;
         const bf16_t* Ab = second ? A2 : A;
         if (second) k0 -= p.ksplit;
+        if (p.conv_wp) k0 = conv_koff(p, k0);                 // implicit convolution: (tap row offset) * lda + channel
 #pragma unroll
         for (int i = 0; i < Cfg::PPW; ++i) {
             if (i * Cfg::NW < Cfg::PA) dma16(Ab + (second ? offA2[i] : offA[i]) + k0, As + (i * Cfg::NW + wave) * 1024);
@@ -861,11 +862,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
         const int row = (i * C::NW + wave) * 8 + (lane_t >> 3);
         const int ch = ((lane_t & 7) ^ ((row >> 1) & 7)) * 16;
         const int ra = m0 + row < p.M ? row : p.M - 1 - m0, rb = n0 + row < p.N ? row : p.N - 1 - n0;
-        offA[i] = ra * (int)p.lda * 2 + ch;
+        offA[i] = (p.conv_wp ? conv_row(p, m0 + ra) : ra) * (int)p.lda * 2 + ch;      // implicit convolution: the pixel's padded row (base = the buffer)
         offA2[i] = ra * (int)p.lda2 * 2 + ch;
         offB[i] = rb * (int)p.ldb * 2 + ch;
     }
-    const bf16_t* baseA = A + (long)m0 * p.lda;
+    const bf16_t* baseA = p.conv_wp ? A : A + (long)m0 * p.lda;
     const bf16_t* baseA2 = A2 ? A2 + (long)m0 * p.lda2 : A;
     const bf16_t* baseB = B + (long)n0 * p.ldb;
     // piece I of A / B of stage `st` (stage index relative to k_beg)
@@ -873,7 +874,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_w4_kernel(GemmArgs p) {
     {                                                                                                  \
         const int k0_ = k_beg + (ST) * 64;                                                             \
         const bool second_ = A2 != nullptr && k0_ >= p.ksplit;                                         \
-        k64_piece<C, I>(smem + ((ST) % 3) * C::A_BYTES, second_ ? baseA2 : baseA, second_ ? offA2[I] : offA[I], second_ ? k0_ - p.ksplit : k0_, wave); \
+        k64_piece<C, I>(smem + ((ST) % 3) * C::A_BYTES, second_ ? baseA2 : baseA, second_ ? offA2[I] : offA[I],                                  \
+                        second_ ? k0_ - p.ksplit : (p.conv_wp ? conv_koff(p, k0_) : k0_), wave);                                                  \
     }
 #define W4_B(I, ST) k64_piece<C, I>(smem + B_BASE + ((ST) & 1) * C::B_BYTES, baseB, offB[I], k_beg + (ST) * 64, wave);
 #define W4_ALL(M, ST) M(0, ST) M(1, ST) M(2, ST) M(3, ST) M(4, ST) M(5, ST) M(6, ST) M(7, ST)

@@ -104,8 +104,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
 // (measured: the K = 4096, N = 1024 product took 16.7 us on 32 workgroups whatever the number of loads in flight), so the products with
 // N <= 4096 -- everything in the decode step but the LM head -- are bounded by how many CUs pull weights.  MB = 16-row blocks of x.
 template <int MB, int EPI, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+__device__ __forceinline__ void skinny16_body(const GemmArgs& p, char* smem_raw) {
     float (*red)[MB][4][64] = reinterpret_cast<float (*)[MB][4][64]>(smem_raw);       // [NW][MB][4][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * 16;
@@ -153,6 +152,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs p) {
         const int m = mb * 16 + 4 * (lane >> 4) + e;          // 16x16 result: row 4 (l >> 4) + e, column l & 15
         if (col_ok && m < p.M) C[(long)m * p.ldc + nrow] = (bf16_t)v;
     }
+}
+template <int MB, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    skinny16_body<MB, EPI, NW>(p, smem_raw);
+}
+// Two INDEPENDENT products of one shape in one launch (grid.y picks the product): the decode step's alpha and beta projections
+// ([yt ; ytab] W_alpha^T and [yt ; yimg] W_beta^T, :738-739) -- each alone is 64 workgroups on a ~7 us floor.
+template <int MB, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny16_pair_kernel(GemmArgs p0, GemmArgs p1) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    skinny16_body<MB, EPI, NW>(blockIdx.y ? p1 : p0, smem_raw);
 }
 
 }  // namespace
@@ -418,4 +429,40 @@ extern "C" int mmsum_dec_gemm(const void* x, long ldx, const void* x2, long ldx2
     DEC_CASE(1) DEC_CASE(2) DEC_CASE(3) DEC_CASE(4) DEC_CASE(5) DEC_CASE(6)
 #undef DEC_CASE
     return MMSUM_ERR_BAD_SHAPE;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// mmsum_gemm_pair: two independent weight-streaming products of the same shape in ONE launch.
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <int MB>
+int launch_skinny16_pair(const GemmArgs& a0, const GemmArgs& a1, hipStream_t stream) {
+    const bool w8 = a0.K >= 2048 || a0.M > 32;
+    const dim3 grid((a0.N + 15) / 16, 2);
+    if (w8) {
+        const size_t lds = (size_t)8 * MB * 4 * 64 * sizeof(float);
+        gemm_skinny16_pair_kernel<MB, MMSUM_EPI_NONE, 8><<<grid, dim3(8 * 64), lds, stream>>>(a0, a1);
+    } else {
+        const size_t lds = (size_t)4 * MB * 4 * 64 * sizeof(float);
+        gemm_skinny16_pair_kernel<MB, MMSUM_EPI_NONE, 4><<<grid, dim3(4 * 64), lds, stream>>>(a0, a1);
+    }
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+}  // namespace
+
+extern "C" int mmsum_gemm_pair(const mmsum_gemm_operands* ops, int M, int N, int K, int ksplit, void* stream) {
+    if (!ops || M <= 0 || M > 64 || N < 16 || N > 4096 || K <= 0 || K % 256 || ksplit < 0 || ksplit >= K || ksplit % 32) return MMSUM_ERR_BAD_SHAPE;
+    GemmArgs a[2];
+    for (int i = 0; i < 2; ++i) {
+        const mmsum_gemm_operands& o = ops[i];
+        if ((ksplit > 0) != (o.A2 != nullptr)) return MMSUM_ERR_BAD_SHAPE;
+        if ((((uintptr_t)o.A | (uintptr_t)o.A2 | (uintptr_t)o.B) & 15) || ((o.lda | o.lda2 | o.ldb) & 7)) return MMSUM_ERR_BAD_ALIGN;
+        a[i] = GemmArgs{o.A, o.A2, o.B, o.C, o.bias, nullptr, M, N, K, o.lda, o.lda2, o.ldb, o.ldc, 0, ksplit, 1.f, o.bias ? MMSUM_GEMM_BIAS : 0, 1, nullptr, nullptr};
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (M <= 16) return launch_skinny16_pair<1>(a[0], a[1], s);
+    if (M <= 32) return launch_skinny16_pair<2>(a[0], a[1], s);
+    if (M <= 48) return launch_skinny16_pair<3>(a[0], a[1], s);
+    return launch_skinny16_pair<4>(a[0], a[1], s);
 }

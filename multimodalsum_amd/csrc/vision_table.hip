@@ -182,6 +182,13 @@ template <typename T, int N> __device__ __forceinline__ void stv(T* p, const flo
         *reinterpret_cast<f32x4_t*>(p) = f32x4_t{v[0], v[1], v[2], v[3]};
     }
 }
+// Row of pixel r = (n, y, x) of an [n, pH, pW] image in the zero-bordered PADDED layout [n, pH + 2, pW + 2] (the operand layout of the
+// implicit 3x3 convolution, mmsum_conv3x3_gemm); pW == 0: the compact layout, row r itself.
+__device__ __forceinline__ long bn_yrow(int r, int pH, int pW) {
+    if (pW == 0) return r;
+    const int hw = pH * pW, n = r / hw, rem = r - n * hw, yy = rem / pW, xx = rem - yy * pW;
+    return (long)n * (pH + 2) * (pW + 2) + (long)(yy + 1) * (pW + 2) + xx + 1;
+}
 // thread -> (channel group, row lane) of a block that spans `cgb` channel groups
 struct BnMap { int cg, rl, lanes; };
 __device__ __forceinline__ BnMap bn_map(int cgb) { return BnMap{(int)threadIdx.x % cgb, (int)threadIdx.x / cgb, 256 / cgb}; }
@@ -193,7 +200,7 @@ inline int bn_cgb(int C, int vec) { const int g = C / vec; return g >= 32 ? 32 :
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                                                          const float* __restrict__ sums, int R, int C, int cgb, int relu,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, int pH = 0, int pW = 0) {
     constexpr int V = BnVec<T>::N;
     __shared__ float red[2][256 * V];
     const BnMap m = bn_map(cgb);
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
                 ldv<T, V>(a + o, av[u]);
                 if (MODE == 1) {
                     ldv<T, V>(x + o, xv[u]);
-                    if (relu) ldv<T, V>(y + o, yv[u]);
+                    if (relu) ldv<T, V>(y + bn_yrow(r + u * m.lanes, pH, pW) * C + col, yv[u]);
                 }
             }
 #pragma unroll
@@ -244,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
             ldv<T, V>(a + o, av);
             if (MODE == 1) {
                 ldv<T, V>(x + o, xv);
-                if (relu) ldv<T, V>(y + o, yv);
+                if (relu) ldv<T, V>(y + bn_yrow(r, pH, pW) * C + col, yv);
             }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -329,7 +336,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual, T* __restrict__ y,
                                                        const float* __restrict__ running_mean, const float* __restrict__ running_var, int R, int C,
-                                                       int cgb, float eps, int relu, int training) {
+                                                       int cgb, float eps, int relu, int training, int pH, int pW) {
     constexpr int V = BnVec<T>::N;
     const BnMap m = bn_map(cgb);
     const int col = (blockIdx.x * cgb + m.cg) * V;
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                 if (residual) o += rv[u][j];
                 xv[u][j] = relu ? fmaxf(o, 0.f) : o;
             }
-            stv<T, V>(y + (long)(r + u * step) * C + col, xv[u]);
+            stv<T, V>(y + bn_yrow(r + u * step, pH, pW) * C + col, xv[u]);
         }
     }
     for (; r < R; r += step) {
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             if (residual) t += rv[j];
             xv[j] = relu ? fmaxf(t, 0.f) : t;
         }
-        stv<T, V>(y + o, xv);
+        stv<T, V>(y + bn_yrow(r, pH, pW) * C + col, xv);
     }
 }
 // running stats update, separate launch so the apply kernel never races with it
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ sums, const float* __restrict__ dsums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, T* __restrict__ dresidual,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C, int cgb,
-                                                           float eps, int relu) {
+                                                           float eps, int relu, int pH, int pW) {
     constexpr int V = BnVec<T>::N;
     const BnMap m = bn_map(cgb);
     const int col = (blockIdx.x * cgb + m.cg) * V;
@@ -437,7 +444,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 const long o = (long)(r + u * step) * C + col;
                 ldv<T, V>(dy + o, g[u]);
                 ldv<T, V>(x + o, xv[u]);
-                if (relu) ldv<T, V>(y + o, yv[u]);
+                if (relu) ldv<T, V>(y + bn_yrow(r + u * step, pH, pW) * C + col, yv[u]);
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const long o = (long)r * C + col;
             ldv<T, V>(dy + o, g);
             ldv<T, V>(x + o, xv);
-            if (relu) ldv<T, V>(y + o, yv);
+            if (relu) ldv<T, V>(y + bn_yrow(r, pH, pW) * C + col, yv);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 if (relu && !(yv[j] > 0.f)) g[j] = 0.f;
@@ -783,21 +790,23 @@ extern "C" int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* s
 
 extern "C" int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gamma, const float* beta, const void* residual,
                               void* y, float* running_mean, float* running_var, int R, int C, float eps, float momentum, int relu,
-                              int training, void* stream) {
+                              int training, int pad_H, int pad_W, void* stream) {
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
     if (R <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
+    if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, relu, training)),
-              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, relu, training)));
+    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, relu, training, pad_H, pad_W)),
+              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, relu, training, pad_H, pad_W)));
     if (training && running_mean && running_var)
         bn_running_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sums, running_mean, running_var, R, C, momentum);
     return ok();
 }
 
 extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* sums, int R, int C, float eps,
-                                   int relu, float* dsums, void* workspace, void* stream) {
+                                   int relu, float* dsums, void* workspace, int pad_H, int pad_W, void* stream) {
+    if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
     if (R <= 0 || C <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -805,22 +814,23 @@ extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, con
     const int splits = bn_splits(R, 256 / cgb, cblocks);
     const dim3 grid(cblocks, splits), block(256);
     float* part = (float*)workspace;
-    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part)),
-              (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part)));
+    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part, pad_H, pad_W)),
+              (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part, pad_H, pad_W)));
     bn_finish_kernel<<<dim3((2 * C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, sums, eps, dsums);
     return ok();
 }
 
 extern "C" int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
                                   const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C, float eps,
-                                  int relu, void* stream) {
+                                  int relu, int pad_H, int pad_W, void* stream) {
+    if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
     if (R <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu)),
-              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu)));
+    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W)),
+              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W)));
     return ok();
 }
 

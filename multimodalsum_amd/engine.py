@@ -135,6 +135,8 @@ class Engine:
         self.table_positions = TABLE_POSITIONS.get(self.table_kind, 0)
         self.bp = bart_prefix
         self.deterministic = deterministic
+        # bf16: stride-1 3x3 convolutions as implicit GEMMs (False / MMSUM_IMPLICIT_CONV=0: im2col + GEMM everywhere; tests and A/B runs compare the two)
+        self.implicit_conv = __import__("os").environ.get("MMSUM_IMPLICIT_CONV") != "0"
         self.training = True
         self.seed_base = 0x5EED
         self.step_count = 0
@@ -803,13 +805,19 @@ class Engine:
                     self.conv_mats_t[name] = mt
                 kn.transpose(m, mt)
 
-    def _bn_fwd(self, name, x, relu, residual=None, raw=None):
+    def _bn_fwd(self, name, x, relu, residual=None, raw=None, pad_hw=None):
         """raw (f32 [2C], optional): {sum x, sum x^2} over the rows of x, left by the convolution's GEMM epilogue (_conv_gemm): the
-        statistics then cost one tiny launch instead of a pass over x."""
+        statistics then cost one tiny launch instead of a pass over x.
+        pad_hw = (H, W): the output is written in the zero-bordered padded NHWC layout [n, H+2, W+2, C] -- the operand of the implicit
+        3x3 convolution that follows (kn.conv3x3_gemm); the backward pass reads its ReLU mask from the same layout."""
         a = self.arena
         R, C = x.shape
-        c = NS(x=x, relu=relu, name=name)
-        c.y = self.empty(R, C)
+        c = NS(x=x, relu=relu, name=name, pad_hw=pad_hw)
+        if pad_hw is not None:
+            H, W = pad_hw
+            c.y = self.zeros(R // (H * W) * (H + 2) * (W + 2), C)      # the borders stay zero: the kernel writes the interior only
+        else:
+            c.y = self.empty(R, C)
         c.sums = self.empty(2 * C, dtype=torch.float32)
         training = self.training
         rm, rv = self.buffers[name + ".running_mean"], self.buffers[name + ".running_var"]
@@ -818,7 +826,7 @@ class Engine:
             rm = rv = None                                   # updated above
         elif training:
             kn.bn_reduce(x, c.sums)
-        kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, rm, rv, 1e-5, 0.1, relu, training)
+        kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, rm, rv, 1e-5, 0.1, relu, training, pad_hw=pad_hw)
         return c.y, c
 
     def _conv_gemm(self, x, w, bn_name=None):
@@ -826,24 +834,37 @@ class Engine:
         training step the BatchNorm statistics of y are taken in the GEMM's epilogue (column sums of y and y^2 of the values as
         stored, f32 atomics): returns (y, raw) with raw = the 2C sums for _bn_fwd, or None where the separate reduction runs."""
         y = self.empty(x.shape[0], w.shape[0])
-        raw = None
-        if (bn_name is not None and self.training and self.dtype == torch.bfloat16 and not self.deterministic and self._bn_raw is not None
-                and kn.gemm_colsum_fusable(x)):
-            n = 2 * w.shape[0]
-            raw = self._bn_raw[self._bn_raw_off:self._bn_raw_off + n]
-            self._bn_raw_off += (n + 63) // 64 * 64
-            assert self._bn_raw_off <= self._bn_raw.numel()
+        raw = self._bn_raw_slot(w.shape[0]) if (bn_name is not None and kn.gemm_colsum_fusable(x)) else None
         kn.gemm(x, w, y, colsum=raw, colsum_sq=raw is not None)
+        return y, raw
+
+    def _bn_raw_slot(self, cout):
+        """2 * cout zeroed floats of the step's statistics buffer for a convolution whose GEMM epilogue leaves {sum y, sum y^2} (bf16
+        training step only; None otherwise: the separate reduction runs)."""
+        if not (self.training and self.dtype == torch.bfloat16 and not self.deterministic and self._bn_raw is not None):
+            return None
+        n = 2 * cout
+        raw = self._bn_raw[self._bn_raw_off:self._bn_raw_off + n]
+        self._bn_raw_off += (n + 63) // 64 * 64
+        assert self._bn_raw_off <= self._bn_raw.numel()
+        return raw
+
+    def _conv3x3_implicit(self, xp, w, n, H, W, C, bn_name):
+        """3x3 / stride 1 / padding 1 convolution of the padded activations xp as an implicit GEMM (no im2col matrix): -> (y compact, raw)."""
+        y = self.empty(n * H * W, w.shape[0])
+        raw = self._bn_raw_slot(w.shape[0]) if bn_name is not None else None
+        kn.conv3x3_gemm(xp, w, y, n, H, W, C, stats=raw)
         return y, raw
 
     def _bn_bwd(self, c, dy, dresidual=None):
         a = self.arena
         R, C = dy.shape
         dsums = self.empty(2 * C, dtype=torch.float32)
-        kn.bn_bwd_reduce(dy, c.y, c.x, c.sums, dsums, 1e-5, c.relu)
+        pad_hw = getattr(c, "pad_hw", None)                  # the forward output (ReLU mask) sits in the padded layout
+        kn.bn_bwd_reduce(dy, c.y, c.x, c.sums, dsums, 1e-5, c.relu, pad_hw=pad_hw)
         dx = self.empty(R, C)
         kn.bn_bwd_apply(dy, c.y, c.x, c.sums, dsums, a.f32(c.name + ".weight"), dx, dresidual, a.g(c.name + ".weight"),
-                        a.g(c.name + ".bias"), 1e-5, c.relu)
+                        a.g(c.name + ".bias"), 1e-5, c.relu, pad_hw=pad_hw)
         self.touch(c.name + ".weight", c.name + ".bias")
         return dx
 
@@ -881,12 +902,19 @@ class Engine:
             b = r + "layer%d.%d." % (li, bi)
             bc = NS(x=x, H=Hc, W=Wc, inp=inp, pl=pl, stride=stride, down=down, name=b, li=li)
             c1, raw = self._conv1x1(x, b + "conv1.weight", b + "bn1")
-            o1, bc.bn1 = self._bn_fwd(b + "bn1", c1, True, raw=raw)
+            # stride-1 3x3 convolutions (every bottleneck but layer2.0 / layer3.0) run as IMPLICIT GEMMs in the bf16 step: bn1 writes its
+            # output in the zero-bordered padded layout and the NT kernels' DMA pieces read one tap's channels straight from it
+            implicit = self.implicit_conv and self.dtype == torch.bfloat16 and stride == 1 and pl >= 64 and (pl & (pl - 1)) == 0
+            o1, bc.bn1 = self._bn_fwd(b + "bn1", c1, True, raw=raw, pad_hw=(Hc, Wc) if implicit else None)
             Ho2, Wo2 = (Hc + 2 - 3) // stride + 1, (Wc + 2 - 3) // stride + 1
             wm = self.conv_mats[b + "conv2.weight"]
-            bc.col = self.empty(n * Ho2 * Wo2, wm.shape[1])
-            kn.im2col(o1, bc.col, n, Hc, Wc, pl, 3, 3, stride, 1, Ho2, Wo2, wm.shape[1])
-            c2, raw = self._conv_gemm(bc.col, wm, b + "bn2")
+            if implicit:
+                bc.col = None                                  # layer3's weight gradient re-creates it from the padded o1 (img_bwd)
+                c2, raw = self._conv3x3_implicit(o1, wm, n, Hc, Wc, pl, b + "bn2")
+            else:
+                bc.col = self.empty(n * Ho2 * Wo2, wm.shape[1])
+                kn.im2col(o1, bc.col, n, Hc, Wc, pl, 3, 3, stride, 1, Ho2, Wo2, wm.shape[1])
+                c2, raw = self._conv_gemm(bc.col, wm, b + "bn2")
             o2, bc.bn2 = self._bn_fwd(b + "bn2", c2, True, raw=raw)
             bc.o1, bc.o2 = o1, o2
             c3, raw3 = self._conv1x1(o2, b + "conv3.weight", b + "bn3")
@@ -931,7 +959,11 @@ class Engine:
             dc2 = self._bn_bwd(bc.bn2, do2)
             wm = self.conv_mats[b + "conv2.weight"]
             dwm = self.zeros(wm.shape[0], wm.shape[1], dtype=torch.float32)
-            self.wgrad(dc2, bc.col, gview=dwm)
+            col = bc.col
+            if col is None:        # the forward ran as an implicit GEMM: the im2col matrix of the PADDED o1 (an (H+2) x (W+2) image, padding 0)
+                col = self.empty(R2, wm.shape[1])
+                kn.im2col(bc.o1, col, n, bc.H + 2, bc.W + 2, bc.pl, 3, 3, 1, 0, bc.H, bc.W, wm.shape[1])
+            self.wgrad(dc2, col, gview=dwm)
             kn.conv_matrix_grad_to_weight(dwm, a.g(b + "conv2.weight"), bc.pl, bc.pl, 3, 3, wm.shape[1], True)
             dcol = self.empty(R2, wm.shape[1])
             wmt = self.conv_mats_t.get(b + "conv2.weight")
@@ -939,7 +971,7 @@ class Engine:
                 kn.gemm(dc2, wmt, dcol)
             else:
                 kn.gemm(dc2, wm, dcol, b_t=True)
-            do1 = self.empty(bc.o1.shape[0], bc.pl)
+            do1 = self.empty(n * bc.H * bc.W, bc.pl)
             Ho2, Wo2 = (bc.H + 2 - 3) // bc.stride + 1, (bc.W + 2 - 3) // bc.stride + 1
             kn.col2im(dcol, do1, n, bc.H, bc.W, bc.pl, 3, 3, bc.stride, 1, Ho2, Wo2, wm.shape[1])
             dc1 = self._bn_bwd(bc.bn1, do1)

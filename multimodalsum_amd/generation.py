@@ -279,8 +279,12 @@ class DecodeSession:
             if e.multimodal:
                 yt, ytab, yimg = yy[:R], yy[R:2 * R], yy[2 * R:]
                 pa, pb = e.empty(R, D), e.empty(R, D)
-                self._mm(yt, a.w(pre + "alpha_proj.weight"), pa, bias=a.f32(pre + "alpha_proj.bias"), x2=ytab)
-                self._mm(yt, a.w(pre + "beta_proj.weight"), pb, bias=a.f32(pre + "beta_proj.bias"), x2=yimg)
+                if R <= 64 and D % 256 == 0 and D <= 4096:          # alpha and beta: two independent products, one launch
+                    kn.gemm_pair([yt, yt], [ytab, yimg], [a.w(pre + "alpha_proj.weight"), a.w(pre + "beta_proj.weight")], [pa, pb],
+                                 [a.f32(pre + "alpha_proj.bias"), a.f32(pre + "beta_proj.bias")])
+                else:
+                    self._mm(yt, a.w(pre + "alpha_proj.weight"), pa, bias=a.f32(pre + "alpha_proj.bias"), x2=ytab)
+                    self._mm(yt, a.w(pre + "beta_proj.weight"), pb, bias=a.f32(pre + "beta_proj.bias"), x2=yimg)
                 y = e.empty(R, D)                     # gate + residual + LayerNorm in one launch
                 kn.gate_add_ln_fwd(pa, pb, yt, ytab, yimg, self.no_table, self.no_img, x, a.f32(lb + "encoder_attn_layer_norm.weight"),
                                    a.f32(lb + "encoder_attn_layer_norm.bias"), y, self.qpb, 1e-5)

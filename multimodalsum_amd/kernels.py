@@ -332,23 +332,36 @@ def bn_stats_from_sums(raw, R, sums, running_mean, running_var, momentum):
     check(lib.mmsum_bn_stats_from_sums(_p(raw), R, C, _p(sums), _p(running_mean), _p(running_var), momentum, _stream()), "mmsum_bn_stats_from_sums")
 
 
-def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training):
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None):
+    """pad_hw = (H, W): y is the zero-bordered padded layout [n, H+2, W+2, C] (the operand of conv3x3_gemm); the caller zeroed it."""
     R, C = x.shape
+    pH, pW = pad_hw or (0, 0)
     check(lib.mmsum_bn_apply(_dt(x), _p(x), _p(sums), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean), _p(running_var),
-                             R, C, eps, momentum, int(relu), int(training), _stream()), "mmsum_bn_apply")
+                             R, C, eps, momentum, int(relu), int(training), pH, pW, _stream()), "mmsum_bn_apply")
 
 
-def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu):
+def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None):
     R, C = x.shape
+    pH, pW = pad_hw or (0, 0)
     ws = _workspace(lib.mmsum_bn_workspace(C), x.device, "bn")
-    check(lib.mmsum_bn_bwd_reduce(_dt(x), _p(dy), _p(y), _p(x), _p(sums), R, C, eps, int(relu), _p(dsums), _p(ws), _stream()),
+    check(lib.mmsum_bn_bwd_reduce(_dt(x), _p(dy), _p(y), _p(x), _p(sums), R, C, eps, int(relu), _p(dsums), _p(ws), pH, pW, _stream()),
           "mmsum_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu):
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None):
     R, C = x.shape
+    pH, pW = pad_hw or (0, 0)
     check(lib.mmsum_bn_bwd_apply(_dt(x), _p(dy), _p(y), _p(x), _p(sums), _p(dsums), _p(gamma), _p(dx), _p(dresidual), _p(dgamma),
-                                 _p(dbeta), R, C, eps, int(relu), _stream()), "mmsum_bn_bwd_apply")
+                                 _p(dbeta), R, C, eps, int(relu), pH, pW, _stream()), "mmsum_bn_bwd_apply")
+
+
+def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None):
+    """y [n*H*W, Cout] = 3x3 convolution (stride 1, padding 1) of xp, the zero-bordered padded NHWC activations [n*(H+2)*(W+2), C] (bf16),
+    with the weight matrix w [Cout, >= 9 C] in (ky, kx, c) column order -- an implicit GEMM: no im2col matrix (mmsum_conv3x3_gemm).
+    stats (f32 [2 Cout], optional) += column sums of y and y^2 (the BatchNorm statistics)."""
+    assert xp.dtype == torch.bfloat16 and xp.shape == (n * (H + 2) * (W + 2), C) and xp.is_contiguous() and y.shape[0] == n * H * W
+    check(lib.mmsum_conv3x3_gemm(_p(xp), _p(w), _ld(w), _p(y), _ld(y), _p(stats), n, H, W, C, w.shape[0], _stream()), "mmsum_conv3x3_gemm")
+    return y
 
 
 def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):
@@ -436,3 +449,18 @@ def decode_cross_attn(q, mods, out, ws, B, qpb, H, scale):
     check(lib.mmsum_decode_cross_attn(_p(q), q.stride(0), arr, len(mods), ldkv, _p(out), out.stride(0), B, qpb, H, float(scale), _p(ws), _stream()),
           "mmsum_decode_cross_attn")
     return out
+
+
+def gemm_pair(xs, x2s, ws, outs, biases):
+    """Two independent bf16 products of one shape in one launch (mmsum_gemm_pair): outs[i] = [xs[i] | x2s[i]] . ws[i]^T + biases[i]."""
+    arr = (_lib.GemmOperands * 2)()
+    M, k1 = xs[0].shape
+    k2 = x2s[0].shape[1] if x2s[0] is not None else 0
+    N, K = ws[0].shape
+    assert K == k1 + k2
+    for i in range(2):
+        assert xs[i].shape == (M, k1) and ws[i].shape == (N, K) and outs[i].shape == (M, N) and xs[i].dtype == torch.bfloat16
+        o = arr[i]
+        o.A, o.A2, o.B, o.C, o.bias = _p(xs[i]), _p(x2s[i]), _p(ws[i]), _p(outs[i]), _p(biases[i])
+        o.lda, o.lda2, o.ldb, o.ldc = _ld(xs[i]), (_ld(x2s[i]) if x2s[i] is not None else 0), _ld(ws[i]), _ld(outs[i])
+    check(lib.mmsum_gemm_pair(arr, M, N, K, k1 if k2 else 0, _stream()), "mmsum_gemm_pair")

@@ -391,8 +391,21 @@ def _bn_stats(sums, R, C, eps):
     return mean, var, (var + eps).rsqrt()
 
 
-def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training):
+def _pad_rows(R, pad_hw):
+    """Rows of the pixels of [n, H, W] in the zero-bordered padded layout [n, H+2, W+2] (mmsum_bn_apply's pad_H / pad_W)."""
+    H, W = pad_hw
+    r = torch.arange(R)
+    n, rem = r // (H * W), r % (H * W)
+    return n * (H + 2) * (W + 2) + (rem // W + 1) * (W + 2) + rem % W + 1
+
+
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None):
     R, C = x.shape
+    if pad_hw is not None:
+        yc = torch.empty(R, C, dtype=y.dtype)
+        bn_apply(x, sums, gamma, beta, residual, yc, running_mean, running_var, eps, momentum, relu, training)
+        y[_pad_rows(R, pad_hw)] = yc               # the borders keep what the caller put there (zeros)
+        return
     if training:
         mean, var, rstd = _bn_stats(sums, R, C, eps)
     else:
@@ -407,16 +420,20 @@ def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, 
         running_var.mul_(1 - momentum).add_(momentum * var * (R / (R - 1) if R > 1 else 1.0))
 
 
-def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu):
+def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None):
     R, C = x.shape
+    if pad_hw is not None:
+        y = y[_pad_rows(R, pad_hw)]
     mean, var, rstd = _bn_stats(sums, R, C, eps)
     g = dy.float() * ((y.float() > 0) if relu else 1.0)
     dsums[:C] = g.sum(0)
     dsums[C:] = (g * (x.float() - mean) * rstd).sum(0)
 
 
-def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu):
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None):
     R, C = x.shape
+    if pad_hw is not None:
+        y = y[_pad_rows(R, pad_hw)]
     mean, var, rstd = _bn_stats(sums, R, C, eps)
     g = dy.float() * ((y.float() > 0) if relu else 1.0)
     xh = (x.float() - mean) * rstd
@@ -426,6 +443,15 @@ def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps
     if dgamma is not None:
         dbeta.add_(dsums[:C])
         dgamma.add_(dsums[C:])
+
+
+def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None):
+    """Contract of mmsum_conv3x3_gemm: the im2col matrix of the padded image (an (H+2) x (W+2) image, padding 0) times w^T."""
+    Kpad = w.shape[1]
+    col = torch.zeros(n * H * W, Kpad, dtype=xp.dtype)
+    im2col(xp, col, n, H + 2, W + 2, C, 3, 3, 1, 0, H, W, Kpad)
+    gemm(col, w, y, colsum=stats, colsum_sq=stats is not None)
+    return y
 
 
 def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):

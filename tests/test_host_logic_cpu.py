@@ -693,3 +693,33 @@ def test_pretrained_paths_are_checked(tmp_path):
     torch.save(bsd, str(b / "pytorch_model.bin"))
     with pytest.raises(RuntimeError):
         MultimodalSum(bart_pretrained=str(b), config=cfg, device="cpu", dtype=torch.float32)
+
+
+def test_implicit_conv_schedule_equals_im2col_schedule(monkeypatch):
+    """The bf16 step runs ResNet's stride-1 3x3 convolutions as implicit GEMMs: bn1 writes the zero-bordered padded layout,
+    kn.conv3x3_gemm reads its taps from it, the backward takes the ReLU mask from the padded output and re-creates layer3's im2col
+    matrix from it for the weight gradient (engine.img_fwd / img_bwd).  Through the kernel emulator the schedule must give exactly
+    what the im2col schedule gives: output, every layer3 gradient, the running statistics."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import MultimodalSum
+    cfg = tiny_cfg(vocab=60, d=1024, ffn=64, layers=1, heads=16, maxpos=40)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(3, 3, 64, 64, generator=g)
+    dy = None
+    res = {}
+    for implicit in (True, False):
+        model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.bfloat16)
+        e = model._engine
+        e.implicit_conv = implicit
+        e.sync_weights()
+        e.arena.prepare_grads()
+        y, c = e.img_fwd(img)
+        if dy is None:
+            dy = (torch.randn(y.shape, generator=g) * 0.1).to(y.dtype)
+        assert any(b.col is None for b in c.blocks) == implicit
+        e.img_bwd(c, dy.clone())
+        res[implicit] = (y.float().clone(), e.arena.grad.clone(), {k: v.clone() for k, v in e.buffers.items() if "running" in k})
+    (y1, g1, b1), (y0, g0, b0) = res[True], res[False]
+    assert torch.equal(y1, y0)
+    assert torch.equal(g1, g0)
+    assert all(torch.equal(b1[k], b0[k]) for k in b0)

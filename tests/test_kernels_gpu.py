@@ -1071,3 +1071,67 @@ def test_gate_add_ln_fwd(dtype):
     z = res.double() + yt.double() + ma * torch.relu(torch.tanh(pa.double())) * ytab.double() + mb * torch.relu(torch.tanh(pb.double())) * yimg.double()
     ref = torch.nn.functional.layer_norm(z, (D,), gamma.double(), beta.double(), 1e-5)
     close(y, ref, dtype, what="gate + add + LayerNorm")
+
+
+@pytest.mark.parametrize("M,N,K,k1", [(32, 1024, 2048, 1024), (12, 1024, 2048, 1024), (8, 256, 512, 256), (32, 1024, 1024, 0)])
+def test_gemm_pair(M, N, K, k1):
+    """mmsum_gemm_pair: two independent products in one launch == the two products alone (f64 of the bf16 operands)."""
+    bf = torch.bfloat16
+    xs = [rnd(M, k1 or K, dtype=bf, seed=1), rnd(M, k1 or K, dtype=bf, seed=2)]
+    x2s = [rnd(M, K - k1, dtype=bf, seed=3), rnd(M, K - k1, dtype=bf, seed=4)] if k1 else [None, None]
+    ws = [rnd(N, K, dtype=bf, seed=5, std=0.05), rnd(N, K, dtype=bf, seed=6, std=0.05)]
+    bs = [rnd(N, seed=7), rnd(N, seed=8)]
+    outs = [torch.full((M, N), float("nan"), device=DEV, dtype=bf) for _ in range(2)]
+    kn.gemm_pair(xs, x2s, ws, outs, bs)
+    for i in range(2):
+        x = torch.cat([xs[i], x2s[i]], dim=1) if k1 else xs[i]
+        ref = x.double() @ ws[i].double().t() + bs[i].double()
+        assert float((outs[i].double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-5, i
+
+
+@pytest.mark.parametrize("n,H,C,Cout", [(5, 14, 256, 256), (3, 28, 128, 128), (2, 56, 64, 64), (37, 14, 256, 256), (1, 7, 64, 136)],
+                         ids=["layer3_w4", "layer2_ring", "layer1_ring", "layer3_several_tiles", "odd"])
+def test_conv3x3_implicit_gemm(n, H, C, Cout):
+    """mmsum_conv3x3_gemm (the NT kernels' DMA pieces read one tap's channels of the zero-bordered padded activations) == the im2col
+    matrix times the same weights through mmsum_gemm: the two take the same kernel, tile and order of summation, so the outputs and the
+    BatchNorm statistics of the epilogue are compared element-wise with a bf16 bound AND against an f64 convolution; the padded layout
+    comes from mmsum_bn_apply (pad_H / pad_W), whose borders must stay zero."""
+    bf = torch.bfloat16
+    W = H
+    R = n * H * W
+    x = rnd(R, C, dtype=bf, seed=1)                                 # conv1's output (compact)
+    sums = torch.cat([0.1 * rnd(C, seed=2), 0.5 + rnd(C, seed=3).abs()])
+    gamma, beta = 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    yc = torch.empty(R, C, device=DEV, dtype=bf)
+    kn.bn_apply(x, sums, gamma, beta, None, yc, None, None, 1e-5, 0.1, True, True)
+    yp = torch.zeros(n * (H + 2) * (W + 2), C, device=DEV, dtype=bf)
+    kn.bn_apply(x, sums, gamma, beta, None, yp, None, None, 1e-5, 0.1, True, True, pad_hw=(H, W))
+    img = yp.view(n, H + 2, W + 2, C)
+    assert torch.equal(img[:, 1:-1, 1:-1].reshape(R, C), yc)
+    assert float(img[:, 0].abs().max()) == 0 and float(img[:, -1].abs().max()) == 0 and float(img[:, :, 0].abs().max()) == 0 and float(img[:, :, -1].abs().max()) == 0
+    K = 9 * C
+    wm = rnd(Cout, K, dtype=bf, seed=6, std=0.03)
+    col = torch.empty(R, K, device=DEV, dtype=bf)
+    kn.im2col(yc, col, n, H, W, C, 3, 3, 1, 1, H, W, K)
+    ref_out, ref_raw = torch.empty(R, Cout, device=DEV, dtype=bf), torch.zeros(2 * Cout, device=DEV)
+    kn.gemm(col, wm, ref_out, colsum=ref_raw, colsum_sq=True)
+    out, raw = torch.full((R, Cout), float("nan"), device=DEV, dtype=bf), torch.zeros(2 * Cout, device=DEV)
+    kn.conv3x3_gemm(yp, wm, out, n, H, W, C, stats=raw)
+    exact = col.double() @ wm.double().t()
+    tol_ = 1e-2 * float(exact.abs().max())
+    assert float((out.double() - exact).abs().max()) <= tol_
+    assert float((out.double() - ref_out.double()).abs().max()) <= 2.0 ** -7 * float(exact.abs().max())
+    assert float((raw - ref_raw).abs().max()) <= 1e-3 * float(ref_raw.abs().max()) + 1e-3
+    out2 = torch.empty(R, Cout, device=DEV, dtype=bf)
+    kn.conv3x3_gemm(yp, wm, out2, n, H, W, C)                       # without the statistics
+    assert float((out2.double() - exact).abs().max()) <= tol_
+    # the backward kernels read the ReLU mask from the padded forward output
+    dy = rnd(R, C, dtype=bf, seed=7)
+    d0, d1 = torch.empty(2 * C, device=DEV), torch.empty(2 * C, device=DEV)
+    kn.bn_bwd_reduce(dy, yc, x, sums, d0, 1e-5, True)
+    kn.bn_bwd_reduce(dy, yp, x, sums, d1, 1e-5, True, pad_hw=(H, W))
+    assert torch.equal(d0, d1)
+    dx0, dx1 = torch.empty(R, C, device=DEV, dtype=bf), torch.empty(R, C, device=DEV, dtype=bf)
+    kn.bn_bwd_apply(dy, yc, x, sums, d0, gamma, dx0, None, None, None, 1e-5, True)
+    kn.bn_bwd_apply(dy, yp, x, sums, d0, gamma, dx1, None, None, None, 1e-5, True, pad_hw=(H, W))
+    assert torch.equal(dx0, dx1)

@@ -8,9 +8,11 @@ dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
 import ddp_rccl_worker as w
 from multimodalsum_amd.parallel import DistributedDataParallel
 res = {}
-for mode, bucket in (("none", 0), ("all_reduce", 1 << 20), ("reduce_scatter", 1 << 20), ("reduce_scatter", 1000003)):
+for mode, bucket in (("none", 0), ("all_reduce", 1 << 20), ("reduce_scatter", 1 << 20), ("reduce_scatter_nooverlap", 1 << 20), ("reduce_scatter_nostats", 1 << 20)):
     cfg, model = w.build(torch.float32, dev)
-    runner = model if mode == "none" else DistributedDataParallel(model, delay_allreduce=True, always_reduce=True, collect_stats=True, bucket_elems=bucket, mode=mode)
+    kw = dict(overlap=False) if mode.endswith("nooverlap") else {}
+    runner = model if mode == "none" else DistributedDataParallel(model, delay_allreduce=True, always_reduce=True, collect_stats=not mode.endswith("nostats"), bucket_elems=bucket,
+                                                                   mode=mode.split("_no")[0], **kw)
     for p in model.parameters():
         p.grad = None
     loss = w.step(runner, w.batch(cfg, 0, dev))
@@ -22,4 +24,9 @@ for key, g in res.items():
         continue
     bad = sorted(((float((g[n] - base[n]).abs().max()), n) for n in base), reverse=True)[:6]
     print(key, "worst:", [(round(e, 6), n) for e, n in bad if e > 0] or "identical")
+    for e, n in bad[:2]:
+        if e > 0:
+            d = (g[n] - base[n]).reshape(-1)
+            nz = d.nonzero().reshape(-1)
+            print("   ", n, "differs at", nz.numel(), "of", d.numel(), "elements; first", nz[:4].tolist(), "rs", g[n].reshape(-1)[nz[:4]].tolist(), "base", base[n].reshape(-1)[nz[:4]].tolist())
 dist.destroy_process_group()
