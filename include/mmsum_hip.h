@@ -118,6 +118,13 @@ int mmsum_dec_gemm(const void* x, long ldx, const void* x2, long ldx2, int kspli
  * The LDS-DMA pieces of the NT kernels read C-contiguous runs of one tap straight from xp: no im2col matrix.  C a power of two >= 64. */
 int mmsum_conv3x3_gemm(const void* xp, const void* w, long ldw, void* y, long ldy, float* stats, int n, int H, int W, int C,
                        int Cout, void* stream);
+/* Weight gradient of that convolution, no im2col matrix either: out[co][(3 ky + kx) C + c] = sum over pixels dy[pixel][co] x[pixel + (ky-1, kx-1)][c]
+ * (the layout mmsum_conv_weight_permute(to_matrix = 0) turns into the [Cout, C, 3, 3] gradient).  dyp [n, H+2, W+2, Cout] and xp [n, H+2, W+2, C]
+ * both PADDED with zero borders (mmsum_bn_bwd_apply's dx_pad / mmsum_bn_apply's pad): the four-wave reduction-major kernel runs over all
+ * padded positions and shifts its xp rows by the tap of the tile.  C a power of two >= 256.  out: f32 [Cout, ldo >= 9 C], or with
+ * splitk > 1 splitk such slabs (slab s at out + s * Cout * ldo; mmsum_slab_reduce adds them). */
+int mmsum_conv3x3_wgrad(const void* dyp, const void* xp, float* out, long ldo, int n, int H, int W, int C, int Cout, int splitk,
+                        void* stream);
 
 /* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
 int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
@@ -275,7 +282,9 @@ int mmsum_col2im(int dtype, const void* dcol, void* dx, int N, int H, int W, int
                  int pad, int Ho, int Wo, int Kpad, void* stream);
 /* f32 [Cout, Cin, KH, KW] <-> dtype [Cout, Kpad] with (kh,kw,c) column order.
  * to_matrix=1: weight -> matrix (cast, zero tail); to_matrix=0: f32 matrix gradient -> weight-layout
- * gradient (+= if accumulate). */
+ * gradient (+= if accumulate); to_matrix=2: weight -> the INPUT-GRADIENT matrix dtype [Cin, Kpad >= KH*KW*Cout],
+ * column ((KH-1-kh) KW + (KW-1-kw)) Cout + co = w[co][ci][kh][kw] (rotated by 180 degrees, channel roles exchanged): the
+ * input gradient of a stride-1 convolution is mmsum_conv3x3_gemm of the padded output gradient with this matrix. */
 int mmsum_conv_weight_permute(int dtype, void* matrix, float* weight, int Cout, int Cin, int KH, int KW, int Kpad,
                               int to_matrix, int accumulate, void* stream);
 /* BatchNorm2d (train mode, batch statistics over R = N*H*W rows of an [R, C] NHWC matrix).
@@ -293,8 +302,11 @@ int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* sums, float*
                              void* stream);
 /* pad_H, pad_W (0, 0 = no): y is written in the zero-bordered PADDED layout [n, pad_H + 2, pad_W + 2, C] of an [n, pad_H, pad_W] image
  * (R = n pad_H pad_W): pixel (n, y, x) lands at row n (pad_H+2)(pad_W+2) + (y+1)(pad_W+2) + x + 1 -- the operand layout of
- * mmsum_conv3x3_gemm.  The borders are NOT written: the caller zeroes the buffer once.  x and residual stay compact. */
-int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gamma, const float* beta,
+ * mmsum_conv3x3_gemm.  The borders are NOT written: the caller zeroes the buffer once.  x and residual stay compact.
+ * raw (f32 [2 C], may be NULL; training only): the statistics as PLAIN column sums {sum x, sum x^2} over the R rows, as the convolution's
+ * GEMM epilogue leaves them (MMSUM_GEMM_COLSUM | MMSUM_GEMM_COLSUM2): the kernel derives {mean, biased variance} itself, WRITES them to
+ * `sums` for the backward pass and updates the running statistics -- no statistics launch (mmsum_bn_stats_from_sums does the same alone). */
+int mmsum_bn_apply(int dtype, const void* x, float* sums, const float* raw, const float* gamma, const float* beta,
                    const void* residual, void* y, float* running_mean, float* running_var, int R, int C, float eps,
                    float momentum, int relu, int training, int pad_H, int pad_W, void* stream);
 /* BN backward, two launches: bn_reduce over (dy', dy'*xhat) via mmsum_bn_bwd_reduce, then bn_bwd_apply.
@@ -302,9 +314,11 @@ int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gam
  * dsums[2*C] = {sum dy', sum dy'*xhat}. */
 int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* sums, int R, int C,
                         float eps, int relu, float* dsums, void* workspace, int pad_H, int pad_W, void* stream);
+/* dx_pad_H, dx_pad_W (0, 0 = no): dx is written in the padded layout as well (borders not written) -- the operand of
+ * mmsum_conv3x3_wgrad and of the input-gradient convolution. */
 int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
                        const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C,
-                       float eps, int relu, int pad_H, int pad_W, void* stream);
+                       float eps, int relu, int pad_H, int pad_W, int dx_pad_H, int dx_pad_W, void* stream);
 int mmsum_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 /* NCHW f32 image -> NHWC dtype. */
 int mmsum_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, void* stream);

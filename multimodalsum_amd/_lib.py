@@ -99,13 +99,14 @@ SIGNATURES = {
     "mmsum_bn_workspace": (c_long, [c_int]),
     "mmsum_bn_reduce": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mmsum_bn_stats_from_sums": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
-    "mmsum_bn_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+    "mmsum_bn_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_bn_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p,
                                     c_void_p, c_int, c_int, c_void_p]),
     "mmsum_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_conv3x3_gemm": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmsum_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_maxpool3x3s2": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_table_gather": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p]),

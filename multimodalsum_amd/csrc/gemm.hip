@@ -233,6 +233,29 @@ extern "C" int mmsum_conv3x3_gemm(const void* xp, const void* w, long ldw, void*
     return launch_gemm_glds(a, static_cast<hipStream_t>(stream));
 }
 
+// Weight gradient of the same convolution, again without an im2col matrix: dW[co][(ky, kx, c)] = sum over the pixels of
+// dy[pixel][co] * x[pixel + (ky - 1, kx - 1)][c].  BOTH operands in the zero-bordered padded layout (dyp [n, H+2, W+2, Cout], xp [n, H+2, W+2, C]):
+// the reduction then runs over ALL padded positions k (border positions of dyp are zero and add nothing), the x row of tap (ky, kx) is
+// row k + (ky - 1) (W + 2) + (kx - 1) of the same image matrix, and a 256-column tile of the [Cout, 9 C] result is one tap's channels,
+// i.e. the four-wave TN kernel with a per-tile row shift of its B operand.  The first and last W + 3 positions are border positions:
+// the reduction skips them, so every shifted row exists.  out: f32 [splitk][Cout][ldo] slabs (splitk > 1) or f32 [Cout][ldo].
+extern "C" int mmsum_conv3x3_wgrad(const void* dyp, const void* xp, float* out, long ldo, int n, int H, int W, int C, int Cout, int splitk,
+                                   void* stream) {
+    if (n <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C < 256 || (C & (C - 1)) || (Cout & 7) || splitk < 1) return MMSUM_ERR_BAD_SHAPE;   // a tile = channels of one tap
+    const long Kp = (long)n * (H + 2) * (W + 2), skip = W + 3;
+    if (Kp * C * 2 >= 0x7fffffffL * 16 || Kp - 2 * skip <= 0) return MMSUM_ERR_BAD_SHAPE;
+    if ((((uintptr_t)dyp | (uintptr_t)xp | (uintptr_t)out) & 15) || ((ldo * 4) & 15)) return MMSUM_ERR_BAD_ALIGN;
+    if (ldo < 9L * C) return MMSUM_ERR_BAD_SHAPE;
+    const bf16_t* A = static_cast<const bf16_t*>(dyp) + skip * Cout;
+    const bf16_t* B = static_cast<const bf16_t*>(xp) + skip * C;
+    GemmArgs a{A, nullptr, B, out, nullptr, nullptr, Cout, 9 * C, (int)(Kp - 2 * skip), (long)Cout, 0, (long)C, ldo, 0, 0, 1.f,
+               MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_OUT_F32 | (splitk > 1 ? MMSUM_GEMM_SLABS : 0), splitk, nullptr, nullptr};
+    a.conv_wp = W + 2;
+    a.conv_cshift = 0;
+    while ((1 << a.conv_cshift) < C) ++a.conv_cshift;
+    return launch_gemm_tn_w4(a, static_cast<hipStream_t>(stream));
+}
+
 // Which kernel, tile and grid mmsum_gemm would launch for these arguments (no device work, no pointers dereferenced):
 // plan[0] = MMSUM_PLAN_* kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (< tiles * splitk
 // means persistent workgroups walking the tile list).  Lets tests assert that a shape reaches the kernel they mean to cover.

@@ -1171,6 +1171,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
     const int ns = s_end - s_beg;
     const bf16_t* A = static_cast<const bf16_t*>(p.A);
     const bf16_t* B = static_cast<const bf16_t*>(p.B);
+    // weight gradient of the implicit 3x3 convolution (mmsum_conv3x3_wgrad): B is the padded activation image [rows, C]; the tile's 256
+    // output columns are channels c0.. of ONE tap, i.e. the same rows shifted by the tap's offset in the padded image
+    long b_off = n0;
+    int b_lim = p.N - n0;
+    if (p.conv_wp) {
+        const int tap = n0 >> p.conv_cshift, c0 = n0 & ((1 << p.conv_cshift) - 1);
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        b_off = (long)((ky - 1) * p.conv_wp + (kx - 1)) * p.ldb + c0;
+        b_lim = (1 << p.conv_cshift) - c0;
+    }
 
     const bool do_bsum = BS && tn == 0;                            // workgroup-uniform; wave (wm, wn) sums A blocks 2 wn, 2 wn + 1 of its row
     float bsum[2] = {0.f, 0.f};
@@ -1211,7 +1221,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
         const int r = piece * RPP + lane / CPR, pcn = lane % CPR;
         const int c64 = (pcn >> 2) ^ (r & 3);
         const int col = (c64 * 4 + (pcn & 3)) * 8;                  // inside the tile
-        const int lim = isA ? p.M - m0 : p.N - n0;
+        const int lim = isA ? p.M - m0 : b_lim;
         voff[i] = col < lim ? (r * (int)(isA ? p.lda : p.ldb) + col) * 2 : (int)0x80000000u;
     }
     // The DMA is issued from inline asm: to the compiler a buffer_load ... lds is a store to LDS that the transposing reads
@@ -1224,9 +1234,9 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_w4_kernel(GemmArgs p) {
         const uint32_t dst = lds0 + (si & 3) * Cfg::STAGE + (isA ? (i * Cfg::NW + wave) * 1024 : Cfg::A_BYTES + (i * Cfg::NW - Cfg::PA + wave) * 1024);
         const long k0 = (long)(s_beg + si) * 32;
         const long ld = isA ? p.lda : p.ldb;
-        const uintptr_t base = (uintptr_t)((isA ? A + m0 : B + n0) + k0 * ld);
+        const uintptr_t base = (uintptr_t)((isA ? A + m0 : B + b_off) + k0 * ld);
         const long rows_left = (long)p.K - k0;                        // > 0: only existing stages are requested
-        const long bytes = ((rows_left - 1) * ld + (((isA ? p.M - m0 : p.N - n0) + 7) & ~7)) * 2;      // whole 16-byte chunks of the last row (the pitch covers them)
+        const long bytes = ((rows_left - 1) * ld + (((isA ? p.M - m0 : b_lim) + 7) & ~7)) * 2;      // whole 16-byte chunks of the last row (the pitch covers them)
         u32x4_t rsrc;                                                 // raw buffer resource: base, stride 0, num_records, dword 3 as make_buffer_rsrc's
         rsrc[0] = (uint32_t)base;
         rsrc[1] = (uint32_t)(base >> 32) & 0xffffu;
@@ -1525,6 +1535,8 @@ int launch_gemm_tn(const GemmArgs& a, hipStream_t stream) {
         default: return launch_tn_cfg<128, 128, 2, 2>(a, stream);
     }
 }
+
+int launch_gemm_tn_w4(const GemmArgs& a, hipStream_t stream) { return launch_tn_w4(a, stream); }      // mmsum_conv3x3_wgrad: the four-wave kernel whatever the tile rule says
 
 int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {

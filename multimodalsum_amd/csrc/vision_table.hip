@@ -142,6 +142,24 @@ __global__ __launch_bounds__(256) void weight_to_matrix_kernel(T* __restrict__ m
         mat[i] = from_f32<T>(v);
     }
 }
+// The input-gradient operand of a stride-1 convolution: mat[ci][((KH-1-kh) KW + (KW-1-kw)) Cout + co] = w[co][ci][kh][kw] -- the weights
+// rotated by 180 degrees with the channel roles exchanged, so that dx = conv(dy, mat) with the forward's own kernel (mmsum_conv3x3_gemm).
+template <typename T>
+__global__ __launch_bounds__(256) void weight_to_dgrad_matrix_kernel(T* __restrict__ mat, const float* __restrict__ w, int Cout, int Cin,
+                                                                     int KH, int KW, int Kpad) {
+    const long total = (long)Cin * Kpad;
+    const int K = KH * KW * Cout;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int col = (int)(i % Kpad), ci = (int)(i / Kpad);
+        float v = 0.f;
+        if (col < K) {
+            const int co = col % Cout, tap = col / Cout;
+            const int kh = KH - 1 - tap / KW, kw = KW - 1 - tap % KW;
+            v = w[(((long)co * Cin + ci) * KH + kh) * KW + kw];
+        }
+        mat[i] = from_f32<T>(v);
+    }
+}
 __global__ __launch_bounds__(256) void matrix_to_weight_grad_kernel(const float* __restrict__ mat, float* __restrict__ dw, int Cout,
                                                                     int Cin, int KH, int KW, int Kpad, int accumulate) {
     const long total = (long)Cout * Cin * KH * KW;
@@ -332,11 +350,16 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __res
 }
 
 // y = relu?((x - mean) rstd gamma + beta (+ residual)) = x * sc + sh (+ residual); grid (channel blocks, row splits)
+// raw != nullptr (training): the statistics arrive as plain column sums {sum x, sum x^2} left by the convolution's GEMM epilogue
+// (MMSUM_GEMM_COLSUM | COLSUM2); every thread turns the sums of its channels into {mean, biased variance} itself, and the first row
+// split's first row lane also WRITES them to `sums` (the backward pass reads them there) and updates the running statistics: nobody
+// reads those three arrays in this launch, so there is no race and no separate statistics launch.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, float* __restrict__ sums, const float* __restrict__ raw,
+                                                       const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual, T* __restrict__ y,
-                                                       const float* __restrict__ running_mean, const float* __restrict__ running_var, int R, int C,
-                                                       int cgb, float eps, int relu, int training, int pH, int pW) {
+                                                       float* __restrict__ running_mean, float* __restrict__ running_var, int R, int C,
+                                                       int cgb, float eps, float momentum, int relu, int training, int pH, int pW) {
     constexpr int V = BnVec<T>::N;
     const BnMap m = bn_map(cgb);
     const int col = (blockIdx.x * cgb + m.cg) * V;
@@ -344,8 +367,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     float sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        const float mean = training ? sums[col + j] : running_mean[col + j];
-        const float var = training ? sums[C + col + j] : running_var[col + j];
+        float mean, var;
+        if (raw != nullptr) {
+            mean = raw[col + j] / R;
+            var = fmaxf(raw[C + col + j] / R - mean * mean, 0.f);
+            if (blockIdx.y == 0 && m.rl == 0) {
+                sums[col + j] = mean;
+                sums[C + col + j] = var;
+                if (running_mean != nullptr && running_var != nullptr) {
+                    const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+                    running_mean[col + j] = (1.f - momentum) * running_mean[col + j] + momentum * mean;
+                    running_var[col + j] = (1.f - momentum) * running_var[col + j] + momentum * unbiased;
+                }
+            }
+        } else {
+            mean = training ? sums[col + j] : running_mean[col + j];
+            var = training ? sums[C + col + j] : running_var[col + j];
+        }
         sc[j] = rsqrtf(var + eps) * gamma[col + j];
         sh[j] = beta[col + j] - mean * sc[j];
     }
@@ -420,7 +458,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ sums, const float* __restrict__ dsums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, T* __restrict__ dresidual,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C, int cgb,
-                                                           float eps, int relu, int pH, int pW) {
+                                                           float eps, int relu, int pH, int pW, int dxH, int dxW) {
     constexpr int V = BnVec<T>::N;
     const BnMap m = bn_map(cgb);
     const int col = (blockIdx.x * cgb + m.cg) * V;
@@ -454,7 +492,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                     if (relu && !(yv[u][j] > 0.f)) g[u][j] = 0.f;
                     xv[u][j] = fmaf(k[j], g[u][j], fmaf(kx[j], xv[u][j], k0[j]));
                 }
-                stv<T, V>(dx + o, xv[u]);
+                stv<T, V>(dx + bn_yrow(r + u * step, dxH, dxW) * C + col, xv[u]);
                 if (dresidual) stv<T, V>(dresidual + o, g[u]);
             }
         }
@@ -469,7 +507,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 if (relu && !(yv[j] > 0.f)) g[j] = 0.f;
                 xv[j] = fmaf(k[j], g[j], fmaf(kx[j], xv[j], k0[j]));
             }
-            stv<T, V>(dx + o, xv);
+            stv<T, V>(dx + bn_yrow(r, dxH, dxW) * C + col, xv);
             if (dresidual) stv<T, V>(dresidual + o, g);
         }
     }
@@ -733,9 +771,13 @@ extern "C" int mmsum_col2im(int dtype, const void* dcol, void* dx, int N, int H,
 
 extern "C" int mmsum_conv_weight_permute(int dtype, void* matrix, float* weight, int Cout, int Cin, int KH, int KW, int Kpad,
                                          int to_matrix, int accumulate, void* stream) {
-    if (Cout <= 0 || Kpad < Cin * KH * KW) return MMSUM_ERR_BAD_SHAPE;
+    if (Cout <= 0 || Kpad < (to_matrix == 2 ? Cout : Cin) * KH * KW) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (to_matrix) {
+    if (to_matrix == 2) {
+        const dim3 grid(grid_for((long)Cin * Kpad, 256)), block(256);
+        DT_SWITCH(dtype, (weight_to_dgrad_matrix_kernel<bf16_t><<<grid, block, 0, s>>>((bf16_t*)matrix, weight, Cout, Cin, KH, KW, Kpad)),
+                  (weight_to_dgrad_matrix_kernel<float><<<grid, block, 0, s>>>((float*)matrix, weight, Cout, Cin, KH, KW, Kpad)));
+    } else if (to_matrix) {
         const dim3 grid(grid_for((long)Cout * Kpad, 256)), block(256);
         DT_SWITCH(dtype, (weight_to_matrix_kernel<bf16_t><<<grid, block, 0, s>>>((bf16_t*)matrix, weight, Cout, Cin, KH, KW, Kpad)),
                   (weight_to_matrix_kernel<float><<<grid, block, 0, s>>>((float*)matrix, weight, Cout, Cin, KH, KW, Kpad)));
@@ -788,18 +830,18 @@ extern "C" int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* s
     return ok();
 }
 
-extern "C" int mmsum_bn_apply(int dtype, const void* x, const float* sums, const float* gamma, const float* beta, const void* residual,
+extern "C" int mmsum_bn_apply(int dtype, const void* x, float* sums, const float* raw, const float* gamma, const float* beta, const void* residual,
                               void* y, float* running_mean, float* running_var, int R, int C, float eps, float momentum, int relu,
                               int training, int pad_H, int pad_W, void* stream) {
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
-    if (R <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
+    if (R <= 0 || C % vec || (raw != nullptr && !training)) return MMSUM_ERR_BAD_SHAPE;
     if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, relu, training, pad_H, pad_W)),
-              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, relu, training, pad_H, pad_W)));
-    if (training && running_mean && running_var)
+    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, raw, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W)),
+              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, raw, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W)));
+    if (training && raw == nullptr && running_mean && running_var)
         bn_running_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sums, running_mean, running_var, R, C, momentum);
     return ok();
 }
@@ -822,15 +864,16 @@ extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, con
 
 extern "C" int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
                                   const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C, float eps,
-                                  int relu, int pad_H, int pad_W, void* stream) {
+                                  int relu, int pad_H, int pad_W, int dx_pad_H, int dx_pad_W, void* stream) {
     if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
+    if (dx_pad_W != 0 && (dx_pad_H <= 0 || dx_pad_W < 0 || R % (dx_pad_H * dx_pad_W))) return MMSUM_ERR_BAD_SHAPE;
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
     if (R <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W)),
-              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W)));
+    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W)),
+              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W)));
     return ok();
 }
 

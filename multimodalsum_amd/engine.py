@@ -16,6 +16,7 @@ Numerics follow the reference op for op (same masks, same -inf/-2^16 semantics, 
 null entities, post-LN, erf-GELU); see the citations at each step.
 """
 import math
+import os
 from types import SimpleNamespace as NS
 
 import torch
@@ -136,7 +137,7 @@ class Engine:
         self.bp = bart_prefix
         self.deterministic = deterministic
         # bf16: stride-1 3x3 convolutions as implicit GEMMs (False / MMSUM_IMPLICIT_CONV=0: im2col + GEMM everywhere; tests and A/B runs compare the two)
-        self.implicit_conv = __import__("os").environ.get("MMSUM_IMPLICIT_CONV") != "0"
+        self.implicit_conv = os.environ.get("MMSUM_IMPLICIT_CONV") != "0"
         self.training = True
         self.seed_base = 0x5EED
         self.step_count = 0
@@ -167,7 +168,7 @@ class Engine:
         self._conv_dirty = "all"
         self.touched = set()
         self.Vpad = (cfg.vocab_size + 127) // 128 * 128
-        self.wt, self.wt_desc, self.conv_mats_t = {}, None, {}
+        self.wt, self.wt_desc, self.conv_mats_t, self.conv_mats_r = {}, None, {}, {}
         if compute_dtype == torch.bfloat16:
             self._build_wt_table()
         self.salt = None                   # device uint64 mixed into every dropout seed (set by graphs.StepGraphs; None = seeds as passed)
@@ -790,8 +791,8 @@ class Engine:
             todo.append((r + "conv1.weight", 64, 3, 7))
         for li, bi, inp, pl, stride, down in resnet_blocks():
             if li <= 3 and (all_layers or li == 3):
-                todo.append((r + "layer%d.%d.conv2.weight" % (li, bi), pl, pl, 3))
-        for name, co, ci, ks in todo:
+                todo.append((r + "layer%d.%d.conv2.weight" % (li, bi), pl, pl, 3, stride))
+        for name, co, ci, ks, *rest in todo:
             Kpad = (ks * ks * ci + 63) // 64 * 64
             m = self.conv_mats.get(name)
             if m is None:
@@ -799,11 +800,25 @@ class Engine:
                 self.conv_mats[name] = m
             kn.conv_weight_to_matrix(m, a.f32(name), co, ci, ks, ks, Kpad)
             if self.dtype == torch.bfloat16 and ".layer3." in name:
+                if rest[0] == 1 and self._implicit_bwd_ok(ci, co):
+                    # stride 1: the input gradient is the forward's implicit convolution of the padded output gradient with the rotated weights
+                    mr = self.conv_mats_r.get(name)
+                    if mr is None:
+                        mr = self.empty(ci, ks * ks * co)
+                        self.conv_mats_r[name] = mr
+                    kn.conv_weight_to_dgrad_matrix(mr, a.f32(name), co, ci, ks, ks, ks * ks * co)
+                    continue
                 mt = self.conv_mats_t.get(name)
                 if mt is None:
                     mt = self.empty(Kpad, co)
                     self.conv_mats_t[name] = mt
                 kn.transpose(m, mt)
+
+    def _implicit_bwd_ok(self, cin, cout):
+        """The backward of a stride-1 3x3 convolution without im2col / col2im (kn.conv3x3_wgrad + the input gradient as a convolution with the
+        rotated weights): bf16 step, channel counts the four-wave TN kernel's tiles fit (one tap per 256-column tile)."""
+        return (self.implicit_conv and os.environ.get("MMSUM_IMPLICIT_CONV") != "fwd" and self.dtype == torch.bfloat16 and cin >= 256 and (cin & (cin - 1)) == 0
+                and cout >= 64 and (cout & (cout - 1)) == 0)
 
     def _bn_fwd(self, name, x, relu, residual=None, raw=None, pad_hw=None):
         """raw (f32 [2C], optional): {sum x, sum x^2} over the rows of x, left by the convolution's GEMM epilogue (_conv_gemm): the
@@ -821,12 +836,11 @@ class Engine:
         c.sums = self.empty(2 * C, dtype=torch.float32)
         training = self.training
         rm, rv = self.buffers[name + ".running_mean"], self.buffers[name + ".running_var"]
-        if training and raw is not None:
-            kn.bn_stats_from_sums(raw, R, c.sums, rm, rv, 0.1)
-            rm = rv = None                                   # updated above
-        elif training:
+        if training and raw is None:
             kn.bn_reduce(x, c.sums)
-        kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, rm, rv, 1e-5, 0.1, relu, training, pad_hw=pad_hw)
+        # raw: the apply kernel derives the statistics from the epilogue's sums, writes c.sums and updates the running statistics itself
+        kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, rm, rv, 1e-5, 0.1, relu, training, pad_hw=pad_hw,
+                    raw=raw if training else None)
         return c.y, c
 
     def _conv_gemm(self, x, w, bn_name=None):
@@ -856,15 +870,16 @@ class Engine:
         kn.conv3x3_gemm(xp, w, y, n, H, W, C, stats=raw)
         return y, raw
 
-    def _bn_bwd(self, c, dy, dresidual=None):
+    def _bn_bwd(self, c, dy, dresidual=None, dx_padded=None, dx_pad_hw=None):
+        """dx_padded / dx_pad_hw: write dx into this zero-bordered padded buffer (interior only) instead of a compact matrix."""
         a = self.arena
         R, C = dy.shape
         dsums = self.empty(2 * C, dtype=torch.float32)
         pad_hw = getattr(c, "pad_hw", None)                  # the forward output (ReLU mask) sits in the padded layout
         kn.bn_bwd_reduce(dy, c.y, c.x, c.sums, dsums, 1e-5, c.relu, pad_hw=pad_hw)
-        dx = self.empty(R, C)
+        dx = dx_padded if dx_padded is not None else self.empty(R, C)
         kn.bn_bwd_apply(dy, c.y, c.x, c.sums, dsums, a.f32(c.name + ".weight"), dx, dresidual, a.g(c.name + ".weight"),
-                        a.g(c.name + ".bias"), 1e-5, c.relu, pad_hw=pad_hw)
+                        a.g(c.name + ".bias"), 1e-5, c.relu, pad_hw=pad_hw, dx_pad_hw=dx_pad_hw)
         self.touch(c.name + ".weight", c.name + ".bias")
         return dx
 
@@ -946,6 +961,7 @@ class Engine:
         self.touch("img_encoder.linear.weight")
         dx = self.empty(c.feat.shape[0], c.feat.shape[1])
         self.dgrad(dy, "img_encoder.linear.weight", a.w("img_encoder.linear.weight"), dx)
+        padded = {}
         for bc in reversed(c.blocks):
             b = bc.name
             first_block = bc.down      # block 0: its input is the detached stage-2 output (:33) -> no input gradient
@@ -956,8 +972,38 @@ class Engine:
             self.wgrad(dc3, bc.o2, gview=a.g(b + "conv3.weight", (w3.shape[0], w3.shape[1])))
             do2 = self.empty(R2, bc.pl)
             self.dgrad(dc3, b + "conv3.weight", w3.view(w3.shape[0], w3.shape[1]), do2)
-            dc2 = self._bn_bwd(bc.bn2, do2)
             wm = self.conv_mats[b + "conv2.weight"]
+            wr = self.conv_mats_r.get(b + "conv2.weight") if bc.col is None else None
+            if wr is not None:
+                assert not first_block
+                # forward ran as an implicit GEMM and the channel counts fit: no im2col matrix in the backward either.  bn2's backward writes
+                # dc2 PADDED (one zero-bordered buffer serves every block of the stage: only the interior is ever written); the weight gradient
+                # is the reduction-major product of the two padded images with a per-tap row shift, the input gradient the forward's implicit
+                # convolution of padded dc2 with the rotated weights
+                key = (n, bc.H, bc.W, bc.pl)
+                dc2p = padded.get(key)
+                if dc2p is None:
+                    dc2p = padded[key] = self.zeros(n * (bc.H + 2) * (bc.W + 2), bc.pl)
+                self._bn_bwd(bc.bn2, do2, dx_padded=dc2p, dx_pad_hw=(bc.H, bc.W))
+                dwm = self.empty(wm.shape[0], 9 * bc.pl, dtype=torch.float32)
+                sk = self.splitk(bc.pl, 9 * bc.pl, dc2p.shape[0])
+                if sk > 1:
+                    ws = self.empty(sk * wm.shape[0], 9 * bc.pl, dtype=torch.float32)
+                    kn.conv3x3_wgrad(dc2p, bc.o1, ws, n, bc.H, bc.W, bc.pl, sk)
+                    kn.slab_reduce(ws, sk, dwm, accumulate=False)
+                else:
+                    kn.conv3x3_wgrad(dc2p, bc.o1, dwm, n, bc.H, bc.W, bc.pl, 1)
+                kn.conv_matrix_grad_to_weight(dwm, a.g(b + "conv2.weight"), bc.pl, bc.pl, 3, 3, 9 * bc.pl, True)
+                do1 = self.empty(n * bc.H * bc.W, bc.pl)
+                kn.conv3x3_gemm(dc2p, wr, do1, n, bc.H, bc.W, bc.pl)
+                dc1 = self._bn_bwd(bc.bn1, do1)
+                w1 = a.w(b + "conv1.weight")
+                self.wgrad(dc1, bc.x, gview=a.g(b + "conv1.weight", (w1.shape[0], w1.shape[1])))
+                self.touch(b + "conv1.weight", b + "conv2.weight", b + "conv3.weight")
+                self.dgrad(dc1, b + "conv1.weight", w1.view(w1.shape[0], w1.shape[1]), didt, accumulate=True)      # never the stage's first block (stride 2)
+                dx = didt
+                continue
+            dc2 = self._bn_bwd(bc.bn2, do2)
             dwm = self.zeros(wm.shape[0], wm.shape[1], dtype=torch.float32)
             col = bc.col
             if col is None:        # the forward ran as an implicit GEMM: the im2col matrix of the PADDED o1 (an (H+2) x (W+2) image, padding 0)

@@ -332,11 +332,13 @@ def bn_stats_from_sums(raw, R, sums, running_mean, running_var, momentum):
     check(lib.mmsum_bn_stats_from_sums(_p(raw), R, C, _p(sums), _p(running_mean), _p(running_var), momentum, _stream()), "mmsum_bn_stats_from_sums")
 
 
-def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None):
-    """pad_hw = (H, W): y is the zero-bordered padded layout [n, H+2, W+2, C] (the operand of conv3x3_gemm); the caller zeroed it."""
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None, raw=None):
+    """pad_hw = (H, W): y is the zero-bordered padded layout [n, H+2, W+2, C] (the operand of conv3x3_gemm); the caller zeroed it.
+    raw (f32 [2C], training): plain column sums {sum x, sum x^2} from the convolution's GEMM epilogue -- the kernel derives the statistics from
+    them, writes {mean, var} to `sums` and updates the running statistics itself (no bn_stats_from_sums launch)."""
     R, C = x.shape
     pH, pW = pad_hw or (0, 0)
-    check(lib.mmsum_bn_apply(_dt(x), _p(x), _p(sums), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean), _p(running_var),
+    check(lib.mmsum_bn_apply(_dt(x), _p(x), _p(sums), _p(raw), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean), _p(running_var),
                              R, C, eps, momentum, int(relu), int(training), pH, pW, _stream()), "mmsum_bn_apply")
 
 
@@ -348,11 +350,15 @@ def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None):
           "mmsum_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None):
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None, dx_pad_hw=None):
+    """pad_hw: y (the ReLU mask) is in the padded layout; dx_pad_hw = (H, W): dx is WRITTEN in the padded layout (interior only)."""
     R, C = x.shape
     pH, pW = pad_hw or (0, 0)
+    dH, dW = dx_pad_hw or (0, 0)
+    if dx_pad_hw is not None:
+        assert dx.shape == (R // (dH * dW) * (dH + 2) * (dW + 2), C) and dx.is_contiguous()
     check(lib.mmsum_bn_bwd_apply(_dt(x), _p(dy), _p(y), _p(x), _p(sums), _p(dsums), _p(gamma), _p(dx), _p(dresidual), _p(dgamma),
-                                 _p(dbeta), R, C, eps, int(relu), pH, pW, _stream()), "mmsum_bn_bwd_apply")
+                                 _p(dbeta), R, C, eps, int(relu), pH, pW, dH, dW, _stream()), "mmsum_bn_bwd_apply")
 
 
 def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None):
@@ -362,6 +368,25 @@ def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None):
     assert xp.dtype == torch.bfloat16 and xp.shape == (n * (H + 2) * (W + 2), C) and xp.is_contiguous() and y.shape[0] == n * H * W
     check(lib.mmsum_conv3x3_gemm(_p(xp), _p(w), _ld(w), _p(y), _ld(y), _p(stats), n, H, W, C, w.shape[0], _stream()), "mmsum_conv3x3_gemm")
     return y
+
+
+def conv3x3_wgrad(dyp, xp, out, n, H, W, C, splitk=1):
+    """out f32 [splitk * Cout, 9 C] (splitk slabs; slab_reduce adds them) = weight gradient of the 3x3 / stride 1 / padding 1 convolution in the
+    (ky, kx, c) matrix layout, from the PADDED output gradient dyp [n*(H+2)*(W+2), Cout] and the PADDED input xp [n*(H+2)*(W+2), C], both
+    with zero borders (mmsum_conv3x3_wgrad: the reduction-major kernel with a per-tile row shift; no im2col matrix)."""
+    Cout = dyp.shape[1]
+    rows = n * (H + 2) * (W + 2)
+    assert dyp.dtype == xp.dtype == torch.bfloat16 and out.dtype == torch.float32 and dyp.is_contiguous() and xp.is_contiguous()
+    assert dyp.shape == (rows, Cout) and xp.shape == (rows, C) and out.shape == (splitk * Cout, 9 * C) and out.is_contiguous()
+    check(lib.mmsum_conv3x3_wgrad(_p(dyp), _p(xp), _p(out), _ld(out), n, H, W, C, Cout, splitk, _stream()), "mmsum_conv3x3_wgrad")
+    return out
+
+
+def conv_weight_to_dgrad_matrix(matrix, weight, Cout, Cin, KH, KW, Kpad):
+    """matrix [Cin, Kpad >= KH*KW*Cout] = the weights rotated by 180 degrees with the channel roles exchanged (mmsum_conv_weight_permute, mode 2):
+    the input gradient of a stride-1 convolution = conv3x3_gemm(padded dy, matrix)."""
+    check(lib.mmsum_conv_weight_permute(_dt(matrix), _p(matrix), _p(weight), Cout, Cin, KH, KW, Kpad, 2, 0, _stream()),
+          "mmsum_conv_weight_permute")
 
 
 def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):

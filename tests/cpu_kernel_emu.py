@@ -399,8 +399,12 @@ def _pad_rows(R, pad_hw):
     return n * (H + 2) * (W + 2) + (rem // W + 1) * (W + 2) + rem % W + 1
 
 
-def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None):
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None, raw=None):
     R, C = x.shape
+    if raw is not None:                            # the statistics from the GEMM epilogue's plain sums; `sums` is written here
+        assert training
+        sums[:C] = raw[:C] / R
+        sums[C:] = (raw[C:] / R - sums[:C] ** 2).clamp_min(0.0)
     if pad_hw is not None:
         yc = torch.empty(R, C, dtype=y.dtype)
         bn_apply(x, sums, gamma, beta, residual, yc, running_mean, running_var, eps, momentum, relu, training)
@@ -430,14 +434,18 @@ def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None):
     dsums[C:] = (g * (x.float() - mean) * rstd).sum(0)
 
 
-def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None):
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None, dx_pad_hw=None):
     R, C = x.shape
     if pad_hw is not None:
         y = y[_pad_rows(R, pad_hw)]
     mean, var, rstd = _bn_stats(sums, R, C, eps)
     g = dy.float() * ((y.float() > 0) if relu else 1.0)
     xh = (x.float() - mean) * rstd
-    dx.copy_(gamma * rstd * (g - dsums[:C] / R - xh * dsums[C:] / R))
+    val = gamma * rstd * (g - dsums[:C] / R - xh * dsums[C:] / R)
+    if dx_pad_hw is not None:
+        dx[_pad_rows(R, dx_pad_hw)] = val.to(dx.dtype)          # interior only: the borders are the caller's zeros
+    else:
+        dx.copy_(val)
     if dresidual is not None:
         dresidual.copy_(g)
     if dgamma is not None:
@@ -452,6 +460,28 @@ def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None):
     im2col(xp, col, n, H + 2, W + 2, C, 3, 3, 1, 0, H, W, Kpad)
     gemm(col, w, y, colsum=stats, colsum_sq=stats is not None)
     return y
+
+
+def conv3x3_wgrad(dyp, xp, out, n, H, W, C, splitk=1):
+    """Contract of mmsum_conv3x3_wgrad, computed the way the kernel does: over ALL padded positions but the first / last W + 3, the x rows
+    shifted by the tap's offset; the k range cut into `splitk` slabs."""
+    Cout = dyp.shape[1]
+    Wp, skip = W + 2, W + 3
+    K = dyp.shape[0] - 2 * skip
+    nst = (K + 31) // 32
+    per = (nst + splitk - 1) // splitk
+    for s_ in range(splitk):
+        k0, k1 = min(K, s_ * per * 32), min(K, (s_ + 1) * per * 32)
+        a = dyp[skip + k0:skip + k1].float()
+        for tap in range(9):
+            sh = (tap // 3 - 1) * Wp + (tap % 3 - 1)
+            out[s_ * Cout:(s_ + 1) * Cout, tap * C:(tap + 1) * C] = a.t() @ xp[skip + sh + k0:skip + sh + k1].float()
+    return out
+
+
+def conv_weight_to_dgrad_matrix(matrix, weight, Cout, Cin, KH, KW, Kpad):
+    matrix.zero_()
+    matrix[:, :KH * KW * Cout] = weight.view(Cout, Cin, KH, KW).flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, -1)
 
 
 def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):

@@ -605,6 +605,19 @@ def test_gemm_epilogue_statistics_small_tiles():
         assert float((sums[:N].double() - mean).abs().max()) <= 1e-4 * float(mean.abs().max()) + 1e-5
         assert float((sums[N:].double() - var).abs().max()) <= 1e-3 * float(var.max()) + 1e-5
         assert float((rm.double() - (0.45 + 0.1 * mean)).abs().max()) <= 1e-4 and float((rv.double() - (1.8 + 0.1 * var * M / (M - 1))).abs().max()) <= 1e-3 * float(var.max()) + 1e-4
+        # the form the bf16 step takes: mmsum_bn_apply derives the statistics from `raw` itself, writes `sums` and updates the running
+        # statistics in the same launch -- equal to the two-launch form above to the last bit, with a residual and in the padded layout too
+        gamma, beta = 1 + 0.1 * rnd(N, seed=3), 0.1 * rnd(N, seed=4)
+        res = rnd(M, N, dtype=torch.bfloat16, seed=5)
+        y_two = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        kn.bn_apply(out, sums, gamma, beta, res, y_two, None, None, 1e-5, 0.1, True, True)
+        sums2 = torch.full((2 * N,), float("nan"), device=DEV)
+        rm2, rv2 = torch.full((N,), 0.5, device=DEV), torch.full((N,), 2.0, device=DEV)
+        y_one = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        kn.bn_apply(out, sums2, gamma, beta, res, y_one, rm2, rv2, 1e-5, 0.1, True, True, raw=raw)
+        assert torch.equal(sums2, sums) and torch.equal(rm2, rm) and torch.equal(rv2, rv) and torch.equal(y_one, y_two), (M, N, K)
+        ref_y = torch.relu((od - mean) / (var + 1e-5).sqrt() * gamma.double() + beta.double() + res.double())
+        assert float((y_one.double() - ref_y).abs().max()) <= 2e-2 * float(ref_y.abs().max())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -1135,3 +1148,46 @@ def test_conv3x3_implicit_gemm(n, H, C, Cout):
     kn.bn_bwd_apply(dy, yc, x, sums, d0, gamma, dx0, None, None, None, 1e-5, True)
     kn.bn_bwd_apply(dy, yp, x, sums, d0, gamma, dx1, None, None, None, 1e-5, True, pad_hw=(H, W))
     assert torch.equal(dx0, dx1)
+    # ... and can write dx in the padded layout (interior only: the borders keep the caller's zeros)
+    dxp = torch.zeros(n * (H + 2) * (W + 2), C, device=DEV, dtype=bf)
+    kn.bn_bwd_apply(dy, yp, x, sums, d0, gamma, dxp, None, None, None, 1e-5, True, pad_hw=(H, W), dx_pad_hw=(H, W))
+    dimg = dxp.view(n, H + 2, W + 2, C)
+    assert torch.equal(dimg[:, 1:-1, 1:-1].reshape(R, C), dx0)
+    assert float(dimg[:, 0].abs().max()) == 0 and float(dimg[:, -1].abs().max()) == 0 and float(dimg[:, :, 0].abs().max()) == 0 and float(dimg[:, :, -1].abs().max()) == 0
+
+
+@pytest.mark.parametrize("n,H,C,Cout,sk", [(5, 14, 256, 256, 1), (9, 14, 256, 256, 4), (3, 7, 512, 128, 3), (212, 14, 256, 256, 28)])
+def test_conv3x3_backward_without_im2col(n, H, C, Cout, sk):
+    """The backward of the implicit 3x3 convolution: mmsum_conv3x3_wgrad (four-wave reduction-major kernel over the two PADDED images, the x
+    rows shifted by the tile's tap) against dy^T . im2col(x) in f64, with split-K slabs; the input gradient as mmsum_conv3x3_gemm of the
+    padded dy with the rotated weights (mmsum_conv_weight_permute, mode 2) against torch's conv2d input gradient in f64."""
+    bf = torch.bfloat16
+    W = H
+    R, Rp = n * H * W, n * (H + 2) * (W + 2)
+    xc = rnd(R, C, dtype=bf, seed=11)
+    dyc = rnd(R, Cout, dtype=bf, seed=12)
+    pad = lambda t, ch: torch.nn.functional.pad(t.view(n, H, W, ch), (0, 0, 1, 1, 1, 1)).reshape(Rp, ch).contiguous()
+    xp, dyp = pad(xc, C), pad(dyc, Cout)
+    # weight gradient
+    col = torch.empty(R, 9 * C, device=DEV, dtype=bf)
+    kn.im2col(xc, col, n, H, W, C, 3, 3, 1, 1, H, W, 9 * C)
+    exact = dyc.double().t() @ col.double()
+    ws = torch.full((sk * Cout, 9 * C), float("nan"), device=DEV)
+    kn.conv3x3_wgrad(dyp, xp, ws, n, H, W, C, sk)
+    got = ws.view(sk, Cout, 9 * C).double().sum(0)
+    assert float((got - exact).abs().max()) <= 2e-5 * float(exact.abs().max()) + 1e-4 * (R ** 0.5)       # f32 accumulation of exact bf16 products
+    if sk > 1:
+        dwm = torch.empty(Cout, 9 * C, device=DEV)
+        kn.slab_reduce(ws, sk, dwm, accumulate=False)
+        assert float((dwm.double() - exact).abs().max()) <= 2e-5 * float(exact.abs().max()) + 1e-4 * (R ** 0.5)
+    # input gradient
+    w4 = rnd(Cout, C, 3, 3, seed=13, std=0.03)
+    wr = torch.empty(C, 9 * Cout, device=DEV, dtype=bf)
+    kn.conv_weight_to_dgrad_matrix(wr, w4, Cout, C, 3, 3, 9 * Cout)
+    ref_wr = w4.flip(2, 3).permute(1, 2, 3, 0).reshape(C, 9 * Cout).to(bf)
+    assert torch.equal(wr, ref_wr)
+    dx = torch.full((R, C), float("nan"), device=DEV, dtype=bf)
+    kn.conv3x3_gemm(dyp, wr, dx, n, H, W, Cout)
+    wq = w4.to(bf).double()                                        # the kernel multiplies bf16 weights
+    ref = torch.nn.functional.conv_transpose2d(dyc.double().view(n, H, W, Cout).permute(0, 3, 1, 2), wq, padding=1).permute(0, 2, 3, 1).reshape(R, C)
+    assert float((dx.double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max())
