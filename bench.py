@@ -424,7 +424,18 @@ def pmc_traffic(shape):
             with open(path) as f:
                 prof = json.load(f)
             if list(prof["shape"]) == list(shape):
-                return prof["hbm_bytes_per_launch"], os.path.basename(path)
+                # a file that records the sha1 of the kernel's sources (tools/pmc_dominant_json.py, round 4 on) is checked against the
+                # sources on disk: counters of another build are reported, but named as such
+                src = os.path.basename(path)
+                want = prof.get("source_sha1")
+                if want is None:
+                    src += " (kernel sources not recorded in this file)"
+                else:
+                    import hashlib
+                    cur = {f: hashlib.sha1(open(os.path.join(ROOT, "multimodalsum_amd", "csrc", f), "rb").read()).hexdigest() for f in want}
+                    if cur != want:
+                        src += " (STALE: the kernel's sources changed since these counters were collected)"
+                return prof["hbm_bytes_per_launch"], src
         except Exception:
             continue
     return None, None

@@ -57,7 +57,10 @@ class DistributedDataParallel(nn.Module):
         self.overlap = overlap and self.arena.grad.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.overlap else None
         self.grad_dtype = grad_dtype
-        self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        # ReduceOp.AVG exists on RCCL only -- and is asked for only when there is something to average: RCCL 2.26.6's ONE-rank AVG path
+        # (a copy kernel with a pre-multiplier) leaves the last 16 bytes of reduce_scatter's output unwritten for some sizes (19,584 f32:
+        # tools/rccl_one_rank_avg_probe.py on a 1-GPU box; SUM and every size tried at AVG in place are fine).  A one-rank mean is the sum.
+        self.native_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl" and self.world_size > 1
         self.collect_stats = bool(collect_stats) and self.arena.grad.is_cuda
         self.stats = collections.deque(maxlen=max(1, int(stats_window)))     # the last steps only: (bucket events, bytes, end events); comm_stats() reads them
         self._events, self._bytes = [], 0
@@ -104,7 +107,7 @@ class DistributedDataParallel(nn.Module):
             dist.all_gather_into_tensor(head, shard, group=self.group)
         if n < buf.numel():                       # all_reduce mode, or the few elements a bucket has beyond a multiple of W
             dist.all_reduce(buf[n:], op=op, group=self.group)
-        if not self.native_avg:
+        if not self.native_avg and W > 1:
             buf.mul_(1.0 / W)
         if buf is not chunk:
             chunk.copy_(buf)
@@ -188,7 +191,7 @@ def bus_microbench(device, sizes_elems=(64 * 1024 * 1024, 16 * 1024 * 1024), dty
     W = dist.get_world_size(group)
     rank = dist.get_rank(group)
     cuda = torch.device(device).type == "cuda"
-    avg = dist.get_backend(group) == "nccl"
+    avg = dist.get_backend(group) == "nccl" and W > 1          # see DistributedDataParallel.native_avg
     op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
     out = []
     for dt in dtypes:

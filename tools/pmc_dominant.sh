@@ -8,3 +8,4 @@ for c in "FETCH_SIZE:f" "WRITE_SIZE:w" "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_C
 done
 cd "$R"
 python tools/pmc_summary.py gemm_nt_w4 gpurun_out/pmcF_f/f_counter_collection.csv gpurun_out/pmcF_w/w_counter_collection.csv gpurun_out/pmcF_s/s_counter_collection.csv gpurun_out/pmcF_t/t_counter_collection.csv
+python tools/pmc_dominant_json.py ${PMC_ROUND:-4} ${PMC_M:-129024} 4096 1024 gpurun_out/pmcF_dominant.json gpurun_out/pmcF_f/f_counter_collection.csv gpurun_out/pmcF_w/w_counter_collection.csv gpurun_out/pmcF_s/s_counter_collection.csv gpurun_out/pmcF_t/t_counter_collection.csv

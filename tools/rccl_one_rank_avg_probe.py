@@ -10,7 +10,7 @@ for op_name, op in (("AVG", dist.ReduceOp.AVG), ("SUM", dist.ReduceOp.SUM)):
         for shard_off in (0, 4):
             g = torch.arange(G, device=dev, dtype=torch.float32) * 1e-3
             want = g.clone()
-            shard_buf = torch.full((1 << 20) + 64, -7.0, device=dev)
+            shard_buf = torch.full(((1 << 20) + 64,), -7.0, device=dev)
             shard = shard_buf[shard_off:shard_off + n]
             head = g[o:o + n]
             dist.reduce_scatter_tensor(shard, head, op=op)
