@@ -1,8 +1,8 @@
 """GPU: parity AT THE SIZES AND ON THE KERNELS THE BENCHMARK RUNS.
 
-The tile chooser sends small test shapes to the 128x128 kernels; the bench (B=112 per GPU: 129,024 decoder rows, ~76,300
-valid encoder rows; B=56, the headline batch of rounds 1-2: 64,512 / ~38,900; F=4096, V=50265) runs the persistent 256x256
-kernels.  This file holds those kernels and sizes to
+The tile chooser sends small test shapes to the 128x128 kernels; the bench (B=128 per GPU: 147,456 decoder rows, ~87,500
+valid encoder rows; earlier headline batches B=112: 129,024 / ~76,300 and B=56: 64,512 / ~38,900; F=4096, V=50265) runs the
+persistent 256x256 kernels.  This file holds those kernels and sizes to
 element-wise bounds against fp32 / fp64 matmuls (a wrong epilogue on a few tiles cannot hide behind a norm), asserts through
 mmsum_gemm_plan that each case really reaches the kernel it means to cover, checks the device-side live row counts at
 those sizes, and compares the HIP path with the reference's own outputs at the real cfg/bart-large.json (fixtures F8, F8b

@@ -14,6 +14,8 @@ for w in $what; do
     benchfast) timeout 600 python bench.py --no-cpu-baseline --no-also > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc $?" >> gpurun_out/${tag}_bench.err ;;
     prof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R"/gpurun_out/${tag}_prof -o r --output-format csv -- python3 "$R"/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-probe --no-also > "$R"/gpurun_out/${tag}_prof.log 2>&1)
           f=$(find gpurun_out/${tag}_prof -name "*kernel_stats.csv" | head -1)
+          t=$(find gpurun_out/${tag}_prof -name "*kernel_trace.csv" | head -1)
+          if [ -n "$t" ]; then python tools/prof_gaps.py "$t" 6 > gpurun_out/${tag}_prof_gaps.txt 2>&1; fi
           if [ -n "$f" ]; then python tools/prof_top.py "$f" 0 60 > gpurun_out/${tag}_prof_summary.txt; python tools/prof_summary.py "$f" 0 >> gpurun_out/${tag}_prof_summary.txt; cp "$f" gpurun_out/${tag}_kernel_stats.csv; fi
           rm -rf gpurun_out/${tag}_prof ;;
   esac
