@@ -168,7 +168,7 @@ class Engine:
         self._conv_dirty = "all"
         self.touched = set()
         self.Vpad = (cfg.vocab_size + 127) // 128 * 128
-        self.wt, self.wt_desc, self.conv_mats_t, self.conv_mats_r = {}, None, {}, {}
+        self.wt, self.wt_desc, self.conv_mats_t, self.conv_mats_r, self._conv_graphs = {}, None, {}, {}, {}
         if compute_dtype == torch.bfloat16:
             self._build_wt_table()
         self.salt = None                   # device uint64 mixed into every dropout seed (set by graphs.StepGraphs; None = seeds as passed)
@@ -279,11 +279,35 @@ class Engine:
         if a.shadow is not None and a.shadow_dirty:
             kn.cast(a.shadow, a.data)
         if self.with_img and self._conv_dirty:
-            self._build_conv_mats(all_layers=(self._conv_dirty == "all"))
+            self._refresh_conv_mats(self._conv_dirty)
         if self.wt_desc is not None and self.training:
             kn.transpose_batched(a.shadow, self.wt_buf, self.wt_desc, self.wt_desc.shape[0], self.wt_max_tiles)
         a.shadow_dirty = True
         self._conv_dirty = "all"
+
+    def _refresh_conv_mats(self, which):
+        """The conv weight matrices from the f32 masters: ~70 launches of a few microseconds each, issued from Python once per step.
+        On the GPU the launch sequence is captured once per `which` ("all" / "layer3": pointers and shapes never change) and replayed
+        as ONE graph launch (kernel trace at B = 8: 45 gaps of ~15 us per step before these kernels)."""
+        all_layers = which == "all"
+        if self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+            return self._build_conv_mats(all_layers)
+        g = self._conv_graphs.get(which)
+        if g is None:
+            self._build_conv_mats(all_layers)            # eagerly first: allocates the matrices
+            import gc
+            torch.cuda.synchronize()
+            gc.collect()
+            gc.disable()                                 # a CUDAGraph finalised by the collector during capture aborts the capture
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self._build_conv_mats(all_layers)
+            finally:
+                gc.enable()
+            self._conv_graphs[which] = g
+            return
+        g.replay()
 
     def mark_weights_changed(self):
         self.arena.shadow_dirty = True

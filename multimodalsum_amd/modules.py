@@ -565,11 +565,16 @@ def _layer_chunks(L, per):
 
 
 def _segment_layers(model):
-    """Layers per gradient segment of the fused step's backward (`model.grad_segment_layers`, default 3; 0 = one segment per
-    stack).  A segment is one captured graph and one notification to the data-parallel wrapper: with three layers per segment
+    """Layers per gradient segment of the fused step's backward (`model.grad_segment_layers`; default 3 under a data-parallel wrapper,
+    otherwise 0 = one segment per stack).  A segment is one captured graph and one notification to the data-parallel wrapper: with three layers per segment
     (~150 MB of f32 gradients) the exchange of a segment hides under the next one and only the last -- the encoder's bottom
     layers and the tied embedding, which the encoder's embedding backward finalises -- is exchanged in the open."""
-    return int(getattr(model, "grad_segment_layers", 3))
+    v = getattr(model, "grad_segment_layers", None)
+    if v is None:
+        # nobody listens for finished segments (no data-parallel wrapper): one segment per stack -- every captured graph costs a launch
+        # (40 - 160 us between graphs in the kernel trace), and the finer split only exists to overlap the gradient exchange
+        v = 3 if model._engine.segment_hooks else 0
+    return int(v)
 
 
 def _decoder_segments(e, s, st, release, upstream, per):
