@@ -183,8 +183,7 @@ class DecodeSession:
         if nb:
             _banned_ngram_table(history, self.ngram, t + 1, hi[2 * R:].reshape(R, nb))
         self.h_sc_np[:] = scores
-        hi = self.h_int
-        self.d_int.copy_(hi, non_blocking=True)
+        self.d_int.copy_(self.h_int, non_blocking=True)
         self.beam_scores.copy_(self.h_sc, non_blocking=True)
         if not self.use_graphs:
             self._step(t)
@@ -438,9 +437,21 @@ def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_lengt
         nxt_s = np.zeros(R, dtype=np.float32)
         nxt_t = np.full(R, pad, dtype=np.int32)
         nxt_p = np.zeros(R, dtype=np.int32)
+        # the common case of a business -- no EOS among its first candidates -- is the first num_beams candidates as they come
+        plain = np.ones(B, dtype=bool) if eos is None else ~(top_tok[:, :num_beams + 1] == eos).any(axis=1)
+        # (checked one past num_beams: if none of the first num_beams is EOS the loop below stops there and never looks further)
+        if plain.any():
+            rows_ = (np.arange(B)[:, None] * num_beams + np.arange(num_beams)[None, :])
+            sel = plain[:, None] & ~np.asarray(done, dtype=bool)[:, None]
+            nxt_s.reshape(B, num_beams)[:] = np.where(sel, top_s[:, :num_beams], 0.0)
+            nxt_t.reshape(B, num_beams)[:] = np.where(sel, top_tok[:, :num_beams], pad)
+            nxt_p.reshape(B, num_beams)[:] = np.where(sel, np.arange(B)[:, None] * num_beams + top_beam[:, :num_beams], 0)
         for b in range(B):
             if done[b]:
                 continue                                                   # padded out: score 0, pad token, parent row 0 (:2938-2941)
+            if plain[b]:
+                done[b] = hyps[b].is_done(float(top_s[b].max()), cur_len)
+                continue
             n_sent = 0
             for rank in range(2 * num_beams):
                 tok, sc = int(top_tok[b, rank]), float(top_s[b, rank])

@@ -12,6 +12,11 @@ for w in $what; do
     testsall) timeout 2700 python -m pytest tests -m gpu -q --durations=15 > gpurun_out/${tag}_tests.log 2>&1; echo "tests rc $?" >> gpurun_out/${tag}_tests.log ;;
     bench) timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc $?" >> gpurun_out/${tag}_bench.err ;;
     benchfast) timeout 600 python bench.py --no-cpu-baseline --no-also > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc $?" >> gpurun_out/${tag}_bench.err ;;
+    profgen) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R"/gpurun_out/${tag}_profgen -o r --output-format csv -- python3 "$R"/bench.py --workload generate --steps 2 --warmup 1 > "$R"/gpurun_out/${tag}_profgen.log 2>&1)
+          f=$(find gpurun_out/${tag}_profgen -name "*kernel_stats.csv" | head -1); t=$(find gpurun_out/${tag}_profgen -name "*kernel_trace.csv" | head -1)
+          if [ -n "$t" ]; then python tools/prof_gaps.py "$t" 0 > gpurun_out/${tag}_profgen_gaps.txt 2>&1; fi
+          if [ -n "$f" ]; then python tools/prof_top.py "$f" 378 40 > gpurun_out/${tag}_profgen_summary.txt; fi
+          rm -rf gpurun_out/${tag}_profgen ;;
     prof8) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R"/gpurun_out/${tag}_prof8 -o r --output-format csv -- python3 "$R"/bench.py --batch 8 --steps 20 --warmup 3 --no-cpu-baseline --no-kernel-probe --no-also > "$R"/gpurun_out/${tag}_prof8.log 2>&1)
           f=$(find gpurun_out/${tag}_prof8 -name "*kernel_stats.csv" | head -1); t=$(find gpurun_out/${tag}_prof8 -name "*kernel_trace.csv" | head -1)
           if [ -n "$t" ]; then python tools/prof_gaps.py "$t" 20 > gpurun_out/${tag}_prof8_gaps.txt 2>&1; fi

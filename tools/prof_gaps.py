@@ -11,7 +11,10 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rows.sort()
 # the timed region = the last `steps` optimizer launches backwards: take everything after the (steps+1)-th last adamw kernel
 ad = [i for i, r in enumerate(rows) if "adamw_kernel" in r[2]]
-if len(ad) > steps:
+if steps <= 0:              # no optimizer in this workload: the last 60 % of the trace (past the warm-up)
+    rows = rows[int(len(rows) * 0.4):]
+    steps = 1
+elif len(ad) > steps:
     rows = rows[ad[-steps - 1] + 1:ad[-1] + 1]
 span = rows[-1][1] - rows[0][0]
 busy_end = rows[0][0]
