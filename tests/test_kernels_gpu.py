@@ -330,6 +330,9 @@ ATTN_CASES = [
     ("cross_img_holes", 1, 2, 2, 196, 128, 1, False, False, False),
     ("cross_img_one_entity", 2, 9, 1, 196, 128, 1, False, False, False),   # the training layout: one image / table entity per business,
     ("cross_table_walk", 3, 4, 1, 47, 40, 2, False, False, False),         # shared by its query blocks (a workgroup walks several of them)
+    # review lengths 5 .. 128: one, two, three and four live key blocks per entity -- every way the dK / dV kernel shares a live block's
+    # query sweep with the waves whose own block is all padding (three helpers; two; one that moves from block to block; none)
+    ("cross_text_lengths", 1, 9, 9, 128, 64, 1, True, False, False),
 ]
 
 
@@ -345,11 +348,14 @@ def test_attention(dtype, case):
         for n in range(N):
             L = int(torch.randint(max(1, S // 3), S + 1, (1,), generator=g))
             pad[b, n, L:] = True
+    if name == "cross_text_lengths":
+        for n, L in enumerate((5, 32, 33, 64, 65, 96, 97, 128, 20)):
+            pad[0, n] = torch.arange(S) >= L
     if name.endswith("_holes"):
         pad = pad | (torch.rand(B, N, S, generator=g) < 0.3)
         pad[:, :, 5] = False
         pad[0, 0, :64] = False              # first masked key of this entity lies in its third key block
-    if not is_self and N > 1:
+    if not is_self and N > 1 and name != "cross_text_lengths":
         pad[0, N - 1, :] = True            # a null entity
     if name in ("cross_table", "cross_table_walk"):
         pad[1, 0, :] = True                 # business without a table: output must be exactly 0
@@ -618,6 +624,27 @@ def test_gemm_epilogue_statistics_small_tiles():
         assert torch.equal(sums2, sums) and torch.equal(rm2, rm) and torch.equal(rv2, rv) and torch.equal(y_one, y_two), (M, N, K)
         ref_y = torch.relu((od - mean) / (var + 1e-5).sqrt() * gamma.double() + beta.double() + res.double())
         assert float((y_one.double() - ref_y).abs().max()) <= 2e-2 * float(ref_y.abs().max())
+
+
+def test_bn_statistics_from_raw_sums_with_large_means():
+    """var = E[y^2] - E[y]^2 from the GEMM epilogue's plain f32 sums cancels when |mean| >> std.  How much: columns whose mean is
+    10 x their standard deviation (far beyond what a convolution with zero-mean weights produces) keep the variance to 2e-3 relative and the
+    mean to 1e-5 against the f64 statistics of the SAME stored bf16 values -- below the 2^-9 rounding of the values themselves."""
+    M, N, K = 20000, 256, 64
+    a = rnd(M, K, dtype=torch.bfloat16, seed=1, std=0.25)
+    a[:, 0] = 1.0                                                  # a constant input channel ...
+    w = rnd(N, K, dtype=torch.bfloat16, seed=2, std=0.5)
+    w[:, 0] = 20.0                                                 # ... whose weight puts a mean of 20 on every output column (std = 0.5 * 0.25 * 8 = 1 -> 2 with the rest)
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    raw = torch.zeros(2 * N, device=DEV)
+    kn.gemm(a, w, out, colsum=raw, colsum_sq=True)
+    od = out.double()
+    mean, var = od.mean(0), od.var(0, unbiased=False)
+    assert float((mean.abs() / var.sqrt()).min()) > 8.0
+    sums = torch.empty(2 * N, device=DEV)
+    kn.bn_stats_from_sums(raw, M, sums, None, None, 0.1)
+    assert float(((sums[:N].double() - mean) / mean).abs().max()) <= 1e-5
+    assert float(((sums[N:].double() - var) / var).abs().max()) <= 2e-3
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
