@@ -575,3 +575,62 @@ def test_img_supervised_step_with_encoder_only_clipping():
     assert moved and all(n.startswith("img_encoder") for n in moved), sorted(moved)[:5]
     assert not any(nd in n for n in moved for nd in ("bias", "bn1.weight", "bn2.weight", "bn3.weight")), "a no-decay parameter moved (Q1)"
     assert "img_encoder.linear.weight" in moved and "img_encoder.resnet.layer3.0.conv1.weight" in moved
+
+
+def test_resnet_bf16_timed_path_against_the_deterministic_path():
+    """The ResNet branch of the bf16 step as it is timed -- BatchNorm statistics from the sums the convolution GEMMs' epilogues leave
+    (one zeroed slot buffer, offsets in launch order), folded into the apply kernel; 3x3 convolutions as implicit GEMMs in forward,
+    weight- and input-gradient -- against the SAME engine in deterministic mode (separate pivot-shifted statistics passes, im2col + GEMM +
+    col2im) and against the f32 engine, same weights, same images (the bf16 end-to-end tests skip the resnet tensors).
+    This small random network amplifies bf16 rounding layer by layer (profiles/r04_resnet_bf16_paths_vs_f32.txt: both bf16 paths are 1e-3
+    from f32 at the stem and 0.2 at layer3.22), so the yardstick is the deterministic bf16 path's own distance from f32:
+      * every BatchNorm's batch mean / variance (read back from the running statistics: a wrong slot offset or a swapped raw3 / rawd
+        would show here): the first layers of the two bf16 paths agree to 1e-3 outright, every layer is no further from f32 than
+        twice the deterministic path + 2e-3;
+      * projected features and every layer3 / projection gradient: the same rule on the relative L2 error; everything finite."""
+    from multimodalsum_amd.modules import MultimodalSum
+    from tests.test_host_logic_cpu import tiny_cfg
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(6, 3, 96, 96, generator=g).to(DEV)
+    dy32 = None
+    res = {}
+    for name, dt, det in (("f32", torch.float32, True), ("det", torch.bfloat16, True), ("timed", torch.bfloat16, False)):
+        model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=dt, deterministic=det)
+        e = model._engine
+        e.sync_weights()
+        e.arena.prepare_grads()
+        y, c = e.img_fwd(img)
+        if dy32 is None:
+            dy32 = (torch.randn(y.shape, generator=g) * 0.1).to(DEV)
+        if name == "timed":
+            assert any(b.col is None for b in c.blocks), "the timed path did not take the implicit convolution"
+        e.img_bwd(c, dy32.to(y.dtype))
+        torch.cuda.synchronize()
+        grads = {n: e.arena.grad[e.arena.offsets[n]:e.arena.offsets[n] + p.numel()].double().cpu() for n, p in model.named_parameters() if n.startswith("img_encoder")}
+        res[name] = (y.double().cpu(), {k: v.double().cpu() for k, v in e.buffers.items() if "running" in k}, grads)
+    (yf, bf_, gf), (yd, bd, gd), (yt, bt, gt) = res["f32"], res["det"], res["timed"]
+    assert torch.isfinite(yt).all() and all(torch.isfinite(v).all() for v in bt.values()) and all(torch.isfinite(v).all() for v in gt.values())
+
+    def batch_part(b, k):                           # running = 0.9 * init + 0.1 * batch statistic
+        return (b[k] - (0.9 if k.endswith("running_var") else 0.0)) * 10
+    keys = [k for k in bf_ if "layer4" not in k and "num_batches" not in k]
+    assert len(keys) >= 2 * 90
+    first = [k for k in keys if k.startswith("img_encoder.resnet.bn1.") or ".layer1.0." in k]
+    for k in keys:
+        sf, sd, st_ = batch_part(bf_, k), batch_part(bd, k), batch_part(bt, k)
+        scale = float(sf.abs().max()) + 1e-9
+        e_det, e_timed = float((sd - sf).abs().max()) / scale, float((st_ - sf).abs().max()) / scale
+        assert e_timed <= 2.0 * e_det + 2e-3, (k, e_timed, e_det)
+        if k in first:
+            assert float((st_ - sd).abs().max()) / scale <= 1e-3, (k, float((st_ - sd).abs().max()) / scale)
+    rel = lambda a, b: float((a - b).norm() / b.norm())          # noqa: E731
+    assert rel(yt, yf) <= 2.0 * rel(yd, yf) + 2e-2, (rel(yt, yf), rel(yd, yf))
+    seen = 0
+    for n in gf:
+        if float(gf[n].norm()) == 0.0:
+            assert float(gt[n].norm()) == 0.0 and float(gd[n].norm()) == 0.0, n      # detached stages: no gradient on any path
+            continue
+        seen += 1
+        assert rel(gt[n], gf[n]) <= 2.0 * rel(gd[n], gf[n]) + 2e-2, (n, rel(gt[n], gf[n]), rel(gd[n], gf[n]))
+    assert seen >= 23 * 9
