@@ -567,6 +567,105 @@ __global__ __launch_bounds__(256) void ls_loss_kernel(T* __restrict__ logits, lo
     }
 }
 
+// The same loss with the row held in REGISTERS between the two passes (bf16, 16-byte rows, ld <= 256 * 8 * MAXC): a thread keeps its
+// MAXC chunks of the row packed as they were loaded (4 registers each: 100 of 50,265 logits per thread at MAXC = 25), so the row is read
+// from memory exactly once -- the second pass of ls_loss_kernel re-reads 14.8 GB per step from L2 / Infinity Cache -- and the maximum is
+// known before the first exponential (no online rescaling).  Columns past V are patched to -inf when they are loaded: no pass carries a
+// per-element column test (200 lane masks per thread otherwise).
+template <int MAXC>
+__global__ __launch_bounds__(256, 2) void ls_loss_reg_kernel(bf16_t* __restrict__ logits, long ld, const int64_t* __restrict__ target,
+                                                             float* __restrict__ row_loss, int V, float smoothing, float gscale, int write_grad) {
+    __shared__ float sm[4], ss[4], sx[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16_t* x = logits + (long)row * ld;
+    const uint32_t NINF2 = 0xff80ff80u;                        // two bf16 -inf
+    u32x4_t reg[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = (i * 256 + tid) * 8;
+        reg[i] = u32x4_t{NINF2, NINF2, NINF2, NINF2};
+        if (c < V) reg[i] = *reinterpret_cast<const u32x4_t*>(x + c);
+        if (c < V && c + 8 > V) {                              // the chunk that straddles V (one thread of the row)
+            bf16_t t[8];
+            __builtin_memcpy(t, &reg[i], 16);
+            for (int k = 0; k < 8; ++k)
+                if (c + k >= V) t[k] = (bf16_t)(-INFINITY);
+            __builtin_memcpy(&reg[i], t, 16);
+        }
+    }
+    float m = -INFINITY, sumx = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        bf16_t t[8];
+        __builtin_memcpy(t, &reg[i], 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = (float)t[k];
+            m = fmaxf(m, v);
+            sumx += (v == -INFINITY) ? 0.f : v;
+        }
+        __builtin_amdgcn_sched_barrier(0);                     // chunk by chunk: do not hold 200 converted floats
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); sumx += __shfl_xor(sumx, o); }
+    if (lane == 0) { sm[wave] = m; sx[wave] = sumx; }
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    sumx = (sx[0] + sx[1]) + (sx[2] + sx[3]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        bf16_t t[8];
+        __builtin_memcpy(t, &reg[i], 16);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += __expf((float)t[k] - m);       // -inf -> 0
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) ss[wave] = s;
+    __syncthreads();
+    s = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+    const float lse = m + logf(s);
+    const int y = (int)target[row];
+    const float eps_p = (V > 1) ? smoothing / (float)(V - 1) : 0.f;
+    const float conf = 1.f - smoothing;
+    if (tid == 0) {
+        const float logp_y = to_f32(x[y]) - lse;
+        const float sum_logp = sumx - (float)V * lse;
+        row_loss[row] = -(conf * logp_y + eps_p * (sum_logp - logp_y));
+    }
+    if (write_grad) {
+        __syncthreads();                                       // x[y] above is read before anybody overwrites the row
+        const float ge = gscale * eps_p;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = (i * 256 + tid) * 8;
+            if (c < (int)ld) {
+                bf16_t t[8];
+                __builtin_memcpy(t, &reg[i], 16);
+                float g[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = (float)t[k];
+                    g[k] = (v == -INFINITY) ? 0.f : fmaf(gscale, __expf(v - lse), -ge);
+                }
+                if (y >= c && y < c + 8) {                     // the target's column: (p - conf) instead of (p - eps)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (c + k == y) g[k] -= gscale * (conf - eps_p);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) t[k] = (bf16_t)g[k];
+                u32x4_t w;
+                __builtin_memcpy(&w, t, 16);
+                *reinterpret_cast<u32x4_t*>(x + c) = w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 __global__ void segment_sum_kernel(const float* __restrict__ x, float* __restrict__ out, int seg, float scale) {
     __shared__ double red[256];
     const float* p = x + (long)blockIdx.x * seg;
@@ -946,7 +1045,9 @@ extern "C" int mmsum_ls_loss(int dtype, void* logits, long ld, const int64_t* ta
     // 16-byte path: aligned rows whose padded length is a whole number of chunks (the engine pads V to 128 columns)
     const bool vec = (((uintptr_t)logits) & 15) == 0 && ((ld * es) & 15) == 0;
     if (dtype == MMSUM_BF16) {
-        if (vec) hipLaunchKernelGGL((ls_loss_kernel<bf16_t, true>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+        constexpr int MAXC = 25;                               // 256 threads x 8 logits x 25 chunks = 51,200 >= the 50,304-column rows of BART's vocabulary
+        if (vec && ld <= 256L * 8 * MAXC) hipLaunchKernelGGL((ls_loss_reg_kernel<MAXC>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
+        else if (vec) hipLaunchKernelGGL((ls_loss_kernel<bf16_t, true>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
         else hipLaunchKernelGGL((ls_loss_kernel<bf16_t, false>), dim3(R), dim3(256), 0, s, (bf16_t*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
     } else if (dtype == MMSUM_F32) {
         if (vec) hipLaunchKernelGGL((ls_loss_kernel<float, true>), dim3(R), dim3(256), 0, s, (float*)logits, ld, target, row_loss, V, smoothing, gscale, write_grad);
