@@ -202,9 +202,27 @@ template <typename T, int N> __device__ __forceinline__ void stv(T* p, const flo
 }
 // Row of pixel r = (n, y, x) of an [n, pH, pW] image in the zero-bordered PADDED layout [n, pH + 2, pW + 2] (the operand layout of the
 // implicit 3x3 convolution, mmsum_conv3x3_gemm); pW == 0: the compact layout, row r itself.
+// floor(a / b) for 0 <= a < 2^24 and b > 0 without the integer-division sequence (~40 instructions per call; the padded-layout kernels
+// call this once per 16-byte access): a float quotient, corrected by at most one.
+__device__ __forceinline__ int fast_div(int a, int b, float inv_b) {
+    int q = (int)((float)a * inv_b);
+    const int r = a - q * b;
+    q += (r >= b) - (r < 0);
+    return q;
+}
 __device__ __forceinline__ long bn_yrow(int r, int pH, int pW) {
     if (pW == 0) return r;
-    const int hw = pH * pW, n = r / hw, rem = r - n * hw, yy = rem / pW, xx = rem - yy * pW;
+    const int hw = pH * pW;
+    int n, yy;
+    if (r < (1 << 24)) {
+        n = fast_div(r, hw, __frcp_rn((float)hw));
+        const int rem = r - n * hw;
+        yy = fast_div(rem, pW, __frcp_rn((float)pW));
+    } else {
+        n = r / hw;
+        yy = (r - n * hw) / pW;
+    }
+    const int xx = r - n * hw - yy * pW;
     return (long)n * (pH + 2) * (pW + 2) + (long)(yy + 1) * (pW + 2) + xx + 1;
 }
 // thread -> (channel group, row lane) of a block that spans `cgb` channel groups
