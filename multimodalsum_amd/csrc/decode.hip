@@ -370,7 +370,9 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_kernel(XaArgs a)
     __shared__ unsigned last;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x;
-    int e = blockIdx.y, m = 0;                                 // global entity index -> (modality, business, entity)
+    // the LAST entities first: the modalities are listed text, table, image, and the 196-key image entities are the longest workgroups --
+    // started last they are the launch's tail (longest-processing-time-first)
+    int e = gridDim.y - 1 - blockIdx.y, m = 0;                 // global entity index -> (modality, business, entity)
     while (m + 1 < a.nmod && e >= a.mod[m + 1].ent0) ++m;
     const XaMod M = a.mod[m];
     const int le = e - M.ent0, b = le / M.N;
