@@ -40,6 +40,11 @@ NO_DECAY = ('bias', 'bn1.weight', 'bn2.weight', 'bn3.weight', 'layer_norm.weight
 TELEMETRY_CODE = r"""
 import glob, os, re, subprocess, sys, time
 path = sys.argv[1]
+parent = int(sys.argv[2])
+deadline = time.time() + 3600.0
+def alive():
+    # the sampler must never outlive the bench process (killed by a timeout, an exception before read_telemetry, ...)
+    return os.getppid() == parent and time.time() < deadline
 def cards():
     out = []
     for h in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
@@ -71,7 +76,7 @@ with open(path, 'w') as f:
             pass
         f.write('# card 0 rocm-smi cap %s\n' % cap)
     f.flush()
-    while True:
+    while alive():
         try:
             if src:
                 t = time.time()
@@ -89,6 +94,11 @@ with open(path, 'w') as f:
                 time.sleep(0.1)
         except Exception:
             time.sleep(0.2)
+try:
+    if not alive():
+        os.unlink(path)
+except Exception:
+    pass
 """
 
 
@@ -99,8 +109,22 @@ def start_telemetry():
     try:
         fd, path = tempfile.mkstemp(prefix="mmsum_telemetry_", suffix=".txt")
         os.close(fd)
-        proc = subprocess.Popen([sys.executable, "-c", TELEMETRY_CODE, path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+        proc = subprocess.Popen([sys.executable, "-c", TELEMETRY_CODE, path, str(os.getpid())], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                 env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+
+        def cleanup():                 # any exit path of this process (SystemExit without a GPU, an exception in the step, ...): the
+            try:                       # child also watches its parent's pid itself, which covers SIGKILL / a `timeout` wrapper
+                if proc.poll() is None:
+                    proc.terminate()
+                    proc.wait(timeout=5)
+            except Exception:
+                pass
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        import atexit
+        atexit.register(cleanup)
         return proc, path
     except Exception:
         return None, None
@@ -435,10 +459,10 @@ def pmc_traffic(shape):
                     cur = {f: hashlib.sha1(open(os.path.join(ROOT, "multimodalsum_amd", "csrc", f), "rb").read()).hexdigest() for f in want}
                     if cur != want:
                         src += " (STALE: the kernel's sources changed since these counters were collected)"
-                return prof["hbm_bytes_per_launch"], src
+                return prof["hbm_bytes_per_launch"], src, prof
         except Exception:
             continue
-    return None, None
+    return None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -629,17 +653,33 @@ def timed_steps(args, model, runner, opt, sch, next_batch, steps, warmup, sync):
     for _ in range(warmup):
         run_step(args, runner, opt, sch, next_batch())
     live_rows = []
+    import torch
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # per-step boundaries on the step's launch stream
     sync()
     w0 = time.time()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    for i in range(steps):
+        marks[i].record()
         b = next_batch()                   # generated on the device inside the timed step
         loss = run_step(args, runner, opt, sch, b)
         live_rows.append((b["reviews_mask"].sum(), b["img_mask"].sum() if args.workload in ("multimodal", "text_table") else None))   # device scalars, read after the region
+    marks[steps].record()
     sync()
     dt = time.perf_counter() - t0
     args.timed_window = (w0, time.time())          # wall-clock bounds of the timed region (the telemetry child's samples are cut to it)
+    args.step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]     # device time of every timed step (HIP events)
     return dt, loss, live_rows, priming, b
+
+
+def step_percentiles(step_ms):
+    """p10 / p50 / p90 / min / max of the per-step device times (nearest-rank on the sorted list)."""
+    v = sorted(step_ms)
+    n = len(v)
+
+    def q(f):
+        return v[min(n - 1, max(0, int(round(f * (n - 1)))))]
+    return {"ms_per_step_p10": q(0.1), "ms_per_step_p50": q(0.5), "ms_per_step_p90": q(0.9), "ms_per_step_min": v[0], "ms_per_step_max": v[-1],
+            "per_step_timing": "HIP event at every step boundary on the launch stream, %d timed steps" % n}
 
 
 def also_configs(args, cfg, model, device):
@@ -866,9 +906,19 @@ def main():
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
                     "scope": step_roof["scope"], "flops_per_business": fpb, "executed": step_roof["executed"]}
         else:
-            traffic, src = pmc_traffic(probe["shape"])
+            traffic, src, pmc = pmc_traffic(probe["shape"])
             roof = {"bound": "mfma", "achieved": probe["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": probe["achieved"] / peak,
                     "traffic": traffic, "traffic_source": src, "step": step_roof}
+            if pmc is not None:
+                # rocprof-reported utilisation of the dominant kernel (north star): MFMA pipe busy cycles per SIMD (1,024 SIMDs) over the
+                # kernel's cycles per XCD (8 XCDs), both from the same PMC pass; HBM rate = PMC bytes per launch / the launch time
+                # measured live in this run
+                try:
+                    roof["mfma_busy_frac"] = (pmc["sq"]["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (pmc["sq"]["GRBM_GUI_ACTIVE"] / 8.0)
+                    roof["hbm_gbps"] = traffic / (probe["decoder_calls"]["avg_launch_ms"] * 1e-3) / 1e9     # the PMC shape = the decoder launches (all rows)
+                    roof["hbm_frac_of_8tbps"] = roof["hbm_gbps"] / 8000.0
+                except Exception:
+                    pass
             roof.update({k: v for k, v in probe.items() if k != "achieved"})
         if families is not None:
             roof["families"] = families
@@ -887,6 +937,8 @@ def main():
                "launch": "eager" if args.no_graphs else "hip-graph replay (1 forward graph + 1 graph per backward gradient segment, ONE set for all "
                          "batches: row counts are device-side), %d priming steps before warmup, %d capture(s) in the whole run" % (priming, captures),
                "graph_captures": captures, "final_loss": loss_val, "peak_hbm_gb": peak_gb, "roofline": roof}
+        if getattr(args, "step_ms", None):
+            out.update(step_percentiles(args.step_ms))
         if telemetry is not None:
             out["telemetry"] = telemetry
         if args.diag_stub_resnet:

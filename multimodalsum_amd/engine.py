@@ -298,13 +298,15 @@ class Engine:
             import gc
             torch.cuda.synchronize()
             gc.collect()
+            gc_was = gc.isenabled()
             gc.disable()                                 # a CUDAGraph finalised by the collector during capture aborts the capture
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self._build_conv_mats(all_layers)
             finally:
-                gc.enable()
+                if gc_was:
+                    gc.enable()
             self._conv_graphs[which] = g
             return
         g.replay()

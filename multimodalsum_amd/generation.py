@@ -127,7 +127,7 @@ class DecodeSession:
         # LayerNorm also leaves its un-rounded f32 result for the LM head (mmsum_gemm's MMSUM_GEMM_A_F32 form: bf16 weights, the
         # f32 activations multiplied as bf16 hi + lo parts, f32 accumulation and f32 store)
         self.logits = e.empty(R, e.Vpad, dtype=torch.float32)
-        self.x32 = e.empty(R, D, dtype=torch.float32) if e.dtype == torch.bfloat16 else None
+        self.x32 = e.empty(R, D, dtype=torch.float32) if (e.dtype == torch.bfloat16 and D % 128 == 0) else None
         K = 2 * num_beams
         self.out_scores = torch.zeros(layout.B, K, dtype=torch.float32, device=dev)
         self.out_ids = torch.zeros(layout.B, K, dtype=torch.int64, device=dev)
@@ -229,6 +229,19 @@ class DecodeSession:
             return kn.dec_gemm(x, w, out, self.ws, bias=bias, epi=epi, x2=x2)
         return kn.gemm(x, w, out, bias=bias, epi=epi, a2=x2)
 
+    def _lm_head(self, x):
+        """logits (f32) = x . shared^T + final_logits_bias.  bf16 mode: the un-rounded f32 LayerNorm output against the bf16 weights
+        (MMSUM_GEMM_A_F32), which only the weight-streaming kernel serves (at most 64 rows per call, K a multiple of 128): more
+        hypothesis rows go through it in row chunks of 64; a width it cannot take falls back to the rounded bf16 rows (f32 output)."""
+        e = self.e
+        V = e.cfg.vocab_size
+        w, bias = e.arena.w(e.bp + "model.shared.weight"), e.buffers[e.bp + "final_logits_bias"].reshape(-1)
+        if self.x32 is None:
+            return kn.gemm(x, w, self.logits[:, :V], bias=bias)
+        for r0 in range(0, self.rows, 64):
+            r1 = min(self.rows, r0 + 64)
+            kn.gemm(self.x32[r0:r1], w, self.logits[r0:r1, :V], bias=bias)
+
     def _step_fast(self, t):
         """The decode step with its own kernels (bf16): per layer the weight-streaming products (the long-K one with its reduction split
         over workgroups), the cache-walking self-attention, ONE cross-attention launch over the cached K / V of every modality (one
@@ -303,7 +316,7 @@ class DecodeSession:
                           0.0, 0, y_f32=self.x32 if last else None)
             x = y
         V = cfg.vocab_size
-        self._mm(self.x32, a.w(e.bp + "model.shared.weight"), self.logits[:, :V], bias=e.buffers[e.bp + "final_logits_bias"].reshape(-1))
+        self._lm_head(x)
         cur_len = t + 1
         eos = cfg.eos_token_id
         force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)
@@ -383,8 +396,7 @@ class DecodeSession:
                           0.0, 0, y_f32=self.x32 if last else None)
             x = y
         V = cfg.vocab_size
-        kn.gemm(self.x32 if self.x32 is not None else x, a.w(e.bp + "model.shared.weight"), self.logits[:, :V],
-                bias=e.buffers[e.bp + "final_logits_bias"].reshape(-1))                                      # :2281
+        self._lm_head(x)                                                                                     # :2281
         # ---- tail: forced BOS / EOS, log-softmax, min-length and n-gram bans, + beam scores, top 2*beams per business
         cur_len = t + 1
         eos = cfg.eos_token_id

@@ -61,7 +61,12 @@ def clip_grad_norm_(parameters, max_norm, fused=False):
     params = [p for p in parameters if p.grad is not None]
     arena = _arena_of(params)
     if arena is None:
-        return torch.nn.utils.clip_grad_norm_(params, max_norm)
+        if not params:
+            return torch.zeros(())
+        raise ValueError("multimodalsum_amd.clip_grad_norm_: parameters outside the package's arena (this path has no torch-op fallback)")
+    foreign = [p for p in params if getattr(p, "_mmsum_arena", None) is not arena]
+    if foreign:
+        raise ValueError("multimodalsum_amd.clip_grad_norm_: %d parameter(s) outside the arena (no torch-op fallback)" % len(foreign))
     eng = params[0]._mmsum_engine
     rs = _ranges(arena, params)
     if not hasattr(eng, "norm_sq"):
