@@ -27,7 +27,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define MMSUM_ABI_VERSION 5
+#define MMSUM_ABI_VERSION 6
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -115,16 +115,18 @@ int mmsum_dec_gemm(const void* x, long ldx, const void* x2, long ldx2, int kspli
  *   xp : the input in the PADDED NHWC layout [n, H+2, W+2, C] with ZERO borders (mmsum_bn_apply writes it: pad_H / pad_W);
  *   w  : [Cout, ldw >= 9 C] in (ky, kx, c) column order (mmsum_conv_weight_permute);  y : [n*H*W, Cout], compact rows.
  *   stats (f32 [2 Cout], may be NULL) += column sums of y and of y^2 as stored (the BatchNorm statistics, as MMSUM_GEMM_COLSUM2).
- * The LDS-DMA pieces of the NT kernels read C-contiguous runs of one tap straight from xp: no im2col matrix.  C a power of two >= 64. */
+ * The LDS-DMA pieces of the NT kernels read C-contiguous runs of one tap straight from xp: no im2col matrix.  C a power of two >= 64.
+ *   live_rows (device int32, may be NULL): output rows (n_run * H * W, mmsum_image_plan) -- rows at and past it are neither computed nor summed. */
 int mmsum_conv3x3_gemm(const void* xp, const void* w, long ldw, void* y, long ldy, float* stats, int n, int H, int W, int C,
-                       int Cout, void* stream);
+                       int Cout, const int* live_rows, void* stream);
 /* Weight gradient of that convolution, no im2col matrix either: out[co][(3 ky + kx) C + c] = sum over pixels dy[pixel][co] x[pixel + (ky-1, kx-1)][c]
  * (the layout mmsum_conv_weight_permute(to_matrix = 0) turns into the [Cout, C, 3, 3] gradient).  dyp [n, H+2, W+2, Cout] and xp [n, H+2, W+2, C]
  * both PADDED with zero borders (mmsum_bn_bwd_apply's dx_pad / mmsum_bn_apply's pad): the four-wave reduction-major kernel runs over all
  * padded positions and shifts its xp rows by the tap of the tile.  C a power of two >= 256.  out: f32 [Cout, ldo >= 9 C], or with
- * splitk > 1 splitk such slabs (slab s at out + s * Cout * ldo; mmsum_slab_reduce adds them). */
+ * splitk > 1 splitk such slabs (slab s at out + s * Cout * ldo; mmsum_slab_reduce adds them).
+ * live_positions (device int32, may be NULL): the reduction's length, n_run * (H+2) * (W+2) - 2 * (W + 3) for the first n_run images. */
 int mmsum_conv3x3_wgrad(const void* dyp, const void* xp, float* out, long ldo, int n, int H, int W, int C, int Cout, int splitk,
-                        void* stream);
+                        const int* live_positions, void* stream);
 
 /* out[r][c] (+)= sum_s ws[s][r][c] over nslabs f32 slabs of [rows, cols] (split-K reduction). */
 int mmsum_slab_reduce(const float* ws, int nslabs, int rows, int cols, float* out, long ldo, int accumulate, void* stream);
@@ -276,10 +278,10 @@ int mmsum_transpose_bf16_batched(const void* src_base, void* dst_base, const lon
  * convolutions are plain GEMMs on the NHWC matrix.  Column order of the im2col matrix is
  * (kh, kw, c), c fastest; Kpad >= kh*kw*C columns (zero-filled tail). */
 int mmsum_im2col(int dtype, const void* x, void* col, int N, int H, int W, int C, int KH, int KW, int stride,
-                 int pad, int Ho, int Wo, int Kpad, void* stream);
+                 int pad, int Ho, int Wo, int Kpad, const int* images, void* stream);
 /* dx[n,h,w,c] = sum of dcol entries that im2col copied from x[n,h,w,c] (gather form, no atomics). */
 int mmsum_col2im(int dtype, const void* dcol, void* dx, int N, int H, int W, int C, int KH, int KW, int stride,
-                 int pad, int Ho, int Wo, int Kpad, void* stream);
+                 int pad, int Ho, int Wo, int Kpad, const int* images, void* stream);
 /* f32 [Cout, Cin, KH, KW] <-> dtype [Cout, Kpad] with (kh,kw,c) column order.
  * to_matrix=1: weight -> matrix (cast, zero tail); to_matrix=0: f32 matrix gradient -> weight-layout
  * gradient (+= if accumulate); to_matrix=2: weight -> the INPUT-GRADIENT matrix dtype [Cin, Kpad >= KH*KW*Cout],
@@ -293,7 +295,28 @@ int mmsum_conv_weight_permute(int dtype, void* matrix, float* weight, int Cout, 
  * them (y = relu?(gamma*(x-mean)*rstd + beta (+ residual))) and updates running stats (momentum,
  * unbiased variance) when running_mean != NULL. */
 long mmsum_bn_workspace(int C);
-int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, void* stream);
+/* `images` + `rows_per_image` of the BatchNorm entry points and `images` of the im2col / pooling / layout kernels = the LIVE-IMAGE WINDOW of
+ * the fused step's image branch (device int32 plan[0..2] of mmsum_image_plan; NULL = every image): only the first images[0] images' rows are
+ * read and written; image images[1] (>= 0) is the representative of the batch's images[2] empty slots -- the statistics count its rows
+ * images[2] times (R stays the row count of ALL images), and its gradient rows travel through the backward pass multiplied by images[2]. */
+int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, const int* images, int rows_per_image, void* stream);
+/* raw (the plain column sums a convolution's GEMM epilogue left over the rows that ran) += (images[2] - 1) * {sum y, sum y^2} over the
+ * representative's rows of y [R, C]: the statistics of all R rows.  No work when the batch has no representative. */
+int mmsum_bn_rep_fix(int dtype, const void* y, float* raw, int R, int C, const int* images, int rows_per_image, void* stream);
+/* Which slots of a batch of n images [n, elems_per_image] f32 (mask [n] uint8, 1 = a real image) the image branch runs (reference:
+ * /root/reference/src/data_utils.py:54-65 pads every business to the batch's image count with all-zero images, img_mask False; the reference
+ * pushes them through ResNet101 and its batch statistics like the real ones, /root/reference/src/multimodal_train.py:186-190).  A slot that is
+ * masked AND all zero is EMPTY; run order = the non-empty slots in batch order, then ONE representative of the empty ones:
+ *   plan [4 + n_rpi] int32 = {images that run, index of the representative among them (-1: none), number of empty slots (1 if none),
+ *                             non-empty slots, max(0, images that run * rows_per_image[k] + row_adjust[k]) ... (device row counts for the
+ *                             live_rows arguments of the GEMM entry points)}
+ *   src [n] int32           = slot whose image runs as image r (mmsum_nchw_to_nhwc gathers through it)
+ *   slot_rows [n*positions] = for slot row (slot, p): the row of the run-order result [n*positions, .] it takes (mmsum_rows_gather map)
+ *   run_rows  [n*positions] = for run-order row (r, p): the slot row whose output gradient it receives, -1 (zero) for the representative
+ * workspace: mmsum_image_plan_workspace(n) bytes.  n <= 8192, n_rpi <= 8. */
+long mmsum_image_plan_workspace(int n);
+int mmsum_image_plan(const float* img, long elems_per_image, const uint8_t* mask, int n, int positions, const int* rows_per_image,
+                     const int* row_adjust, int n_rpi, int* plan, int* src, int64_t* slot_rows, int64_t* run_rows, void* workspace, void* stream);
 /* BatchNorm batch statistics from plain column sums: raw = {sum_r x[r][c], sum_r x[r][c]^2} (2 C floats, as the convolution's GEMM
  * epilogue leaves them with MMSUM_GEMM_COLSUM | MMSUM_GEMM_COLSUM2) -> sums = {mean, biased variance}; running_mean / running_var
  * (may be NULL) receive the momentum update with the unbiased variance (torchvision BatchNorm2d in train mode,
@@ -308,20 +331,22 @@ int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* sums, float*
  * `sums` for the backward pass and updates the running statistics -- no statistics launch (mmsum_bn_stats_from_sums does the same alone). */
 int mmsum_bn_apply(int dtype, const void* x, float* sums, const float* raw, const float* gamma, const float* beta,
                    const void* residual, void* y, float* running_mean, float* running_var, int R, int C, float eps,
-                   float momentum, int relu, int training, int pad_H, int pad_W, void* stream);
+                   float momentum, int relu, int training, int pad_H, int pad_W, const int* images, int rows_per_image, void* stream);
 /* BN backward, two launches: bn_reduce over (dy', dy'*xhat) via mmsum_bn_bwd_reduce, then bn_bwd_apply.
  * dy' = dy * (y > 0) when relu (y = forward output; pad_H / pad_W: y is in the padded layout mmsum_bn_apply wrote).
  * dsums[2*C] = {sum dy', sum dy'*xhat}. */
 int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* sums, int R, int C,
-                        float eps, int relu, float* dsums, void* workspace, int pad_H, int pad_W, void* stream);
+                        float eps, int relu, float* dsums, void* workspace, int pad_H, int pad_W, const int* images, int rows_per_image,
+                        void* stream);
 /* dx_pad_H, dx_pad_W (0, 0 = no): dx is written in the padded layout as well (borders not written) -- the operand of
  * mmsum_conv3x3_wgrad and of the input-gradient convolution. */
 int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
                        const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C,
-                       float eps, int relu, int pad_H, int pad_W, int dx_pad_H, int dx_pad_W, void* stream);
-int mmsum_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
-/* NCHW f32 image -> NHWC dtype. */
-int mmsum_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, void* stream);
+                       float eps, int relu, int pad_H, int pad_W, int dx_pad_H, int dx_pad_W, const int* images, int rows_per_image,
+                       void* stream);
+int mmsum_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, const int* images, void* stream);
+/* NCHW f32 image -> NHWC dtype.  src (device int32 [N], may be NULL): image n of y is image src[n] of x (mmsum_image_plan's run order). */
+int mmsum_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, const int* images, const int* src, void* stream);
 
 /* ---- Table encoder (table_encoder.py:14-83) ---------------------------------------------------
  * Builds all_embeddings [B,47,2D] = [field-name masked sum | field value] and the mask [B,47];

@@ -19,7 +19,7 @@ GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
 GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM, GEMM_COLSUM2, GEMM_A_F32 = 0x40, 0x80, 0x100, 0x200, 0x400, 0x800
 PLAN_GENERIC, PLAN_NT_RING, PLAN_TN_RING, PLAN_SKINNY = 0, 1, 2, 3
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def gemm_epi(e):
@@ -93,22 +93,26 @@ SIGNATURES = {
     "mmsum_bump_u64": (c_int, [c_void_p, ctypes.c_ulonglong, c_void_p]),
     "mmsum_transpose_bf16": (c_int, [c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmsum_transpose_bf16_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "mmsum_im2col": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
-    "mmsum_col2im": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p]),
+    "mmsum_im2col": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_void_p]),
+    "mmsum_col2im": (c_int, [c_int, c_void_p, c_void_p] + [c_int] * 11 + [c_void_p, c_void_p]),
     "mmsum_conv_weight_permute": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_bn_workspace": (c_long, [c_int]),
-    "mmsum_bn_reduce": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mmsum_bn_reduce": (c_int, [c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "mmsum_bn_rep_fix": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mmsum_image_plan_workspace": (c_long, [c_int]),
+    "mmsum_image_plan": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmsum_bn_stats_from_sums": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p]),
     "mmsum_bn_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                               c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
+                               c_int, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mmsum_bn_bwd_reduce": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p,
-                                    c_void_p, c_int, c_int, c_void_p]),
+                                    c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mmsum_bn_bwd_apply": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "mmsum_conv3x3_gemm": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "mmsum_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "mmsum_maxpool3x3s2": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "mmsum_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+                                   c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "mmsum_conv3x3_gemm": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mmsum_conv3x3_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mmsum_maxpool3x3s2": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mmsum_nchw_to_nhwc": (c_int, [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mmsum_table_gather": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p]),
     "mmsum_table_gather_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmsum_amazon_table_gather": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p]),

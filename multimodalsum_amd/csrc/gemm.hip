@@ -219,13 +219,13 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
 // 3x3 convolution, stride 1, padding 1, as an IMPLICIT GEMM on the LDS-DMA NT kernels: the operand rows are read from the activations
 // in the zero-bordered padded NHWC layout (gemm_common.h: conv_row / conv_koff); no im2col matrix exists.
 extern "C" int mmsum_conv3x3_gemm(const void* xp, const void* w, long ldw, void* y, long ldy, float* stats, int n, int H, int W, int C,
-                                  int Cout, void* stream) {
+                                  int Cout, const int* live_rows, void* stream) {
     if (n <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C < 64 || (C & (C - 1))) return MMSUM_ERR_BAD_SHAPE;      // C: a power of two >= 64 (stages of one tap)
     if ((long)n * (H + 2) * (W + 2) * C * 2 >= 0x7fffffffL || (long)n * H * W >= 0x7fffffffL) return MMSUM_ERR_BAD_SHAPE;   // 32-bit buffer offsets
     if ((((uintptr_t)xp | (uintptr_t)w | (uintptr_t)y) & 15) || ((ldw * 2) & 15) || ((ldy * 2) & 15)) return MMSUM_ERR_BAD_ALIGN;
     if (ldw < 9L * C) return MMSUM_ERR_BAD_SHAPE;
     GemmArgs a{xp, nullptr, w, y, stats, nullptr, n * H * W, Cout, 9 * C, (long)C, 0, ldw, ldy, 0, 0, 1.f,
-               stats ? (MMSUM_GEMM_COLSUM | MMSUM_GEMM_COLSUM2) : 0, 1, nullptr, nullptr};
+               stats ? (MMSUM_GEMM_COLSUM | MMSUM_GEMM_COLSUM2) : 0, 1, live_rows, nullptr};
     a.conv_wp = W + 2; a.conv_w = W; a.conv_hw = H * W; a.conv_hpwp = (H + 2) * (W + 2);
     a.conv_cshift = 0;
     while ((1 << a.conv_cshift) < C) ++a.conv_cshift;
@@ -240,7 +240,7 @@ extern "C" int mmsum_conv3x3_gemm(const void* xp, const void* w, long ldw, void*
 // i.e. the four-wave TN kernel with a per-tile row shift of its B operand.  The first and last W + 3 positions are border positions:
 // the reduction skips them, so every shifted row exists.  out: f32 [splitk][Cout][ldo] slabs (splitk > 1) or f32 [Cout][ldo].
 extern "C" int mmsum_conv3x3_wgrad(const void* dyp, const void* xp, float* out, long ldo, int n, int H, int W, int C, int Cout, int splitk,
-                                   void* stream) {
+                                   const int* live_positions, void* stream) {
     if (n <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C < 256 || (C & (C - 1)) || (Cout & 7) || splitk < 1) return MMSUM_ERR_BAD_SHAPE;   // a tile = channels of one tap
     const long Kp = (long)n * (H + 2) * (W + 2), skip = W + 3;
     if (Kp * C * 2 >= 0x7fffffffL * 16 || Kp - 2 * skip <= 0) return MMSUM_ERR_BAD_SHAPE;
@@ -249,7 +249,7 @@ extern "C" int mmsum_conv3x3_wgrad(const void* dyp, const void* xp, float* out, 
     const bf16_t* A = static_cast<const bf16_t*>(dyp) + skip * Cout;
     const bf16_t* B = static_cast<const bf16_t*>(xp) + skip * C;
     GemmArgs a{A, nullptr, B, out, nullptr, nullptr, Cout, 9 * C, (int)(Kp - 2 * skip), (long)Cout, 0, (long)C, ldo, 0, 0, 1.f,
-               MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_OUT_F32 | (splitk > 1 ? MMSUM_GEMM_SLABS : 0), splitk, nullptr, nullptr};
+               MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_OUT_F32 | (splitk > 1 ? MMSUM_GEMM_SLABS : 0), splitk, live_positions, nullptr};
     a.conv_wp = W + 2;
     a.conv_cshift = 0;
     while ((1 << a.conv_cshift) < C) ++a.conv_cshift;

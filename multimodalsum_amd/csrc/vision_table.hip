@@ -25,12 +25,33 @@ inline int grid_for(long items, int per_block, int cap = 4096) {
 }
 inline int ok() { return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP; }
 
+// ---- live-image window ------------------------------------------------------------------------------
+// The image branch of the fused step runs on the images that need running only (mmsum_image_plan): the filled slots first, then ONE
+// representative of the empty (masked, all-zero) slots -- identical inputs give identical activations in every layer, so the
+// representative stands for all `mult` of them with a multiplicity in the BatchNorm sums and in the weight gradients.  The window is
+// device-resident (one captured graph serves every batch): images[0] = images to process, images[1] = index of the representative
+// among them (-1: none), images[2] = its multiplicity.  NULL = every image, no representative.
+__device__ __forceinline__ int img_count(const int* __restrict__ images, int N) {
+    return images != nullptr ? min(N, max(0, images[0])) : N;
+}
+struct ImgWin { int rows, rep0; float mult; };
+__device__ __forceinline__ ImgWin img_window(const int* __restrict__ images, int rpi, int R) {
+    ImgWin w{R, R, 1.f};
+    if (images != nullptr) {
+        w.rows = min(R, max(0, images[0]) * rpi);
+        if (images[1] >= 0) { w.rep0 = images[1] * rpi; w.mult = (float)images[2]; }
+    }
+    return w;
+}
+
 // ---- im2col / col2im ---------------------------------------------------------------------------
 // A tap (kh, kw) of an output pixel is C contiguous elements on both sides: copied as raw 16-byte vectors (EV elements).
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T* __restrict__ col, int N, int H, int W, int C,
-                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
+                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad,
+                                                     const int* __restrict__ images) {
     constexpr int EV = 16 / sizeof(T);
+    N = img_count(images, N);
     const int cv = C / EV;
     const long total = (long)N * Ho * Wo * KH * KW * cv;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -60,8 +81,10 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* __restrict__ x, T*
 // one 16-byte vector, zero padding of the K tail included.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_few_channels_kernel(const T* __restrict__ x, T* __restrict__ col, int N, int H, int W, int C,
-                                                                  int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
+                                                                  int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad,
+                                                                  const int* __restrict__ images) {
     constexpr int EV = 16 / sizeof(T);
+    N = img_count(images, N);
     const int kv = Kpad / EV, K = KH * KW * C;
     const long total = (long)N * Ho * Wo * kv;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -87,8 +110,10 @@ __global__ __launch_bounds__(256) void im2col_few_channels_kernel(const T* __res
 
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, int N, int H, int W, int C,
-                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
+                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad,
+                                                     const int* __restrict__ images) {
     constexpr int EV = 16 / sizeof(T);
+    N = img_count(images, N);
     const int cv = C / EV;
     const long total = (long)N * H * W * cv;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -236,13 +261,17 @@ inline int bn_cgb(int C, int vec) { const int g = C / vec; return g >= 32 ? 32 :
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                                                          const float* __restrict__ sums, int R, int C, int cgb, int relu,
-                                                         float* __restrict__ part, int pH = 0, int pW = 0) {
+                                                         float* __restrict__ part, int pH = 0, int pW = 0,
+                                                         const int* __restrict__ images = nullptr, int rpi = 0) {
     constexpr int V = BnVec<T>::N;
     __shared__ float red[2][256 * V];
     const BnMap m = bn_map(cgb);
     const int col = (blockIdx.x * cgb + m.cg) * V;
     const int rows_per = (R + gridDim.y - 1) / gridDim.y;
-    const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    // live-image window: rows past it are not read; MODE 0 counts the representative's rows `mult` times (MODE 1 needs no weights: the
+    // representative's gradient rows arrive already multiplied, see bn_bwd_apply_kernel)
+    const ImgWin win = img_window(images, rpi, R);
+    const int r0 = blockIdx.y * rows_per, r1 = min(win.rows, r0 + rows_per);
     float s0[V], s1[V], ref[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) s0[j] = s1[j] = ref[j] = 0.f;
@@ -272,8 +301,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
                 for (int j = 0; j < V; ++j) {
                     if (MODE == 0) {
                         const float d = av[u][j] - ref[j];
-                        s0[j] += d;
-                        s1[j] = fmaf(d, d, s1[j]);
+                        const float wd = (r + u * m.lanes >= win.rep0) ? win.mult * d : d;
+                        s0[j] += wd;
+                        s1[j] = fmaf(wd, d, s1[j]);
                     } else {
                         const float g = (relu && !(yv[u][j] > 0.f)) ? 0.f : av[u][j];
                         s0[j] += g;
@@ -293,8 +323,9 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
             for (int j = 0; j < V; ++j) {
                 if (MODE == 0) {
                     const float d = av[j] - ref[j];
-                    s0[j] += d;
-                    s1[j] = fmaf(d, d, s1[j]);
+                    const float wd = (r >= win.rep0) ? win.mult * d : d;
+                    s0[j] += wd;
+                    s1[j] = fmaf(wd, d, s1[j]);
                 } else {
                     const float g = (relu && !(yv[j] > 0.f)) ? 0.f : av[j];
                     s0[j] += g;
@@ -377,11 +408,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual, T* __restrict__ y,
                                                        float* __restrict__ running_mean, float* __restrict__ running_var, int R, int C,
-                                                       int cgb, float eps, float momentum, int relu, int training, int pH, int pW) {
+                                                       int cgb, float eps, float momentum, int relu, int training, int pH, int pW,
+                                                       const int* __restrict__ images, int rpi) {
     constexpr int V = BnVec<T>::N;
     const BnMap m = bn_map(cgb);
     const int col = (blockIdx.x * cgb + m.cg) * V;
     if (col >= C) return;
+    const int Rl = img_window(images, rpi, R).rows;          // rows of the images that run; the statistics keep all R rows as their count
     float sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const int step = m.lanes * gridDim.y;
     constexpr int UN = 4;
     int r = blockIdx.y * m.lanes + m.rl;
-    for (; r + (UN - 1) * step < R; r += UN * step) {
+    for (; r + (UN - 1) * step < Rl; r += UN * step) {
         float xv[UN][V], rv[UN][V];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
@@ -427,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             stv<T, V>(y + bn_yrow(r + u * step, pH, pW) * C + col, xv[u]);
         }
     }
-    for (; r < R; r += step) {
+    for (; r < Rl; r += step) {
         float xv[V], rv[V];
         const long o = (long)r * C + col;
         ldv<T, V>(x + o, xv);
@@ -476,10 +509,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ sums, const float* __restrict__ dsums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, T* __restrict__ dresidual,
                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int R, int C, int cgb,
-                                                           float eps, int relu, int pH, int pW, int dxH, int dxW) {
+                                                           float eps, int relu, int pH, int pW, int dxH, int dxW,
+                                                           const int* __restrict__ images, int rpi) {
     constexpr int V = BnVec<T>::N;
     const BnMap m = bn_map(cgb);
     const int col = (blockIdx.x * cgb + m.cg) * V;
+    // live-image window.  The representative of the empty slots carries its gradient rows MULTIPLIED by its multiplicity through the whole
+    // backward pass (every consumer is linear in them: the weight gradients then hold the sum over all `mult` identical images, the
+    // statistics sums too); what this kernel adds to a row -- the two batch-mean terms -- is therefore multiplied as well.
+    const ImgWin win = img_window(images, rpi, R);
     if (col < C) {
         const float invR = 1.f / R;
         float k[V], kx[V], k0[V];
@@ -493,7 +531,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         const int step = m.lanes * gridDim.y;
         constexpr int UN = 2;
         int r = blockIdx.y * m.lanes + m.rl;
-        for (; r + (UN - 1) * step < R; r += UN * step) {
+        for (; r + (UN - 1) * step < win.rows; r += UN * step) {
             float g[UN][V], yv[UN][V], xv[UN][V];
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -505,25 +543,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const long o = (long)(r + u * step) * C + col;
+                const float wm = (r + u * step >= win.rep0) ? win.mult : 1.f;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
                     if (relu && !(yv[u][j] > 0.f)) g[u][j] = 0.f;
-                    xv[u][j] = fmaf(k[j], g[u][j], fmaf(kx[j], xv[u][j], k0[j]));
+                    xv[u][j] = fmaf(k[j], g[u][j], wm * fmaf(kx[j], xv[u][j], k0[j]));
                 }
                 stv<T, V>(dx + bn_yrow(r + u * step, dxH, dxW) * C + col, xv[u]);
                 if (dresidual) stv<T, V>(dresidual + o, g[u]);
             }
         }
-        for (; r < R; r += step) {
+        for (; r < win.rows; r += step) {
             float g[V], yv[V], xv[V];
             const long o = (long)r * C + col;
             ldv<T, V>(dy + o, g);
             ldv<T, V>(x + o, xv);
             if (relu) ldv<T, V>(y + bn_yrow(r, pH, pW) * C + col, yv);
+            const float wm = (r >= win.rep0) ? win.mult : 1.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 if (relu && !(yv[j] > 0.f)) g[j] = 0.f;
-                xv[j] = fmaf(k[j], g[j], fmaf(kx[j], xv[j], k0[j]));
+                xv[j] = fmaf(k[j], g[j], wm * fmaf(kx[j], xv[j], k0[j]));
             }
             stv<T, V>(dx + bn_yrow(r, dxH, dxW) * C + col, xv);
             if (dresidual) stv<T, V>(dresidual + o, g);
@@ -534,8 +574,126 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int c = threadIdx.x; c < C; c += 256) { dbeta[c] += dsums[c]; dgamma[c] += dsums[C + c]; }
 }
 
+// The representative's share of the statistics that arrive as plain column sums from the convolution's GEMM epilogue: the epilogue counted its
+// rows once, raw += (mult - 1) * {sum y, sum y^2} over them (of the values as stored, like the epilogue's own sums).  grid (channel blocks,
+// row splits); returns at once when the batch has no representative.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void bn_rep_fix_kernel(const T* __restrict__ y, float* __restrict__ raw, int R, int C, int cgb,
+                                                         const int* __restrict__ images, int rpi) {
+    constexpr int V = BnVec<T>::N;
+    __shared__ float red[2][256 * V];
+    const ImgWin win = img_window(images, rpi, R);
+    if (win.rep0 >= win.rows || !(win.mult > 1.f)) return;
+    const BnMap m = bn_map(cgb);
+    const int col = (blockIdx.x * cgb + m.cg) * V;
+    const int r1 = min(win.rows, win.rep0 + rpi);
+    float s0[V], s1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s0[j] = s1[j] = 0.f;
+    if (col < C) {
+        for (int r = win.rep0 + blockIdx.y * m.lanes + m.rl; r < r1; r += m.lanes * gridDim.y) {
+            float v[V];
+            ldv<T, V>(y + (long)r * C + col, v);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { s0[j] += v[j]; s1[j] = fmaf(v[j], v[j], s1[j]); }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        red[0][(m.rl * cgb + m.cg) * V + j] = s0[j];
+        red[1][(m.rl * cgb + m.cg) * V + j] = s1[j];
+    }
+    __syncthreads();
+    const int ncol = cgb * V;
+    const float extra = win.mult - 1.f;
+    for (int i = threadIdx.x; i < 2 * ncol; i += 256) {
+        const int w = i / ncol, c = i % ncol;
+        if (blockIdx.x * ncol + c < C) {
+            float t = 0.f;
+            for (int k = 0; k < m.lanes; ++k) t += red[w][k * ncol + c];
+            atomicAdd(raw + (long)w * C + blockIdx.x * ncol + c, extra * t);
+        }
+    }
+}
+
+// ---- image plan: which slots of the batch the image branch runs (mmsum_image_plan) ------------------------------------------------
+// empty[i] = 1 when slot i is masked (mask[i] == 0) AND every element of its image is zero: only then are its activations those of
+// every other empty slot and its output gradient zero (a masked key).  One workgroup per slot; unmasked slots are not read.
+__global__ __launch_bounds__(256) void image_empty_kernel(const float* __restrict__ img, long elems, const uint8_t* __restrict__ mask, int n,
+                                                          int* __restrict__ empty) {
+    const int i = blockIdx.x;
+    if (mask[i] != 0) {
+        if (threadIdx.x == 0) empty[i] = 0;
+        return;
+    }
+    const float* p = img + (long)i * elems;
+    int nz = 0;
+    if ((elems & 3) == 0 && (((uintptr_t)p) & 15) == 0) {
+        const f32x4_t* q = reinterpret_cast<const f32x4_t*>(p);
+        for (long k = threadIdx.x; k < elems / 4; k += 256) {
+            const f32x4_t v = q[k];
+            nz |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
+        }
+    } else {
+        for (long k = threadIdx.x; k < elems; k += 256) nz |= (p[k] != 0.f);
+    }
+    nz = __syncthreads_or(nz);
+    if (threadIdx.x == 0) empty[i] = nz ? 0 : 1;
+}
+struct ImgRpi { int v[8], adj[8]; };
+constexpr int IMG_PLAN_MAX = 8192;
+// One workgroup.  Run order = the non-empty slots in batch order, then the first empty slot as the representative of all `mult` empty ones.
+//   plan      = {images that run, index of the representative among them (-1: none), mult, non-empty slots, (images that run) * rpi[k] ...}
+//   src[r]    = slot whose image runs as image r (0 past the images that run)
+//   slot_rows = row of the run-order matrix [n * positions, .] that slot row (slot, p) takes its result from
+//   run_rows  = slot row whose output gradient run-order row (r, p) receives; -1 (zeros) for the representative and past the images that run
+__global__ __launch_bounds__(256) void image_plan_kernel(const int* __restrict__ empty, int n, int positions, ImgRpi rpi, int n_rpi,
+                                                         int* __restrict__ plan, int* __restrict__ src, int64_t* __restrict__ slot_rows,
+                                                         int64_t* __restrict__ run_rows) {
+    __shared__ int run_of[IMG_PLAN_MAX];
+    __shared__ int s_live, s_mult, s_first;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int live = 0, mult = 0, first = -1;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            const bool in = i < n;
+            const bool e = in && empty[i] != 0;
+            const unsigned long long lv = __ballot(in && !e), em = __ballot(e);
+            if (in && !e) {
+                const int r = live + __popcll(lv & ((1ull << lane) - 1ull));
+                run_of[i] = r;
+                src[r] = i;
+            }
+            if (first < 0 && em != 0) first = base + __ffsll((long long)em) - 1;
+            live += __popcll(lv);
+            mult += __popcll(em);
+        }
+        if (lane == 0) { s_live = live; s_mult = mult; s_first = first; }
+    }
+    __syncthreads();
+    const int live = s_live, mult = s_mult;
+    const int rep = mult > 0 ? live : -1, nrun = live + (mult > 0 ? 1 : 0);
+    for (int r = nrun + threadIdx.x; r < n; r += 256) src[r] = 0;
+    if (threadIdx.x == 0) {
+        if (rep >= 0) src[rep] = s_first;
+        plan[0] = nrun; plan[1] = rep; plan[2] = mult > 0 ? mult : 1; plan[3] = live;
+        for (int k = 0; k < n_rpi; ++k) plan[4 + k] = max(0, nrun * rpi.v[k] + rpi.adj[k]);
+    }
+    __syncthreads();
+    const long total = (long)n * positions;
+    for (long e = threadIdx.x; e < total; e += 256) {
+        const int a = (int)(e / positions), p = (int)(e - (long)a * positions);
+        const int run = empty[a] != 0 ? rep : run_of[a];
+        slot_rows[e] = (long)run * positions + p;
+        run_rows[e] = a < live ? (long)src[a] * positions + p : -1;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo,
+                                                      const int* __restrict__ images) {
+    N = img_count(images, N);
     const int cv = C / 4;
     const long total = (long)N * Ho * Wo * cv;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -561,7 +719,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ x, T
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W) {
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int N, int C, int H, int W,
+                                                           const int* __restrict__ images, const int* __restrict__ src) {
+    N = img_count(images, N);
     const long total = (long)N * C * H * W;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C);
@@ -569,7 +729,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         const int w = (int)(t % W); t /= W;
         const int h = (int)(t % H);
         const int n = (int)(t / H);
-        y[i] = from_f32<T>(x[(((long)n * C + c) * H + h) * W + w]);
+        const int ns = src != nullptr ? src[n] : n;                // image of the caller's batch that runs as image n
+        y[i] = from_f32<T>(x[(((long)ns * C + c) * H + h) * W + w]);
     }
 }
 
@@ -757,7 +918,7 @@ __global__ __launch_bounds__(256) void amazon_gather_bwd_kernel(const T* __restr
     } while (0)
 
 extern "C" int mmsum_im2col(int dtype, const void* x, void* col, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
-                            int Ho, int Wo, int Kpad, void* stream) {
+                            int Ho, int Wo, int Kpad, const int* images, void* stream) {
     const int ev = dtype == MMSUM_BF16 ? 8 : 4;
     if (N <= 0 || Kpad < KH * KW * C || Kpad % ev) return MMSUM_ERR_BAD_SHAPE;
     if (((uintptr_t)x | (uintptr_t)col) & 15) return MMSUM_ERR_BAD_ALIGN;
@@ -765,25 +926,25 @@ extern "C" int mmsum_im2col(int dtype, const void* x, void* col, int N, int H, i
     const dim3 block(256);
     if (C % ev == 0) {
         const dim3 grid(grid_for((long)N * Ho * Wo * KH * KW * (C / ev), 256, 16384));
-        DT_SWITCH(dtype, (im2col_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
-                  (im2col_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
+        DT_SWITCH(dtype, (im2col_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images)),
+                  (im2col_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images)));
     } else {
         const dim3 grid(grid_for((long)N * Ho * Wo * (Kpad / ev), 256, 16384));
-        DT_SWITCH(dtype, (im2col_few_channels_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
-                  (im2col_few_channels_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
+        DT_SWITCH(dtype, (im2col_few_channels_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images)),
+                  (im2col_few_channels_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images)));
     }
     return ok();
 }
 
 extern "C" int mmsum_col2im(int dtype, const void* dcol, void* dx, int N, int H, int W, int C, int KH, int KW, int stride, int pad,
-                            int Ho, int Wo, int Kpad, void* stream) {
+                            int Ho, int Wo, int Kpad, const int* images, void* stream) {
     const int ev = dtype == MMSUM_BF16 ? 8 : 4;
     if (N <= 0 || C % ev || Kpad % ev) return MMSUM_ERR_BAD_SHAPE;
     if (((uintptr_t)dcol | (uintptr_t)dx) & 15) return MMSUM_ERR_BAD_ALIGN;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_for((long)N * H * W * C / ev, 256, 16384)), block(256);
-    DT_SWITCH(dtype, (col2im_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dcol, (bf16_t*)dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)),
-              (col2im_kernel<float><<<grid, block, 0, s>>>((const float*)dcol, (float*)dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad)));
+    DT_SWITCH(dtype, (col2im_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dcol, (bf16_t*)dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images)),
+              (col2im_kernel<float><<<grid, block, 0, s>>>((const float*)dcol, (float*)dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images)));
     return ok();
 }
 
@@ -826,16 +987,20 @@ inline int bn_splits(int R, int lanes, int col_blocks) {
     return want < 1 ? 1 : want;
 }
 
-extern "C" int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, void* stream) {
+// images / rows_per_image of the BatchNorm entry points: the live-image window (NULL: every row, no representative)
+static bool img_args_ok(const int* images, int rpi, int R) { return images == nullptr || (rpi > 0 && R % rpi == 0); }
+
+extern "C" int mmsum_bn_reduce(int dtype, const void* x, int R, int C, float* sums, void* workspace, const int* images, int rows_per_image,
+                               void* stream) {
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
-    if (R <= 0 || C <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
+    if (R <= 0 || C <= 0 || C % vec || !img_args_ok(images, rows_per_image, R)) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const int splits = bn_splits(R, 256 / cgb, cblocks);
     const dim3 grid(cblocks, splits), block(256);
     float* part = (float*)workspace;
-    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 0><<<grid, block, 0, s>>>((const bf16_t*)x, nullptr, nullptr, nullptr, R, C, cgb, 0, part)),
-              (bn_partial_kernel<float, 0><<<grid, block, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, R, C, cgb, 0, part)));
+    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 0><<<grid, block, 0, s>>>((const bf16_t*)x, nullptr, nullptr, nullptr, R, C, cgb, 0, part, 0, 0, images, rows_per_image)),
+              (bn_partial_kernel<float, 0><<<grid, block, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, R, C, cgb, 0, part, 0, 0, images, rows_per_image)));
     DT_SWITCH(dtype, (bn_stats_finish_kernel<bf16_t><<<dim3((C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, R, (const bf16_t*)x, sums)),
               (bn_stats_finish_kernel<float><<<dim3((C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, R, (const float*)x, sums)));
     return ok();
@@ -850,23 +1015,25 @@ extern "C" int mmsum_bn_stats_from_sums(const float* raw, int R, int C, float* s
 
 extern "C" int mmsum_bn_apply(int dtype, const void* x, float* sums, const float* raw, const float* gamma, const float* beta, const void* residual,
                               void* y, float* running_mean, float* running_var, int R, int C, float eps, float momentum, int relu,
-                              int training, int pad_H, int pad_W, void* stream) {
+                              int training, int pad_H, int pad_W, const int* images, int rows_per_image, void* stream) {
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
-    if (R <= 0 || C % vec || (raw != nullptr && !training)) return MMSUM_ERR_BAD_SHAPE;
+    if (R <= 0 || C % vec || (raw != nullptr && !training) || !img_args_ok(images, rows_per_image, R)) return MMSUM_ERR_BAD_SHAPE;
     if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, raw, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W)),
-              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, raw, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W)));
+    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, raw, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)),
+              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, raw, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)));
     if (training && raw == nullptr && running_mean && running_var)
         bn_running_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sums, running_mean, running_var, R, C, momentum);
     return ok();
 }
 
 extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, const void* x, const float* sums, int R, int C, float eps,
-                                   int relu, float* dsums, void* workspace, int pad_H, int pad_W, void* stream) {
+                                   int relu, float* dsums, void* workspace, int pad_H, int pad_W, const int* images, int rows_per_image,
+                                   void* stream) {
     if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
+    if (!img_args_ok(images, rows_per_image, R)) return MMSUM_ERR_BAD_SHAPE;
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
     if (R <= 0 || C <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
@@ -874,42 +1041,75 @@ extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, con
     const int splits = bn_splits(R, 256 / cgb, cblocks);
     const dim3 grid(cblocks, splits), block(256);
     float* part = (float*)workspace;
-    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part, pad_H, pad_W)),
-              (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part, pad_H, pad_W)));
+    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)),
+              (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)));
     bn_finish_kernel<<<dim3((2 * C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, sums, eps, dsums);
     return ok();
 }
 
 extern "C" int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, const void* x, const float* sums, const float* dsums,
                                   const float* gamma, void* dx, void* dresidual, float* dgamma, float* dbeta, int R, int C, float eps,
-                                  int relu, int pad_H, int pad_W, int dx_pad_H, int dx_pad_W, void* stream) {
+                                  int relu, int pad_H, int pad_W, int dx_pad_H, int dx_pad_W, const int* images, int rows_per_image,
+                                  void* stream) {
     if (pad_W != 0 && (pad_H <= 0 || pad_W < 0 || R % (pad_H * pad_W))) return MMSUM_ERR_BAD_SHAPE;
+    if (!img_args_ok(images, rows_per_image, R)) return MMSUM_ERR_BAD_SHAPE;
     if (dx_pad_W != 0 && (dx_pad_H <= 0 || dx_pad_W < 0 || R % (dx_pad_H * dx_pad_W))) return MMSUM_ERR_BAD_SHAPE;
     const int vec = dtype == MMSUM_BF16 ? 8 : 4;
     if (R <= 0 || C % vec) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W)),
-              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W)));
+    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W, images, rows_per_image)),
+              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W, images, rows_per_image)));
     return ok();
 }
 
-extern "C" int mmsum_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+extern "C" int mmsum_bn_rep_fix(int dtype, const void* y, float* raw, int R, int C, const int* images, int rows_per_image, void* stream) {
+    const int vec = dtype == MMSUM_BF16 ? 8 : 4;
+    if (R <= 0 || C <= 0 || C % vec || images == nullptr || raw == nullptr || !img_args_ok(images, rows_per_image, R)) return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb, lanes = 256 / cgb;
+    int splits = (rows_per_image + lanes * 4 - 1) / (lanes * 4);
+    splits = splits < 1 ? 1 : (splits > 64 ? 64 : splits);
+    const dim3 grid(cblocks, splits), block(256);
+    DT_SWITCH(dtype, (bn_rep_fix_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)y, raw, R, C, cgb, images, rows_per_image)),
+              (bn_rep_fix_kernel<float><<<grid, block, 0, s>>>((const float*)y, raw, R, C, cgb, images, rows_per_image)));
+    return ok();
+}
+
+extern "C" long mmsum_image_plan_workspace(int n) { return (long)sizeof(int) * (n > 0 ? n : 1); }
+
+extern "C" int mmsum_image_plan(const float* img, long elems_per_image, const uint8_t* mask, int n, int positions, const int* rows_per_image,
+                                const int* row_adjust, int n_rpi, int* plan, int* src, int64_t* slot_rows, int64_t* run_rows, void* workspace, void* stream) {
+    if (n <= 0 || n > IMG_PLAN_MAX || positions <= 0 || elems_per_image <= 0 || n_rpi < 0 || n_rpi > 8) return MMSUM_ERR_BAD_SHAPE;
+    if (img == nullptr || mask == nullptr || plan == nullptr || src == nullptr || slot_rows == nullptr || run_rows == nullptr || workspace == nullptr)
+        return MMSUM_ERR_BAD_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    ImgRpi rpi{};
+    for (int k = 0; k < n_rpi; ++k) { rpi.v[k] = rows_per_image[k]; rpi.adj[k] = row_adjust != nullptr ? row_adjust[k] : 0; }
+    int* empty = (int*)workspace;
+    image_empty_kernel<<<dim3(n), dim3(256), 0, s>>>(img, elems_per_image, mask, n, empty);
+    image_plan_kernel<<<dim3(1), dim3(256), 0, s>>>(empty, n, positions, rpi, n_rpi, plan, src, slot_rows, run_rows);
+    return ok();
+}
+
+extern "C" int mmsum_maxpool3x3s2(int dtype, const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, const int* images,
+                                  void* stream) {
     if (N <= 0 || C % 4) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_for((long)N * Ho * Wo * C / 4, 256)), block(256);
-    DT_SWITCH(dtype, (maxpool_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo)),
-              (maxpool_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)y, N, H, W, C, Ho, Wo)));
+    DT_SWITCH(dtype, (maxpool_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, (bf16_t*)y, N, H, W, C, Ho, Wo, images)),
+              (maxpool_kernel<float><<<grid, block, 0, s>>>((const float*)x, (float*)y, N, H, W, C, Ho, Wo, images)));
     return ok();
 }
 
-extern "C" int mmsum_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, void* stream) {
+extern "C" int mmsum_nchw_to_nhwc(int dtype, const float* x, void* y, int N, int C, int H, int W, const int* images, const int* src,
+                                  void* stream) {
     if (N <= 0) return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid(grid_for((long)N * C * H * W, 256)), block(256);
-    DT_SWITCH(dtype, (nchw_to_nhwc_kernel<bf16_t><<<grid, block, 0, s>>>(x, (bf16_t*)y, N, C, H, W)),
-              (nchw_to_nhwc_kernel<float><<<grid, block, 0, s>>>(x, (float*)y, N, C, H, W)));
+    DT_SWITCH(dtype, (nchw_to_nhwc_kernel<bf16_t><<<grid, block, 0, s>>>(x, (bf16_t*)y, N, C, H, W, images, src)),
+              (nchw_to_nhwc_kernel<float><<<grid, block, 0, s>>>(x, (float*)y, N, C, H, W, images, src)));
     return ok();
 }
 

@@ -171,6 +171,7 @@ class Engine:
         self.wt, self.wt_desc, self.conv_mats_t, self.conv_mats_r, self._conv_graphs = {}, None, {}, {}, {}
         if compute_dtype == torch.bfloat16:
             self._build_wt_table()
+        self._ip = None                    # live-image window of the image branch while img_fwd / img_bwd run (kn.ImagePlan or None)
         self.salt = None                   # device uint64 mixed into every dropout seed (set by graphs.StepGraphs; None = seeds as passed)
         self.post_backward_hooks = []      # run once when a whole backward pass has finished (DDP finalisation)
         self.segment_hooks = []            # run when a parameter segment's gradients are final (DDP overlap)
@@ -862,11 +863,14 @@ class Engine:
         c.sums = self.empty(2 * C, dtype=torch.float32)
         training = self.training
         rm, rv = self.buffers[name + ".running_mean"], self.buffers[name + ".running_var"]
+        ip = self._ip                                  # live-image window (None: every image runs)
         if training and raw is None:
-            kn.bn_reduce(x, c.sums)
+            kn.bn_reduce(x, c.sums, images=ip)
+        elif training and ip is not None:
+            kn.bn_rep_fix(x, raw, ip)                  # the epilogue counted the representative's rows once: add the other (multiplicity - 1) shares
         # raw: the apply kernel derives the statistics from the epilogue's sums, writes c.sums and updates the running statistics itself
         kn.bn_apply(x, c.sums, a.f32(name + ".weight"), a.f32(name + ".bias"), residual, c.y, rm, rv, 1e-5, 0.1, relu, training, pad_hw=pad_hw,
-                    raw=raw if training else None)
+                    raw=raw if training else None, images=ip)
         return c.y, c
 
     def _conv_gemm(self, x, w, bn_name=None):
@@ -875,7 +879,7 @@ class Engine:
         stored, f32 atomics): returns (y, raw) with raw = the 2C sums for _bn_fwd, or None where the separate reduction runs."""
         y = self.empty(x.shape[0], w.shape[0])
         raw = self._bn_raw_slot(w.shape[0]) if (bn_name is not None and kn.gemm_colsum_fusable(x)) else None
-        kn.gemm(x, w, y, colsum=raw, colsum_sq=raw is not None)
+        kn.gemm(x, w, y, colsum=raw, colsum_sq=raw is not None, live=self._lv(x.shape[0]))
         return y, raw
 
     def _bn_raw_slot(self, cout):
@@ -893,7 +897,7 @@ class Engine:
         """3x3 / stride 1 / padding 1 convolution of the padded activations xp as an implicit GEMM (no im2col matrix): -> (y compact, raw)."""
         y = self.empty(n * H * W, w.shape[0])
         raw = self._bn_raw_slot(w.shape[0]) if bn_name is not None else None
-        kn.conv3x3_gemm(xp, w, y, n, H, W, C, stats=raw)
+        kn.conv3x3_gemm(xp, w, y, n, H, W, C, stats=raw, live=self._lv(n * H * W))
         return y, raw
 
     def _bn_bwd(self, c, dy, dresidual=None, dx_padded=None, dx_pad_hw=None):
@@ -902,10 +906,10 @@ class Engine:
         R, C = dy.shape
         dsums = self.empty(2 * C, dtype=torch.float32)
         pad_hw = getattr(c, "pad_hw", None)                  # the forward output (ReLU mask) sits in the padded layout
-        kn.bn_bwd_reduce(dy, c.y, c.x, c.sums, dsums, 1e-5, c.relu, pad_hw=pad_hw)
+        kn.bn_bwd_reduce(dy, c.y, c.x, c.sums, dsums, 1e-5, c.relu, pad_hw=pad_hw, images=self._ip)
         dx = dx_padded if dx_padded is not None else self.empty(R, C)
         kn.bn_bwd_apply(dy, c.y, c.x, c.sums, dsums, a.f32(c.name + ".weight"), dx, dresidual, a.g(c.name + ".weight"),
-                        a.g(c.name + ".bias"), 1e-5, c.relu, pad_hw=pad_hw, dx_pad_hw=dx_pad_hw)
+                        a.g(c.name + ".bias"), 1e-5, c.relu, pad_hw=pad_hw, dx_pad_hw=dx_pad_hw, images=self._ip)
         self.touch(c.name + ".weight", c.name + ".bias")
         return dx
 
@@ -913,14 +917,50 @@ class Engine:
         w = self.arena.w(name)
         return self._conv_gemm(x, w.view(w.shape[0], w.shape[1]), bn_name)
 
-    def img_fwd(self, img, out=None):
-        """img [n,3,H,W] f32 NCHW -> [n*196, D] (rows (n, h, w)); saves what layer3's backward needs."""
+    def _lv(self, rows, adjust=0):
+        """Device row count of a [rows, .] image-branch matrix under the live-image window (None: every row)."""
+        ip = self._ip
+        return None if ip is None else ip.rows(rows // ip.n, adjust)
+
+    def _image_row_kinds(self, Hh, Ww):
+        """(rows per image, adjustment) of every matrix of the image branch whose GEMM needs a device row count: the compact activations of
+        each resolution, and the padded positions of layer3's implicit weight-gradient reduction (mmsum_conv3x3_wgrad)."""
+        kinds = []
+
+        def add(k):
+            if k not in kinds:
+                kinds.append(k)
+        H, W = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
+        add((H * W, 0))
+        H, W = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        add((H * W, 0))
+        for li, bi, inp, pl, stride, down in resnet_blocks():
+            if li > 3:
+                break
+            if li == 3 and stride == 1:
+                add(((H + 2) * (W + 2), -2 * (W + 3)))
+            H, W = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+            add((H * W, 0))
+        return kinds, H * W
+
+    def img_fwd(self, img, out=None, img_mask=None):
+        """img [n,3,H,W] f32 NCHW -> [n*196, D] (rows (n, h, w)); saves what layer3's backward needs.
+        img_mask ([n], non-zero = a real image; the fused step passes it): the EMPTY slots -- masked and all zero, the padding
+        data_utils.py:54-65 adds up to the batch's image count -- are identical inputs, so ONE representative runs for all of them with a
+        multiplicity in the BatchNorm sums and (through its gradient rows) in the weight gradients; the filled slots run first, in batch
+        order (kn.image_plan: device-side, one captured graph serves every batch).  Results are those of running every slot."""
         a = self.arena
         r = "img_encoder.resnet."
         n, _, Hh, Ww = img.shape
         c = NS(n=n, blocks=[])
+        img = img.contiguous()
+        ip = None
+        if img_mask is not None and os.environ.get("MMSUM_IMAGE_DEDUPE") != "0":
+            kinds, positions = self._image_row_kinds(Hh, Ww)
+            ip = kn.image_plan(img, img_mask, kn.ImagePlan(n, positions, kinds, img.device))
+        self._ip = c.ip = ip
         x = self.empty(n * Hh * Ww, 3)
-        kn.nchw_to_nhwc(img.contiguous(), x, n, 3, Hh, Ww)
+        kn.nchw_to_nhwc(img, x, n, 3, Hh, Ww, images=ip)
         if self.training:
             self._nbt_all[:self._nbt_live] += 1          # BatchNorm num_batches_tracked of every layer this pass runs
         # one zeroed buffer for the {sum, sum of squares} every convolution's epilogue accumulates (stages 1-3: 94 BatchNorm layers)
@@ -930,12 +970,12 @@ class Engine:
         Ho, Wo = (Hh + 6 - 7) // 2 + 1, (Ww + 6 - 7) // 2 + 1
         wm = self.conv_mats[r + "conv1.weight"]
         col = self.empty(n * Ho * Wo, wm.shape[1])
-        kn.im2col(x, col, n, Hh, Ww, 3, 7, 7, 2, 3, Ho, Wo, wm.shape[1])
+        kn.im2col(x, col, n, Hh, Ww, 3, 7, 7, 2, 3, Ho, Wo, wm.shape[1], images=ip)
         y, raw = self._conv_gemm(col, wm, r + "bn1")
         y, _ = self._bn_fwd(r + "bn1", y, True, raw=raw)
         Hp, Wp = (Ho + 2 - 3) // 2 + 1, (Wo + 2 - 3) // 2 + 1
         x = self.empty(n * Hp * Wp, 64)
-        kn.maxpool3x3s2(y, x, n, Ho, Wo, 64, Hp, Wp)
+        kn.maxpool3x3s2(y, x, n, Ho, Wo, 64, Hp, Wp, images=ip)
         Hc, Wc = Hp, Wp
         for li, bi, inp, pl, stride, down in resnet_blocks():
             if li > 3:
@@ -954,7 +994,7 @@ class Engine:
                 c2, raw = self._conv3x3_implicit(o1, wm, n, Hc, Wc, pl, b + "bn2")
             else:
                 bc.col = self.empty(n * Ho2 * Wo2, wm.shape[1])
-                kn.im2col(o1, bc.col, n, Hc, Wc, pl, 3, 3, stride, 1, Ho2, Wo2, wm.shape[1])
+                kn.im2col(o1, bc.col, n, Hc, Wc, pl, 3, 3, stride, 1, Ho2, Wo2, wm.shape[1], images=ip)
                 c2, raw = self._conv_gemm(bc.col, wm, b + "bn2")
             o2, bc.bn2 = self._bn_fwd(b + "bn2", c2, True, raw=raw)
             bc.o1, bc.o2 = o1, o2
@@ -964,7 +1004,7 @@ class Engine:
                     xs = x
                 else:
                     xs = self.empty(n * Ho2 * Wo2, inp)
-                    kn.im2col(x, xs, n, Hc, Wc, inp, 1, 1, stride, 0, Ho2, Wo2, inp)
+                    kn.im2col(x, xs, n, Hc, Wc, inp, 1, 1, stride, 0, Ho2, Wo2, inp, images=ip)
                 bc.xs = xs
                 cd, rawd = self._conv1x1(xs, b + "downsample.0.weight", b + "downsample.1")
                 idt, bc.bnd = self._bn_fwd(b + "downsample.1", cd, False, raw=rawd)
@@ -977,16 +1017,25 @@ class Engine:
         self._bn_raw = None
         c.feat = x                                   # [n*14*14, 1024] for 224x224 inputs
         y = out if out is not None else self.empty(x.shape[0], self.cfg.d_model)
-        kn.gemm(x, a.w("img_encoder.linear.weight"), y)
+        if ip is None:
+            kn.gemm(x, a.w("img_encoder.linear.weight"), y)
+        else:          # run order -> slot order: every empty slot takes the representative's rows (what running it would have given)
+            yr = self.empty(x.shape[0], self.cfg.d_model)
+            kn.gemm(x, a.w("img_encoder.linear.weight"), yr, live=self._lv(x.shape[0]))
+            kn.rows_gather(yr, y, ip.slot_rows)
+        self._ip = None
         return y, c
 
     def img_bwd(self, c, dy):
         a = self.arena
         n = c.n
-        self.wgrad(dy, c.feat, "img_encoder.linear.weight")
+        ip = self._ip = getattr(c, "ip", None)
+        if ip is not None:     # slot order -> run order; the representative's rows are zero (its slots are masked keys: no gradient reaches them)
+            dy = kn.rows_gather(dy, self.empty(dy.shape[0], dy.shape[1]), ip.run_rows, live=self._lv(dy.shape[0]))
+        self.wgrad(dy, c.feat, "img_encoder.linear.weight", live=self._lv(dy.shape[0]))
         self.touch("img_encoder.linear.weight")
         dx = self.empty(c.feat.shape[0], c.feat.shape[1])
-        self.dgrad(dy, "img_encoder.linear.weight", a.w("img_encoder.linear.weight"), dx)
+        self.dgrad(dy, "img_encoder.linear.weight", a.w("img_encoder.linear.weight"), dx, live=self._lv(dy.shape[0]))
         padded = {}
         for bc in reversed(c.blocks):
             b = bc.name
@@ -995,9 +1044,9 @@ class Engine:
             didt = self.empty(dx.shape[0], dx.shape[1])
             dc3 = self._bn_bwd(bc.bn3, dx, dresidual=didt)
             w3 = a.w(b + "conv3.weight")
-            self.wgrad(dc3, bc.o2, gview=a.g(b + "conv3.weight", (w3.shape[0], w3.shape[1])))
+            self.wgrad(dc3, bc.o2, gview=a.g(b + "conv3.weight", (w3.shape[0], w3.shape[1])), live=self._lv(R2))
             do2 = self.empty(R2, bc.pl)
-            self.dgrad(dc3, b + "conv3.weight", w3.view(w3.shape[0], w3.shape[1]), do2)
+            self.dgrad(dc3, b + "conv3.weight", w3.view(w3.shape[0], w3.shape[1]), do2, live=self._lv(R2))
             wm = self.conv_mats[b + "conv2.weight"]
             wr = self.conv_mats_r.get(b + "conv2.weight") if bc.col is None else None
             if wr is not None:
@@ -1013,20 +1062,22 @@ class Engine:
                 self._bn_bwd(bc.bn2, do2, dx_padded=dc2p, dx_pad_hw=(bc.H, bc.W))
                 dwm = self.empty(wm.shape[0], 9 * bc.pl, dtype=torch.float32)
                 sk = self.splitk(bc.pl, 9 * bc.pl, dc2p.shape[0])
+                lvp = self._lv(dc2p.shape[0], -2 * (bc.W + 3))         # the reduction's length over the images that run
                 if sk > 1:
                     ws = self.empty(sk * wm.shape[0], 9 * bc.pl, dtype=torch.float32)
-                    kn.conv3x3_wgrad(dc2p, bc.o1, ws, n, bc.H, bc.W, bc.pl, sk)
+                    kn.conv3x3_wgrad(dc2p, bc.o1, ws, n, bc.H, bc.W, bc.pl, sk, live=lvp)
                     kn.slab_reduce(ws, sk, dwm, accumulate=False)
                 else:
-                    kn.conv3x3_wgrad(dc2p, bc.o1, dwm, n, bc.H, bc.W, bc.pl, 1)
+                    kn.conv3x3_wgrad(dc2p, bc.o1, dwm, n, bc.H, bc.W, bc.pl, 1, live=lvp)
                 kn.conv_matrix_grad_to_weight(dwm, a.g(b + "conv2.weight"), bc.pl, bc.pl, 3, 3, 9 * bc.pl, True)
                 do1 = self.empty(n * bc.H * bc.W, bc.pl)
-                kn.conv3x3_gemm(dc2p, wr, do1, n, bc.H, bc.W, bc.pl)
+                kn.conv3x3_gemm(dc2p, wr, do1, n, bc.H, bc.W, bc.pl, live=self._lv(do1.shape[0]))
                 dc1 = self._bn_bwd(bc.bn1, do1)
                 w1 = a.w(b + "conv1.weight")
-                self.wgrad(dc1, bc.x, gview=a.g(b + "conv1.weight", (w1.shape[0], w1.shape[1])))
+                self.wgrad(dc1, bc.x, gview=a.g(b + "conv1.weight", (w1.shape[0], w1.shape[1])), live=self._lv(dc1.shape[0]))
                 self.touch(b + "conv1.weight", b + "conv2.weight", b + "conv3.weight")
-                self.dgrad(dc1, b + "conv1.weight", w1.view(w1.shape[0], w1.shape[1]), didt, accumulate=True)      # never the stage's first block (stride 2)
+                self.dgrad(dc1, b + "conv1.weight", w1.view(w1.shape[0], w1.shape[1]), didt, accumulate=True,
+                           live=self._lv(dc1.shape[0]))      # never the stage's first block (stride 2)
                 dx = didt
                 continue
             dc2 = self._bn_bwd(bc.bn2, do2)
@@ -1034,28 +1085,29 @@ class Engine:
             col = bc.col
             if col is None:        # the forward ran as an implicit GEMM: the im2col matrix of the PADDED o1 (an (H+2) x (W+2) image, padding 0)
                 col = self.empty(R2, wm.shape[1])
-                kn.im2col(bc.o1, col, n, bc.H + 2, bc.W + 2, bc.pl, 3, 3, 1, 0, bc.H, bc.W, wm.shape[1])
-            self.wgrad(dc2, col, gview=dwm)
+                kn.im2col(bc.o1, col, n, bc.H + 2, bc.W + 2, bc.pl, 3, 3, 1, 0, bc.H, bc.W, wm.shape[1], images=ip)
+            self.wgrad(dc2, col, gview=dwm, live=self._lv(R2))
             kn.conv_matrix_grad_to_weight(dwm, a.g(b + "conv2.weight"), bc.pl, bc.pl, 3, 3, wm.shape[1], True)
             dcol = self.empty(R2, wm.shape[1])
             wmt = self.conv_mats_t.get(b + "conv2.weight")
             if wmt is not None:
-                kn.gemm(dc2, wmt, dcol)
+                kn.gemm(dc2, wmt, dcol, live=self._lv(R2))
             else:
-                kn.gemm(dc2, wm, dcol, b_t=True)
+                kn.gemm(dc2, wm, dcol, b_t=True, live=self._lv(R2))
             do1 = self.empty(n * bc.H * bc.W, bc.pl)
             Ho2, Wo2 = (bc.H + 2 - 3) // bc.stride + 1, (bc.W + 2 - 3) // bc.stride + 1
-            kn.col2im(dcol, do1, n, bc.H, bc.W, bc.pl, 3, 3, bc.stride, 1, Ho2, Wo2, wm.shape[1])
+            kn.col2im(dcol, do1, n, bc.H, bc.W, bc.pl, 3, 3, bc.stride, 1, Ho2, Wo2, wm.shape[1], images=ip)
             dc1 = self._bn_bwd(bc.bn1, do1)
             w1 = a.w(b + "conv1.weight")
-            self.wgrad(dc1, bc.x, gview=a.g(b + "conv1.weight", (w1.shape[0], w1.shape[1])))
+            self.wgrad(dc1, bc.x, gview=a.g(b + "conv1.weight", (w1.shape[0], w1.shape[1])), live=self._lv(dc1.shape[0]))
             self.touch(b + "conv1.weight", b + "conv2.weight", b + "conv3.weight")
             if first_block:
                 dcd = self._bn_bwd(bc.bnd, didt)
                 wd = a.w(b + "downsample.0.weight")
-                self.wgrad(dcd, bc.xs, gview=a.g(b + "downsample.0.weight", (wd.shape[0], wd.shape[1])))
+                self.wgrad(dcd, bc.xs, gview=a.g(b + "downsample.0.weight", (wd.shape[0], wd.shape[1])), live=self._lv(dcd.shape[0]))
                 self.touch(b + "downsample.0.weight")
                 dx = None
             else:
-                self.dgrad(dc1, b + "conv1.weight", w1.view(w1.shape[0], w1.shape[1]), didt, accumulate=True)
+                self.dgrad(dc1, b + "conv1.weight", w1.view(w1.shape[0], w1.shape[1]), didt, accumulate=True, live=self._lv(dc1.shape[0]))
                 dx = didt
+        self._ip = None

@@ -301,12 +301,55 @@ def scale_by_clip(g, norm_sq, max_norm):
     check(lib.mmsum_scale_by_clip(_p(g), g.numel(), _p(norm_sq), max_norm, _stream()), "mmsum_scale_by_clip")
 
 
-def im2col(x, col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
-    check(lib.mmsum_im2col(_dt(x), _p(x), _p(col), N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, _stream()), "mmsum_im2col")
+class ImagePlan:
+    """Which slots of a batch of `n` images the image branch runs (mmsum_image_plan): the non-empty slots first, then ONE representative
+    of the empty (masked, all-zero) ones with a multiplicity.  Everything is device-resident (the counts differ from batch to batch inside
+    one captured graph): plan int32 [4 + len(rows)] = {images that run, representative's index or -1, multiplicity, non-empty slots,
+    row counts ...}; rows(rpi, adjust) = the device row count `images that run * rpi + adjust` for the GEMM entry points' live_rows."""
+
+    def __init__(self, n, positions, row_kinds, device):
+        assert len(row_kinds) <= 8
+        self.n, self.positions, self.row_kinds = n, positions, list(row_kinds)
+        self.plan = torch.empty(4 + len(self.row_kinds), dtype=torch.int32, device=device)       # all four are written whole by the plan kernel
+        self.src = torch.empty(n, dtype=torch.int32, device=device)
+        self.slot_rows = torch.empty(n * positions, dtype=torch.int64, device=device)
+        self.run_rows = torch.empty(n * positions, dtype=torch.int64, device=device)
+
+    def rows(self, rpi, adjust=0):
+        k = self.row_kinds.index((rpi, adjust))
+        return self.plan[4 + k:5 + k]
 
 
-def col2im(dcol, dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
-    check(lib.mmsum_col2im(_dt(dcol), _p(dcol), _p(dx), N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, _stream()), "mmsum_col2im")
+def image_plan(img, mask, ip):
+    """Fills ip (ImagePlan) for the images img f32 [n, ...] with mask [n] (non-zero = a real image)."""
+    n = ip.n
+    assert img.dtype == torch.float32 and img.is_contiguous() and img.shape[0] == n and mask.numel() == n
+    m8 = mask.reshape(-1).to(torch.uint8).contiguous()
+    nk = len(ip.row_kinds)
+    rpi = (ctypes.c_int * max(nk, 1))(*[r for r, _ in ip.row_kinds])
+    adj = (ctypes.c_int * max(nk, 1))(*[a for _, a in ip.row_kinds])
+    ws = _workspace(lib.mmsum_image_plan_workspace(n), img.device, "imgplan")
+    check(lib.mmsum_image_plan(_p(img), img.numel() // n, _p(m8), n, ip.positions, rpi, adj, nk, _p(ip.plan), _p(ip.src), _p(ip.slot_rows),
+                               _p(ip.run_rows), _p(ws), _stream()), "mmsum_image_plan")
+    return ip
+
+
+def _img(images, R=None):
+    """(device pointer of the live-image window, rows per image) for an ImagePlan or None."""
+    if images is None:
+        return None, 0
+    if R is None:
+        return _p(images.plan), 0
+    assert R % images.n == 0
+    return _p(images.plan), R // images.n
+
+
+def im2col(x, col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images=None):
+    check(lib.mmsum_im2col(_dt(x), _p(x), _p(col), N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, _img(images)[0], _stream()), "mmsum_im2col")
+
+
+def col2im(dcol, dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images=None):
+    check(lib.mmsum_col2im(_dt(dcol), _p(dcol), _p(dx), N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, _img(images)[0], _stream()), "mmsum_col2im")
 
 
 def conv_weight_to_matrix(matrix, weight, Cout, Cin, KH, KW, Kpad):
@@ -319,10 +362,18 @@ def conv_matrix_grad_to_weight(matrix_f32, dweight, Cout, Cin, KH, KW, Kpad, acc
           "mmsum_conv_weight_permute")
 
 
-def bn_reduce(x, sums):
+def bn_reduce(x, sums, images=None):
     R, C = x.shape
     ws = _workspace(lib.mmsum_bn_workspace(C), x.device, "bn")
-    check(lib.mmsum_bn_reduce(_dt(x), _p(x), R, C, _p(sums), _p(ws), _stream()), "mmsum_bn_reduce")
+    ip, rpi = _img(images, R)
+    check(lib.mmsum_bn_reduce(_dt(x), _p(x), R, C, _p(sums), _p(ws), ip, rpi, _stream()), "mmsum_bn_reduce")
+
+
+def bn_rep_fix(y, raw, images):
+    """raw (the GEMM epilogue's plain column sums over the rows that ran) += (multiplicity - 1) * the representative's rows' share."""
+    R, C = y.shape
+    ip, rpi = _img(images, R)
+    check(lib.mmsum_bn_rep_fix(_dt(y), _p(y), _p(raw), R, C, ip, rpi, _stream()), "mmsum_bn_rep_fix")
 
 
 def bn_stats_from_sums(raw, R, sums, running_mean, running_var, momentum):
@@ -332,45 +383,48 @@ def bn_stats_from_sums(raw, R, sums, running_mean, running_var, momentum):
     check(lib.mmsum_bn_stats_from_sums(_p(raw), R, C, _p(sums), _p(running_mean), _p(running_var), momentum, _stream()), "mmsum_bn_stats_from_sums")
 
 
-def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None, raw=None):
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None, raw=None, images=None):
     """pad_hw = (H, W): y is the zero-bordered padded layout [n, H+2, W+2, C] (the operand of conv3x3_gemm); the caller zeroed it.
     raw (f32 [2C], training): plain column sums {sum x, sum x^2} from the convolution's GEMM epilogue -- the kernel derives the statistics from
     them, writes {mean, var} to `sums` and updates the running statistics itself (no bn_stats_from_sums launch)."""
     R, C = x.shape
     pH, pW = pad_hw or (0, 0)
+    ip, rpi = _img(images, R)
     check(lib.mmsum_bn_apply(_dt(x), _p(x), _p(sums), _p(raw), _p(gamma), _p(beta), _p(residual), _p(y), _p(running_mean), _p(running_var),
-                             R, C, eps, momentum, int(relu), int(training), pH, pW, _stream()), "mmsum_bn_apply")
+                             R, C, eps, momentum, int(relu), int(training), pH, pW, ip, rpi, _stream()), "mmsum_bn_apply")
 
 
-def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None):
+def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None, images=None):
     R, C = x.shape
     pH, pW = pad_hw or (0, 0)
     ws = _workspace(lib.mmsum_bn_workspace(C), x.device, "bn")
-    check(lib.mmsum_bn_bwd_reduce(_dt(x), _p(dy), _p(y), _p(x), _p(sums), R, C, eps, int(relu), _p(dsums), _p(ws), pH, pW, _stream()),
+    ip, rpi = _img(images, R)
+    check(lib.mmsum_bn_bwd_reduce(_dt(x), _p(dy), _p(y), _p(x), _p(sums), R, C, eps, int(relu), _p(dsums), _p(ws), pH, pW, ip, rpi, _stream()),
           "mmsum_bn_bwd_reduce")
 
 
-def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None, dx_pad_hw=None):
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None, dx_pad_hw=None, images=None):
     """pad_hw: y (the ReLU mask) is in the padded layout; dx_pad_hw = (H, W): dx is WRITTEN in the padded layout (interior only)."""
     R, C = x.shape
     pH, pW = pad_hw or (0, 0)
     dH, dW = dx_pad_hw or (0, 0)
     if dx_pad_hw is not None:
         assert dx.shape == (R // (dH * dW) * (dH + 2) * (dW + 2), C) and dx.is_contiguous()
+    ip, rpi = _img(images, R)
     check(lib.mmsum_bn_bwd_apply(_dt(x), _p(dy), _p(y), _p(x), _p(sums), _p(dsums), _p(gamma), _p(dx), _p(dresidual), _p(dgamma),
-                                 _p(dbeta), R, C, eps, int(relu), pH, pW, dH, dW, _stream()), "mmsum_bn_bwd_apply")
+                                 _p(dbeta), R, C, eps, int(relu), pH, pW, dH, dW, ip, rpi, _stream()), "mmsum_bn_bwd_apply")
 
 
-def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None):
+def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None, live=None):
     """y [n*H*W, Cout] = 3x3 convolution (stride 1, padding 1) of xp, the zero-bordered padded NHWC activations [n*(H+2)*(W+2), C] (bf16),
     with the weight matrix w [Cout, >= 9 C] in (ky, kx, c) column order -- an implicit GEMM: no im2col matrix (mmsum_conv3x3_gemm).
     stats (f32 [2 Cout], optional) += column sums of y and y^2 (the BatchNorm statistics)."""
     assert xp.dtype == torch.bfloat16 and xp.shape == (n * (H + 2) * (W + 2), C) and xp.is_contiguous() and y.shape[0] == n * H * W
-    check(lib.mmsum_conv3x3_gemm(_p(xp), _p(w), _ld(w), _p(y), _ld(y), _p(stats), n, H, W, C, w.shape[0], _stream()), "mmsum_conv3x3_gemm")
+    check(lib.mmsum_conv3x3_gemm(_p(xp), _p(w), _ld(w), _p(y), _ld(y), _p(stats), n, H, W, C, w.shape[0], _live(live), _stream()), "mmsum_conv3x3_gemm")
     return y
 
 
-def conv3x3_wgrad(dyp, xp, out, n, H, W, C, splitk=1):
+def conv3x3_wgrad(dyp, xp, out, n, H, W, C, splitk=1, live=None):
     """out f32 [splitk * Cout, 9 C] (splitk slabs; slab_reduce adds them) = weight gradient of the 3x3 / stride 1 / padding 1 convolution in the
     (ky, kx, c) matrix layout, from the PADDED output gradient dyp [n*(H+2)*(W+2), Cout] and the PADDED input xp [n*(H+2)*(W+2), C], both
     with zero borders (mmsum_conv3x3_wgrad: the reduction-major kernel with a per-tile row shift; no im2col matrix)."""
@@ -378,7 +432,7 @@ def conv3x3_wgrad(dyp, xp, out, n, H, W, C, splitk=1):
     rows = n * (H + 2) * (W + 2)
     assert dyp.dtype == xp.dtype == torch.bfloat16 and out.dtype == torch.float32 and dyp.is_contiguous() and xp.is_contiguous()
     assert dyp.shape == (rows, Cout) and xp.shape == (rows, C) and out.shape == (splitk * Cout, 9 * C) and out.is_contiguous()
-    check(lib.mmsum_conv3x3_wgrad(_p(dyp), _p(xp), _p(out), _ld(out), n, H, W, C, Cout, splitk, _stream()), "mmsum_conv3x3_wgrad")
+    check(lib.mmsum_conv3x3_wgrad(_p(dyp), _p(xp), _p(out), _ld(out), n, H, W, C, Cout, splitk, _live(live), _stream()), "mmsum_conv3x3_wgrad")
     return out
 
 
@@ -389,12 +443,14 @@ def conv_weight_to_dgrad_matrix(matrix, weight, Cout, Cin, KH, KW, Kpad):
           "mmsum_conv_weight_permute")
 
 
-def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):
-    check(lib.mmsum_maxpool3x3s2(_dt(x), _p(x), _p(y), N, H, W, C, Ho, Wo, _stream()), "mmsum_maxpool3x3s2")
+def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo, images=None):
+    check(lib.mmsum_maxpool3x3s2(_dt(x), _p(x), _p(y), N, H, W, C, Ho, Wo, _img(images)[0], _stream()), "mmsum_maxpool3x3s2")
 
 
-def nchw_to_nhwc(x, y, N, C, H, W):
-    check(lib.mmsum_nchw_to_nhwc(_dt(y), _p(x), _p(y), N, C, H, W, _stream()), "mmsum_nchw_to_nhwc")
+def nchw_to_nhwc(x, y, N, C, H, W, images=None):
+    """images (ImagePlan): image r of y is slot images.src[r] of x, and only the images that run are converted."""
+    check(lib.mmsum_nchw_to_nhwc(_dt(y), _p(x), _p(y), N, C, H, W, _img(images)[0], _p(images.src) if images is not None else None, _stream()),
+          "mmsum_nchw_to_nhwc")
 
 
 def table_gather(E, field, fv, w_rating, w_hours, out, mask, B, pad_id):

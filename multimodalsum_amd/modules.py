@@ -700,13 +700,13 @@ class MultimodalSum(_StepGraphMixin, nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _, s.tab = e.table_fwd(field, field_value, out=s.mem[o1:o2])
-                _, s.img = e.img_fwd(imgs, out=s.mem[o2:])
+                _, s.img = e.img_fwd(imgs, out=s.mem[o2:], img_mask=img_mask.reshape(-1))
         _, s.enc = e.encoder_fwd(reviews.reshape(B * NR, S), reviews_mask.reshape(B * NR, S), out=s.mem[:o1], compact=compact)
         if side is not None:
             main.wait_stream(side)
         else:
             _, s.tab = e.table_fwd(field, field_value, out=s.mem[o1:o2])
-            _, s.img = e.img_fwd(imgs, out=s.mem[o2:])
+            _, s.img = e.img_fwd(imgs, out=s.mem[o2:], img_mask=img_mask.reshape(-1))
         pads = [reviews_mask.eq(0).to(torch.uint8).contiguous(), (1 - s.tab.mask).view(B, 1, TP).contiguous(),
                 img_mask.eq(0).to(torch.uint8).unsqueeze(-1).expand(B, I, P).contiguous()]
         dec_in = shift_tokens_right_batched(reviews, reviews[:1], cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id)

@@ -343,7 +343,62 @@ def scale_by_clip(g, norm_sq, max_norm):
     g.mul_(_clip(norm_sq, max_norm))
 
 
-def im2col(x, col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
+class ImagePlan:
+    """CPU twin of kernels.ImagePlan (mmsum_image_plan's outputs)."""
+
+    def __init__(self, n, positions, row_kinds, device):
+        self.n, self.positions, self.row_kinds = n, positions, list(row_kinds)
+        self.plan = torch.zeros(4 + len(self.row_kinds), dtype=torch.int32)
+        self.src = torch.zeros(n, dtype=torch.int32)
+        self.slot_rows = torch.zeros(n * positions, dtype=torch.int64)
+        self.run_rows = torch.zeros(n * positions, dtype=torch.int64)
+
+    def rows(self, rpi, adjust=0):
+        k = self.row_kinds.index((rpi, adjust))
+        return self.plan[4 + k:5 + k]
+
+
+def image_plan(img, mask, ip):
+    """Contract of mmsum_image_plan: empty = masked AND all zero; run order = the non-empty slots in batch order, then the first empty
+    slot as the representative of all of them."""
+    n, P = ip.n, ip.positions
+    empty = [bool(mask.reshape(-1)[i] == 0) and not bool(img[i].ne(0).any()) for i in range(n)]
+    live = [i for i in range(n) if not empty[i]]
+    mult = sum(empty)
+    rep = len(live) if mult else -1
+    nrun = len(live) + (1 if mult else 0)
+    ip.src.zero_()
+    ip.src[:len(live)] = torch.tensor(live, dtype=torch.int32)
+    if mult:
+        ip.src[rep] = empty.index(True)
+    ip.plan[0], ip.plan[1], ip.plan[2], ip.plan[3] = nrun, rep, max(mult, 1), len(live)
+    for k, (r, adj) in enumerate(ip.row_kinds):
+        ip.plan[4 + k] = max(0, nrun * r + adj)
+    run_of = {s_: r for r, s_ in enumerate(live)}
+    ar = torch.arange(P)
+    for a in range(n):
+        ip.slot_rows[a * P:(a + 1) * P] = (rep if empty[a] else run_of[a]) * P + ar
+        ip.run_rows[a * P:(a + 1) * P] = (live[a] * P + ar) if a < len(live) else -1
+    return ip
+
+
+def _win(images, R):
+    """(rows that run, first row of the representative, multiplicity) of an [R, .] matrix under the live-image window."""
+    if images is None:
+        return R, R, 1.0
+    rpi = R // images.n
+    nrun, rep, mult = (int(v) for v in images.plan[:3])
+    return min(R, nrun * rpi), (rep * rpi if rep >= 0 else R), (float(mult) if rep >= 0 else 1.0)
+
+
+def _nimg(images, N):
+    return N if images is None else min(N, int(images.plan[0]))
+
+
+def im2col(x, col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images=None):
+    if images is not None:
+        n = _nimg(images, N)
+        return im2col(x[:n * H * W], col[:n * Ho * Wo], n, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad) if n else None
     xi = x.float().view(N, H, W, C).permute(0, 3, 1, 2)
     u = F.unfold(xi, (KH, KW), padding=pad, stride=stride)              # [N, C*KH*KW, L], rows (c, kh, kw)
     u = u.view(N, C, KH * KW, Ho * Wo).permute(0, 3, 2, 1).reshape(N * Ho * Wo, KH * KW * C)
@@ -351,7 +406,10 @@ def im2col(x, col, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
     col[:, :KH * KW * C] = u
 
 
-def col2im(dcol, dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad):
+def col2im(dcol, dx, N, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad, images=None):
+    if images is not None:
+        n = _nimg(images, N)
+        return col2im(dcol[:n * Ho * Wo], dx[:n * H * W], n, H, W, C, KH, KW, stride, pad, Ho, Wo, Kpad) if n else None
     u = dcol[:, :KH * KW * C].float().view(N, Ho * Wo, KH * KW, C).permute(0, 3, 2, 1).reshape(N, C * KH * KW, Ho * Wo)
     xi = F.fold(u, (H, W), (KH, KW), padding=pad, stride=stride)
     dx.copy_(xi.permute(0, 2, 3, 1).reshape(N * H * W, C))
@@ -370,10 +428,25 @@ def conv_matrix_grad_to_weight(matrix_f32, dweight, Cout, Cin, KH, KW, Kpad, acc
         dweight.copy_(g)
 
 
-def bn_reduce(x, sums):
-    C = x.shape[1]
-    sums[:C] = x.float().mean(0)
-    sums[C:] = x.float().var(0, unbiased=False)
+def bn_reduce(x, sums, images=None):
+    R, C = x.shape
+    rows, rep0, mult = _win(images, R)
+    w = torch.ones(rows, 1)
+    w[rep0:] = mult                                  # the representative's rows count `mult` times; the count stays all R rows
+    xf = x[:rows].float()
+    mean = (w * xf).sum(0) / R
+    sums[:C] = mean
+    sums[C:] = (w * (xf - mean) ** 2).sum(0) / R
+
+
+def bn_rep_fix(y, raw, images):
+    R, C = y.shape
+    rows, rep0, mult = _win(images, R)
+    if rep0 >= rows or mult <= 1:
+        return
+    yr = y[rep0:min(rows, rep0 + R // images.n)].float()
+    raw[:C] += (mult - 1) * yr.sum(0)
+    raw[C:2 * C] += (mult - 1) * (yr ** 2).sum(0)
 
 
 def bn_stats_from_sums(raw, R, sums, running_mean, running_var, momentum):
@@ -399,75 +472,87 @@ def _pad_rows(R, pad_hw):
     return n * (H + 2) * (W + 2) + (rem // W + 1) * (W + 2) + rem % W + 1
 
 
-def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None, raw=None):
+def bn_apply(x, sums, gamma, beta, residual, y, running_mean, running_var, eps, momentum, relu, training, pad_hw=None, raw=None, images=None):
     R, C = x.shape
+    rows = _win(images, R)[0]
     if raw is not None:                            # the statistics from the GEMM epilogue's plain sums; `sums` is written here
         assert training
         sums[:C] = raw[:C] / R
         sums[C:] = (raw[C:] / R - sums[:C] ** 2).clamp_min(0.0)
     if pad_hw is not None:
         yc = torch.empty(R, C, dtype=y.dtype)
-        bn_apply(x, sums, gamma, beta, residual, yc, running_mean, running_var, eps, momentum, relu, training)
-        y[_pad_rows(R, pad_hw)] = yc               # the borders keep what the caller put there (zeros)
+        bn_apply(x, sums, gamma, beta, residual, yc, running_mean, running_var, eps, momentum, relu, training, images=images)
+        y[_pad_rows(R, pad_hw)[:rows]] = yc[:rows]               # the borders keep what the caller put there (zeros)
         return
     if training:
         mean, var, rstd = _bn_stats(sums, R, C, eps)
     else:
         mean, var = running_mean, running_var
         rstd = (var + eps).rsqrt()
-    o = (x.float() - mean) * rstd * gamma + beta
+    o = (x[:rows].float() - mean) * rstd * gamma + beta
     if residual is not None:
-        o = o + residual.float()
-    y.copy_(F.relu(o) if relu else o)
+        o = o + residual[:rows].float()
+    y[:rows].copy_(F.relu(o) if relu else o)       # rows of images that do not run are neither read nor written
     if training and running_mean is not None:
         running_mean.mul_(1 - momentum).add_(momentum * mean)
         running_var.mul_(1 - momentum).add_(momentum * var * (R / (R - 1) if R > 1 else 1.0))
 
 
-def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None):
+def bn_bwd_reduce(dy, y, x, sums, dsums, eps, relu, pad_hw=None, images=None):
     R, C = x.shape
+    rows = _win(images, R)[0]
     if pad_hw is not None:
         y = y[_pad_rows(R, pad_hw)]
     mean, var, rstd = _bn_stats(sums, R, C, eps)
-    g = dy.float() * ((y.float() > 0) if relu else 1.0)
+    g = dy[:rows].float() * ((y[:rows].float() > 0) if relu else 1.0)     # (the representative's rows arrive multiplied: no weights here)
     dsums[:C] = g.sum(0)
-    dsums[C:] = (g * (x.float() - mean) * rstd).sum(0)
+    dsums[C:] = (g * (x[:rows].float() - mean) * rstd).sum(0)
 
 
-def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None, dx_pad_hw=None):
+def bn_bwd_apply(dy, y, x, sums, dsums, gamma, dx, dresidual, dgamma, dbeta, eps, relu, pad_hw=None, dx_pad_hw=None, images=None):
     R, C = x.shape
+    rows, rep0, mult = _win(images, R)
     if pad_hw is not None:
         y = y[_pad_rows(R, pad_hw)]
     mean, var, rstd = _bn_stats(sums, R, C, eps)
-    g = dy.float() * ((y.float() > 0) if relu else 1.0)
-    xh = (x.float() - mean) * rstd
-    val = gamma * rstd * (g - dsums[:C] / R - xh * dsums[C:] / R)
+    g = dy[:rows].float() * ((y[:rows].float() > 0) if relu else 1.0)
+    xh = (x[:rows].float() - mean) * rstd
+    w = torch.ones(rows, 1)
+    w[rep0:] = mult                 # the representative's gradient rows travel multiplied by its multiplicity: so do the batch-mean terms
+    val = gamma * rstd * (g - w * (dsums[:C] / R + xh * dsums[C:] / R))
     if dx_pad_hw is not None:
-        dx[_pad_rows(R, dx_pad_hw)] = val.to(dx.dtype)          # interior only: the borders are the caller's zeros
+        dx[_pad_rows(R, dx_pad_hw)[:rows]] = val.to(dx.dtype)          # interior only: the borders are the caller's zeros
     else:
-        dx.copy_(val)
+        dx[:rows].copy_(val)
     if dresidual is not None:
-        dresidual.copy_(g)
+        dresidual[:rows].copy_(g)
     if dgamma is not None:
         dbeta.add_(dsums[:C])
         dgamma.add_(dsums[C:])
 
 
-def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None):
+def conv3x3_gemm(xp, w, y, n, H, W, C, stats=None, live=None):
     """Contract of mmsum_conv3x3_gemm: the im2col matrix of the padded image (an (H+2) x (W+2) image, padding 0) times w^T."""
     Kpad = w.shape[1]
+    if live is not None:
+        rows = _n(live, n * H * W)
+        assert rows % (H * W) == 0
+        n = rows // (H * W)
+        if n == 0:
+            return y
+        xp, y = xp[:n * (H + 2) * (W + 2)], y[:rows]
     col = torch.zeros(n * H * W, Kpad, dtype=xp.dtype)
     im2col(xp, col, n, H + 2, W + 2, C, 3, 3, 1, 0, H, W, Kpad)
     gemm(col, w, y, colsum=stats, colsum_sq=stats is not None)
     return y
 
 
-def conv3x3_wgrad(dyp, xp, out, n, H, W, C, splitk=1):
+def conv3x3_wgrad(dyp, xp, out, n, H, W, C, splitk=1, live=None):
     """Contract of mmsum_conv3x3_wgrad, computed the way the kernel does: over ALL padded positions but the first / last W + 3, the x rows
     shifted by the tap's offset; the k range cut into `splitk` slabs."""
     Cout = dyp.shape[1]
     Wp, skip = W + 2, W + 3
-    K = dyp.shape[0] - 2 * skip
+    K = _n(live, dyp.shape[0] - 2 * skip)
     nst = (K + 31) // 32
     per = (nst + splitk - 1) // splitk
     for s_ in range(splitk):
@@ -484,12 +569,18 @@ def conv_weight_to_dgrad_matrix(matrix, weight, Cout, Cin, KH, KW, Kpad):
     matrix[:, :KH * KW * Cout] = weight.view(Cout, Cin, KH, KW).flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, -1)
 
 
-def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo):
-    y.copy_(F.max_pool2d(x.float().view(N, H, W, C).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, C))
+def maxpool3x3s2(x, y, N, H, W, C, Ho, Wo, images=None):
+    n = _nimg(images, N)
+    if n:
+        y[:n * Ho * Wo].copy_(F.max_pool2d(x[:n * H * W].float().view(n, H, W, C).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).reshape(-1, C))
 
 
-def nchw_to_nhwc(x, y, N, C, H, W):
-    y.copy_(x.permute(0, 2, 3, 1).reshape(-1, C))
+def nchw_to_nhwc(x, y, N, C, H, W, images=None):
+    if images is None:
+        y.copy_(x.permute(0, 2, 3, 1).reshape(-1, C))
+        return
+    n = _nimg(images, N)
+    y[:n * H * W].copy_(x[images.src[:n].long()].permute(0, 2, 3, 1).reshape(-1, C))
 
 
 def table_gather(E, field, fv, w_rating, w_hours, out, mask, B, pad_id):

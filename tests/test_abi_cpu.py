@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(_lib.lib, s), "libmmsum_hip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_argument_validation_without_gpu():
@@ -35,6 +35,9 @@ def test_argument_validation_without_gpu():
     d.T, d.S, d.N, d.H, d.qpb, d.n_qblocks = 200, 10, 1, 1, 1, 1
     assert lib.mmsum_attn_fwd(_lib.BF16, ctypes.byref(d), None) == -1  # T > 128
     assert lib.mmsum_add_ln_fwd(_lib.F32, None, None, None, None, None, None, None, 4, 100, 1e-5, 0.0, 0, None, None, None, None) == -1  # D unsupported
+    # live-image window: rows_per_image must divide the row count; the plan takes at most 8192 slots and 8 row kinds
+    assert lib.mmsum_bn_apply(_lib.BF16, None, None, None, None, None, None, None, None, None, 100, 64, 1e-5, 0.1, 1, 1, 0, 0, 1, 7, None) == -1
+    assert lib.mmsum_image_plan(None, 10, None, 9000, 4, None, None, 0, None, None, None, None, None, None) == -1
 
 
 def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():

@@ -98,6 +98,81 @@ def test_multimodal_step_matches_oracle_and_golden(monkeypatch, golden_dir):
         assert k in keys, k
 
 
+@pytest.mark.parametrize("mode", ["f32_schedule", "bf16_schedule"])
+@pytest.mark.parametrize("valid", [(1, 0, 2), (2, 2, 2), (0, 0, 0)], ids=["half_empty", "none_empty", "all_empty"])
+def test_image_branch_runs_one_representative_of_the_empty_slots(monkeypatch, valid, mode):
+    """The image branch under the live-image window (engine.img_fwd(img_mask=...), kernels.image_plan): the filled slots plus ONE
+    representative of the empty (masked, all-zero) ones, with a multiplicity in the BatchNorm sums and -- through its multiplied gradient
+    rows -- in the weight gradients, must give what pushing EVERY slot through the ResNet gives (the reference: multimodal_train.py:186-190):
+    outputs, every img_encoder gradient, the BatchNorm running statistics.  ResNet101's 23 stacked BatchNorm blocks over a few small images
+    amplify f32 rounding to tens of per cent (see test_modules_gpu.py), so this check of the SCHEDULE runs the emulator in float64 (scratch
+    tensors forced to f64, `.float()` widened): the two runs then agree to 1e-6 or the window is wrong.  Scratch rows past the window are
+    NaN-poisoned, so a reduction that reads one fails loudly.  Both schedules: f32 (im2col, separate statistics pass: weighted bn_reduce)
+    and bf16 (implicit convolutions, statistics from the GEMM epilogue + bn_rep_fix)."""
+    emu.install(monkeypatch)
+    import multimodalsum_amd.engine as eng_mod
+    from multimodalsum_amd.modules import MultimodalSum
+
+    def empty64(self, *shape, dtype=None):
+        dt = dtype or self.dtype
+        if dt in (torch.float32, torch.bfloat16, torch.float64):
+            return torch.full(shape, float("nan"), dtype=torch.float64)
+        return torch.empty(*shape, dtype=dt)
+
+    def zeros64(self, *shape, dtype=None):
+        dt = dtype or self.dtype
+        return torch.zeros(*shape, dtype=torch.float64 if dt in (torch.float32, torch.bfloat16) else dt)
+    monkeypatch.setattr(eng_mod.Engine, "empty", empty64)
+    monkeypatch.setattr(eng_mod.Engine, "zeros", zeros64)
+    monkeypatch.setattr(torch.Tensor, "float", lambda t: t.double())
+    monkeypatch.setattr(emu, "gemm_colsum_fusable", lambda a, a_t=False, b_t=False, a2=None: mode == "bf16_schedule" and a.shape[1] % 64 == 0)
+    cfg = tiny_cfg(vocab=60, d=1024, ffn=64, layers=1, heads=16, maxpos=40)
+    B, I, HW = 3, 2, 64
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.arange(I).unsqueeze(0) < torch.tensor(valid).unsqueeze(1)).reshape(-1)
+    img = torch.randn(B * I, 3, HW, HW, generator=g) * mask[:, None, None, None].float()
+    n_live, n_empty = int(mask.sum()), int((~mask).sum())
+    res, dy = {}, None
+    for dedupe in (True, False):
+        model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32 if mode == "f32_schedule" else torch.bfloat16)
+        e = model._engine
+        e.sync_weights()
+        e.arena.prepare_grads()
+        plans = []
+        real_plan = emu.image_plan
+        monkeypatch.setattr(emu, "image_plan", lambda im, mk, ip: plans.append(real_plan(im, mk, ip)) or ip)
+        y, c = e.img_fwd(img, img_mask=mask if dedupe else None)
+        monkeypatch.setattr(emu, "image_plan", real_plan)
+        if dedupe:
+            assert [int(v) for v in plans[0].plan[:4]] == [n_live + (n_empty > 0), n_live if n_empty else -1, max(n_empty, 1), n_live]
+            assert mode == "f32_schedule" or any(b.col is None for b in c.blocks)        # the implicit schedule is the one under test
+        else:
+            assert not plans
+        if dy is None:         # empty slots are masked keys of the cross-attention: no gradient reaches their rows
+            P = y.shape[0] // (B * I)
+            dy = torch.randn(y.shape, generator=g, dtype=torch.float64) * 0.1 * mask.repeat_interleave(P)[:, None].double()
+        assert not torch.isnan(y).any()
+        e.img_bwd(c, dy.clone())
+        res[dedupe] = (y.clone(), e.arena.grad.clone(), {k: v.clone() for k, v in e.buffers.items() if "running" in k})
+    (y1, g1, b1), (y0, g0, b0) = res[True], res[False]
+    assert float((y1 - y0).abs().max()) <= 1e-9 * float(y0.abs().max()), float((y1 - y0).abs().max())
+    for k in b0:
+        _close(b1[k], b0[k], 1e-5, 1e-7, k)
+    checked = 0
+    for name, p_ in model.named_parameters():
+        if "img_encoder" not in name:
+            continue
+        o, k = e.arena.offsets[name], p_.numel()
+        a1, a0 = g1[o:o + k].double(), g0[o:o + k].double()
+        assert not torch.isnan(a1).any(), name
+        if float(a0.norm()) == 0.0:
+            assert float(a1.norm()) == 0.0, name
+            continue
+        assert float((a1 - a0).norm()) <= 1e-5 * float(a0.norm()), (name, float((a1 - a0).norm() / a0.norm()))
+        checked += 1
+    assert checked > 200 or n_live == 0               # layer3's 23 blocks + the projection (all empty: every gradient is zero)
+
+
 def test_text_step_c1(monkeypatch, golden_dir):
     """BASELINE config 1: text_pretrain plumbing (reviews [2,2,64], CrossEntropy)."""
     emu.install(monkeypatch)
@@ -598,9 +673,10 @@ def test_bf16_compact_step_reads_attention_through_row_maps(monkeypatch):
     (lc, gc, sc), (lp, gp, sp) = runs[True], runs[False]
     L = cfg.encoder_layers
     # compact run: every encoder self-attention and every text / table / image cross-attention is mapped; what is left of the
-    # gathers is once per step, not per layer: the encoder's input / output (2 forward + 2 backward) and the memory's (1 + 1)
-    assert sc["mapped"] == L + 3 * cfg.decoder_layers and sc["gathers"] == 6, sc
-    assert sp["mapped"] == 0 and sp["gathers"] == 0, sp
+    # gathers is once per step, not per layer: the encoder's input / output (2 forward + 2 backward) and the memory's (1 + 1); in either
+    # run the image branch's run order <-> slot order (1 + 1: engine.img_fwd / img_bwd under the live-image window)
+    assert sc["mapped"] == L + 3 * cfg.decoder_layers and sc["gathers"] == 6 + 2, sc
+    assert sp["mapped"] == 0 and sp["gathers"] == 2, sp
     assert abs(lc - lp) <= 2e-2 * abs(lp), (lc, lp)
     for n, g in gp.items():
         if "img_encoder" in n or n.endswith("k_proj.bias"):      # a key bias shifts every score of a row alike: its exact gradient is 0, what is left is rounding
