@@ -173,12 +173,16 @@ def read_telemetry(proc, path, t0, t1, bdf=None):
         return {"samples": 0, "error": repr(exc)[:200]}
 
 
+RESNET_FLOPS_PER_IMAGE = 3.63e9 + 3 * 10.35e9 + 3 * 0.41e9      # stage 1-2 forward, stage 3 + projection forward + backward (224 x 224)
+
+
 def flops_per_business(D, F, V, L_enc, L_dec, NR, S, T, I, P=196, Ft=47, multimodal=True, with_resnet=True, enc_rows=None,
-                       mem_rows=None):
+                       mem_rows=None, img_run=None):
     """Algorithmic FLOPs (2*MAC) of ONE training step for ONE business, de-duplicated count of
     SURVEY.md section 8d: forward x3 for everything with weights + input grads, ResNet stage 1-2 forward only.
     enc_rows / mem_rows (per business): rows the padding-free encoder layers / K-V projections really work on -- the
-    'executed' count; None = all padded rows, the canonical count."""
+    'executed' count; None = all padded rows, the canonical count.  img_run (per business): images the image branch really runs (the filled
+    slots + the one representative of the batch's empty slots); None = all I slots."""
     R = NR * S
     Re = R if enc_rows is None else enc_rows
     enc = L_enc * (8 * Re * D * D + 4 * Re * D * F + 4 * S * D * R)
@@ -196,7 +200,7 @@ def flops_per_business(D, F, V, L_enc, L_dec, NR, S, T, I, P=196, Ft=47, multimo
     if multimodal:
         total += 0.9e9                                           # table encoder (fwd+bwd)
         if with_resnet:
-            total += I * (3.63e9 + 3 * 10.35e9 + 3 * 0.41e9)      # stage1-2 fwd, stage3 + projection fwd+bwd
+            total += (I if img_run is None else img_run) * RESNET_FLOPS_PER_IMAGE
     return total
 
 
@@ -360,17 +364,44 @@ def probe_step_kernels(args, model, runner, opt, sch, b, cfg):
         e1.record()
         attns.append((e0, e1, attn_flops(desc, 2.5)))       # five products against the forward's two
 
+    # the image branch as a whole (ResNet101 stages 1-3 + projection, forward and layer3's backward): on the main stream in this step, so the
+    # event pairs around img_fwd / img_bwd bracket exactly its kernels
+    resnet = {"fwd": None, "bwd": None, "plan": None, "n": 0}
+    real_img_fwd, real_img_bwd = getattr(e, "img_fwd", None), getattr(e, "img_bwd", None)
+
+    def timed_img_fwd(img, *a, **kw):
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = real_img_fwd(img, *a, **kw)
+        e1.record()
+        resnet["fwd"], resnet["n"] = (e0, e1), img.shape[0]
+        ip = getattr(r[1], "ip", None)
+        resnet["plan"] = ip.plan if ip is not None else None
+        return r
+
+    def timed_img_bwd(*a, **kw):
+        e0, e1 = ev(), ev()
+        e0.record()
+        r = real_img_bwd(*a, **kw)
+        e1.record()
+        resnet["bwd"] = (e0, e1)
+        return r
+
     graphs = getattr(model, "_step_graphs", None)
     object.__setattr__(model, "_step_graphs", None)
     had_side = hasattr(e, "_side_stream")
     side = getattr(e, "_side_stream", None)
     e._side_stream = None
     kn.gemm, kn.attn_fwd, kn.attn_bwd = timed_gemm, timed_fwd, timed_bwd
+    if e.with_img and not getattr(args, "diag_stub_resnet", False):
+        e.img_fwd, e.img_bwd = timed_img_fwd, timed_img_bwd
     try:
         run_step(args, runner, opt, sch, b)
         torch.cuda.synchronize()
     finally:
         kn.gemm, kn.attn_fwd, kn.attn_bwd = real_gemm, real_fwd, real_bwd
+        if "img_fwd" in e.__dict__ and e.__dict__["img_fwd"] is timed_img_fwd:
+            del e.__dict__["img_fwd"], e.__dict__["img_bwd"]
         object.__setattr__(model, "_step_graphs", graphs)
         if had_side:
             e._side_stream = side
@@ -402,6 +433,17 @@ def probe_step_kernels(args, model, runner, opt, sch, b, cfg):
         f["ms"] += e0.elapsed_time(e1)
         f["flops"] += fl
     fam["gemm"] = {k: fam["gemm_nt"][k] + fam["gemm_tn"][k] for k in ("launches", "ms", "flops")}
+    if resnet["fwd"] is not None and resnet["bwd"] is not None:
+        n = resnet["n"]
+        plan = resnet["plan"].cpu().tolist() if resnet["plan"] is not None else None
+        n_run = plan[0] if plan is not None else n
+        ms_f, ms_b = resnet["fwd"][0].elapsed_time(resnet["fwd"][1]), resnet["bwd"][0].elapsed_time(resnet["bwd"][1])
+        fam["resnet"] = {"launches": 2, "ms": ms_f + ms_b, "ms_forward": ms_f, "ms_backward": ms_b, "flops": n_run * RESNET_FLOPS_PER_IMAGE,
+                         "flops_all_slots": n * RESNET_FLOPS_PER_IMAGE, "image_slots": n, "images_run": n_run,
+                         "empty_slots": (plan[2] if plan is not None and plan[1] >= 0 else 0),
+                         "scope": "engine.img_fwd + engine.img_bwd as issued on the main stream (every kernel of the image branch: layout, im2col, "
+                                  "convolution GEMMs, BatchNorm, pooling, projection; its GEMMs are also counted in the gemm families); flops = the "
+                                  "images that run (filled slots + one representative of the empty ones) x the per-image count of SURVEY 8d"}
     for name, table in shapes.items():        # the ten shapes that take the most time, per family
         rows = sorted(table.items(), key=lambda kv: -kv[1][1])[:10]
         fam[name]["by_shape"] = [{"MNK": list(k[:3]), "live_rows": k[3], "launches": v[0], "ms": round(v[1], 3),
@@ -410,6 +452,8 @@ def probe_step_kernels(args, model, runner, opt, sch, b, cfg):
     for f in fam.values():
         f["achieved"] = f["flops"] / f["ms"] / 1e9 if f["ms"] > 0 else None
         f["frac"] = f["achieved"] / peak if f["achieved"] else None
+    if "resnet" in fam:
+        fam["resnet"]["frac_all_slots"] = fam["resnet"]["flops_all_slots"] / fam["resnet"]["ms"] / 1e9 / peak
     fam["note"] = ("one eager step after the timed region, HIP events around every launch; gemm = every mmsum_gemm launch at its live row "
                    "count (executed FLOPs), attention = every mmsum_attn_fwd / mmsum_attn_bwd launch priced at the canonical count (all "
                    "padded keys, full rectangle under the causal mask, backward = 2.5 x forward)")
@@ -893,14 +937,20 @@ def main():
         dims = (cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, I)
         fpb = flops_per_business(*dims, multimodal=multimodal)
         text_rows = sum(t for t, _ in live_rows) / len(live_rows) / args.batch
-        mem_rows = text_rows + ((47 + 196 * sum(im for _, im in live_rows) / len(live_rows) / args.batch) if multimodal else 0)
-        fpb_exec = flops_per_business(*dims, multimodal=multimodal, enc_rows=text_rows, mem_rows=mem_rows)
+        filled = (sum(im for _, im in live_rows) / len(live_rows) / args.batch) if multimodal else 0.0          # filled image slots per business
+        mem_rows = text_rows + ((47 + 196 * filled) if multimodal else 0)
+        # images the branch runs per business: the filled slots + ONE representative per batch of its empty slots (engine.img_fwd's live-image window)
+        windowed = multimodal and os.environ.get("MMSUM_IMAGE_DEDUPE") != "0"
+        img_run = min(float(I), filled + 1.0 / args.batch) if windowed else None
+        fpb_exec = flops_per_business(*dims, multimodal=multimodal, enc_rows=text_rows, mem_rows=mem_rows, img_run=img_run)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = value / world * fpb / 1e12
         step_roof = {"achieved": achieved, "frac": achieved / peak, "flops_per_business": fpb,
                      "executed": {"achieved": value / world * fpb_exec / 1e12, "frac": value / world * fpb_exec / 1e12 / peak,
                                   "flops_per_business": fpb_exec, "encoder_rows_per_business": text_rows, "memory_rows_per_business": mem_rows,
-                                  "note": "FLOPs of the rows the padding-free encoder layers / K-V projections really process (results identical)"},
+                                  "images_run_per_business": img_run,
+                                  "note": "FLOPs of the rows the padding-free encoder layers / K-V projections really process and of the images the "
+                                          "image branch really runs (filled slots + one representative of the empty ones); results identical"},
                      "scope": "whole training step per GPU (canonical algorithmic FLOPs of SURVEY.md 8d, padded rows) / step time"}
         if probe is None:
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
