@@ -755,3 +755,50 @@ def test_multimodal_step_with_empty_image_slots_f32():
     for k, v in run64.items():
         close(model._engine.buffers[k], v.float(), 1e-3, 1e-5, k)
 
+
+def test_pretrain_wrappers_against_the_reference_classes(golden_dir):
+    """ImgSupervised / TableSupervised on the HIP path (f32 mode) against outputs of the REFERENCE's own wrapper classes
+    (img_pretrain.ImgSupervised with the oracle's ResNet standing in for torchvision, table_pretrain.TableSupervised;
+    tests/golden/p2_pretrain_wrappers.npz from oracle/make_golden_r5.py): losses and the decoder-side / table-encoder gradients within the
+    north star's 1e-3; the ResNet-side gradients (the BatchNorm stack over 4 images amplifies f32 rounding) within 2e-2 of their scale."""
+    from multimodalsum_amd.modules import ImgSupervised, TableSupervised
+    from tests.test_oracle_golden import p2_setup
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(golden_dir, "p2_pretrain_wrappers.npz")).items()}
+    ocfg, sd, labels, imgs, imask, tlabels, field, fv = p2_setup()
+    cfg = tiny_cfg(vocab=200, d=1024, ffn=64, layers=1, heads=16, maxpos=32)
+    D = "bart_model.model.decoder.layers.0."
+    im = ImgSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    im.load_state_dict({k: v for k, v in sd.items() if not k.startswith("table_encoder.")})
+    im.train()
+    loss = im(imgs.to(DEV), imask.to(DEV), labels=labels.to(DEV))[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    n = dict(im.named_parameters())
+    close(loss, g["img_loss"], TOL_F32, 1e-6, "ImgSupervised loss vs the reference class")
+    close(n[D + "encoder_attn.k_proj.weight"].grad[:32], g["img_g_kproj"], TOL_F32, 2e-6, "img k_proj")
+    close(n["bart_model.model.shared.weight"].grad[:64], g["img_g_shared"], TOL_F32, 2e-6, "img shared")
+    close(n[D + "fc1.weight"].grad[:16], g["img_g_fc1"], TOL_F32, 2e-6, "img fc1")
+    worst = 0.0
+    for key, name, sl in (("img_g_linear", "img_encoder.linear.weight", lambda t: t[:16]),
+                          ("img_g_l3_22_conv3", "img_encoder.resnet.layer3.22.conv3.weight", lambda t: t[:16, :, 0, 0]),
+                          ("img_g_l3_22_bn3_w", "img_encoder.resnet.layer3.22.bn3.weight", lambda t: t),
+                          ("img_g_l3_0_conv1", "img_encoder.resnet.layer3.0.conv1.weight", lambda t: t[:16, :, 0, 0])):
+        a, b = sl(n[name].grad).double().cpu(), g[key].double()
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-30))
+        worst = max(worst, err)
+        assert err <= 2e-2, (name, err)
+    print("ImgSupervised vs the reference class: worst ResNet-side gradient error %.2e of its scale" % worst)
+    tm = TableSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True)
+    tm.load_state_dict({k: v for k, v in sd.items() if not k.startswith("img_encoder.")})
+    tm.train()
+    lt = tm(field.to(DEV), [t.to(DEV) for t in fv], labels=tlabels.to(DEV))[0]
+    lt.backward()
+    torch.cuda.synchronize()
+    n = dict(tm.named_parameters())
+    close(lt, g["tab_loss"], TOL_F32, 1e-6, "TableSupervised loss vs the reference class")
+    for key, name, sl in (("tab_g_fc", "table_encoder.fc.weight", lambda t: t[:16]), ("tab_g_fc_b", "table_encoder.fc.bias", lambda t: t),
+                          ("tab_g_linear", "table_encoder.linear.weight", lambda t: t[:16]), ("tab_g_rating", "table_encoder.rating_embedding.weight", lambda t: t),
+                          ("tab_g_hours", "table_encoder.hours_embedding.weight", lambda t: t), ("tab_g_kproj", D + "encoder_attn.k_proj.weight", lambda t: t[:32]),
+                          ("tab_g_shared", "bart_model.model.shared.weight", lambda t: t[:64])):
+        close(sl(n[name].grad), g[key], TOL_F32, 2e-6, "table " + name)
+

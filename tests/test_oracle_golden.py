@@ -284,3 +284,59 @@ def test_amazon_table_encoder(golden_dir):
     _close(sd["table_encoder.fc.weight"].grad[:64], g["g_fc_w"], **TOL)
     _close(sd["table_encoder.fc.bias"].grad, g["g_fc_b"], **TOL)
     _close(sd["table_encoder.linear.weight"].grad[:64], g["g_linear"], **TOL)
+
+
+def p2_setup():
+    """Inputs and weights of oracle/make_golden_r5.py's p2 fixture, rebuilt from the same closed forms / seeds."""
+    cfg = bo.BartCfg(vocab_size=200, d_model=1024, ffn_dim=64, encoder_layers=1, decoder_layers=1, heads=16, max_position_embeddings=32, dropout=0.0)
+    labels = syn.token_batch(2, 12, cfg.vocab_size, seed=5, min_len=4)
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn(2, 2, 3, 224, 224, generator=g)
+    imask = torch.tensor([[True, True], [True, False]])
+    imgs = imgs * imask[:, :, None, None, None].float()
+    tlabels = syn.token_batch(3, 12, cfg.vocab_size, seed=6, min_len=4)
+    field, fv = syn.table_batch(3, cfg.vocab_size, seed=9)
+    shapes = bo.bart_param_shapes(cfg, False, prefix="bart_model.")
+    shapes.update(eo.table_param_shapes())
+    sd = formula_state_dict(shapes, std=0.02)
+    sd.update(formula_state_dict(eo.resnet_param_shapes(cfg.d_model), std=0.05))
+    return cfg, sd, labels, imgs, imask, tlabels, field, fv
+
+
+def test_p2_pretrain_wrappers(golden_dir):
+    """The reference's own step-2 wrapper classes (img_pretrain.ImgSupervised with the stand-in backbone, table_pretrain.TableSupervised:
+    oracle/make_golden_r5.py) against the oracle composition the HIP wrappers are tested with: encoder -> unimodal decoder branch with a
+    zero rating difference -> label-smoothing loss (img_pretrain.py:85-141, table_pretrain.py:84-129)."""
+    g = _load(golden_dir, "p2_pretrain_wrappers.npz")
+    cfg, sd, labels, imgs, imask, tlabels, field, fv = p2_setup()
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() > 0 and "running" not in k:
+            v.requires_grad_(True)
+    D = "bart_model.model.decoder.layers.0."
+    ih = eo.resnet101_features(sd, imgs.reshape(-1, 3, 224, 224), training=True).reshape(2, 2, -1, cfg.d_model)
+    lg = bo.enc_forward(sd, cfg, ih, torch.zeros(2, 1), imask.unsqueeze(-1).repeat(1, 1, ih.shape[2]), labels, training=True, prefix="bart_model.")
+    li = bo.label_smoothing_loss(lg.view(-1, cfg.vocab_size), labels.view(-1), cfg.vocab_size, 0.1)
+    li.backward()
+    _close(li.detach(), g["img_loss"], 1e-5, 1e-6)
+    # the stand-in backbone IS this restatement, so the ResNet gradients agree to rounding; they pin the wrapper's plumbing (mask, reshape)
+    _close(sd["img_encoder.linear.weight"].grad[:16], g["img_g_linear"], **TOL)
+    _close(sd["img_encoder.resnet.layer3.22.conv3.weight"].grad[:16, :, 0, 0], g["img_g_l3_22_conv3"], **TOL)
+    _close(sd["img_encoder.resnet.layer3.22.bn3.weight"].grad, g["img_g_l3_22_bn3_w"], **TOL)
+    _close(sd[D + "encoder_attn.k_proj.weight"].grad[:32], g["img_g_kproj"], **TOL)
+    _close(sd["bart_model.model.shared.weight"].grad[:64], g["img_g_shared"], **TOL)
+    _close(sd[D + "fc1.weight"].grad[:16], g["img_g_fc1"], **TOL)
+    for v in sd.values():
+        v.grad = None
+    th, tmask = eo.yelp_table_encoder(sd, sd["bart_model.model.shared.weight"], field, fv)
+    lt_ = bo.enc_forward(sd, cfg, th.unsqueeze(1), torch.zeros(3, 1), tmask.unsqueeze(1), tlabels, training=True, prefix="bart_model.")
+    lt = bo.label_smoothing_loss(lt_.view(-1, cfg.vocab_size), tlabels.view(-1), cfg.vocab_size, 0.1)
+    lt.backward()
+    _close(lt.detach(), g["tab_loss"], 1e-5, 1e-6)
+    _close(sd["table_encoder.fc.weight"].grad[:16], g["tab_g_fc"], **TOL)
+    _close(sd["table_encoder.fc.bias"].grad, g["tab_g_fc_b"], **TOL)
+    _close(sd["table_encoder.linear.weight"].grad[:16], g["tab_g_linear"], **TOL)
+    _close(sd["table_encoder.rating_embedding.weight"].grad, g["tab_g_rating"], **TOL)
+    _close(sd["table_encoder.hours_embedding.weight"].grad, g["tab_g_hours"], **TOL)
+    _close(sd[D + "encoder_attn.k_proj.weight"].grad[:32], g["tab_g_kproj"], **TOL)
+    _close(sd["bart_model.model.shared.weight"].grad[:64], g["tab_g_shared"], **TOL)
+
