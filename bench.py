@@ -761,9 +761,15 @@ def also_configs(args, cfg, model, device):
             object.__setattr__(model, "_step_graphs", None)
             gc.collect()
             torch.cuda.empty_cache()
+        fpb4 = flops_per_business(cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, 4)
         train_cfg("multimodal_B8", "multimodal", 8, model)
-        out["multimodal_B8"]["step_roofline_frac"] = out["multimodal_B8"]["value"] * flops_per_business(
-            cfg.d_model, cfg.encoder_ffn_dim, cfg.vocab_size, cfg.encoder_layers, cfg.decoder_layers, 9, 128, 128, 4) / 1e12 / PEAK_BF16_TFLOPS
+        out["multimodal_B8"]["step_roofline_frac"] = out["multimodal_B8"]["value"] * fpb4 / 1e12 / PEAK_BF16_TFLOPS
+        object.__setattr__(model, "_step_graphs", None)
+        gc.collect()
+        torch.cuda.empty_cache()
+        # the reference's own default: one business per GPU and step (multimodal_train.py:420, --batch_size 1)
+        train_cfg("multimodal_B1", "multimodal", 1, model, steps=8, warmup=2)
+        out["multimodal_B1"]["step_roofline_frac"] = out["multimodal_B1"]["value"] * fpb4 / 1e12 / PEAK_BF16_TFLOPS
         g = run_generate(model, cfg, device, 8, 2, 1, args.dtype)
         out["generate_B8"] = {k: g[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "decode_steps", "ms_per_decode_step", "tokens_per_s",
                                                 "decode_step_bytes", "decode_hbm_frac")}

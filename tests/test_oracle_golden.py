@@ -340,3 +340,24 @@ def test_p2_pretrain_wrappers(golden_dir):
     _close(sd[D + "encoder_attn.k_proj.weight"].grad[:32], g["tab_g_kproj"], **TOL)
     _close(sd["bart_model.model.shared.weight"].grad[:64], g["tab_g_shared"], **TOL)
 
+
+def test_g2_generate_full_size_short(golden_dir):
+    """The oracle's beam search on the full-size generation fixture (cfg/bart-large.json, 12 + 12 layers, BASELINE config 5's memory for two
+    businesses; oracle/make_golden_r5.py ran the REFERENCE's generate() on it) at max_length 32: ids equal to the reference's.  The
+    max_length 128 ids of the same fixture were compared with the oracle's when the fixture was made (`oracle_ids`, minutes of CPU) and are
+    what the GPU test holds the HIP search to."""
+    from multimodalsum_amd.config import BartConfig
+    from oracle import generate_oracle as go
+    from oracle.gen_fixture import G2, g2_inputs, g2_kwargs
+    g = _load(golden_dir, "g2_generate_full.npz")
+    assert torch.equal(g["ids"], g["oracle_ids"]) and g["ids"].shape[0] == G2["B"] and g["ids"].shape[1] <= G2["max_length"]
+    cfg = BartConfig.from_json_file(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cfg", "bart-large.json"))
+    ocfg = bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim, encoder_layers=cfg.encoder_layers,
+                      decoder_layers=cfg.decoder_layers, heads=cfg.heads, max_position_embeddings=cfg.max_position_embeddings, dropout=0.0)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=G2["std"])
+    text_h, text_m, table_h, table_m, img_h, img_m = g2_inputs(cfg, int(g["seed"]))
+    with torch.no_grad():
+        out = go.beam_search(sd, ocfg, [text_h, table_h, img_h], [text_m, table_m, img_m], torch.zeros(G2["B"], 1), True,
+                             decoder_start_token_id=cfg.decoder_start_token_id, **g2_kwargs(G2["short_length"]))
+    assert torch.equal(out, g["ids_short"]), (out[:, :12], g["ids_short"][:, :12])
+
