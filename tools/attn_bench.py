@@ -57,6 +57,9 @@ def main():
             kv_rows[keep] = torch.arange(nlive, dtype=torch.int32, device="cuda")
             kv = kv[keep].contiguous()
             k, v = kv[:, :D], kv[:, D:]
+        if os.environ.get("ATTN_BENCH_HOT") == "1" and kv_rows is not None:     # DIAGNOSTIC: every entity reads the same S rows (K / V always cache-hot)
+            kv_rows = (torch.arange(B * N * S, device="cuda") % S).to(torch.int32)
+            kv_rows[pad.ne(0)] = -1
         desc = kn.make_attn_desc(q, k, v, out, pad, null, nq, T, qpb, N, S, H, excl, causal, 0.125, kv_rows=kv_rows)
         dout = torch.randn(nq * T, D, device="cuda").to(dt)
         dq = torch.empty_like(q)
