@@ -210,6 +210,7 @@ extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, lo
     GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk, live_rows, alpha_dev};
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (gemm_skinny_eligible(dtype, a)) return launch_gemm_skinny(a, s);
+    if (gemm_skinny_f32_eligible(dtype, a)) return launch_gemm_skinny_f32(a, s);
     if (flags & MMSUM_GEMM_A_F32) return MMSUM_ERR_BAD_DTYPE;          // no other kernel reads an f32 A beside bf16 weights
     if (gemm_glds_eligible(dtype, a)) return launch_gemm_glds(a, s);
     if (gemm_tn_eligible(dtype, a)) return launch_gemm_tn(a, s);
@@ -267,6 +268,7 @@ extern "C" int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A
     GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, live_rows, alpha_dev};
     GemmPlan g;
     if (gemm_skinny_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 32, (a.N + 31) / 32};
+    else if (gemm_skinny_f32_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 16, (a.N + 15) / 16};
     else if (flags & MMSUM_GEMM_A_F32) return MMSUM_ERR_BAD_DTYPE;
     else if (gemm_glds_eligible(dtype, a)) g = plan_gemm_glds(a);
     else if (gemm_tn_eligible(dtype, a)) g = plan_gemm_tn(a);

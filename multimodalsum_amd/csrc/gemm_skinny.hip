@@ -166,7 +166,99 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny16_pair_kernel(GemmArgs p0
     skinny16_body<MB, EPI, NW>(blockIdx.y ? p1 : p0, smem_raw);
 }
 
+// The f32 compute mode's decode step (the mode whose generated token ids are held to the reference's, tests/test_generation_gpu.py): f32 x,
+// f32 weights, f32 result.  The generic f32 kernel puts one workgroup on a 128-column tile -- 8 workgroups pull the 4 MB of an N = K = 1024
+// weight matrix (measured: 15.7 ms per decode step, 2 % of its HBM roofline).  Same scheme as gemm_skinny16_kernel: 16 output columns per
+// workgroup, the NW waves split K, both operands straight from global memory in the MFMA operand layout -- v_mfma_f32_16x16x4_f32, lane
+// (r = l & 15, g = l >> 4) holds A[r][k = g] / B[k = g][r].  A lane loads FOUR consecutive k of its row with one 16-byte load; MFMA j of a
+// 16-k slab takes element j of every lane, i.e. the k set {j, 4 + j, 8 + j, 12 + j} -- the same set on both operands, and a sum over k does
+// not care about the order.  f32 products, f32 accumulation (as the generic f32 kernel's v_mfma_f32_32x32x2_f32).
+template <int MB, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float (*red)[MB][4][64] = reinterpret_cast<float (*)[MB][4][64]>(smem_raw);       // [NW][MB][4][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16;
+    const float* A = static_cast<const float*>(p.A);
+    const float* A2 = static_cast<const float*>(p.A2);
+    const float* B = static_cast<const float*>(p.B);
+    const int nslab = p.K / 16, per = nslab / NW;
+    const int s0 = wave * per, s1 = s0 + per;
+    const int lr = lane & 15, kg = (lane >> 4) * 4;
+    const int nrow = n0 + lr;
+    const float* brow = B + (long)(nrow < p.N ? nrow : p.N - 1) * p.ldb + kg;
+    f32x4_t acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int s = s0; s < s1; ++s) {
+        int k0 = s * 16;
+        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(brow + k0);
+        const float* Ab = A;
+        long lda = p.lda;
+        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            const int m = mb * 16 + lr;
+            f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (m < p.M) a = *reinterpret_cast<const f32x4_t*>(Ab + (long)m * lda + k0 + kg);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[mb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave][mb][e][lane] = acc[mb][e];
+    __syncthreads();
+    const bool col_ok = nrow < p.N;
+    const float bv = ((p.flags & MMSUM_GEMM_BIAS) && col_ok) ? p.bias[nrow] : 0.f;
+    float* C = static_cast<float*>(p.C);
+    for (int i = wave; i < MB * 4; i += NW) {
+        const int mb = i / 4, e = i % 4;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][mb][e][lane];                       // fixed order: bit-reproducible
+        v = v * p.alpha + bv;
+        if constexpr (EPI == MMSUM_EPI_GELU) v = gelu_f(v);                           // the parity mode keeps erff
+        const int m = mb * 16 + 4 * (lane >> 4) + e;
+        if (col_ok && m < p.M) C[(long)m * p.ldc + nrow] = v;
+    }
+}
+
 }  // namespace
+
+bool gemm_skinny_f32_eligible(int dtype, const GemmArgs& a) {
+    if (dtype != MMSUM_F32 || a.M > 64 || a.splitk != 1 || a.live != nullptr || a.alpha_dev != nullptr) return false;
+    if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_ACCUM | MMSUM_GEMM_SLABS | MMSUM_GEMM_COLSUM | MMSUM_GEMM_A_F32)) return false;
+    const int epi = (a.flags >> 3) & 7;
+    if (!(epi == MMSUM_EPI_NONE || (epi == MMSUM_EPI_GELU && a.aux == nullptr))) return false;
+    if (a.K % 128 || (a.A2 && a.ksplit % 16) || a.N < 256) return false;
+    if ((((uintptr_t)a.A) | ((uintptr_t)a.B) | ((uintptr_t)a.A2)) & 15) return false;
+    if ((a.lda & 3) || (a.ldb & 3) || (a.A2 && (a.lda2 & 3))) return false;
+    return true;
+}
+
+template <int MB, int EPI, int NW>
+int launch_skinny_f32_one(const GemmArgs& a, hipStream_t stream) {
+    const size_t lds = (size_t)NW * MB * 4 * 64 * sizeof(float);
+    gemm_skinny_f32_kernel<MB, EPI, NW><<<dim3((a.N + 15) / 16), dim3(NW * 64), lds, stream>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+int launch_gemm_skinny_f32(const GemmArgs& a, hipStream_t stream) {
+    const int epi = (a.flags >> 3) & 7;
+#define SKF(MB)                                                                                                           \
+    do {                                                                                                                  \
+        return epi == MMSUM_EPI_GELU ? launch_skinny_f32_one<MB, MMSUM_EPI_GELU, 8>(a, stream)                            \
+                                     : launch_skinny_f32_one<MB, MMSUM_EPI_NONE, 8>(a, stream);                           \
+    } while (0)
+    if (a.M <= 16) SKF(1);
+    else if (a.M <= 32) SKF(2);
+    else if (a.M <= 48) SKF(3);
+    else SKF(4);
+#undef SKF
+}
 
 bool gemm_skinny_eligible(int dtype, const GemmArgs& a) {
     if (dtype != MMSUM_BF16 || a.M > 128 || a.splitk != 1 || a.live != nullptr || a.alpha_dev != nullptr) return false;
