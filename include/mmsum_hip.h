@@ -213,7 +213,8 @@ int mmsum_attn_bwd(int dtype, const mmsum_attn_desc* d, const void* dout, long l
                    int accumulate_dq, void* dk, long lddk, void* dv, long lddv, void* stats, void* stream);
 
 /* The decode step's cross-attention over the CACHED K / V of every modality in one launch (generation.py; reference: the cached branch
- * of SelfAttention.get_head_output, modeling_multimodalsum.py:794-815,819-869, at one query per hypothesis).  q [B * qpb, H*64] bf16:
+ * of SelfAttention.get_head_output, modeling_multimodalsum.py:794-815,819-869, at one query per hypothesis).  dtype: MMSUM_BF16 (the
+ * timed mode) or MMSUM_F32 (the parity mode: q / k / v / out f32, pitches in elements).  q [B * qpb, H*64] bf16:
  * the qpb hypotheses of business b are rows b*qpb ..; modality m: k / v [B * N * S rows, pitch ldkv] bf16 (entity (b, n) at row
  * (b*N + n)*S), pad [B*N*S] uint8 (1 = masked key, filled with -2^16 like the reference) or NULL, null_entity [B*N] uint8 or NULL.
  * out [nmod * B*qpb, H*64] bf16: row m * B*qpb + r = the entity MEAN of modality m for hypothesis r (null entities dropped, zeros
@@ -221,7 +222,7 @@ int mmsum_attn_bwd(int dtype, const mmsum_attn_desc* d, const void* dout, long l
  * (mmsum_decode_cross_attn_workspace bytes, ZERO before its first use; the kernel leaves its ticket words zero). */
 typedef struct { const void* k; const void* v; const uint8_t* pad; const uint8_t* null_entity; int N, S; } mmsum_xattn_memory;
 long mmsum_decode_cross_attn_workspace(int n_entities, int H, int qpb, int B, int nmod);
-int mmsum_decode_cross_attn(const void* q, long ldq, const mmsum_xattn_memory* mods, int nmod, long ldkv, void* out, long ldo,
+int mmsum_decode_cross_attn(int dtype, const void* q, long ldq, const mmsum_xattn_memory* mods, int nmod, long ldkv, void* out, long ldo,
                             int B, int qpb, int H, float scale, void* workspace, void* stream);
 
 /* K13 elementwise part (modeling_multimodalsum.py:732-744): given pre-activations pa, pb,

@@ -53,7 +53,7 @@ SIGNATURES = {
     "mmsum_gemm_plan": (c_int, [c_int, c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p,
                                 c_long, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int)]),
     "mmsum_decode_cross_attn_workspace": (c_long, [c_int, c_int, c_int, c_int, c_int]),
-    "mmsum_decode_cross_attn": (c_int, [c_void_p, c_long, ctypes.POINTER(XattnMemory), c_int, c_long, c_void_p, c_long, c_int, c_int, c_int,
+    "mmsum_decode_cross_attn": (c_int, [c_int, c_void_p, c_long, ctypes.POINTER(XattnMemory), c_int, c_long, c_void_p, c_long, c_int, c_int, c_int,
                                         c_float, c_void_p, c_void_p]),
     "mmsum_gemm_pair": (c_int, [ctypes.POINTER(GemmOperands), c_int, c_int, c_int, c_int, c_void_p]),
     "mmsum_dec_gemm_workspace": (c_long, [c_int, c_int, c_int]),

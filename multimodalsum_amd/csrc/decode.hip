@@ -484,6 +484,139 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_kernel(XaArgs a)
     }
 }
 
+// The same launch in the f32 compute mode (the mode whose generated ids are held to the reference's): f32 q / K / V / out.  Same
+// decomposition (one workgroup per (entity, head), 32 key-row slots x 8 chunks of 8 dims, DPP row sums, one wave per query for the
+// softmax, thread = (query, dim) for P V, the entity mean through the last arriver).  A chunk is 32 bytes here: K in two 16-byte
+// loads per row, V through registers into a row-major [S][64] f32 LDS tile (a row = 256 bytes = all 64 banks: the P V pass reads
+// one row per step, conflict-free).  Replaces three launches of the training kernel with 4 live query rows in a 128-row tile
+// (attn_fwd_pipe_kernel<float>: 150 us per layer).
+struct XaModF { const float* k; const float* v; const uint8_t* pad; const uint8_t* null_entity; int N, S, ent0; };
+struct XaArgsF {
+    XaModF mod[3];
+    const float* q; float* out; float* part; unsigned* tickets;
+    long ldq, ldkv, ldo;
+    int nmod, B, H, qpb, R;
+    float scale;
+};
+template <int QPB>
+__global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_f32_kernel(XaArgsF a) {
+    extern __shared__ __attribute__((aligned(16))) char xa_smem[];
+    float* vl = reinterpret_cast<float*>(xa_smem);                                       // V tile [XA_MAXROWS * 32][64]
+    float (*sc)[XA_MAXROWS * 32] = reinterpret_cast<float (*)[XA_MAXROWS * 32]>(xa_smem + XA_MAXROWS * 32 * 256);   // [QPB][keys]
+    __shared__ unsigned last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x;
+    int e = gridDim.y - 1 - blockIdx.y, m = 0;
+    while (m + 1 < a.nmod && e >= a.mod[m + 1].ent0) ++m;
+    const XaModF M = a.mod[m];
+    const int le = e - M.ent0, b = le / M.N;
+    const int S = M.S;
+    float* mypart = a.part + ((long)e * a.H + h) * (QPB * 64);
+    unsigned* ticket = a.tickets + ((long)m * a.B + b) * a.H + h;
+    const bool is_null = M.null_entity != nullptr && M.null_entity[le] != 0;
+    if (!is_null) {
+        const int kslot = tid >> 3, dch = tid & 7;
+        const long row0 = (long)le * S;
+        const float* kb = M.k + row0 * a.ldkv + h * 64 + dch * 8;
+        const float* vb = M.v + row0 * a.ldkv + h * 64 + dch * 8;
+        const int nrow = (S + 31) >> 5;
+        f32x4_t kreg[XA_MAXROWS][2], vreg[XA_MAXROWS][2];
+#pragma unroll
+        for (int i = 0; i < XA_MAXROWS; ++i) {
+            const int s = i * 32 + kslot;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) kreg[i][hh] = vreg[i][hh] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (i < nrow && s < S) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    kreg[i][hh] = *reinterpret_cast<const f32x4_t*>(kb + (long)s * a.ldkv + 4 * hh);
+                    vreg[i][hh] = *reinterpret_cast<const f32x4_t*>(vb + (long)s * a.ldkv + 4 * hh);
+                }
+            }
+        }
+        float qv[QPB][8];
+#pragma unroll
+        for (int qi = 0; qi < QPB; ++qi) {
+            const float* qp = a.q + (long)(b * QPB + qi) * a.ldq + h * 64 + dch * 8;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const f32x4_t t = *reinterpret_cast<const f32x4_t*>(qp + 4 * hh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) qv[qi][4 * hh + j] = t[j] * a.scale;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < XA_MAXROWS; ++i) {
+            if (i >= nrow) break;
+            const int key = i * 32 + kslot;
+            float part[QPB];
+#pragma unroll
+            for (int qi = 0; qi < QPB; ++qi) {
+                float x = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x = fmaf(qv[qi][j], kreg[i][j >> 2][j & 3], x);
+                part[qi] = row8_sum(x);
+            }
+            if (key < S) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4_t*>(vl + key * 64 + dch * 8 + 4 * hh) = vreg[i][hh];
+                if (dch == 0) {
+                    const bool masked = M.pad != nullptr && M.pad[row0 + key] != 0;
+#pragma unroll
+                    for (int qi = 0; qi < QPB; ++qi) sc[qi][key] = masked ? -65536.0f : part[qi];      // masked_fill(-2^16), :841-845
+                }
+            }
+        }
+        __syncthreads();
+        for (int qi = wave; qi < QPB; qi += XA_THREADS / 64) {
+            float mx = -INFINITY;
+            for (int s = lane; s < S; s += 64) mx = fmaxf(mx, sc[qi][s]);
+            mx = warp_max(mx);
+            float l = 0.f;
+            for (int s = lane; s < S; s += 64) { const float p = expf(sc[qi][s] - mx); sc[qi][s] = p; l += p; }
+            l = warp_sum(l);
+            const float inv = 1.f / l;
+            for (int s = lane; s < S; s += 64) sc[qi][s] *= inv;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < QPB * 64; idx += XA_THREADS) {
+            const int qi = idx >> 6, dd = idx & 63;
+            const float* vcol = vl + dd;
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            int s = 0;
+            for (; s + 3 < S; s += 4) {
+                o0 = fmaf(sc[qi][s], vcol[s * 64], o0);
+                o1 = fmaf(sc[qi][s + 1], vcol[(s + 1) * 64], o1);
+                o2 = fmaf(sc[qi][s + 2], vcol[(s + 2) * 64], o2);
+                o3 = fmaf(sc[qi][s + 3], vcol[(s + 3) * 64], o3);
+            }
+            for (; s < S; ++s) o0 = fmaf(sc[qi][s], vcol[s * 64], o0);
+            __hip_atomic_store(mypart + qi * 64 + dd, (o0 + o1) + (o2 + o3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (unsigned)(M.N - 1)) ? 1u : 0u;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last) return;
+    for (int idx = tid; idx < QPB * 64; idx += XA_THREADS) {
+        const int qi = idx >> 6, dd = idx & 63;
+        float x = 0.f;
+        int cnt = 0;
+        for (int nn = 0; nn < M.N; ++nn) {
+            if (M.null_entity != nullptr && M.null_entity[b * M.N + nn] != 0) continue;
+            x += __hip_atomic_load(a.part + ((long)(M.ent0 + b * M.N + nn) * a.H + h) * (QPB * 64) + qi * 64 + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ++cnt;
+        }
+        x = cnt > 0 ? x / (float)cnt : 0.f;
+        a.out[((long)m * a.R + b * QPB + qi) * a.ldo + h * 64 + dd] = x;
+    }
+}
+
 // Single-query self-attention over the caches through the ancestor table, bf16, in the layout of the cross-attention kernel above:
 // 256 threads = 32 key slots x 8 chunks; every K row of the hypothesis requested at once into registers and every V row by LDS-DMA
 // (the one-wave kernel further up walks the V rows eight at a time: up to 16 dependent round trips at 128 keys, 13 us per layer).
@@ -575,10 +708,55 @@ extern "C" long mmsum_decode_cross_attn_workspace(int n_entities, int H, int qpb
     return (((long)nmod * B * H * 4 + 255) / 256) * 256 + (long)n_entities * H * qpb * 64 * (long)sizeof(float);
 }
 
-extern "C" int mmsum_decode_cross_attn(const void* q, long ldq, const mmsum_xattn_memory* mods, int nmod, long ldkv, void* out, long ldo,
+template <int QPB>
+static int launch_xattn_f32(const XaArgsF& a, dim3 grid, hipStream_t s) {
+    const size_t lds = (size_t)XA_MAXROWS * 32 * 256 + (size_t)QPB * XA_MAXROWS * 32 * sizeof(float);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(decode_cross_attn_f32_kernel<QPB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return MMSUM_ERR_HIP;
+    decode_cross_attn_f32_kernel<QPB><<<grid, dim3(XA_THREADS), lds, s>>>(a);
+    return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+}
+
+static int decode_cross_attn_f32(const void* q, long ldq, const mmsum_xattn_memory* mods, int nmod, long ldkv, void* out, long ldo,
+                                 int B, int qpb, int H, float scale, void* workspace, void* stream) {
+    if ((((uintptr_t)q) & 15) || (ldq & 3) || (ldkv & 3)) return MMSUM_ERR_BAD_ALIGN;
+    XaArgsF a;
+    int ent = 0;
+    for (int m = 0; m < 3; ++m) {
+        if (m < nmod) {
+            if (mods[m].N <= 0 || mods[m].N > 32 || mods[m].S <= 0 || mods[m].S > XA_MAXROWS * 32) return MMSUM_ERR_BAD_SHAPE;
+            if ((((uintptr_t)mods[m].k | (uintptr_t)mods[m].v) & 15)) return MMSUM_ERR_BAD_ALIGN;
+            a.mod[m] = XaModF{static_cast<const float*>(mods[m].k), static_cast<const float*>(mods[m].v), mods[m].pad, mods[m].null_entity, mods[m].N, mods[m].S, ent};
+            ent += B * mods[m].N;
+        } else {
+            a.mod[m] = XaModF{nullptr, nullptr, nullptr, nullptr, 1, 1, 1 << 30};
+        }
+    }
+    a.q = static_cast<const float*>(q); a.out = static_cast<float*>(out);
+    a.tickets = static_cast<unsigned*>(workspace);
+    a.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + (((long)nmod * B * H * 4 + 255) / 256) * 256);
+    a.ldq = ldq; a.ldkv = ldkv; a.ldo = ldo;
+    a.nmod = nmod; a.B = B; a.H = H; a.qpb = qpb; a.R = B * qpb; a.scale = scale;
+    const dim3 grid(H, ent);
+    hipStream_t s = (hipStream_t)stream;
+    switch (qpb) {
+        case 1: return launch_xattn_f32<1>(a, grid, s);
+        case 2: return launch_xattn_f32<2>(a, grid, s);
+        case 3: return launch_xattn_f32<3>(a, grid, s);
+        case 4: return launch_xattn_f32<4>(a, grid, s);
+        case 5: return launch_xattn_f32<5>(a, grid, s);
+        case 6: return launch_xattn_f32<6>(a, grid, s);
+        case 7: return launch_xattn_f32<7>(a, grid, s);
+        default: return launch_xattn_f32<8>(a, grid, s);
+    }
+}
+
+extern "C" int mmsum_decode_cross_attn(int dtype, const void* q, long ldq, const mmsum_xattn_memory* mods, int nmod, long ldkv, void* out, long ldo,
                                        int B, int qpb, int H, float scale, void* workspace, void* stream) {
     if (nmod < 1 || nmod > 3 || B <= 0 || H <= 0 || qpb < 1 || qpb > XA_MAXQ || !mods) return MMSUM_ERR_BAD_SHAPE;
     if (workspace == nullptr) return MMSUM_ERR_WORKSPACE;
+    if (dtype == MMSUM_F32) return decode_cross_attn_f32(q, ldq, mods, nmod, ldkv, out, ldo, B, qpb, H, scale, workspace, stream);
+    if (dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
     if ((((uintptr_t)q) & 1) || ((ldkv * 2) & 15)) return MMSUM_ERR_BAD_ALIGN;
     XaArgs a;
     int ent = 0;

@@ -194,7 +194,7 @@ int launch_gemm_glds(const GemmArgs& a, hipStream_t stream);   // gemm_fast.hip
 bool gemm_glds_eligible(int dtype, const GemmArgs& a);
 int launch_gemm_skinny(const GemmArgs& a, hipStream_t stream);   // gemm_skinny.hip: M <= 64 (decode step)
 bool gemm_skinny_eligible(int dtype, const GemmArgs& a);
-int launch_gemm_skinny_f32(const GemmArgs& a, hipStream_t stream);   // gemm_skinny.hip: f32 x, W, out with M <= 64 (decode step of the f32 mode)
+int launch_gemm_skinny_f32(const GemmArgs& a, hipStream_t stream);   // gemm_skinny.hip: f32 x, W, out with M <= 96 (decode step of the f32 mode)
 bool gemm_skinny_f32_eligible(int dtype, const GemmArgs& a);
 int launch_gemm_tn(const GemmArgs& a, hipStream_t stream);     // gemm_fast.hip: A [K,M], B [K,N] (weight gradients)
 int launch_gemm_tn_w4(const GemmArgs& a, hipStream_t stream);  // gemm_fast.hip: the 256x256 four-wave TN kernel (implicit-convolution weight gradient)

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmArgs p) {
 }  // namespace
 
 bool gemm_skinny_f32_eligible(int dtype, const GemmArgs& a) {
-    if (dtype != MMSUM_F32 || a.M > 64 || a.splitk != 1 || a.live != nullptr || a.alpha_dev != nullptr) return false;
+    if (dtype != MMSUM_F32 || a.M > 96 || a.splitk != 1 || a.live != nullptr || a.alpha_dev != nullptr) return false;
     if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_ACCUM | MMSUM_GEMM_SLABS | MMSUM_GEMM_COLSUM | MMSUM_GEMM_A_F32)) return false;
     const int epi = (a.flags >> 3) & 7;
     if (!(epi == MMSUM_EPI_NONE || (epi == MMSUM_EPI_GELU && a.aux == nullptr))) return false;
@@ -256,7 +256,9 @@ int launch_gemm_skinny_f32(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 16) SKF(1);
     else if (a.M <= 32) SKF(2);
     else if (a.M <= 48) SKF(3);
-    else SKF(4);
+    else if (a.M <= 64) SKF(4);
+    else if (a.M <= 80) SKF(5);
+    else SKF(6);                 // 96 rows: the three modalities' head outputs of 32 hypotheses through out_proj in one product
 #undef SKF
 }
 

@@ -138,13 +138,13 @@ class DecodeSession:
         # cross-attention + entity mean over the cached K / V in ONE launch of one workgroup per (entity, head)
         # (mmsum_decode_cross_attn).  f32 (the parity mode) and shapes outside those kernels keep the generic path below.
         nm = len(layout.mods)
-        self.fast = (dev.type == "cuda" and e.dtype == torch.bfloat16 and nm * R <= 96 and num_beams <= 8 and D % 256 == 0
+        self.fast = (dev.type == "cuda" and e.dtype in (torch.bfloat16, torch.float32) and nm * R <= 96 and num_beams <= 8 and D % 256 == 0
                      and all(S <= 224 and N <= 32 for (N, S) in layout.mods) and __import__("os").environ.get("MMSUM_DECODE_FAST") != "0")
         if self.fast:
             Fd = cfg.decoder_ffn_dim
             shapes = [(R, 3 * D, D), (R, D, D), (nm * R, D, D), (R, D, 2 * D), (R, Fd, D), (R, D, Fd), (R, cfg.vocab_size, D)]
             nbytes = max(kn.lib.mmsum_dec_gemm_workspace(M_, N_, K_) for (M_, N_, K_) in shapes if K_ % 256 == 0)
-            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)         # (bf16 only: the f32 mode's products all take mmsum_gemm's f32 weight-streaming kernel)
             n_ent = sum(layout.B * N for (N, S) in layout.mods)
             self.xws = kn.decode_cross_attn_workspace(n_ent, cfg.heads, num_beams, layout.B, nm, dev)
         self.use_graphs = dev.type == "cuda" and __import__("os").environ.get("MMSUM_DECODE_GRAPHS") != "0"
@@ -225,7 +225,7 @@ class DecodeSession:
         # long -- fc2, K = 4096: 12.0 against 14.5 us -- and loses 1 .. 2 us where K <= 2048 (qkv 9.1 / 6.9, out 7.6 / 6.7, alpha 10.4 / 8.4,
         # fc1 9.0 / 7.2): a product of a few MB sits on a ~7 us floor of launch + one memory round trip + epilogue either way, and the
         # hand-off adds to it.  So: K >= 4096 here, everything else on mmsum_gemm's weight-streaming kernels.
-        if K >= 4096 and K % 256 == 0 and x2 is None and x.shape[0] <= 96 and w.shape[0] <= 8192:
+        if x.dtype == torch.bfloat16 and K >= 4096 and K % 256 == 0 and x2 is None and x.shape[0] <= 96 and w.shape[0] <= 8192:
             return kn.dec_gemm(x, w, out, self.ws, bias=bias, epi=epi, x2=x2)
         return kn.gemm(x, w, out, bias=bias, epi=epi, a2=x2)
 
@@ -243,7 +243,8 @@ class DecodeSession:
             kn.gemm(self.x32[r0:r1], w, self.logits[r0:r1, :V], bias=bias)
 
     def _step_fast(self, t):
-        """The decode step with its own kernels (bf16): per layer the weight-streaming products (the long-K one with its reduction split
+        """The decode step with its own kernels (bf16, and f32 -- the parity mode -- on the f32 forms of the same kernels: mmsum_gemm's f32
+        weight-streaming kernel, mmsum_decode_cross_attn / mmsum_decode_self_attn in f32): per layer the weight-streaming products (the long-K one with its reduction split
         over workgroups), the cache-walking self-attention, ONE cross-attention launch over the cached K / V of every modality (one
         workgroup per entity and head), the gate and three LayerNorms: 14 launches (16 before)."""
         e, cfg, a = self.e, self.e.cfg, self.e.arena
@@ -291,7 +292,7 @@ class DecodeSession:
             if e.multimodal:
                 yt, ytab, yimg = yy[:R], yy[R:2 * R], yy[2 * R:]
                 pa, pb = e.empty(R, D), e.empty(R, D)
-                if R <= 64 and D % 256 == 0 and D <= 4096:          # alpha and beta: two independent products, one launch
+                if R <= 64 and D % 256 == 0 and D <= 4096 and e.dtype == torch.bfloat16:          # alpha and beta: two independent products, one launch
                     kn.gemm_pair([yt, yt], [ytab, yimg], [a.w(pre + "alpha_proj.weight"), a.w(pre + "beta_proj.weight")], [pa, pb],
                                  [a.f32(pre + "alpha_proj.bias"), a.f32(pre + "beta_proj.bias")])
                 else:

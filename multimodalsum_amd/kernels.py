@@ -519,15 +519,15 @@ def decode_cross_attn_workspace(n_entities, H, qpb, B, nmod, device):
 
 def decode_cross_attn(q, mods, out, ws, B, qpb, H, scale):
     """The decode step's cross-attention + entity mean over the cached K / V of every modality in one launch (mmsum_decode_cross_attn).
-    q bf16 [B*qpb, H*64]; mods: list of (k, v, pad uint8 [B,N,S] or None, null_entity uint8 [B*N] or None, N, S) with k / v bf16
-    [B*N*S, H*64] views of one pitch; out bf16 [len(mods) * B*qpb, H*64]."""
+    q bf16 (or f32: the parity mode) [B*qpb, H*64]; mods: list of (k, v, pad uint8 [B,N,S] or None, null_entity uint8 [B*N] or None, N, S)
+    with k / v [B*N*S, H*64] views of one pitch in q's dtype; out [len(mods) * B*qpb, H*64] in q's dtype."""
     arr = (_lib.XattnMemory * len(mods))()
     ldkv = mods[0][0].stride(0)
     for i, (k, v, pad, nul, N, S) in enumerate(mods):
-        assert k.dtype == torch.bfloat16 and k.stride(0) == ldkv and v.stride(0) == ldkv and k.shape[0] == B * N * S
+        assert k.dtype == q.dtype and v.dtype == q.dtype and k.stride(0) == ldkv and v.stride(0) == ldkv and k.shape[0] == B * N * S
         arr[i].k, arr[i].v, arr[i].pad, arr[i].null_entity, arr[i].N, arr[i].S = _p(k), _p(v), _p(pad), _p(nul), N, S
-    assert q.dtype == torch.bfloat16 and out.shape[0] == len(mods) * B * qpb
-    check(lib.mmsum_decode_cross_attn(_p(q), q.stride(0), arr, len(mods), ldkv, _p(out), out.stride(0), B, qpb, H, float(scale), _p(ws), _stream()),
+    assert out.dtype == q.dtype and out.shape[0] == len(mods) * B * qpb
+    check(lib.mmsum_decode_cross_attn(_dt(q), _p(q), q.stride(0), arr, len(mods), ldkv, _p(out), out.stride(0), B, qpb, H, float(scale), _p(ws), _stream()),
           "mmsum_decode_cross_attn")
     return out
 
