@@ -182,29 +182,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_f32_kernel(GemmArgs p) {
     const float* A = static_cast<const float*>(p.A);
     const float* A2 = static_cast<const float*>(p.A2);
     const float* B = static_cast<const float*>(p.B);
-    const int nslab = p.K / 16, per = nslab / NW;
-    const int s0 = wave * per, s1 = s0 + per;
+    // a wave's share of K in BATCHES of NS 16-k slabs: every load of a batch (NS of the weights, MB x NS of x) is issued before its first
+    // MFMA and unconditionally (rows past M re-read row 0: they only feed output rows that are never stored) -- a loop of load, wait,
+    // four MFMAs per slab (what the compiler made of the guarded form) is one dependent memory round trip per slab: 18 us per product
+    constexpr int NS = MB <= 3 ? 8 : 4;                              // (MB x NS + NS) 16-byte loads in flight per lane: 96 rows x 8 slabs would not fit the registers
+    const int nslab = p.K / 16, per = nslab / NW;                  // per % NS == 0 (eligibility: K % (16 * NS * NW) == 0)
+    const int s0 = wave * per;
     const int lr = lane & 15, kg = (lane >> 4) * 4;
     const int nrow = n0 + lr;
     const float* brow = B + (long)(nrow < p.N ? nrow : p.N - 1) * p.ldb + kg;
     f32x4_t acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) {
-        int k0 = s * 16;
-        const f32x4_t b = *reinterpret_cast<const f32x4_t*>(brow + k0);
+    for (int bt = 0; bt < per / NS; ++bt) {
+        int k0 = (s0 + bt * NS) * 16;
+        f32x4_t b[NS], a[MB][NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) b[s] = *reinterpret_cast<const f32x4_t*>(brow + k0 + s * 16);
         const float* Ab = A;
         long lda = p.lda;
-        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }      // a batch lies in ONE of the two tensors (ksplit % 128 == 0)
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const int m = mb * 16 + lr;
-            f32x4_t a = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (m < p.M) a = *reinterpret_cast<const f32x4_t*>(Ab + (long)m * lda + k0 + kg);
+            const float* ar = Ab + (long)(m < p.M ? m : 0) * lda + k0 + kg;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc[mb], 0, 0, 0);
+            for (int s = 0; s < NS; ++s) a[mb][s] = *reinterpret_cast<const f32x4_t*>(ar + s * 16);
         }
+        __builtin_amdgcn_sched_barrier(0);           // every load above is issued before the first MFMA below (the scheduler sank most of them)
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb][s][j], b[s][j], acc[mb], 0, 0, 0);
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
@@ -233,7 +244,7 @@ bool gemm_skinny_f32_eligible(int dtype, const GemmArgs& a) {
     if (a.flags & (MMSUM_GEMM_A_T | MMSUM_GEMM_B_T | MMSUM_GEMM_ACCUM | MMSUM_GEMM_SLABS | MMSUM_GEMM_COLSUM | MMSUM_GEMM_A_F32)) return false;
     const int epi = (a.flags >> 3) & 7;
     if (!(epi == MMSUM_EPI_NONE || (epi == MMSUM_EPI_GELU && a.aux == nullptr))) return false;
-    if (a.K % 128 || (a.A2 && a.ksplit % 16) || a.N < 256) return false;
+    if (a.K % 1024 || (a.A2 && a.ksplit % 128) || a.N < 256) return false;          // eight waves x batches of eight 16-k slabs
     if ((((uintptr_t)a.A) | ((uintptr_t)a.B) | ((uintptr_t)a.A2)) & 15) return false;
     if ((a.lda & 3) || (a.ldb & 3) || (a.A2 && (a.lda2 & 3))) return false;
     return true;

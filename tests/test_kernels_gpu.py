@@ -74,7 +74,7 @@ def test_gemm_skinny_decode_shapes(M, N, K):
         close(out, torch.cat([x.float(), x2.float()], 1) @ w2.float().t() + bias, dt, scale=math.sqrt(K / 64), what="skinny a2")
 
 
-@pytest.mark.parametrize("M,N,K", [(32, 1024, 1024), (12, 3072, 1024), (64, 1024, 4096), (33, 4096, 1024), (1, 256, 128), (32, 50265, 1024), (40, 2048, 2048), (96, 1024, 1024)])
+@pytest.mark.parametrize("M,N,K", [(32, 1024, 1024), (12, 3072, 1024), (64, 1024, 4096), (33, 4096, 1024), (1, 256, 1024), (32, 50265, 1024), (40, 2048, 2048), (96, 1024, 1024)])
 def test_gemm_skinny_f32_decode_shapes(M, N, K):
     """gemm_skinny_f32_kernel (f32 x, W, out, M <= 96: the decode step of the f32 compute mode, whose token ids are held to the
     reference's): bias, erf-GELU, K split over two operands, against an f64 product; the plan names the weight-streaming kernel."""
@@ -88,11 +88,12 @@ def test_gemm_skinny_f32_decode_shapes(M, N, K):
     close(out, x.double() @ w.double().t() + bias.double(), dt, scale=math.sqrt(K / 64), what="skinny f32 bias")
     kn.gemm(x, w, out, bias=bias, epi=kn.EPI_GELU, alpha=0.125)
     close(out, F.gelu((x.double() @ w.double().t()) * 0.125 + bias.double()), dt, scale=math.sqrt(K / 64), what="skinny f32 gelu")
-    if K >= 256:
-        x2 = rnd(M, 128, seed=63, std=0.5)
-        w2 = rnd(N, K + 128, seed=64, std=0.5)
+    if K == 1024:                      # the alpha / beta products: [yt | ytab] against a [N, 2 K] weight
+        x2 = rnd(M, K, seed=63, std=0.5)
+        w2 = rnd(N, 2 * K, seed=64, std=0.5)
+        assert kn.gemm_plan(x, w2, out, a2=x2, bias=bias)[0] == _lib.PLAN_SKINNY
         kn.gemm(x, w2, out, a2=x2, bias=bias)
-        close(out, torch.cat([x.double(), x2.double()], 1) @ w2.double().t() + bias.double(), dt, scale=math.sqrt(K / 64), what="skinny f32 a2")
+        close(out, torch.cat([x.double(), x2.double()], 1) @ w2.double().t() + bias.double(), dt, scale=math.sqrt(K / 32), what="skinny f32 a2")
     # a strided view of the output (the logits buffer is padded to 128 columns) and rows the kernel must not touch
     big = torch.full((M + 3, N + 7), float("nan"), device=DEV, dtype=dt)
     kn.gemm(x, w, big[:M, :N], bias=bias)
