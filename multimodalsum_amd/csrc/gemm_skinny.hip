@@ -7,6 +7,7 @@
 // loads per lane per 32-deep slab and operand, no LDS in the loop), the partial accumulators meet in LDS and the waves
 // share the bias / GELU / store work.  N = 1024 gives 32 workgroups of 4 (or 8, see below) waves streaming.
 #include "gemm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -52,28 +53,76 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p) {
     f32x16_t acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = zero_acc();
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) {
-        int k0 = s * 32;
-        const Frag b = global_frag<bf16_t>(brow + k0, lane, true);
-        const bf16_t* Ab = A;
-        long lda = p.lda;
-        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+    // slabs in batches of NSB with every load of a batch issued before its first MFMA (see skinny16_body); rows past M re-read row 0
+    auto batch = [&](int s, auto nsb_c) {
+        constexpr int NSB = decltype(nsb_c)::value;
+        Frag b[NSB];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = mt * 32 + ln;
-            if constexpr (AF32) {
-                const float* arow = static_cast<const float*>(p.A) + (long)(m < p.M ? m : 0) * p.lda + k0;
-                Frag hi, lo;
+        for (int i = 0; i < NSB; ++i) b[i] = global_frag<bf16_t>(brow + (s + i) * 32, lane, true);
+        if constexpr (AF32) {
+            f32x4_t xa[MT][NSB][2][2];                          // [row block][slab][16-byte chunk of the fragment][half]: 8 floats per chunk
 #pragma unroll
-                for (int i = 0; i < 2; ++i) split_hi_lo(arow + lane_chunk<bf16_t>(lane >> 5, i) * 8, m < p.M, hi.c[i], lo.c[i]);
-                mma_slab<bf16_t>(acc[mt], hi, b);
-                mma_slab<bf16_t>(acc[mt], lo, b);
-            } else {
-                const Frag a = global_frag<bf16_t>(Ab + (long)(m < p.M ? m : 0) * lda + k0, lane, m < p.M);
-                mma_slab<bf16_t>(acc[mt], a, b);
+            for (int i = 0; i < NSB; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = mt * 32 + ln;
+                    const float* arow = static_cast<const float*>(p.A) + (long)(m < p.M ? m : 0) * p.lda + (s + i) * 32;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) xa[mt][i][c][q] = *reinterpret_cast<const f32x4_t*>(arow + lane_chunk<bf16_t>(lane >> 5, c) * 8 + 4 * q);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NSB; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    Frag hi, lo;
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        bf16_t h[8], l[8];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = xa[mt][i][c][q][e];
+                                h[4 * q + e] = (bf16_t)v;
+                                l[4 * q + e] = (bf16_t)(v - (float)h[4 * q + e]);
+                            }
+                        __builtin_memcpy(&hi.c[c], h, 16);
+                        __builtin_memcpy(&lo.c[c], l, 16);
+                    }
+                    mma_slab<bf16_t>(acc[mt], hi, b[i]);
+                    mma_slab<bf16_t>(acc[mt], lo, b[i]);
+                }
+        } else {
+            Frag a[MT][NSB];
+#pragma unroll
+            for (int i = 0; i < NSB; ++i) {
+                int k0 = (s + i) * 32;
+                const bf16_t* Ab = A;
+                long lda = p.lda;
+                if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = mt * 32 + ln;
+                    a[mt][i] = global_frag<bf16_t>(Ab + (long)(m < p.M ? m : 0) * lda + k0, lane, true);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NSB; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mma_slab<bf16_t>(acc[mt], a[mt][i], b[i]);
         }
+    };
+    {
+        constexpr int NSMAX = (AF32 || MT > 1) ? 4 : 8;
+        int s = s0;
+        for (; s + NSMAX <= s1; s += NSMAX) batch(s, std::integral_constant<int, NSMAX>{});
+        if constexpr (NSMAX == 8) if (s + 4 <= s1) { batch(s, std::integral_constant<int, 4>{}); s += 4; }
+        if (s + 2 <= s1) { batch(s, std::integral_constant<int, 2>{}); s += 2; }
+        if (s < s1) batch(s, std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -119,20 +168,41 @@ __device__ __forceinline__ void skinny16_body(const GemmArgs& p, char* smem_raw)
     f32x4_t acc[MB];
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb) acc[mb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-    for (int s = s0; s < s1; ++s) {
-        int k0 = s * 32;
-        const u32x4_t b = *reinterpret_cast<const u32x4_t*>(brow + k0);
-        const bf16_t* Ab = A;
-        long lda = p.lda;
-        if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }
+    // A wave's slabs in BATCHES: every load of a batch (NSB of the weights, MB x NSB of x) is issued before its first MFMA, and
+    // unconditionally -- rows past M re-read row 0 (they only feed output rows that are never stored).  Round 5: the guarded
+    // one-slab-at-a-time form this replaces compiled to load, wait, MFMA per slab (`#pragma unroll` did not apply to it), i.e. one
+    // dependent memory round trip per slab: the "7 us floor" of these products was eight round trips, not one.
+    auto batch = [&](int s, auto nsb_c) {
+        constexpr int NSB = decltype(nsb_c)::value;
+        u32x4_t b[NSB], a[MB][NSB];
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-            const int m = mb * 16 + lr;
-            u32x4_t a = u32x4_t{0, 0, 0, 0};
-            if (m < p.M) a = *reinterpret_cast<const u32x4_t*>(Ab + (long)m * lda + k0 + kg);
-            acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc[mb], 0, 0, 0);
+        for (int i = 0; i < NSB; ++i) b[i] = *reinterpret_cast<const u32x4_t*>(brow + (s + i) * 32);
+#pragma unroll
+        for (int i = 0; i < NSB; ++i) {
+            int k0 = (s + i) * 32;
+            const bf16_t* Ab = A;
+            long lda = p.lda;
+            if (A2 != nullptr && k0 >= p.ksplit) { Ab = A2; lda = p.lda2; k0 -= p.ksplit; }       // (uniform: scalar selects)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int m = mb * 16 + lr;
+                a[mb][i] = *reinterpret_cast<const u32x4_t*>(Ab + (long)(m < p.M ? m : 0) * lda + k0 + kg);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NSB; ++i)
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[mb][i]), __builtin_bit_cast(bf16x8_t, b[i]), acc[mb], 0, 0, 0);
+    };
+    {
+        constexpr int NSMAX = MB <= 2 ? 8 : 4;                 // (MB + 1) x NSB 16-byte loads in flight per lane
+        int s = s0;
+        for (; s + NSMAX <= s1; s += NSMAX) batch(s, std::integral_constant<int, NSMAX>{});
+        if constexpr (NSMAX == 8) if (s + 4 <= s1) { batch(s, std::integral_constant<int, 4>{}); s += 4; }
+        if (s + 2 <= s1) { batch(s, std::integral_constant<int, 2>{}); s += 2; }
+        if (s < s1) batch(s, std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
