@@ -386,6 +386,20 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_kernel(XaArgs a)
         const bf16_t* kb = M.k + row0 * a.ldkv + h * 64 + dch * 8;
         const bf16_t* vb = M.v + row0 * a.ldkv + h * 64 + dch * 8;
         const int nrow = (S + 31) >> 5;                        // rows per slot (<= XA_MAXROWS)
+        // the key mask of this thread's rows, requested with the K / V rows (inside the score loop each byte was a load + wait of its own)
+        int padv[XA_MAXROWS];
+        {
+            // every load unconditional, from a clamped position of a buffer that always exists (a NULL mask reads the null-entity flags'
+            // first byte and is ignored below): a guarded load is a branch, and the compiler waits at every join
+            const uint8_t* pm = M.pad != nullptr ? M.pad + row0 : M.null_entity;
+            const int lim = M.pad != nullptr ? S - 1 : 0;
+#pragma unroll
+            for (int i = 0; i < XA_MAXROWS; ++i) padv[i] = pm != nullptr ? (int)__builtin_nontemporal_load(pm + min(i * 32 + kslot, lim)) : 0;
+            if (M.pad == nullptr) {
+#pragma unroll
+                for (int i = 0; i < XA_MAXROWS; ++i) padv[i] = 0;
+            }
+        }
         u32x4_t kreg[XA_MAXROWS];
 #pragma unroll
         for (int i = 0; i < XA_MAXROWS; ++i) {
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_kernel(XaArgs a)
             }
             const int key = i * 32 + kslot;
             if (dch == 0 && key < S) {
-                const bool masked = M.pad != nullptr && M.pad[row0 + key] != 0;
+                const bool masked = padv[i] != 0;
 #pragma unroll
                 for (int qi = 0; qi < QPB; ++qi) sc[qi][key] = masked ? -65536.0f : part[qi];      // masked_fill(-2^16), :841-845
             }
@@ -520,6 +534,19 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_f32_kernel(XaArg
         const float* kb = M.k + row0 * a.ldkv + h * 64 + dch * 8;
         const float* vb = M.v + row0 * a.ldkv + h * 64 + dch * 8;
         const int nrow = (S + 31) >> 5;
+        int padv[XA_MAXROWS];
+        {
+            // every load unconditional, from a clamped position of a buffer that always exists (a NULL mask reads the null-entity flags'
+            // first byte and is ignored below): a guarded load is a branch, and the compiler waits at every join
+            const uint8_t* pm = M.pad != nullptr ? M.pad + row0 : M.null_entity;
+            const int lim = M.pad != nullptr ? S - 1 : 0;
+#pragma unroll
+            for (int i = 0; i < XA_MAXROWS; ++i) padv[i] = pm != nullptr ? (int)__builtin_nontemporal_load(pm + min(i * 32 + kslot, lim)) : 0;
+            if (M.pad == nullptr) {
+#pragma unroll
+                for (int i = 0; i < XA_MAXROWS; ++i) padv[i] = 0;
+            }
+        }
         f32x4_t kreg[XA_MAXROWS][2], vreg[XA_MAXROWS][2];
 #pragma unroll
         for (int i = 0; i < XA_MAXROWS; ++i) {
@@ -561,7 +588,7 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_f32_kernel(XaArg
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) *reinterpret_cast<f32x4_t*>(vl + key * 64 + dch * 8 + 4 * hh) = vreg[i][hh];
                 if (dch == 0) {
-                    const bool masked = M.pad != nullptr && M.pad[row0 + key] != 0;
+                    const bool masked = padv[i] != 0;
 #pragma unroll
                     for (int qi = 0; qi < QPB; ++qi) sc[qi][key] = masked ? -65536.0f : part[qi];      // masked_fill(-2^16), :841-845
                 }
@@ -636,6 +663,13 @@ __global__ __launch_bounds__(XA_THREADS) void decode_self_attn_bf16_kernel(const
     const bool fresh = k_new != nullptr;
     const int nrow = (len + 31) >> 5;
     const long col = h * 64 + dch * 8;
+    // the cache row of every key this thread holds comes from the ancestor table: ALL of its entries are requested first (unconditionally,
+    // from a clamped position) -- looked up inside the loop below, each K / V request waited for its own index (round 5: the ISA showed
+    // load, wait, load per row slot: eight dependent round trips instead of two)
+    int ancv[MAXROWS];
+#pragma unroll
+    for (int i = 0; i < MAXROWS; ++i) ancv[i] = anc[(long)r * Tmax + min(i * 32 + kslot, len - 1)];
+    __builtin_amdgcn_sched_barrier(0);
     u32x4_t kreg[MAXROWS];
 #pragma unroll
     for (int i = 0; i < MAXROWS; ++i) {
@@ -643,19 +677,16 @@ __global__ __launch_bounds__(XA_THREADS) void decode_self_attn_bf16_kernel(const
         kreg[i] = u32x4_t{0, 0, 0, 0};
         if (i < nrow && s < len) {
             const bool isnew = fresh && s == len - 1;
-            const long crow = ((long)anc[(long)r * Tmax + s] * Tmax + s) * ldc + col;
+            const long crow = ((long)ancv[i] * Tmax + s) * ldc + col;
             const bf16_t* ksrc = isnew ? k_new + (long)r * ldn + col : kc + crow;
             const bf16_t* vsrc = isnew ? v_new + (long)r * ldn + col : vc + crow;
             kreg[i] = *reinterpret_cast<const u32x4_t*>(ksrc);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vsrc,
                                              (__attribute__((address_space(3))) void*)(vl + (i * 32 + wave * 8) * 128), 16, 0, 0);
-            if (isnew) {                                        // append this step's K / V to the caches (row r itself: anc[r][len - 1] == r)
-                const long nrow_off = ((long)r * Tmax + s) * ldc + col;
-                *reinterpret_cast<u32x4_t*>(kc + nrow_off) = kreg[i];
-                *reinterpret_cast<u32x4_t*>(vc + nrow_off) = *reinterpret_cast<const u32x4_t*>(vsrc);
-            }
         }
     }
+    // (this step's K / V are appended to the caches further down, once the loads above have landed: stored from inside the loop, the
+    // store of the freshly loaded K row made every wave wait for its loads row slot by row slot)
     float qv[8];
     {
         const u32x4_t raw = *reinterpret_cast<const u32x4_t*>(q + (long)r * ldq + col);
@@ -677,6 +708,17 @@ __global__ __launch_bounds__(XA_THREADS) void decode_self_attn_bf16_kernel(const
         if (dch == 0 && key < len) sc[key] = x;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (fresh) {                                                // append this step's K / V to the caches (row r itself: anc[r][len - 1] == r)
+        const int sn = len - 1;
+        if (kslot == (sn & 31)) {
+            const long nrow_off = ((long)r * Tmax + sn) * ldc + col;
+            u32x4_t kn = kreg[0];
+#pragma unroll
+            for (int i = 1; i < MAXROWS; ++i) if ((sn >> 5) == i) kn = kreg[i];
+            *reinterpret_cast<u32x4_t*>(kc + nrow_off) = kn;
+            *reinterpret_cast<u32x4_t*>(vc + nrow_off) = *reinterpret_cast<const u32x4_t*>(v_new + (long)r * ldn + col);
+        }
+    }
     __syncthreads();
     if (wave == 0) {
         float mx = -INFINITY;
