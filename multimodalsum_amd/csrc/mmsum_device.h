@@ -18,6 +18,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// gfx950 only, and not just for the MFMA shapes: the in-launch hand-offs of mmsum_dec_gemm and mmsum_decode_cross_attn (sc1 write-through
+// payload stores, vmcnt(0), a relaxed agent-scope ticket, sc1 loads in the last arriver -- no release / acquire fence) rely on how THIS
+// target lowers relaxed agent-scope atomics (gemm_skinny.hip, decode.hip; stress test: tests/test_kernels_gpu.py::test_handoff_stress).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libmmsum_hip is written for gfx950 (MI355X): its cross-workgroup hand-offs depend on this target's code generation"
+#endif
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;

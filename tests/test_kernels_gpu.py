@@ -1063,6 +1063,52 @@ def test_dec_gemm(M, N, K, epi, k2, f32):
     assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(first, nan=7.0))
 
 
+def test_handoff_stress():
+    """The in-launch hand-offs: mmsum_dec_gemm's split-K slabs and mmsum_decode_cross_attn's entity mean meet in the LAST
+    ARRIVER through write-through stores + a relaxed ticket, without release / acquire fences -- an ordering that rests on this target's
+    code generation.  600 back-to-back replays of a product with 16 slices per column tile (512 one-wave workgroups: slices of a tile on
+    different CUs and XCDs) and 300 of the three-modality cross-attention, all on one workspace each: every replay must be BIT-identical to the
+    first (the reduction order is fixed) and the first must be right; a lost or stale slab, or a ticket left non-zero, shows as a mismatch."""
+    bf = torch.bfloat16
+    M, N, K = 32, 1024, 4096
+    x, w, bias = rnd(M, K, dtype=bf, seed=1), rnd(N, K, dtype=bf, seed=2, std=0.05), rnd(N, seed=3)
+    ws = kn.dec_gemm_workspace(M, N, K, DEV)
+    out = torch.empty(M, N, device=DEV, dtype=bf)
+    kn.dec_gemm(x, w, out, ws, bias=bias)
+    ref = x.double() @ w.double().t() + bias.double()
+    assert float((out.double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-5
+    first = out.clone()
+    bad = 0
+    for _ in range(600):
+        out.zero_()
+        kn.dec_gemm(x, w, out, ws, bias=bias)
+        bad += int(not torch.equal(out, first))
+    assert bad == 0, bad
+    B, H, qpb = 8, 16, 4
+    D = H * 64
+    shapes = [(8, 128), (1, 47), (4, 196)]
+    q = rnd(B * qpb, D, dtype=bf, seed=4)
+    rows = sum(B * n * s_ for n, s_ in shapes)
+    kv = rnd(rows, 2 * D, dtype=bf, seed=5)
+    mods, off = [], 0
+    for n, s_ in shapes:
+        sl = slice(off, off + B * n * s_)
+        mods.append((kv[sl, :D], kv[sl, D:], None, None, n, s_))
+        off += B * n * s_
+    o = torch.empty(3 * B * qpb, D, device=DEV, dtype=bf)
+    xws = kn.decode_cross_attn_workspace(sum(B * n for n, _ in shapes), H, qpb, B, 3, DEV)
+    kn.decode_cross_attn(q, mods, o, xws, B, qpb, H, 0.125)
+    first = o.clone()
+    assert torch.isfinite(first.float()).all()
+    bad = 0
+    for _ in range(300):
+        o.zero_()
+        kn.decode_cross_attn(q, mods, o, xws, B, qpb, H, 0.125)
+        bad += int(not torch.equal(o, first))
+    assert bad == 0, bad
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("bf", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
 @pytest.mark.parametrize("qpb", [4, 2])
 def test_decode_cross_attn(qpb, bf):
