@@ -258,7 +258,7 @@ inline int bn_cgb(int C, int vec) { const int g = C / vec; return g >= 32 ? 32 :
 // MODE 0: sums of (x - pivot, (x - pivot)^2), pivot = row 0 (var = E[(x-p)^2] - E[x-p]^2 does not cancel catastrophically when
 // |mean| >> std).  MODE 1: sums of (dy', dy' * (x - mean)) for the backward pass (dy' = dy where the ReLU passed).
 // grid (channel blocks, row splits); part[split][2][C].
-template <typename T, int MODE>
+template <typename T, int MODE, bool RELU = false>
 __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a, const T* __restrict__ y, const T* __restrict__ x,
                                                          const float* __restrict__ sums, int R, int C, int cgb, int relu,
                                                          float* __restrict__ part, int pH = 0, int pW = 0,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
                 ldv<T, V>(a + o, av[u]);
                 if (MODE == 1) {
                     ldv<T, V>(x + o, xv[u]);
-                    if (relu) ldv<T, V>(y + bn_yrow(r + u * m.lanes, pH, pW) * C + col, yv[u]);
+                    if constexpr (RELU) ldv<T, V>(y + bn_yrow(r + u * m.lanes, pH, pW) * C + col, yv[u]);     // (a run-time test here serialises the rows' loads)
                 }
             }
 #pragma unroll
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
                         s0[j] += wd;
                         s1[j] = fmaf(wd, d, s1[j]);
                     } else {
-                        const float g = (relu && !(yv[u][j] > 0.f)) ? 0.f : av[u][j];
+                        const float g = (RELU && !(yv[u][j] > 0.f)) ? 0.f : av[u][j];
                         s0[j] += g;
                         s1[j] = fmaf(g, xv[u][j] - ref[j], s1[j]);
                     }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
             ldv<T, V>(a + o, av);
             if (MODE == 1) {
                 ldv<T, V>(x + o, xv);
-                if (relu) ldv<T, V>(y + bn_yrow(r, pH, pW) * C + col, yv);
+                if constexpr (RELU) ldv<T, V>(y + bn_yrow(r, pH, pW) * C + col, yv);
             }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const T* __restrict__ a
                     s0[j] += wd;
                     s1[j] = fmaf(wd, d, s1[j]);
                 } else {
-                    const float g = (relu && !(yv[j] > 0.f)) ? 0.f : av[j];
+                    const float g = (RELU && !(yv[j] > 0.f)) ? 0.f : av[j];
                     s0[j] += g;
                     s1[j] = fmaf(g, xv[j] - ref[j], s1[j]);
                 }
@@ -403,7 +403,9 @@ __global__ __launch_bounds__(256) void bn_stats_finish_kernel(const float* __res
 // (MMSUM_GEMM_COLSUM | COLSUM2); every thread turns the sums of its channels into {mean, biased variance} itself, and the first row
 // split's first row lane also WRITES them to `sums` (the backward pass reads them there) and updates the running statistics: nobody
 // reads those three arrays in this launch, so there is no race and no separate statistics launch.
-template <typename T>
+// RES (a residual is added) is a template parameter: as a run-time test around the residual's load it made every row of the
+// "four rows in flight" loop its own load -> wait round (the compiler waits at the join of a branch that holds a load): 3.3 TB/s
+template <typename T, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, float* __restrict__ sums, const float* __restrict__ raw,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ residual, T* __restrict__ y,
@@ -415,28 +417,56 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const int col = (blockIdx.x * cgb + m.cg) * V;
     if (col >= C) return;
     const int Rl = img_window(images, rpi, R).rows;          // rows of the images that run; the statistics keep all R rows as their count
-    float sc[V], sh[V];
+    // per-channel constants of this thread's V channels: every array as 16-byte vector loads issued together (element by element inside
+    // the raw / training branches, the compiler had made V dependent load -> wait -> store rounds of this prologue)
+    float sc[V], sh[V], mean[V], var[V], ga[V], be[V];
+    auto ldf = [](const float* p, float (&v)[V]) {
+#pragma unroll
+        for (int q4 = 0; q4 < V / 4; ++q4) {
+            const f32x4_t t = *reinterpret_cast<const f32x4_t*>(p + 4 * q4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * q4 + e] = t[e];
+        }
+    };
+    auto stf = [](float* p, const float (&v)[V]) {
+#pragma unroll
+        for (int q4 = 0; q4 < V / 4; ++q4) *reinterpret_cast<f32x4_t*>(p + 4 * q4) = f32x4_t{v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]};
+    };
+    ldf(gamma + col, ga);
+    ldf(beta + col, be);
+    if (raw != nullptr) {
+        ldf(raw + col, mean);
+        ldf(raw + C + col, var);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            mean[j] = mean[j] / R;
+            var[j] = fmaxf(var[j] / R - mean[j] * mean[j], 0.f);
+        }
+        if (blockIdx.y == 0 && m.rl == 0) {
+            stf(sums + col, mean);
+            stf(sums + C + col, var);
+            if (running_mean != nullptr && running_var != nullptr) {
+                float rm[V], rv[V];
+                ldf(running_mean + col, rm);
+                ldf(running_var + col, rv);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float unbiased = R > 1 ? var[j] * ((float)R / (float)(R - 1)) : var[j];
+                    rm[j] = (1.f - momentum) * rm[j] + momentum * mean[j];
+                    rv[j] = (1.f - momentum) * rv[j] + momentum * unbiased;
+                }
+                stf(running_mean + col, rm);
+                stf(running_var + col, rv);
+            }
+        }
+    } else {
+        ldf((training ? sums : running_mean) + col, mean);
+        ldf((training ? sums + C : running_var) + col, var);
+    }
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-        float mean, var;
-        if (raw != nullptr) {
-            mean = raw[col + j] / R;
-            var = fmaxf(raw[C + col + j] / R - mean * mean, 0.f);
-            if (blockIdx.y == 0 && m.rl == 0) {
-                sums[col + j] = mean;
-                sums[C + col + j] = var;
-                if (running_mean != nullptr && running_var != nullptr) {
-                    const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
-                    running_mean[col + j] = (1.f - momentum) * running_mean[col + j] + momentum * mean;
-                    running_var[col + j] = (1.f - momentum) * running_var[col + j] + momentum * unbiased;
-                }
-            }
-        } else {
-            mean = training ? sums[col + j] : running_mean[col + j];
-            var = training ? sums[C + col + j] : running_var[col + j];
-        }
-        sc[j] = rsqrtf(var + eps) * gamma[col + j];
-        sh[j] = beta[col + j] - mean * sc[j];
+        sc[j] = rsqrtf(var[j] + eps) * ga[j];
+        sh[j] = be[j] - mean[j] * sc[j];
     }
     const int step = m.lanes * gridDim.y;
     constexpr int UN = 4;
@@ -447,14 +477,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         for (int u = 0; u < UN; ++u) {
             const long o = (long)(r + u * step) * C + col;
             ldv<T, V>(x + o, xv[u]);
-            if (residual) ldv<T, V>(residual + o, rv[u]);
+            if constexpr (RES) ldv<T, V>(residual + o, rv[u]);
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 float o = fmaf(xv[u][j], sc[j], sh[j]);
-                if (residual) o += rv[u][j];
+                if constexpr (RES) o += rv[u][j];
                 xv[u][j] = relu ? fmaxf(o, 0.f) : o;
             }
             stv<T, V>(y + bn_yrow(r + u * step, pH, pW) * C + col, xv[u]);
@@ -464,11 +494,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         float xv[V], rv[V];
         const long o = (long)r * C + col;
         ldv<T, V>(x + o, xv);
-        if (residual) ldv<T, V>(residual + o, rv);
+        if constexpr (RES) ldv<T, V>(residual + o, rv);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             float t = fmaf(xv[j], sc[j], sh[j]);
-            if (residual) t += rv[j];
+            if constexpr (RES) t += rv[j];
             xv[j] = relu ? fmaxf(t, 0.f) : t;
         }
         stv<T, V>(y + bn_yrow(r, pH, pW) * C + col, xv);
@@ -504,7 +534,7 @@ __global__ void bn_stats_from_sums_kernel(const float* __restrict__ raw, int R, 
 }
 
 // dx = gamma rstd (g - sum(g)/R - xhat sum(g xhat)/R) = k g + kx x + k0 with per-channel constants; dresidual = g
-template <typename T>
+template <typename T, bool RELU, bool DRES>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y, const T* __restrict__ x,
                                                            const float* __restrict__ sums, const float* __restrict__ dsums,
                                                            const float* __restrict__ gamma, T* __restrict__ dx, T* __restrict__ dresidual,
@@ -538,7 +568,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 const long o = (long)(r + u * step) * C + col;
                 ldv<T, V>(dy + o, g[u]);
                 ldv<T, V>(x + o, xv[u]);
-                if (relu) ldv<T, V>(y + bn_yrow(r + u * step, pH, pW) * C + col, yv[u]);
+                if constexpr (RELU) ldv<T, V>(y + bn_yrow(r + u * step, pH, pW) * C + col, yv[u]);
             }
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
@@ -546,11 +576,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                 const float wm = (r + u * step >= win.rep0) ? win.mult : 1.f;
 #pragma unroll
                 for (int j = 0; j < V; ++j) {
-                    if (relu && !(yv[u][j] > 0.f)) g[u][j] = 0.f;
+                    if constexpr (RELU) if (!(yv[u][j] > 0.f)) g[u][j] = 0.f;
                     xv[u][j] = fmaf(k[j], g[u][j], wm * fmaf(kx[j], xv[u][j], k0[j]));
                 }
                 stv<T, V>(dx + bn_yrow(r + u * step, dxH, dxW) * C + col, xv[u]);
-                if (dresidual) stv<T, V>(dresidual + o, g[u]);
+                if constexpr (DRES) stv<T, V>(dresidual + o, g[u]);
             }
         }
         for (; r < win.rows; r += step) {
@@ -558,15 +588,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             const long o = (long)r * C + col;
             ldv<T, V>(dy + o, g);
             ldv<T, V>(x + o, xv);
-            if (relu) ldv<T, V>(y + bn_yrow(r, pH, pW) * C + col, yv);
+            if constexpr (RELU) ldv<T, V>(y + bn_yrow(r, pH, pW) * C + col, yv);
             const float wm = (r >= win.rep0) ? win.mult : 1.f;
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                if (relu && !(yv[j] > 0.f)) g[j] = 0.f;
+                if constexpr (RELU) if (!(yv[j] > 0.f)) g[j] = 0.f;
                 xv[j] = fmaf(k[j], g[j], wm * fmaf(kx[j], xv[j], k0[j]));
             }
             stv<T, V>(dx + bn_yrow(r, dxH, dxW) * C + col, xv);
-            if (dresidual) stv<T, V>(dresidual + o, g);
+            if constexpr (DRES) stv<T, V>(dresidual + o, g);
         }
     }
     // parameter gradients: dbeta = sum dy', dgamma = sum dy'*xhat (accumulate into the f32 arena)
@@ -1022,8 +1052,13 @@ extern "C" int mmsum_bn_apply(int dtype, const void* x, float* sums, const float
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)x, sums, raw, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)),
-              (bn_apply_kernel<float><<<grid, block, 0, s>>>((const float*)x, sums, raw, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)));
+    if (residual != nullptr) {
+        DT_SWITCH(dtype, (bn_apply_kernel<bf16_t, true><<<grid, block, 0, s>>>((const bf16_t*)x, sums, raw, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)),
+                  (bn_apply_kernel<float, true><<<grid, block, 0, s>>>((const float*)x, sums, raw, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)));
+    } else {
+        DT_SWITCH(dtype, (bn_apply_kernel<bf16_t, false><<<grid, block, 0, s>>>((const bf16_t*)x, sums, raw, gamma, beta, (const bf16_t*)residual, (bf16_t*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)),
+                  (bn_apply_kernel<float, false><<<grid, block, 0, s>>>((const float*)x, sums, raw, gamma, beta, (const float*)residual, (float*)y, running_mean, running_var, R, C, cgb, eps, momentum, relu, training, pad_H, pad_W, images, rows_per_image)));
+    }
     if (training && raw == nullptr && running_mean && running_var)
         bn_running_kernel<<<dim3((C + 255) / 256), dim3(256), 0, s>>>(sums, running_mean, running_var, R, C, momentum);
     return ok();
@@ -1041,8 +1076,13 @@ extern "C" int mmsum_bn_bwd_reduce(int dtype, const void* dy, const void* y, con
     const int splits = bn_splits(R, 256 / cgb, cblocks);
     const dim3 grid(cblocks, splits), block(256);
     float* part = (float*)workspace;
-    DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)),
-              (bn_partial_kernel<float, 1><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)));
+    if (relu) {
+        DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1, true><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)),
+                  (bn_partial_kernel<float, 1, true><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)));
+    } else {
+        DT_SWITCH(dtype, (bn_partial_kernel<bf16_t, 1, false><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)),
+                  (bn_partial_kernel<float, 1, false><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, R, C, cgb, relu, part, pad_H, pad_W, images, rows_per_image)));
+    }
     bn_finish_kernel<<<dim3((2 * C + 15) / 16), dim3(256), 0, s>>>(part, splits, C, sums, eps, dsums);
     return ok();
 }
@@ -1059,8 +1099,12 @@ extern "C" int mmsum_bn_bwd_apply(int dtype, const void* dy, const void* y, cons
     hipStream_t s = (hipStream_t)stream;
     const int cgb = bn_cgb(C, vec), cblocks = (C / vec + cgb - 1) / cgb;
     const dim3 grid(cblocks, bn_row_blocks(R, 256 / cgb, cblocks)), block(256);
-    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W, images, rows_per_image)),
-              (bn_bwd_apply_kernel<float><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W, images, rows_per_image)));
+#define BN_BWD_APPLY(RL, DR)                                                                                                                          \
+    DT_SWITCH(dtype, (bn_bwd_apply_kernel<bf16_t, RL, DR><<<grid, block, 0, s>>>((const bf16_t*)dy, (const bf16_t*)y, (const bf16_t*)x, sums, dsums, gamma, (bf16_t*)dx, (bf16_t*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W, images, rows_per_image)), \
+              (bn_bwd_apply_kernel<float, RL, DR><<<grid, block, 0, s>>>((const float*)dy, (const float*)y, (const float*)x, sums, dsums, gamma, (float*)dx, (float*)dresidual, dgamma, dbeta, R, C, cgb, eps, relu, pad_H, pad_W, dx_pad_H, dx_pad_W, images, rows_per_image)))
+    if (relu) { if (dresidual) { BN_BWD_APPLY(true, true); } else { BN_BWD_APPLY(true, false); } }
+    else { if (dresidual) { BN_BWD_APPLY(false, true); } else { BN_BWD_APPLY(false, false); } }
+#undef BN_BWD_APPLY
     return ok();
 }
 
