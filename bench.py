@@ -269,7 +269,7 @@ def build(args, device):
     if getattr(args, "diag_stub_resnet", False) and args.workload in ("multimodal", "text_table"):
         e = model._engine
 
-        def img_fwd(img, out=None):
+        def img_fwd(img, out=None, img_mask=None):
             y = out if out is not None else e.empty(img.shape[0] * 196, cfg.d_model)
             y.zero_()
             return y, None

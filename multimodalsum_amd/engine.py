@@ -955,7 +955,7 @@ class Engine:
         c = NS(n=n, blocks=[])
         img = img.contiguous()
         ip = None
-        if img_mask is not None and os.environ.get("MMSUM_IMAGE_DEDUPE") != "0":
+        if img_mask is not None and n <= 8192 and os.environ.get("MMSUM_IMAGE_DEDUPE") != "0":      # (mmsum_image_plan plans up to 8192 slots)
             kinds, positions = self._image_row_kinds(Hh, Ww)
             ip = kn.image_plan(img, img_mask, kn.ImagePlan(n, positions, kinds, img.device))
         self._ip = c.ip = ip
