@@ -253,6 +253,19 @@ __device__ __forceinline__ long bn_yrow(int r, int pH, int pW) {
 // thread -> (channel group, row lane) of a block that spans `cgb` channel groups
 struct BnMap { int cg, rl, lanes; };
 __device__ __forceinline__ BnMap bn_map(int cgb) { return BnMap{(int)threadIdx.x % cgb, (int)threadIdx.x / cgb, 256 / cgb}; }
+// {sum x, sum x^2} over R rows -> {mean, biased variance}, and the running-statistics update: ONE spelling with explicit fused operations,
+// shared by every kernel that does either (the apply kernel's in-launch form must equal mmsum_bn_stats_from_sums to the last bit; left to
+// the compiler's contraction, the same source expression came out differently in different kernels)
+__device__ __forceinline__ void bn_mean_var(float sum, float sumsq, int R, float& mean, float& var) {
+    const float invR = 1.f / (float)R;
+    mean = sum * invR;
+    var = fmaxf(fmaf(-mean, mean, sumsq * invR), 0.f);
+}
+__device__ __forceinline__ void bn_running_update(float& rm, float& rv, float mean, float var, int R, float momentum) {
+    const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
+    rm = fmaf(momentum, mean, (1.f - momentum) * rm);
+    rv = fmaf(momentum, unbiased, (1.f - momentum) * rv);
+}
 inline int bn_cgb(int C, int vec) { const int g = C / vec; return g >= 32 ? 32 : (g >= 16 ? 16 : (g >= 8 ? 8 : (g >= 4 ? 4 : (g >= 2 ? 2 : 1)))); }
 
 // MODE 0: sums of (x - pivot, (x - pivot)^2), pivot = row 0 (var = E[(x-p)^2] - E[x-p]^2 does not cancel catastrophically when
@@ -438,10 +451,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         ldf(raw + col, mean);
         ldf(raw + C + col, var);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            mean[j] = mean[j] / R;
-            var[j] = fmaxf(var[j] / R - mean[j] * mean[j], 0.f);
-        }
+        for (int j = 0; j < V; ++j) bn_mean_var(mean[j], var[j], R, mean[j], var[j]);
         if (blockIdx.y == 0 && m.rl == 0) {
             stf(sums + col, mean);
             stf(sums + C + col, var);
@@ -450,11 +460,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                 ldf(running_mean + col, rm);
                 ldf(running_var + col, rv);
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    const float unbiased = R > 1 ? var[j] * ((float)R / (float)(R - 1)) : var[j];
-                    rm[j] = (1.f - momentum) * rm[j] + momentum * mean[j];
-                    rv[j] = (1.f - momentum) * rv[j] + momentum * unbiased;
-                }
+                for (int j = 0; j < V; ++j) bn_running_update(rm[j], rv[j], mean[j], var[j], R, momentum);
                 stf(running_mean + col, rm);
                 stf(running_var + col, rv);
             }
@@ -509,11 +515,10 @@ __global__ void bn_running_kernel(const float* __restrict__ sums, float* __restr
                                   int R, int C, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mean = sums[c];
-    const float var = sums[C + c];
-    const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    float rm = running_mean[c], rv = running_var[c];
+    bn_running_update(rm, rv, sums[c], sums[C + c], R, momentum);
+    running_mean[c] = rm;
+    running_var[c] = rv;
 }
 
 // Statistics that arrive as plain column sums (the convolution's GEMM epilogue leaves raw = {sum x, sum x^2} of the values it
@@ -522,14 +527,15 @@ __global__ void bn_stats_from_sums_kernel(const float* __restrict__ raw, int R, 
                                           float* __restrict__ running_var, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mean = raw[c] / R;
-    const float var = fmaxf(raw[C + c] / R - mean * mean, 0.f);
+    float mean, var;
+    bn_mean_var(raw[c], raw[C + c], R, mean, var);
     sums[c] = mean;
     sums[C + c] = var;
     if (running_mean != nullptr && running_var != nullptr) {
-        const float unbiased = R > 1 ? var * ((float)R / (float)(R - 1)) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+        float rm = running_mean[c], rv = running_var[c];
+        bn_running_update(rm, rv, mean, var, R, momentum);
+        running_mean[c] = rm;
+        running_var[c] = rv;
     }
 }
 
