@@ -88,6 +88,9 @@ def _run_and_check(layers, Bz, max_length, dtype, tie, enc_tol, independent=True
             clear = next((i for i, m in enumerate(margins) if m < 4 * tie), len(margins))
             if clear == len(margins):           # the oracle's own ranking never came near a tie: the independent runs must agree outright
                 assert min(same) == L, ("ids differ from the oracle's independent run although it met no near-tie", same, L)
+            # (a near-tie at ANY step can change which beam survives, and with it earlier tokens of the final hypothesis: a prefix rule would
+            # be unsound; where near-ties occur the guided check above is what holds the search, and the fixture of
+            # test_generation_ids_equal_the_reference_at_config5_size is the case chosen to have none)
             st.update(clear=clear, oracle_steps=len(margins))
     print("generation %d+%d layers, max_length %d, %s: guided check over %d steps: worst candidate-score deviation %.2e nats, worst passed-over "
           "margin %.2e; ids equal to the oracle's independent run for %s of %d tokens (its first margin below %.0e at step %s)"
@@ -98,26 +101,29 @@ def _run_and_check(layers, Bz, max_length, dtype, tie, enc_tol, independent=True
 
 def test_generation_f32_max_length_128_at_bart_large_width():
     """BASELINE config 5's lengths: 8 reviews x 128 tokens + table + images, num_beams 4, no_repeat_ngram_size 3, max_length 128, at
-    BART-large width (D 1024, H 16, F 4096, V 50265; 2 + 2 layers), f32 compute mode.  TIE = 2e-3 nats: f32 logits of two summation
-    orders (1e-5 relative of |logit| <= ~30) accumulated into running scores over 127 steps."""
-    same, L, st = _run_and_check(2, 2, 128, torch.float32, tie=2e-3, enc_tol=1e-3)
+    BART-large width (D 1024, H 16, F 4096, V 50265; 2 + 2 layers), f32 compute mode.  TIE = 5e-4 nats (measured deviation 6e-5: f32 logits
+    of two summation orders accumulated into running scores over 127 steps)."""
+    same, L, st = _run_and_check(2, 2, 128, torch.float32, tie=5e-4, enc_tol=1e-3)
     assert L >= 100 and st["steps"] == 127 and min(same) >= 4
 
 
 def test_generation_f32_at_full_depth():
     """The 12 + 12-layer model (cfg/bart-large.json as it is), one business, max_length 32, f32 compute mode: the decode path at the
-    depth test.py runs (24 self-attention caches, 12 cross-attention K / V sets, the cache walk through every layer).  TIE = 3e-2:
+    depth test.py runs (24 self-attention caches, 12 cross-attention K / V sets, the cache walk through every layer).  TIE = 1e-2 (measured 1.1e-3):
     the post-LN stack amplifies f32 rounding ~1e4 times at this depth -- measured: scores of -50 that differ from
     the oracle's by a common 5e-3 (1e-4 relative), i.e. the running beam score, while the candidates' order is the oracle's."""
-    same, L, st = _run_and_check(12, 1, 32, torch.float32, tie=3e-2, enc_tol=2e-3)
+    same, L, st = _run_and_check(12, 1, 32, torch.float32, tie=1e-2, enc_tol=2e-3)
     assert L >= 24 and st["steps"] == 31
 
 
-def test_generation_bf16_tokens_equal_to_the_oracle():
-    """The timed mode (bf16 kernels, f32 final LayerNorm output and f32 logits): the step-by-step rule of
-    tests/test_timed_path_gpu.py (TIE 0.4 nats) over max_length 64, and the count of leading tokens that equal the fp32 oracle's
-    (reported; at least the first four, which are far from any tie)."""
-    same, L, st = _run_and_check(2, 2, 64, torch.bfloat16, tie=0.4, enc_tol=5e-2)
+def test_generation_bf16_guided_against_the_oracle():
+    """The timed mode (bf16 kernels, f32 final LayerNorm output and f32 logits) is NOT held to token-id equality: its candidate scores are
+    ~0.25 nats from the fp32 oracle's (measured), more than most ranking gaps.  What is held: the step-by-step guided rule of
+    tests/test_timed_path_gpu.py at TIE 0.35 nats over max_length 64 (same hypotheses at every step, every returned candidate within TIE of the
+    oracle's score, nothing better than TIE passed over), and the first four tokens, which are far from any tie; the count of leading tokens
+    equal to the oracle's independent run is reported.  Token-id equality is the f32 mode's property
+    (test_generation_ids_equal_the_reference_at_config5_size)."""
+    same, L, st = _run_and_check(2, 2, 64, torch.bfloat16, tie=0.35, enc_tol=5e-2)
     assert min(same) >= 4 and st["steps"] == 63
 
 
