@@ -324,42 +324,7 @@ class Engine:
     def splitk(self, M, N, Kred):
         return splitk_rule(M, N, Kred, bf16=self.dtype == torch.bfloat16, deterministic=self.deterministic)
 
-    # ---- small batches: weight gradients on a second stream ---------------------------------------------------------------------
-    # With few rows per step (the reference's own batch sizes: 1 - 8 businesses per GPU) a product is 36 - 144 tiles on 256 CUs and the
-    # step's ~2,400 launches run one after the other.  The weight gradient of a Linear depends on nothing that follows it in the
-    # backward pass but the optimiser, so it is issued on a side stream (a parallel branch of the captured backward graph) and runs
-    # beside the input-gradient chain; decoder_bwd / encoder_bwd / lm_head_bwd join before they return.  Large batches fill the chip
-    # with every launch (persistent 256-workgroup kernels): they keep the single stream.
-    WGRAD_SIDE_MAX_ROWS = 32768
-
-    def _wgrad_side(self, rows):
-        if rows > self.WGRAD_SIDE_MAX_ROWS or self.device.type != "cuda" or os.environ.get("MMSUM_WGRAD_STREAM") == "0":
-            return None
-        if getattr(self, "_wgrad_stream", None) is None:
-            self._wgrad_stream = torch.cuda.Stream(device=self.device)
-            self._wgrad_keep = []
-        cur = torch.cuda.current_stream()
-        if cur == self._wgrad_stream or (getattr(self, "_side_stream", None) is not None and cur == self._side_stream):
-            return None                    # already on a branch (the image / table backward): stay there
-        return self._wgrad_stream
-
-    def join_wgrads(self):
-        """The launching stream waits for the weight gradients issued on the side stream since the last join."""
-        keep = getattr(self, "_wgrad_keep", None)
-        if keep:
-            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
-            keep.clear()                   # (operands were held so that the allocator could not hand their memory to the main stream meanwhile)
-
     def wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
-        side = self._wgrad_side(dy.shape[0])
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream())
-            self._wgrad_keep.append((dy, x, alpha_dev, live))
-            with torch.cuda.stream(side):
-                return self._wgrad(dy, x, gname, gview, bias_g, live, alpha_dev)
-        return self._wgrad(dy, x, gname, gview, bias_g, live, alpha_dev)
-
-    def _wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
         """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena (live: device count of the rows R).
         bias_g (f32 [N_out], optional) += column sums of dy, the bias gradient of the same Linear: inside the weight-gradient
         kernel where it can carry them (bf16 four-wave TN kernel: the sums come from the operand tiles it stages anyway), by the
@@ -461,7 +426,6 @@ class Engine:
             dx = self._ffn_block_bwd(b + "layers.%d." % i, fc, dx)
             dx = self._self_block_bwd(b + "layers.%d." % i, lc, dx)
         if lo > 0:
-            self.join_wgrads()
             return dx
         if c.maps is not None:
             dx = kn.rows_gather(dx, self.empty(c.Bn * c.S, cfg.d_model), c.maps.p2c)
@@ -472,7 +436,6 @@ class Engine:
                         salt=self.salt)
         self.touch(self.bp + "model.shared.weight", b + "embed_positions.weight", b + "layernorm_embedding.weight",
                    b + "layernorm_embedding.bias")
-        self.join_wgrads()
         return None
 
     # ---- shared blocks ----------------------------------------------------------------------------
@@ -647,7 +610,6 @@ class Engine:
             dx = self._cross_block_bwd(lb, cc, c, dx, dmem, first=(i == L - 1))
             dx = self._self_block_bwd(lb, sc, dx)
         if lo > 0:
-            self.join_wgrads()
             return dx, dmem
         has_r = c.rd is not None
         kn.embed_ln_bwd(dx, c.ids, a.w(self.bp + "model.shared.weight"), a.w(b + "embed_positions.weight"), c.rd,
@@ -662,7 +624,6 @@ class Engine:
             self.touch(b + "rating_embeddings")
         if c.mem_maps is not None:
             dmem = kn.rows_gather(dmem, self.empty(c.layout.rows, cfg.d_model), c.mem_maps.p2c)
-        self.join_wgrads()
         return dmem
 
     def _cross_block_fwd(self, lb, x, dc):
@@ -788,7 +749,6 @@ class Engine:
             kn.gemm(dlogits[:, :V], self.arena.w(name), dh, b_t=True, alpha_dev=upstream)
         self.wgrad(dlogits[:, :V], h, name, alpha_dev=upstream)
         self.touch(name)
-        self.join_wgrads()       # (the tied embedding's gradient also receives the embedding kernels' contributions later in the pass)
         return dh
 
     def lm_loss_fwd(self, h, labels, smoothing, n_segments):
