@@ -202,3 +202,29 @@ def test_generation_ids_equal_the_reference_at_config5_size(golden_dir):
     assert torch.equal(f32, ref), (f32[:, :16], ref[:, :16], [int((f32[b] == ref[b]).long().cumprod(0).sum()) for b in range(ref.shape[0])])
     assert min(same16) >= 4, same16
 
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_generation_with_more_than_64_hypothesis_rows(dtype):
+    """17 businesses x 4 beams = 68 hypothesis rows -- past the 32 rows of the decode step's own kernels (the general step runs) and
+    past the 64 rows one call of the f32-activation LM head takes (bf16 mode: mmsum_gemm's MMSUM_GEMM_A_F32 form goes through in row chunks;
+    before round 5 this raised MMSUM_ERR_BAD_DTYPE).  The businesses alternate between two inputs: every copy of an input must come out with
+    the same ids (hypothesis rows do not interact), equal to the ids a two-business call returns for it on the same path-independent f32 mode;
+    in bf16 the two-business call takes the fast step, whose rounding differs: compared over the first four tokens only."""
+    cfg, ocfg, sd, model, ids, text_m, table_h, table_m, img_h, img_m = _setup(2, 2, dtype)
+    N, S, Bz = 8, 128, 17
+    kw = dict(num_beams=4, max_length=12, no_repeat_ngram_size=3, early_stopping=True, length_penalty=1.0)
+    pick = torch.arange(Bz) % 2
+    cast = (lambda t: t.to(DEV).to(dtype))
+    with torch.no_grad():
+        enc2 = model.model.encoder(input_ids=ids.view(-1, S).to(DEV), attention_mask=text_m.view(-1, S).to(DEV))[0].view(2, N, S, -1)
+        small = model.generate(enc2, text_m.to(DEV), cast(table_h), table_m.to(DEV), cast(img_h), img_m.to(DEV), rating_diff=torch.zeros(2, 1, device=DEV),
+                               decoder_start_token_id=cfg.bos_token_id, **kw).cpu()
+        big = model.generate(enc2[pick.to(DEV)].contiguous(), text_m[pick].to(DEV), cast(table_h[pick]), table_m[pick].to(DEV), cast(img_h[pick]), img_m[pick].to(DEV),
+                             rating_diff=torch.zeros(Bz, 1, device=DEV), decoder_start_token_id=cfg.bos_token_id, **kw).cpu()
+    assert big.shape[0] == Bz
+    for b in range(Bz):
+        assert torch.equal(big[b], big[int(pick[b])]), (b, big[b], big[int(pick[b])])              # copies of one input agree among themselves
+    L = min(big.shape[1], small.shape[1])
+    n = L if dtype == torch.float32 else 4
+    assert torch.equal(big[:2, :n], small[:, :n]), (big[:2, :L], small[:, :L])
+
