@@ -1071,6 +1071,15 @@ __device__ __forceinline__ void read_key_mask(const int* slots, int& extent, int
 // step between a thread's rows is a scalar offset).  With a row map (compact matrices) the descriptor covers the matrix and
 // every pass takes its physical row from RowIdx -- looked up one tile AHEAD, so the tile's loads do not wait for the map --
 // with an out-of-range offset for rows that do not exist.  THREADS / 8 rows per pass.
+// Slab 1 (columns 32..63) of a staged tile starts 64 bytes past a multiple of 128.  ds_write_b128 is served in groups of 8 contiguous
+// lanes over 32 four-byte banks, and a group of commit() is one row: lanes 0-3 write its 64 bytes of slab 0, lanes 4-7 those of slab 1.
+// With slab 1 at a multiple of 128 bytes from slab 0 the two halves of every group met in the same 16 banks (a 2-way conflict on every
+// staging store: SQ_LDS_BANK_CONFLICT = 3.775e7 cycles per launch in forward AND dQ, 15 - 25 % of the LDS-array cycles,
+// profiles/r05_attention_pmc_B128.txt); skewed by 64 bytes they cover all 32.  The reads address one slab at a time: a constant
+// offset only rotates their banks.  A tile is padded to a multiple of 128 bytes again.
+constexpr int SLAB_SKEW = 64, TR_TILE_PAD = 128;
+__host__ __device__ constexpr int slab_stride(int rows) { return rows * SLAB_BYTES + SLAB_SKEW; }
+__host__ __device__ constexpr int tr_tile_bytes(int rows) { return rows * HD * 2 + TR_TILE_PAD; }
 template <int ROWS>
 struct RowIdx {
     static constexpr int NIT = ROWS * 8 / ATT_THREADS;
@@ -1108,7 +1117,7 @@ struct BufTile {
     }
     __device__ __forceinline__ void commit(char* lds, int tid) const {
         const int r = tid >> 3, cc = tid & 7;
-        char* p = lds + (cc >> 2) * (ROWS * SLAB_BYTES) + slab_off(r, cc & 3);
+        char* p = lds + (cc >> 2) * slab_stride(ROWS) + slab_off(r, cc & 3);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x4_t*>(p + it * (ATT_THREADS / 8) * SLAB_BYTES) = v[it];     // (r + 32 it) >> 2 keeps r's swizzle
     }
@@ -1130,7 +1139,7 @@ __device__ __forceinline__ void scores_tr(f32x16_t (&sacc)[NKB], const char* kti
         sacc[kb] = zero_acc();
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
-            const Frag a = lds_frag_o(ktile + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+            const Frag a = lds_frag_o(ktile + sl * slab_stride(SPAD) + kb * 32 * SLAB_BYTES, fo);
             mma_slab<bf16_t>(sacc[kb], a, qf[sl]);
         }
     }
@@ -1203,7 +1212,7 @@ __device__ __forceinline__ int active_blocks(int slen, int wave) {
 // barrier ends the iteration.
 template <int NKB> struct TrStage {
     static constexpr int SPAD = NKB * 32;
-    static constexpr int TILE = SPAD * HD * 2;
+    static constexpr int TILE = tr_tile_bytes(SPAD);
     static constexpr int BYTES = 2 * TILE + SPAD * 4 + 32;
     char* base;
     __device__ __forceinline__ char* k() const { return base; }
@@ -1298,7 +1307,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
                     const bf16x8_t pb = pack8(sacc[kb], s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        mfma16(tmp[db], tr_frag(st.v() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                        mfma16(tmp[db], tr_frag(st.v() + db * slab_stride(SPAD) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
                 }
             }
 #pragma unroll
@@ -1446,7 +1455,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_fwd_chunk_kernel(mmsum
                     const bf16x8_t pb = pack8(sacc[kb], s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        mfma16(eacc[db], tr_frag(st.v() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                        mfma16(eacc[db], tr_frag(st.v() + db * slab_stride(SPAD) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
                 }
             }
         });
@@ -1564,7 +1573,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    const Frag a = lds_frag_o(st.v() + sl * slab_stride(SPAD) + kb * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
@@ -1583,7 +1592,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    const Frag a = lds_frag_o(st.v() + sl * slab_stride(SPAD) + kb * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
@@ -1593,7 +1602,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                     const bf16x8_t sb = pack8(dpk, s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        mfma16(dqacc[db], tr_frag(st.k() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
+                        mfma16(dqacc[db], tr_frag(st.k() + db * slab_stride(SPAD) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
                 }
             }
         });
@@ -1678,7 +1687,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_sha
                         const bf16x8_t pb = pack8(sacc[kb], s2);
 #pragma unroll
                         for (int db = 0; db < 2; ++db)
-                            mfma16(oacc[db], tr_frag(st.v() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                            mfma16(oacc[db], tr_frag(st.v() + db * slab_stride(SPAD) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
                     }
                 }
 #pragma unroll
@@ -1767,7 +1776,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                     f32x16_t dpk = zero_acc();
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl) {
-                        const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                        const Frag a = lds_frag_o(st.v() + sl * slab_stride(SPAD) + kb * 32 * SLAB_BYTES, fo);
                         mma_slab<T>(dpk, a, dof[sl]);
                     }
 #pragma unroll
@@ -1785,7 +1794,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                     f32x16_t dpk = zero_acc();
 #pragma unroll
                     for (int sl = 0; sl < 2; ++sl) {
-                        const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                        const Frag a = lds_frag_o(st.v() + sl * slab_stride(SPAD) + kb * 32 * SLAB_BYTES, fo);
                         mma_slab<T>(dpk, a, dof[sl]);
                     }
 #pragma unroll
@@ -1795,7 +1804,7 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
                         const bf16x8_t sb = pack8(dpk, s2);
 #pragma unroll
                         for (int db = 0; db < 2; ++db)
-                            mfma16(dqacc[db], tr_frag(st.k() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
+                            mfma16(dqacc[db], tr_frag(st.k() + db * slab_stride(SPAD) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
                     }
                 }
             });
@@ -1820,7 +1829,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
     constexpr int TQ = 128;                                  // query rows per staged chunk: a whole query block per iteration
     constexpr int NOWN = 1;                                  // one key block per wave; entities of more than 128 keys take gridDim.z rounds of four blocks
     const int kb0 = blockIdx.z * 4;
-    constexpr int QT_TILE = TQ * HD * 2;
+    constexpr int QT_TILE = tr_tile_bytes(TQ);
     constexpr int STAGE = 2 * QT_TILE + 2 * TQ * 4;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1928,9 +1937,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
                 f32x16_t s = zero_acc(), dp = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    const Frag aq = lds_frag_o(qn + sl * (TQ * SLAB_BYTES) + qq * 32 * SLAB_BYTES, fo);
+                    const Frag aq = lds_frag_o(qn + sl * slab_stride(TQ) + qq * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(s, aq, kf[o][sl]);
-                    const Frag ad = lds_frag_o(don + sl * (TQ * SLAB_BYTES) + qq * 32 * SLAB_BYTES, fo);
+                    const Frag ad = lds_frag_o(don + sl * slab_stride(TQ) + qq * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dp, ad, vf[o][sl]);
                 }
 #pragma unroll
@@ -1952,8 +1961,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
                     const bf16x8_t pb = pack8(s, s2), sb = pack8(dp, s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
-                        mfma16(dvacc[o][db], tr_frag(don + db * (TQ * SLAB_BYTES) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
-                        mfma16(dkacc[o][db], tr_frag(qn + db * (TQ * SLAB_BYTES) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
+                        mfma16(dvacc[o][db], tr_frag(don + db * slab_stride(TQ) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), pb);
+                        mfma16(dkacc[o][db], tr_frag(qn + db * slab_stride(TQ) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), sb);
                     }
                 }
             }
@@ -1993,7 +2002,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_self_kernel(mmsum_
     typedef bf16_t T;
     static_assert(NKB <= 4, "one key block per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SPAD = NKB * 32, TQ = 128, QT_TILE = TQ * HD * 2, XROW = 264;
+    constexpr int SPAD = NKB * 32, TQ = 128, QT_TILE = tr_tile_bytes(TQ), XROW = 264;
     typedef TrStage<NKB> Stage;
     constexpr int XOFF = ((Stage::BYTES > 2 * QT_TILE ? Stage::BYTES : 2 * QT_TILE) + 15) & ~15;
     const Stage st{smem};
@@ -2080,7 +2089,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_self_kernel(mmsum_
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    const Frag a = lds_frag_o(st.v() + sl * slab_stride(SPAD) + kb * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
@@ -2093,7 +2102,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_self_kernel(mmsum_
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
-                    const Frag a = lds_frag_o(st.v() + sl * (SPAD * SLAB_BYTES) + kb * 32 * SLAB_BYTES, fo);
+                    const Frag a = lds_frag_o(st.v() + sl * slab_stride(SPAD) + kb * 32 * SLAB_BYTES, fo);
                     mma_slab<T>(dpk, a, dof[sl]);
                 }
 #pragma unroll
@@ -2103,7 +2112,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_self_kernel(mmsum_
                     dspk[kb][s2] = pack8(dpk, s2);
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
-                        mfma16(dqacc[db], tr_frag(st.k() + db * (SPAD * SLAB_BYTES) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), dspk[kb][s2]);
+                        mfma16(dqacc[db], tr_frag(st.k() + db * slab_stride(SPAD) + (kb * 32 + 16 * s2) * SLAB_BYTES, tro), dspk[kb][s2]);
                 }
             }
         });
@@ -2134,7 +2143,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_self_kernel(mmsum_
                 const bf16x8_t b = __builtin_bit_cast(bf16x8_t, w);
 #pragma unroll
                 for (int db = 0; db < 2; ++db)
-                    mfma16(acc[db], tr_frag(tile + db * (TQ * SLAB_BYTES) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), b);
+                    mfma16(acc[db], tr_frag(tile + db * slab_stride(TQ) + (qq * 32 + 16 * s2) * SLAB_BYTES, tro), b);
             }
         }
     };
@@ -2200,15 +2209,15 @@ template <typename T> size_t pipe_lds(int nkb, int ntiles) {
 // Self-attention: one entity per sequence, attended by that sequence's one query block (the merged backward kernel)
 inline bool self_attention(const mmsum_attn_desc& d) { return d.N == 1 && d.qpb == 1 && !d.exclude_self && d.S <= 128 && d.T <= 128; }
 inline size_t self_lds(int nkb) {
-    const size_t stage = (size_t)2 * nkb * 32 * HD * 2 + nkb * 32 * sizeof(float) + 32, tiles = 2 * (size_t)128 * HD * 2;
+    const size_t stage = (size_t)2 * tr_tile_bytes(nkb * 32) + nkb * 32 * sizeof(float) + 32, tiles = 2 * (size_t)tr_tile_bytes(128);
     const size_t xoff = ((stage > tiles ? stage : tiles) + 15) & ~(size_t)15, x = (size_t)nkb * 32 * 264;
     return xoff + (x > 4 * (size_t)OUT_STAGE_BYTES ? x : 4 * (size_t)OUT_STAGE_BYTES);
 }
 inline bool shared_entity(const mmsum_attn_desc& d) { return d.N == 1 && d.qpb > 1 && !d.exclude_self && !d.causal; }
 inline int shared_splits(const mmsum_attn_desc& d) { return d.qpb % 3 == 0 ? 3 : 1; }
-template <typename T> size_t shared_lds(int nkb) { return (size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 32 + 4 * (size_t)OUT_STAGE_BYTES; }
+template <typename T> size_t shared_lds(int nkb) { return (size_t)2 * tr_tile_bytes(nkb * 32) + nkb * 32 * sizeof(float) + 32 + 4 * (size_t)OUT_STAGE_BYTES; }
 template <typename T> size_t tr_lds(int nkb) {
-    const size_t need = 2 * ((size_t)2 * nkb * 32 * HD * sizeof(T) + nkb * 32 * sizeof(float) + 32);      // two TrStage
+    const size_t need = 2 * ((size_t)2 * tr_tile_bytes(nkb * 32) + nkb * 32 * sizeof(float) + 32);      // two TrStage
     return need > 4 * (size_t)OUT_STAGE_BYTES ? need : 4 * (size_t)OUT_STAGE_BYTES;          // the output staging reuses it
 }
 #define LAUNCH_TR(kern, nkb, causal, mapped, grid, block, lds, s, ...)                                                \
@@ -2294,7 +2303,7 @@ int attn_bwd_t(const mmsum_attn_desc& d, const void* dout, long lddo, void* dq, 
         {
             const int n_ent = (d.n_qblocks / d.qpb) * d.N;
             const dim3 grid(d.H, n_ent, (nkb + 3) / 4), block(ATT_THREADS);
-            const size_t lds = 2 * (2 * (size_t)128 * HD * sizeof(T) + 2 * 128 * sizeof(float));      // two stages of Q + dO tiles + statistics (> the output staging)
+            const size_t lds = 2 * (2 * (size_t)tr_tile_bytes(128) + 2 * 128 * sizeof(float));      // two stages of Q + dO tiles + statistics (> the output staging)
             LAUNCH_TR(attn_tr_bwd_dkv_kernel, nkb, d.causal, d.q_rows != nullptr, grid, block, lds, s, d, (const T*)dout, lddo, (T*)dk, lddk, (T*)dv, lddv, (const float*)stats);
         }
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
