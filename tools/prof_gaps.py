@@ -26,7 +26,8 @@ for s, e, n in rows:
     if s > busy_end:
         g = s - busy_end
         idle += g
-        key = n.split("(")[0][-60:]
+        nm = n[5:] if n.startswith("void ") else n
+        key = nm.replace("(anonymous namespace)::", "").split("(")[0][-60:] or nm[:60]
         by[key] += g
         cnt[key] += 1
         hist[min(int(g / 1000), 50)] += 1
