@@ -1131,7 +1131,8 @@ extern "C" long mmsum_image_plan_workspace(int n) { return (long)sizeof(int) * (
 
 extern "C" int mmsum_image_plan(const float* img, long elems_per_image, const uint8_t* mask, int n, int positions, const int* rows_per_image,
                                 const int* row_adjust, int n_rpi, int* plan, int* src, int64_t* slot_rows, int64_t* run_rows, void* workspace, void* stream) {
-    if (n <= 0 || n > IMG_PLAN_MAX || positions <= 0 || elems_per_image <= 0 || n_rpi < 0 || n_rpi > 8) return MMSUM_ERR_BAD_SHAPE;
+    if (n <= 0 || n > IMG_PLAN_MAX || positions <= 0 || elems_per_image <= 0 || n_rpi < 0 || n_rpi > 8 || (n_rpi > 0 && rows_per_image == nullptr))
+        return MMSUM_ERR_BAD_SHAPE;
     if (img == nullptr || mask == nullptr || plan == nullptr || src == nullptr || slot_rows == nullptr || run_rows == nullptr || workspace == nullptr)
         return MMSUM_ERR_BAD_SHAPE;
     hipStream_t s = (hipStream_t)stream;

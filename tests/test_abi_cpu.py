@@ -38,6 +38,7 @@ def test_argument_validation_without_gpu():
     # live-image window: rows_per_image must divide the row count; the plan takes at most 8192 slots and 8 row kinds
     assert lib.mmsum_bn_apply(_lib.BF16, None, None, None, None, None, None, None, None, None, 100, 64, 1e-5, 0.1, 1, 1, 0, 0, 1, 7, None) == -1
     assert lib.mmsum_image_plan(None, 10, None, 9000, 4, None, None, 0, None, None, None, None, None, None) == -1
+    assert lib.mmsum_image_plan(None, 10, None, 16, 4, None, None, 2, None, None, None, None, None, None) == -1   # row kinds announced, none given
 
 
 def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
