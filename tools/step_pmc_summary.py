@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """Whole-step counters from rocprofv3 --pmc passes over `bench.py --no-graphs` (one counter_collection.csv per pass).
-usage: step_pmc_summary.py nsteps file.csv [file.csv ...]   -> MFMA pipe utilisation and HBM-side traffic per step."""
+usage: step_pmc_summary.py nsteps [--after-first-adamw] file.csv [file.csv ...]   -> MFMA pipe utilisation and HBM-side traffic per step."""
 import collections
 import csv
 import sys
 
 nsteps = float(sys.argv[1])
+files = sys.argv[2:]
+# --after-first-adamw: count only the dispatches that follow the first optimizer kernel (a run of `--warmup 1 --steps 1`: the second step alone,
+# without the one-time initialisation and warm-up launches)
+after = "--after-first-adamw" in files
+files = [f for f in files if not f.startswith("--")]
 tot = collections.Counter()
 dur = collections.Counter()
-for f in sys.argv[2:]:
+for f in files:
     seen = set()
-    for r in csv.DictReader(open(f)):
+    rows = list(csv.DictReader(open(f)))
+    if after:
+        first = min((int(r["Dispatch_Id"]) for r in rows if "adamw_kernel" in r["Kernel_Name"]), default=-1)
+        rows = [r for r in rows if int(r["Dispatch_Id"]) > first]
+    for r in rows:
         tot[r["Counter_Name"]] += float(r["Counter_Value"])
         key = (r["Dispatch_Id"], r["Counter_Name"])
         if key not in seen:
