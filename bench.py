@@ -509,6 +509,24 @@ def pmc_traffic(shape):
     return None, None, None
 
 
+def step_pmc(workload, batch):
+    """rocprofv3 counters of the WHOLE step from the newest committed profiles/r*_step_pmc.json of this workload and batch (a separate, serialised
+    profiler run -- tools/r5_step_pmc.sh -- not this run: named as such): MFMA pipe busy fraction of all kernels' cycles, per family, and the
+    MFMA FLOPs the hardware counted per business (to hold against roofline.step.executed.flops_per_business)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_pmc.json")), reverse=True):
+        try:
+            with open(path) as f:
+                prof = json.load(f)
+            if prof.get("workload") == workload and int(prof.get("per_gpu_batch", -1)) == int(batch):
+                return {"source": os.path.basename(path) + " (a separate rocprofv3 --pmc run of one eager step, kernels serialised; not collected by this run)",
+                        "mfma_busy_frac": prof["mfma_busy_frac"], "by_family": {k: v.get("mfma_busy_frac") for k, v in prof.get("by_family", {}).items()},
+                        "mfma_flops_per_business": prof.get("mfma_flops_per_business"), "hbm_traffic": prof.get("hbm_traffic")}
+        except Exception:
+            continue
+    return None
+
+
 # ------------------------------------------------------------------------------------------------
 # CPU baseline: whole steps of the restated reference algorithm on the host cores
 # ------------------------------------------------------------------------------------------------
@@ -979,6 +997,9 @@ def main():
             roof.update({k: v for k, v in probe.items() if k != "achieved"})
         if families is not None:
             roof["families"] = families
+        sp = step_pmc(args.workload, args.batch)
+        if sp is not None and "step" in roof:
+            roof["step"]["pmc"] = sp
         out = {"metric": "training samples/sec (businesses/sec) BART-large multimodal" if multimodal else
                "training samples/sec (businesses/sec) BART-large text-only",
                "value": value, "unit": "businesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
