@@ -31,6 +31,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ROCm runtime switch, read when the HIP runtime loads (i.e. before `import torch`): kernel arguments are written to device memory instead of
+# host-coherent memory, so a small kernel starts about a microsecond earlier.  Same results; same box, interleaved (profiles/r05_kernarg_ab.txt):
+# B = 1 32.4 -> 34.1 businesses/s, B = 8 142.9 -> 146.0, B = 128 and the decode step unchanged.  An exported value wins; the line reports it.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
@@ -1017,6 +1021,7 @@ def main():
                "graph_captures": captures, "final_loss": loss_val, "peak_hbm_gb": peak_gb, "roofline": roof}
         if getattr(args, "step_ms", None):
             out.update(step_percentiles(args.step_ms))
+        out["runtime_env"] = {k: os.environ.get(k) for k in ("HIP_FORCE_DEV_KERNARG", "MMSUM_SIDE_STREAM", "MMSUM_IMAGE_DEDUPE", "MMSUM_IMPLICIT_CONV") if os.environ.get(k) is not None}
         if telemetry is not None:
             out["telemetry"] = telemetry
         if args.diag_stub_resnet:
