@@ -141,6 +141,7 @@ class Engine:
         self.training = True
         self.seed_base = 0x5EED
         self.step_count = 0
+        self.seed_log = None
         specs = bart_specs(cfg, multimodal, bart_prefix)
         self.buffers = {bart_prefix + "final_logits_bias": torch.zeros(1, cfg.vocab_size, device=self.device)}
         frozen = []
@@ -201,8 +202,13 @@ class Engine:
         return float(self.cfg.dropout) if self.training else 0.0
 
     def next_seed(self):
+        """Seed of the next dropout site (embedding, self-attention, cross-attention, FFN blocks in schedule order).  `seed_log`
+        (a list, None = off) records them: with dropout.keep_mask a checker rebuilds every mask of a step on the host."""
         self.step_count += 1
-        return (self.seed_base * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
+        seed = (self.seed_base * 1000003 + self.step_count) & 0xFFFFFFFFFFFF
+        if self.seed_log is not None:
+            self.seed_log.append(seed)
+        return seed
 
     # ---- transposed bf16 weight shadows: dgrad dx = dy W runs as the NT product dy (W^T)^T --------
     def _wt_groups(self):
@@ -381,10 +387,21 @@ class Engine:
         come out as zeros; nothing downstream reads them: they are masked keys of the cross-attention)."""
         cfg, a = self.cfg, self.arena
         D, H = cfg.d_model, cfg.heads
-        Bn, S = ids.shape
+        Bn, S_in = ids.shape
+        # Sequences of more than 128 tokens (test.py:56-60 tokenises Yelp reviews to 158): the attention kernels take query blocks of
+        # at most 128 rows, so a sequence is cut into `nsplit` equal query blocks that share the sequence's keys (_self_block_fwd).
+        # An odd length gets one more padding column here (pad token, mask 0: a masked key and a query nobody reads -- the valid
+        # positions' results do not change, BART's learned positions are absolute) and loses it again on the way out.
+        nsplit = self.seq_splits(S_in)
+        S = -(-S_in // nsplit) * nsplit
+        unpad = None
+        if S != S_in:
+            ids = torch.nn.functional.pad(ids, (0, S - S_in), value=cfg.pad_token_id)
+            attention_mask = torch.nn.functional.pad(attention_mask, (0, S - S_in), value=0)
+            unpad = (torch.arange(Bn, device=ids.device).view(Bn, 1) * S + torch.arange(S_in, device=ids.device).view(1, S_in)).reshape(-1)
         R = Bn * S
         b = self.bp + "model.encoder."
-        c = NS(Bn=Bn, S=S, ids=ids.contiguous(), layers=[], p=self.p_drop())
+        c = NS(Bn=Bn, S=S, S_in=S_in, unpad=unpad, ids=ids.contiguous(), layers=[], p=self.p_drop())
         c.pad = attention_mask.eq(0).to(torch.uint8).contiguous()
         c.seed0 = self.next_seed()
         x = self.empty(R, D)
@@ -400,12 +417,28 @@ class Engine:
         for i in range(cfg.encoder_layers):
             last = i == cfg.encoder_layers - 1
             x, lc = self._self_block_fwd(b + "layers.%d." % i, x, c.pad, Bn, S, causal=False, maps=c.maps)
-            x, fc = self._ffn_block_fwd(b + "layers.%d." % i, x, out if (last and c.maps is None) else None, maps=c.maps)
+            x, fc = self._ffn_block_fwd(b + "layers.%d." % i, x, out if (last and c.maps is None and unpad is None) else None, maps=c.maps)
             c.layers.append((lc, fc))
         if c.maps is not None:
-            x = kn.rows_gather(x, out if out is not None else self.empty(R, D), c.maps.p2c)
+            x = kn.rows_gather(x, out if out is not None else self.empty(Bn * S_in, D), c.maps.p2c if unpad is None else c.maps.p2c[unpad])
+        elif unpad is not None:
+            x = kn.rows_gather(x, out if out is not None else self.empty(Bn * S_in, D), unpad)
         c.out = x
         return x, c
+
+    @staticmethod
+    def seq_splits(S):
+        """Query blocks per sequence of S tokens in the encoder's self-attention (blocks of <= 128 rows over <= 224 keys)."""
+        if S > 224:
+            raise ValueError("encoder sequences of %d tokens: the self-attention kernels stage at most 224 keys per sequence "
+                             "(the reference's inputs are 128 tokens in training and 158 / 118 in test.py)" % S)
+        return 1 if S <= 128 else 2
+
+    def _pad_rows(self, c):
+        """int64 map [Bn * S]: row of the caller's [Bn * S_in] layout behind every row of the internally padded one (-1 = the padding column)."""
+        m = torch.full((c.Bn * c.S,), -1, dtype=torch.int64, device=c.unpad.device)
+        m[c.unpad] = torch.arange(c.Bn * c.S_in, dtype=torch.int64, device=c.unpad.device)
+        return m
 
     def encoder_bwd(self, c, dout, split=None):
         """dout [Bn*S, D] (consumed).  Accumulates every encoder parameter gradient.
@@ -418,7 +451,12 @@ class Engine:
         if carry is None:
             dx = dout
             if c.maps is not None:
-                dx = kn.rows_gather(dout, self.empty(c.maps.rows, cfg.d_model), c.maps.c2p, live=c.maps.count)
+                c2p = c.maps.c2p
+                if c.unpad is not None:                          # compact row -> row of the caller's unpadded layout
+                    c2p = torch.where(c2p >= 0, self._pad_rows(c)[c2p.clamp(min=0)], c2p)
+                dx = kn.rows_gather(dout, self.empty(c.maps.rows, cfg.d_model), c2p, live=c.maps.count)
+            elif c.unpad is not None:
+                dx = kn.rows_gather(dout, self.empty(c.Bn * c.S, cfg.d_model), self._pad_rows(c))
         else:
             dx = carry
         for i in reversed(range(lo, hi)):
@@ -458,7 +496,16 @@ class Engine:
             c.qkv = kn.rows_gather(c.qkv, self.empty(Bn * T, 3 * D), maps.p2c)
         rmap = maps.p2c32 if c.mapped else None
         attn = self.empty(R if c.mapped else Bn * T, D)
-        c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn, pad, None, Bn, T, 1, 1, T, H,
+        nq = 1
+        if T > 128:
+            # more than 128 tokens per sequence (the encoder at test.py's 158-token reviews; encoder_fwd made T a multiple of the
+            # split): `nq` query blocks of T / nq rows attend the sequence's T keys -- the descriptor of one entity shared by the
+            # query blocks of a "business" (the table / image memory's form), forward and backward
+            if causal:
+                raise ValueError("causal self-attention over %d > 128 positions is not built (the reference trains and generates at <= 128)" % T)
+            nq = self.seq_splits(T)
+            assert T % nq == 0
+        c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn, pad, None, Bn * nq, T // nq, nq, 1, T, H,
                                    False, causal, 64 ** -0.5, q_rows=rmap, kv_rows=rmap)
         kn.attn_fwd(c.desc, x)
         c.attn = attn if (maps is None or c.mapped) else kn.rows_gather(attn, self.empty(R, D), maps.c2p, live=live)

@@ -221,7 +221,18 @@ def _ln(sd, name, x):
     return store(F.layer_norm(store(x, fwd=False), (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5))
 
 
+# Injected dropout masks (tests only): None = torch's own stream; otherwise a callable(shape) -> bool keep tensor, called once per dropout
+# site IN THE ORDER THE REFERENCE REACHES THEM (encoder: embedding :371, per layer self-attention :294, FFN :305; every decoder pass:
+# embedding :596, per layer self-attention :458, cross-attention :474, FFN :486).  The HIP kernels' masks are a counter hash, not
+# Philox (multimodalsum_amd/dropout.py): handing the same masks to this restatement is how a dropout-on step is compared tensor by tensor.
+DROPOUT_MASKS = None
+
+
 def _drop(x, p, training):
+    if DROPOUT_MASKS is not None and training and p > 0.0:
+        keep = DROPOUT_MASKS(tuple(x.shape))
+        assert keep.shape == x.shape and keep.dtype == torch.bool
+        return x * (keep.to(x.dtype) * (1.0 / (1.0 - p)))          # F.dropout: mask * 1/(1-p), elementwise (the kernels apply it in registers: nothing stored)
     return F.dropout(x, p=p, training=training)
 
 

@@ -40,7 +40,7 @@ def _bart_large(layers):
     return cfg
 
 
-def _setup(layers, Bz, dtype, std=0.06):
+def _setup(layers, Bz, dtype, std=0.06, S=128):
     from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
     cfg = _bart_large(layers)
     ocfg = bo.BartCfg(vocab_size=cfg.vocab_size, d_model=cfg.d_model, ffn_dim=cfg.encoder_ffn_dim, encoder_layers=layers, decoder_layers=layers,
@@ -49,8 +49,8 @@ def _setup(layers, Bz, dtype, std=0.06):
     model = BartForMultiEncConditionalGeneration(cfg, device=DEV, dtype=dtype, deterministic=dtype == torch.float32)
     model.load_state_dict(sd)
     model.eval()
-    N, S = 8, 128
-    ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=21, mean_len=75.0, std_len=20.0, min_len=32).view(Bz, N, S)
+    N = 8
+    ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=21, mean_len=75.0 * S / 128, std_len=20.0 * S / 128, min_len=S // 4).view(Bz, N, S)
     text_m = ids.ne(1).clone()
     table_h = formula_tensor("g.table_h", (Bz, 1, 47, cfg.d_model), std=1.0)
     img_h = formula_tensor("g.img_h", (Bz, 2, 196, cfg.d_model), std=1.0)
@@ -60,11 +60,11 @@ def _setup(layers, Bz, dtype, std=0.06):
     return cfg, ocfg, sd, model, ids, text_m, table_h, table_m, img_h, img_m
 
 
-def _run_and_check(layers, Bz, max_length, dtype, tie, enc_tol, independent=True):
+def _run_and_check(layers, Bz, max_length, dtype, tie, enc_tol, independent=True, S=128):
     """-> (leading tokens of the HIP output equal to the oracle's independent run per business, generated length, guided-check statistics)."""
     from tests.gen_check import guided_check
-    cfg, ocfg, sd, model, ids, text_m, table_h, table_m, img_h, img_m = _setup(layers, Bz, dtype)
-    N, S, beams = 8, 128, 4
+    cfg, ocfg, sd, model, ids, text_m, table_h, table_m, img_h, img_m = _setup(layers, Bz, dtype, S=S)
+    N, beams = 8, 4
     kw = dict(num_beams=beams, max_length=max_length, no_repeat_ngram_size=3, early_stopping=True, length_penalty=1.0)
     rd = torch.zeros(Bz, 1)
     cast = (lambda t: t.to(DEV).to(dtype))
@@ -105,6 +105,14 @@ def test_generation_f32_max_length_128_at_bart_large_width():
     of two summation orders accumulated into running scores over 127 steps)."""
     same, L, st = _run_and_check(2, 2, 128, torch.float32, tie=5e-4, enc_tol=1e-3)
     assert L >= 100 and st["steps"] == 127 and min(same) >= 4
+
+
+def test_generation_f32_on_158_token_reviews():
+    """test.py's own Yelp inputs (src/test.py:56-60: max_length 160 -> 158 tokens per review after the strip at data_utils.py:48-52): the
+    encoder over [16, 158] (two query blocks per sequence over 158 keys), the decode step's cross-attention over 158-key text entities +
+    table + images, 4 beams, max_length 64, f32 compute mode.  Same checks as the 128-token case above."""
+    same, L, st = _run_and_check(2, 2, 64, torch.float32, tie=5e-4, enc_tol=1e-3, S=158)
+    assert L >= 48 and st["steps"] == 63 and min(same) >= 4
 
 
 def test_generation_f32_at_full_depth():

@@ -816,3 +816,58 @@ def test_implicit_conv_schedule_equals_im2col_schedule(monkeypatch):
         tol = 5e-3 if ".layer3.22." in name else 6e-2
         assert float((a1 - a0).norm()) <= tol * float(a0.norm()), (name, float((a1 - a0).norm() / a0.norm()))
     assert worst > 0.0 or not model._engine._implicit_bwd_ok(256, 256)
+
+
+@pytest.mark.parametrize("S,compact", [(158, False), (141, False), (141, True)])
+def test_encoder_longer_than_128_tokens_schedule(monkeypatch, S, compact):
+    """Sequences of more than 128 tokens (test.py:56-60: 158-token Yelp reviews): engine.encoder_fwd cuts a sequence into two query
+    blocks over the sequence's keys (one extra padding column inside for an odd length) and the caller sees [Bn, S] rows in and out,
+    forward and backward, padded and padding-free (compact rows + row maps, bf16) -- against the oracle's encoder."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
+    cfg = tiny_cfg(vocab=100, d=256, ffn=64, layers=2, heads=4, maxpos=S + 2)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
+    dtype = torch.bfloat16 if compact else torch.float32
+    model = BartForMultiEncConditionalGeneration(cfg, device="cpu", dtype=dtype)
+    model.load_state_dict(sd)
+    model.train()
+    Bn = 3
+    ids = syn.token_batch(Bn, S, cfg.vocab_size, seed=5, mean_len=0.8 * S, std_len=0.1 * S, min_len=S // 2)
+    ids[0] = torch.randint(3, cfg.vocab_size, (S,), generator=torch.Generator().manual_seed(1))
+    mask = ids.ne(1)
+    w = formula_tensor("long.w", (Bn, S, cfg.d_model), std=1.0) * mask.unsqueeze(-1)
+    e = model._engine
+    seen = []
+    import multimodalsum_amd.engine as eng_mod
+    od = eng_mod.kn.make_attn_desc
+    monkeypatch.setattr(eng_mod.kn, "make_attn_desc", lambda *a, **k: seen.append(a[6:11]) or od(*a, **k))
+    if compact:
+        e.sync_weights()
+        e.arena.prepare_grads()
+        e.touched = set()
+        x, c = e.encoder_fwd(ids, mask, compact=True)
+        e.encoder_bwd(c, w.reshape(Bn * S, -1).to(dtype))
+        enc = x.view(Bn, S, -1).float() * mask.unsqueeze(-1)
+        grads = {n: e.arena.g(n).clone() for n in e.arena.params}
+    else:
+        enc = model.model.encoder(input_ids=ids, attention_mask=mask)[0]
+        (enc * w).sum().backward()
+        grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    Sp = S + (S & 1)
+    assert seen == [(Bn * 2, Sp // 2, 2, 1, Sp)] * cfg.encoder_layers, seen       # (query blocks, T, qpb, N, S)
+    for v in sd.values():
+        v.requires_grad_(True)
+    o = bo.bart_encoder(sd, ocfg, ids, mask, training=True)
+    (o * w).sum().backward()
+    tol = 5e-2 if compact else 5e-4
+    assert ((enc - o) * mask.unsqueeze(-1)).abs().max() <= tol * o.abs().max()
+    for n, g in grads.items():
+        if sd[n].grad is None:
+            continue
+        if compact:
+            if g.numel() >= 1024 and not n.endswith("k_proj.bias"):
+                err = (g.float() - sd[n].grad).norm() / (sd[n].grad.norm() + 1e-6)
+                assert err <= 6e-2, (n, float(err))
+        else:           # (a key bias shifts every score of a row alike: its exact gradient is 0, both sides hold rounding)
+            _close(g, sd[n].grad, 5e-4, 3e-5 if n.endswith("k_proj.bias") else 5e-6, n)
