@@ -12,7 +12,8 @@ def source_build_id():
     csrc = os.path.join(_HERE, "csrc")
     names = sorted(os.path.basename(f) for pat in ("*.hip", "*.h", "*.inc") for f in glob.glob(os.path.join(csrc, pat)))
     files = [os.path.join(csrc, n) for n in names if n != "build_id.inc"]
-    files += [os.path.join(_HERE, "..", "include", "mmsum_hip.h"), os.path.join(csrc, "Makefile"), os.path.join(csrc, "check_resources.py")]
+    files += [os.path.join(_HERE, "..", "include", "mmsum_hip.h"), os.path.join(csrc, "Makefile"), os.path.join(csrc, "check_resources.py"),
+              os.path.join(csrc, "check_handoff.py")]
     h = hashlib.sha256()
     for f in files:
         with open(f, "rb") as fh:

@@ -15,11 +15,13 @@ import torch.nn.functional as F
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
 
 
-def _keep_mask(shape, p, seed):
+def _keep_mask(shape, p, seed, salt=None):
+    """The device's masks (multimodalsum_amd/dropout.py restates the kernels' counter hash): a function of the seed, the salt and
+    row * D + column, so a live-row prefix of a matrix draws the prefix of the full mask."""
     if p <= 0:
         return torch.ones(shape)
-    g = torch.Generator().manual_seed(int(seed) & 0x7FFFFFFF)
-    return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)
+    from multimodalsum_amd.dropout import keep_mask
+    return keep_mask(seed, int(shape[0]), int(shape[1]), p, None if salt is None else int(salt)).float() / (1.0 - p)
 
 
 def gemm_colsum_fusable(a, a_t=False, b_t=False, a2=None):
@@ -112,7 +114,7 @@ def embed_ln_fwd(ids, E, P, rating_diff, rvec, gamma, beta, y, mean, rstd, nseq,
     mean.copy_(mu)
     rstd.copy_(rs)
     o = (z - mu[:, None]) * rs[:, None] * gamma + beta
-    y.copy_(o * _keep_mask(o.shape, p_drop, seed))
+    y.copy_(o * _keep_mask(o.shape, p_drop, seed, salt))
 
 
 def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, drvec, dgamma, dbeta, nseq, T, pos_offset, pad_id,
@@ -122,7 +124,7 @@ def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, dr
     if rating_diff is not None:
         z = z + rating_diff.view(nseq, 1, 1) * rvec.float()
     z = z.view(nseq * T, D)
-    g = dy.float() * _keep_mask(dy.shape, p_drop, seed)
+    g = dy.float() * _keep_mask(dy.shape, p_drop, seed, salt)
     xh = (z - mean[:, None]) * rstd[:, None]
     gdy = g * gamma
     dz = rstd[:, None] * (gdy - gdy.mean(-1, keepdim=True) - xh * (gdy * xh).mean(-1, keepdim=True))
@@ -139,9 +141,8 @@ def embed_ln_bwd(dy, ids, E, P, rating_diff, rvec, gamma, mean, rstd, dE, dP, dr
 def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None, live=None, y_f32=None):
     if live is not None:
         n = _n(live, x.shape[0])
-        assert p_drop == 0, "the emulator's dropout mask is keyed by the full shape"
-        return add_ln_fwd(x[:n], res[:n], gamma, beta, y[:n], mean[:n], rstd[:n], eps, p_drop, seed)
-    z = x.float() * _keep_mask(x.shape, p_drop, seed) + res.float()
+        return add_ln_fwd(x[:n], res[:n], gamma, beta, y[:n], mean[:n], rstd[:n], eps, p_drop, seed, salt)
+    z = x.float() * _keep_mask(x.shape, p_drop, seed, salt) + res.float()
     mu = z.mean(-1)
     rs = (z.var(-1, unbiased=False) + eps).rsqrt()
     mean.copy_(mu)
@@ -154,10 +155,9 @@ def add_ln_fwd(x, res, gamma, beta, y, mean, rstd, eps, p_drop, seed, salt=None,
 def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma, dbeta, p_drop, seed, dxsum=None, salt=None, live=None):
     if live is not None:
         n = _n(live, x.shape[0])
-        assert p_drop == 0, "the emulator's dropout mask is keyed by the full shape"
         return add_ln_bwd(dy[:n], x[:n], res[:n], gamma, mean[:n], rstd[:n], dx[:n], dres[:n], accumulate_dres, dgamma, dbeta, p_drop,
-                          seed, dxsum)
-    km = _keep_mask(x.shape, p_drop, seed)
+                          seed, dxsum, salt)
+    km = _keep_mask(x.shape, p_drop, seed, salt)
     z = x.float() * km + res.float()
     xh = (z - mean[:, None]) * rstd[:, None]
     g = dy.float()

@@ -871,3 +871,61 @@ def test_encoder_longer_than_128_tokens_schedule(monkeypatch, S, compact):
                 assert err <= 6e-2, (n, float(err))
         else:           # (a key bias shifts every score of a row alike: its exact gradient is 0, both sides hold rounding)
             _close(g, sd[n].grad, 5e-4, 3e-5 if n.endswith("k_proj.bias") else 5e-6, n)
+
+
+@pytest.mark.parametrize("kind", ["multimodal", "text"])
+def test_dropout_on_step_vs_oracle_on_the_same_masks(monkeypatch, kind):
+    """Dropout on (cfg/bart-large.json:23): the kernels' masks are a counter hash the host can restate (multimodalsum_amd/dropout.py;
+    the emulator draws the same ones), the engine logs the seed of every dropout site, and the oracle takes the masks in the order
+    the reference reaches its F.dropout calls (bart_oracle.DROPOUT_MASKS) -- the fused step, padding-free encoder rows included, is
+    then compared tensor by tensor with dropout 0.1.  The GPU twin: tests/test_parity_gaps_gpu.py."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import MultimodalSum, TextSupervised
+    from tests.test_parity_gaps_gpu import StepMasks
+    p = 0.1
+    cfg = tiny_cfg(vocab=120, d=1024, ffn=64, layers=2, heads=16, maxpos=32, dropout=p)
+    ocfg = oracle_cfg(cfg)
+    B, NR, S, I = 2, 3, 12, 1
+    bc = syn.yelp_batch(B, NR, S, I, cfg.vocab_size, seed=91, img_hw=32)
+    # (no images: the f32 ResNet stack over two 32 x 32 images amplifies rounding by itself -- 5 % on the image gate's gradients with or
+    # without dropout, tests/test_bench_shapes_gpu.py holds it to distributions -- and would hide what this test is about)
+    bc["img"], bc["img_mask"] = torch.zeros_like(bc["img"]), torch.zeros_like(bc["img_mask"])
+    if kind == "multimodal":
+        shapes = bo.bart_param_shapes(ocfg, True, prefix="bart_model.")
+        shapes.update(eo.table_param_shapes())
+        sd = formula_state_dict(shapes, std=0.02)
+        sd.update(formula_state_dict(eo.resnet_param_shapes(cfg.d_model), std=0.05))
+        model = MultimodalSum(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
+        args = (bc["reviews"], bc["reviews_mask"], bc["reviews_rating"], bc["field"], bc["field_value"], bc["img"], bc["img_mask"])
+    else:
+        sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.02)
+        model = TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32)
+        args = (bc["reviews"], bc["reviews_mask"], bc["reviews_rating"])
+    model.load_state_dict(sd)
+    model.train()
+    e = model._engine
+    e.seed_log = []
+    loss = model(*args)[0]
+    loss.backward()
+    masks = StepMasks(list(e.seed_log), p, B, NR, S, cfg.d_model, cfg.encoder_layers, cfg.decoder_layers, bc["reviews_mask"], True)
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() > 0 and "running" not in k:
+            v.requires_grad_(True)
+    bo.DROPOUT_MASKS = masks
+    try:
+        if kind == "multimodal":
+            ol = so.multimodal_step_loss(sd, ocfg, *args, 0.1, training=True)
+        else:
+            ol = so.text_step_loss(sd, ocfg, *args, 0.1, training=True)
+        ol.backward()
+    finally:
+        bo.DROPOUT_MASKS = None
+    assert masks.calls == len(masks.order)
+    nodrop = (so.multimodal_step_loss if kind == "multimodal" else so.text_step_loss)(sd, oracle_cfg(tiny_cfg(vocab=120, d=1024, ffn=64, layers=2, heads=16, maxpos=32)), *args, 0.1, training=True)
+    assert abs(float(nodrop.detach()) - float(ol.detach())) > 1e-2 * abs(float(ol.detach()))          # the masks matter: the comparison is not vacuous
+    _close(loss, ol, 5e-4, 1e-6, "loss")
+    for name, q in model.named_parameters():
+        ref = sd[name].grad
+        if ref is None or "img_encoder.resnet" in name:
+            continue
+        _close(q.grad, ref, 1e-3, 3e-5 if name.endswith("k_proj.bias") else 5e-6, name)
