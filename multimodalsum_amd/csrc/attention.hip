@@ -21,6 +21,9 @@ namespace {
 
 constexpr int HD = 64;
 constexpr int ATT_THREADS = 256;
+#ifndef MMSUM_ATTN_W64
+#define MMSUM_ATTN_W64 0                  // 1 (make EXTRA=-DMMSUM_ATTN_W64=1): the round-6 one-wave-per-SIMD forward, measured 24 % SLOWER than the
+#endif                                    // two-waves-per-SIMD kernel it was to replace (profiles/r06_attention_w64_fwd_pmc.txt, tools/r6_attn_ab.sh); kept for the record
 
 template <typename T> struct AttnTraits {
     static constexpr int kSlabsHD = HD * sizeof(T) / SLAB_BYTES;      // slabs covering head_dim (2 bf16 / 4 f32)
@@ -1054,10 +1057,11 @@ __device__ __forceinline__ void publish_key_mask(float* biasf, int* slots, uint8
         slots[4 + (tid >> 6)] = shut ? tid + __builtin_ctzll(shut) : spad;
     }
 }
+template <int NW = ATT_THREADS / 64>
 __device__ __forceinline__ void read_key_mask(const int* slots, int& extent, int& first_masked) {
     int e = 0, f = 1 << 30;
 #pragma unroll
-    for (int w = 0; w < ATT_THREADS / 64; ++w) {
+    for (int w = 0; w < NW; ++w) {
         e = max(e, slots[w]);
         f = min(f, slots[4 + w]);
     }
@@ -1080,22 +1084,22 @@ __device__ __forceinline__ void read_key_mask(const int* slots, int& extent, int
 constexpr int SLAB_SKEW = 64, TR_TILE_PAD = 128;
 __host__ __device__ constexpr int slab_stride(int rows) { return rows * SLAB_BYTES + SLAB_SKEW; }
 __host__ __device__ constexpr int tr_tile_bytes(int rows) { return rows * HD * 2 + TR_TILE_PAD; }
-template <int ROWS>
+template <int ROWS, int THREADS = ATT_THREADS>
 struct RowIdx {
-    static constexpr int NIT = ROWS * 8 / ATT_THREADS;
+    static constexpr int NIT = ROWS * 8 / THREADS;
     int v[NIT];
     // map + first = the tile's first logical row; rows = valid logical rows of the tile
     __device__ __forceinline__ void load(const int* map, long first, int rows, int tid) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int lr = (tid >> 3) + it * (ATT_THREADS / 8);
+            const int lr = (tid >> 3) + it * (THREADS / 8);
             v[it] = lr < rows ? map[first + lr] : -1;
         }
     }
 };
-template <int ROWS>
+template <int ROWS, int THREADS = ATT_THREADS>
 struct BufTile {
-    static constexpr int NIT = ROWS * 8 / ATT_THREADS;
+    static constexpr int NIT = ROWS * 8 / THREADS;
     u32x4_t v[NIT];
     // mat: the matrix, column offset applied; first: first logical row of the tile; ld in elements
     __device__ __forceinline__ void load(const bf16_t* mat, long ld, long first, int rows, int tid) {
@@ -1105,9 +1109,9 @@ struct BufTile {
         const int voff = (tid >> 3) * (int)(ld * 2) + (tid & 7) * 16;
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
-            v[it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, it * (ATT_THREADS / 8) * (int)(ld * 2), 0));
+            v[it] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, it * (THREADS / 8) * (int)(ld * 2), 0));
     }
-    __device__ __forceinline__ void load_mapped(const bf16_t* mat, long ld, const RowIdx<ROWS>& idx, int tid) {
+    __device__ __forceinline__ void load_mapped(const bf16_t* mat, long ld, const RowIdx<ROWS, THREADS>& idx, int tid) {
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(mat), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -1119,7 +1123,7 @@ struct BufTile {
         const int r = tid >> 3, cc = tid & 7;
         char* p = lds + (cc >> 2) * slab_stride(ROWS) + slab_off(r, cc & 3);
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x4_t*>(p + it * (ATT_THREADS / 8) * SLAB_BYTES) = v[it];     // (r + 32 it) >> 2 keeps r's swizzle
+        for (int it = 0; it < NIT; ++it) *reinterpret_cast<u32x4_t*>(p + it * (THREADS / 8) * SLAB_BYTES) = v[it];     // (r + 32 it) >> 2 keeps r's swizzle (THREADS / 8 rows per pass: a multiple of 4)
     }
 };
 
@@ -1320,6 +1324,354 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
     }
     flush_tile_t(reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES), oacc, O + h * HD, d.ldo, (long)qb * d.T + wave * 32, d.q_rows,
                  d.T - wave * 32, false, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Round 6: the same forward at ONE wave per SIMD with 64 queries per wave (entities of <= 128 keys, not causal: the text memory's
+// cross-attention and the encoder's self-attention).
+//
+// STATE (round 6): built, parity-green (58 attention tests through MMSUM_LIB), and SLOWER than the kernel above on the bench shape:
+// 1,152 us against 927 us (B = 128, trailing pads, compact K / V; same box).  Counters per wave and entity (64 queries): 4,700 cycles
+// issuing (VALU 3,260 -- 27 % more VALU instructions than two 32-query waves: the pre-scaled probabilities cost a multiply each, the
+// 16-register accumulators a zero fill per key block), 2,340 waiting (one wave per SIMD: nobody covers an s_waitcnt or a barrier),
+// MFMA pipe busy 1,460 of 7,960.  Two 32-query waves of the kernel above issue 4,380 cycles for the same work and overlap each
+// other's waits: 5,570 elapsed.  Not dispatched (MMSUM_ATTN_W64 = 0); profiles/r06_attention_w64_fwd_pmc.txt has the counters.
+//
+// Why it was tried: the kernel above is issue-bound, not MFMA-bound (profiles/NOTES_r05.md section 7: per wave and entity ~1,580 issue cycles --
+// 1,300 of them softmax VALU -- against 1,024 cycles of MFMA pipe), and its two waves per SIMD do not hide each other's dependency
+// stalls: 6,300 cycles per entity and pair of waves, MFMA pipe 24 % busy.  Here a workgroup is TWO waves (128 queries = the query
+// block), two workgroups share a CU (one wave per SIMD, 512 registers each), and a wave owns two independent 32-query groups whose
+// instruction streams the scheduler overlaps inside ONE wave: the S^T MFMAs of group 1 run under the softmax arithmetic of group 0,
+// the P V MFMAs of group 0 under the softmax of group 1.  Staging, masks, entity walk and the arithmetic per score are the kernel
+// above's (same results bit for bit per query: a query's row never leaves its lane).
+// ---------------------------------------------------------------------------------------------
+constexpr int W64_THREADS = 128;
+
+// Row maximum of one 32-query group's scores in the log2 domain (first half of scores_tr's arithmetic, scalar forms: beside MFMAs at
+// one wave per SIMD the packed f32 instructions cost more than the two scalar ones they replace -- MI355X_MICROARCH.md, 'price of
+// one filler').  Key blocks kb >= NFAST leave t = s * c2 + bias in place of s.  Returns the maximum (0 when every key is masked).
+template <int NKB, int NACT, int NFAST>
+__device__ __forceinline__ float w64_row_max(f32x16_t (&sacc)[NKB], const float* biasf, float c2, int lane) {
+    const int h = lane >> 5;
+    float mraw = -INFINITY, m = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NACT; ++kb) {
+        if (kb < NFAST) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mraw = fmaxf(mraw, sacc[kb][r]);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(biasf + kb * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = fmaf(sacc[kb][4 * g + j], c2, bias[j]);
+                    sacc[kb][4 * g + j] = t;
+                    m = fmaxf(m, t);
+                }
+            }
+        }
+    }
+    m = wave_half_max(fmaxf(m, mraw * c2));                   // scale > 0
+    return (m == -INFINITY) ? 0.f : m;
+}
+// p = 2^(t - m) for registers r0 .. r0 + 3 of one key block, added into four running sums.
+template <bool FAST>
+__device__ __forceinline__ void w64_exp4(f32x16_t& s, int r0, float c2, float ms, float (&l)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t = FAST ? fmaf(s[r0 + j], c2, -ms) : s[r0 + j] - ms;
+        const float pv = __builtin_amdgcn_exp2f(t);
+        s[r0 + j] = pv;
+        l[j] += pv;
+    }
+}
+// The B operand of one 16-key step of P V: registers 8 s2 .. 8 s2 + 7 of a key block's probabilities, normalised, as bf16.
+__device__ __forceinline__ bf16x8_t w64_pack(const f32x16_t& p, int s2, float norm) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x8_t r;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {                         // one v_cvt_pk_bf16_f32 per pair
+        const f32x2_t x = {p[8 * s2 + j] * norm, p[8 * s2 + j + 1] * norm};
+        const bf16x2_t y = __builtin_convertvector(x, bf16x2_t);
+        r[j] = y[0];
+        r[j + 1] = y[1];
+    }
+    return r;
+}
+
+// O^T of the wave's two query groups lives in NAMED accumulation registers a[192:255] (block 2 g + db at a[192 + 16 (2 g + db)]):
+// the P V MFMAs are issued from inline asm on those names, so the register allocator never sees a 64-register value that is
+// live across the eight (key blocks, masked blocks) variants of the entity loop -- as compiler-managed values it copied them
+// around every variant (~200 v_accvgpr moves per entity).  The compiler allocates its own AGPRs from a0 upwards; the build checks that
+// no compiler-generated instruction of these kernels names a192 or above (csrc/check_resources.py).
+#define W64_AGPRS_0 "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207"
+#define W64_AGPRS_1 "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223"
+#define W64_AGPRS_2 "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239"
+#define W64_AGPRS_3 "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+// (s_nop 1: an operand the compiler's VALU code wrote just before the statement -- the converted probabilities -- needs two wait states
+// before an MFMA reads it, and the compiler does not know this statement is one)
+template <int BLK>
+__device__ __forceinline__ void w64_pv(const bf16x8_t a, const bf16x8_t b) {
+    if constexpr (BLK == 0) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[192:207], %0, %1, a[192:207]" ::"v"(a), "v"(b));
+    else if constexpr (BLK == 1) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[208:223], %0, %1, a[208:223]" ::"v"(a), "v"(b));
+    else if constexpr (BLK == 2) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[224:239], %0, %1, a[224:239]" ::"v"(a), "v"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[240:255], %0, %1, a[240:255]" ::"v"(a), "v"(b));
+}
+__device__ __forceinline__ void w64_zero_acc() {
+    const bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[192:207], %0, %0, 0" ::"v"(z) : W64_AGPRS_0);
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[208:223], %0, %0, 0" ::"v"(z) : W64_AGPRS_1);
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[224:239], %0, %0, 0" ::"v"(z) : W64_AGPRS_2);
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[240:255], %0, %0, 0" ::"v"(z) : W64_AGPRS_3);
+}
+#define W64_RD(dst, i, reg) asm volatile("v_accvgpr_read_b32 %0, " reg : "=v"(w64_t_)); dst[i] = w64_t_;
+#define W64_RD16(dst, base)                                                                                                             \
+    W64_RD(dst, 0, "a" #base "+0") W64_RD(dst, 1, "a" #base "+1")
+// (register names cannot be computed in an asm string: the sixteen reads of a block are spelled out per block below)
+template <int BLK>
+__device__ __forceinline__ f32x16_t w64_read_acc() {
+    f32x16_t o;
+    float t;
+#define W64_R(i, name) asm volatile("v_accvgpr_read_b32 %0, " name : "=v"(t)); o[i] = t;
+    if constexpr (BLK == 0) {
+        W64_R(0, "a192") W64_R(1, "a193") W64_R(2, "a194") W64_R(3, "a195") W64_R(4, "a196") W64_R(5, "a197") W64_R(6, "a198") W64_R(7, "a199")
+        W64_R(8, "a200") W64_R(9, "a201") W64_R(10, "a202") W64_R(11, "a203") W64_R(12, "a204") W64_R(13, "a205") W64_R(14, "a206") W64_R(15, "a207")
+    } else if constexpr (BLK == 1) {
+        W64_R(0, "a208") W64_R(1, "a209") W64_R(2, "a210") W64_R(3, "a211") W64_R(4, "a212") W64_R(5, "a213") W64_R(6, "a214") W64_R(7, "a215")
+        W64_R(8, "a216") W64_R(9, "a217") W64_R(10, "a218") W64_R(11, "a219") W64_R(12, "a220") W64_R(13, "a221") W64_R(14, "a222") W64_R(15, "a223")
+    } else if constexpr (BLK == 2) {
+        W64_R(0, "a224") W64_R(1, "a225") W64_R(2, "a226") W64_R(3, "a227") W64_R(4, "a228") W64_R(5, "a229") W64_R(6, "a230") W64_R(7, "a231")
+        W64_R(8, "a232") W64_R(9, "a233") W64_R(10, "a234") W64_R(11, "a235") W64_R(12, "a236") W64_R(13, "a237") W64_R(14, "a238") W64_R(15, "a239")
+    } else {
+        W64_R(0, "a240") W64_R(1, "a241") W64_R(2, "a242") W64_R(3, "a243") W64_R(4, "a244") W64_R(5, "a245") W64_R(6, "a246") W64_R(7, "a247")
+        W64_R(8, "a248") W64_R(9, "a249") W64_R(10, "a250") W64_R(11, "a251") W64_R(12, "a252") W64_R(13, "a253") W64_R(14, "a254") W64_R(15, "a255")
+    }
+#undef W64_R
+    return o;
+}
+#undef W64_RD
+#undef W64_RD16
+
+template <int NKB, bool KVMAP>
+__global__ __launch_bounds__(W64_THREADS, 1) void attn_w64_fwd_kernel(mmsum_attn_desc d) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPAD = NKB * 32;
+    typedef TrStage<NKB> Stage;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FragOff fo = frag_off<T>(lane);
+    const TrOff tro = tr_off(lane);
+    const int h = blockIdx.x, qb = blockIdx.y;
+    const int b = qb / d.qpb;
+    const int excl = d.exclude_self ? (qb % d.qpb) : -1;
+    uint32_t rem = valid_entities(d, b, excl);
+    const int cnt = __popc(rem);
+    const float inv_cnt = cnt > 0 ? 1.f / (float)cnt : 0.f;
+    const float c2 = d.scale * LOG2E_F;
+
+    const T* Q = static_cast<const T*>(d.q);
+    const T* K = static_cast<const T*>(d.k);
+    const T* V = static_cast<const T*>(d.v);
+    T* O = static_cast<T*>(d.out);
+
+    Frag qf[2][2];                                            // [query group][slab]
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int qpos = wave * 64 + g * 32 + (lane & 31);
+        const long qr = phys_row(d.q_rows, (long)qb * d.T + qpos, qpos < d.T);
+        const T* qrow = Q + (qr >= 0 ? qr : 0) * d.ldq + h * HD;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) qf[g][sl] = global_frag<T>(qrow + sl * 32, lane, qr >= 0);
+    }
+    pin_frags(qf[0]);
+    pin_frags(qf[1]);
+    w64_zero_acc();
+
+    // K and V of the next entity are requested at the top of an iteration and committed to the other stage in its last phase: a whole
+    // iteration (> 4,000 cycles) for the rows to arrive -- with one wave per SIMD nobody else covers a wait
+    BufTile<SPAD, W64_THREADS> kreg, vreg;
+    RowIdx<SPAD, W64_THREADS> kvidx;
+    uint8_t mreg = 1;
+    auto lookup = [&](int n) { kvidx.load(d.kv_rows, ((long)b * d.N + n) * d.S, d.S, tid); };
+    auto request = [&](int n) {
+        if constexpr (KVMAP) {
+            kreg.load_mapped(K + h * HD, d.ldk, kvidx, tid);
+            vreg.load_mapped(V + h * HD, d.ldv, kvidx, tid);
+        } else {
+            kreg.load(K + h * HD, d.ldk, ((long)b * d.N + n) * d.S, d.S, tid);
+            vreg.load(V + h * HD, d.ldv, ((long)b * d.N + n) * d.S, d.S, tid);
+        }
+        mreg = (tid >= d.S) ? 1 : (d.pad ? d.pad[((long)b * d.N + n) * d.S + tid] : 0);
+    };
+    int cur = 0;
+    if (rem) {
+        const int n0 = __builtin_ctz(rem);
+        if constexpr (KVMAP) lookup(n0);
+        request(n0);
+        if constexpr (KVMAP) if (rem & (rem - 1)) lookup(__builtin_ctz(rem & (rem - 1)));
+        kreg.commit(Stage{smem}.k(), tid);
+        vreg.commit(Stage{smem}.v(), tid);
+        publish_key_mask(Stage{smem}.bias(), Stage{smem}.slots(), mreg, d.S, SPAD, tid);
+    }
+    __syncthreads();
+    // a wave whose 64 queries lie past T (T <= 64: wave 1) still stages and meets the barriers, and skips the arithmetic
+    const bool wave_live = wave * 64 < d.T;
+    while (rem) {
+        rem &= rem - 1;
+        const Stage st{smem + cur * Stage::BYTES}, nx{smem + (cur ^ 1) * Stage::BYTES};
+        const int nn = rem ? __builtin_ctz(rem) : 0;          // the entity staged during this iteration (none left: entity 0 again, nobody reads that stage)
+        int slen, fmask;
+        read_key_mask<W64_THREADS / 64>(st.slots(), slen, fmask);
+        request(nn);
+        if constexpr (KVMAP) lookup((rem & (rem - 1)) ? __builtin_ctz(rem & (rem - 1)) : nn);      // one entity ahead of the loads that use it
+        bool done = false;
+        if (wave_live) {
+            dispatch_blocks<NKB>((slen + 31) >> 5, fmask >> 5, [&](auto nact, auto nfast) {
+                constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
+                constexpr int NGAP = 4 * NACT;                 // MFMAs of one product of one group (S^T or P V): the gaps the other group's VALU work is dealt into
+                constexpr int J0 = (NACT + 1) / 2;             // gaps that take the row maximum (two key blocks each); the exponentials follow
+                f32x16_t s0[NKB], s1[NKB];
+                const char* kt = st.k();
+                const char* vt = st.v();
+                // operand fragment f (two 16-deep steps) of the K tile: key block f >> 1, slab f & 1
+                auto kfrag = [&](int f) { return lds_frag_o(kt + (f & 1) * slab_stride(SPAD) + (f >> 1) * 32 * SLAB_BYTES, fo); };
+                // A operand of P V step `stp` (16 keys) for output columns db * 32 ..
+                auto vfrag = [&](int stp, int db) { return tr_frag(vt + db * slab_stride(SPAD) + ((stp >> 1) * 32 + 16 * (stp & 1)) * SLAB_BYTES, tro); };
+                // the VALU work of one group's softmax, dealt into gaps: gap j < J0 folds key blocks 2 j, 2 j + 1 into the running maximum
+                // (the last of them finishes it across the wave's halves), gap j >= J0 takes its share of the 4 NACT exp units
+                auto softmax_gap = [&](int j, f32x16_t (&sg)[NKB], float& mraw, float& m, float& ms, float (&l)[4]) {
+                    if (j < J0) {
+                        const int h2 = lane >> 5;
+#pragma unroll
+                        for (int kb = 2 * j; kb < 2 * j + 2 && kb < NACT; ++kb) {
+                            if (kb < NFAST) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) mraw = fmaxf(mraw, sg[kb][r]);
+                            } else {
+#pragma unroll
+                                for (int g4 = 0; g4 < 4; ++g4) {
+                                    const f32x4_t bias = *reinterpret_cast<const f32x4_t*>(st.bias() + kb * 32 + 8 * g4 + 4 * h2);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float t = fmaf(sg[kb][4 * g4 + e], c2, bias[e]);
+                                        sg[kb][4 * g4 + e] = t;
+                                        m = fmaxf(m, t);
+                                    }
+                                }
+                            }
+                        }
+                        if (j == J0 - 1) {
+                            m = wave_half_max(fmaxf(m, mraw * c2));        // scale > 0
+                            ms = (m == -INFINITY) ? 0.f : m;
+                        }
+                    } else {
+                        const int u0 = (j - J0) * (4 * NACT) / (NGAP - J0), u1 = (j - J0 + 1) * (4 * NACT) / (NGAP - J0);
+#pragma unroll
+                        for (int u = u0; u < u1; ++u) {
+                            if ((u >> 2) < NFAST) w64_exp4<true>(sg[u >> 2], 4 * (u & 3), c2, ms, l);
+                            else w64_exp4<false>(sg[u >> 2], 4 * (u & 3), c2, ms, l);
+                        }
+                    }
+                };
+                // ---- phase 1: S^T of group 0 (nothing to put beside it: the compiler requests all fragments up front)
+#pragma unroll
+                for (int kb = 0; kb < NACT; ++kb) {
+                    s0[kb] = zero_acc();
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) mma_slab<bf16_t>(s0[kb], kfrag(2 * kb + sl), qf[0][sl]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- phase 2: S^T of group 1 on the MFMA pipe, gap by gap, under the softmax arithmetic of group 0
+                float mr0 = -INFINITY, mm0 = -INFINITY, m0 = 0.f, l0[4] = {0.f, 0.f, 0.f, 0.f};
+                {
+                    Frag fa = kfrag(0), fb = kfrag(1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NGAP; ++j) {
+                        const int f = j >> 1, kb = j >> 2, sl = (j >> 1) & 1;
+                        const Frag& cur = (f & 1) ? fb : fa;
+                        if ((j & 3) == 0) s1[kb] = zero_acc();
+                        s1[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, cur.c[j & 1]), __builtin_bit_cast(bf16x8_t, qf[1][sl].c[j & 1]), s1[kb], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        softmax_gap(j, s0, mr0, mm0, m0, l0);
+                        if ((j & 1) == 1 && f + 2 < 2 * NACT) {           // the fragment two ahead replaces the one just used up
+                            if (f & 1) fb = kfrag(f + 2); else fa = kfrag(f + 2);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                const float ls0 = wave_half_sum((l0[0] + l0[1]) + (l0[2] + l0[3]));
+                const float norm0 = (ls0 > 0.f) ? inv_cnt * __builtin_amdgcn_rcpf(ls0) : 0.f;
+                // ---- phase 3: P V of group 0 (asm MFMAs on the named accumulators), gap by gap, under the softmax of group 1; K of the next
+                // (K / V of the next entity are committed after phase 4)
+                float mr1 = -INFINITY, mm1 = -INFINITY, m1 = 0.f, l1[4] = {0.f, 0.f, 0.f, 0.f};
+                {
+                    bf16x8_t pb = w64_pack(s0[0], 0, norm0);
+                    bf16x8_t va = vfrag(0, 0), vb = vfrag(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NGAP; ++j) {
+                        const int stp = j >> 1;
+                        if (j & 1) w64_pv<1>(vb, pb); else w64_pv<0>(va, pb);
+                        __builtin_amdgcn_sched_barrier(0);
+                        softmax_gap(j, s1, mr1, mm1, m1, l1);
+                        if ((j & 1) == 0) {
+                            if (stp + 1 < 2 * NACT) va = vfrag(stp + 1, 0);
+                        } else if (stp + 1 < 2 * NACT) {
+                            vb = vfrag(stp + 1, 1);
+                            pb = w64_pack(s0[(stp + 1) >> 1], (stp + 1) & 1, norm0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                // ---- phase 4: P V of group 1 (its operands converted one step ahead)
+                const float ls1 = wave_half_sum((l1[0] + l1[1]) + (l1[2] + l1[3]));
+                const float norm1 = (ls1 > 0.f) ? inv_cnt * __builtin_amdgcn_rcpf(ls1) : 0.f;
+                {
+                    bf16x8_t pb = w64_pack(s1[0], 0, norm1);
+                    bf16x8_t va = vfrag(0, 0), vb = vfrag(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NGAP; ++j) {
+                        const int stp = j >> 1;
+                        if (j & 1) w64_pv<3>(vb, pb); else w64_pv<2>(va, pb);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if ((j & 1) == 0) {
+                            if (stp + 1 < 2 * NACT) va = vfrag(stp + 1, 0);
+                        } else if (stp + 1 < 2 * NACT) {
+                            vb = vfrag(stp + 1, 1);
+                            pb = w64_pack(s1[(stp + 1) >> 1], (stp + 1) & 1, norm1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                kreg.commit(nx.k(), tid);
+                vreg.commit(nx.v(), tid);
+                done = true;
+            });
+        }
+        if (!done) {                                          // (an entity without an unmasked key, or an idle wave: the staging goes on)
+            kreg.commit(nx.k(), tid);
+            vreg.commit(nx.v(), tid);
+        }
+        publish_key_mask(nx.bias(), nx.slots(), mreg, d.S, SPAD, tid);
+        __syncthreads();
+        cur ^= 1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");         // the last MFMA's result -> v_accvgpr_read (the loop's barrier lies between already)
+    {
+        float* stg = reinterpret_cast<float*>(smem + wave * OUT_STAGE_BYTES);
+        f32x16_t o[2];
+        o[0] = w64_read_acc<0>();
+        o[1] = w64_read_acc<1>();
+        flush_tile_t(stg, o, O + h * HD, d.ldo, (long)qb * d.T + wave * 64, d.q_rows, d.T - wave * 64, false, lane);
+        o[0] = w64_read_acc<2>();
+        o[1] = w64_read_acc<3>();
+        flush_tile_t(stg, o, O + h * HD, d.ldo, (long)qb * d.T + wave * 64 + 32, d.q_rows, d.T - wave * 64 - 32, false, lane);
+    }
 }
 
 // Entities of more than 128 keys (the image memory: 196 keys per image) walked in CHUNKS of up to 128 keys with a running softmax
@@ -2252,6 +2604,15 @@ int attn_fwd_t(const mmsum_attn_desc& d, hipStream_t s) {
             return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
         }
         const size_t lds = tr_lds<T>(nkb);
+#if MMSUM_ATTN_W64
+        if (!d.causal) {                  // entities of <= 128 keys, not causal: 64 queries per wave, one wave per SIMD (two 2-wave workgroups per CU)
+            const dim3 wblock(W64_THREADS);
+            const bool mp = d.kv_rows != nullptr;
+            if (nkb == 2) { if (mp) LAUNCH_LDS((attn_w64_fwd_kernel<2, true>), grid, wblock, lds, s, d); else LAUNCH_LDS((attn_w64_fwd_kernel<2, false>), grid, wblock, lds, s, d); }
+            else { if (mp) LAUNCH_LDS((attn_w64_fwd_kernel<4, true>), grid, wblock, lds, s, d); else LAUNCH_LDS((attn_w64_fwd_kernel<4, false>), grid, wblock, lds, s, d); }
+            return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+        }
+#endif
         LAUNCH_TR(attn_tr_fwd_kernel, nkb, d.causal, d.kv_rows != nullptr, grid, block, lds, s, d);
         return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
     } else if (pipe_lds<T>(nkb, 2) <= LDS_MAX) {            // f32 (parity mode): the register-prefetch kernels
