@@ -488,10 +488,20 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_kernel(XaArgs a)
         const int qi = idx >> 6, dd = idx & 63;
         float x = 0.f;
         int cnt = 0;
-        for (int nn = 0; nn < M.N; ++nn) {
-            if (M.null_entity != nullptr && M.null_entity[b * M.N + nn] != 0) continue;      // null entities are dropped from the mean (:856-866)
-            x += __hip_atomic_load(a.part + ((long)(M.ent0 + b * M.N + nn) * a.H + h) * (QPB * 64) + qi * 64 + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ++cnt;
+        // the entities' outputs (and null flags) eight at a time, every load unconditional from a clamped entity: a load per loop
+        // iteration behind a `continue` was one dependent memory round trip per entity on the launch's critical path (round 6)
+        for (int n0 = 0; n0 < M.N; n0 += 8) {
+            float pv[8];
+            int nul[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int nn = min(n0 + j, M.N - 1);
+                nul[j] = M.null_entity != nullptr ? (int)__builtin_nontemporal_load(M.null_entity + b * M.N + nn) : 0;      // null entities are dropped from the mean (:856-866)
+                pv[j] = __hip_atomic_load(a.part + ((long)(M.ent0 + b * M.N + nn) * a.H + h) * (QPB * 64) + qi * 64 + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (n0 + j < M.N && nul[j] == 0) { x += pv[j]; ++cnt; }
         }
         x = cnt > 0 ? x / (float)cnt : 0.f;                    // every entity null: zeros (the out_proj bias still enters, :884-885)
         a.out[((long)m * a.R + b * QPB + qi) * a.ldo + h * 64 + dd] = (bf16_t)x;
@@ -634,10 +644,20 @@ __global__ __launch_bounds__(XA_THREADS) void decode_cross_attn_f32_kernel(XaArg
         const int qi = idx >> 6, dd = idx & 63;
         float x = 0.f;
         int cnt = 0;
-        for (int nn = 0; nn < M.N; ++nn) {
-            if (M.null_entity != nullptr && M.null_entity[b * M.N + nn] != 0) continue;
-            x += __hip_atomic_load(a.part + ((long)(M.ent0 + b * M.N + nn) * a.H + h) * (QPB * 64) + qi * 64 + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ++cnt;
+        // the entities' outputs (and null flags) eight at a time, every load unconditional from a clamped entity: a load per loop
+        // iteration behind a `continue` was one dependent memory round trip per entity on the launch's critical path (round 6)
+        for (int n0 = 0; n0 < M.N; n0 += 8) {
+            float pv[8];
+            int nul[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int nn = min(n0 + j, M.N - 1);
+                nul[j] = M.null_entity != nullptr ? (int)__builtin_nontemporal_load(M.null_entity + b * M.N + nn) : 0;      // null entities are dropped from the mean (:856-866)
+                pv[j] = __hip_atomic_load(a.part + ((long)(M.ent0 + b * M.N + nn) * a.H + h) * (QPB * 64) + qi * 64 + dd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (n0 + j < M.N && nul[j] == 0) { x += pv[j]; ++cnt; }
         }
         x = cnt > 0 ? x / (float)cnt : 0.f;
         a.out[((long)m * a.R + b * QPB + qi) * a.ldo + h * 64 + dd] = x;

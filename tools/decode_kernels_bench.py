@@ -53,6 +53,33 @@ for name, m, N, K, epi, k2 in cases:
     print("%-26s M=%3d N=%5d K=%4d   mmsum_gemm %6.1f us (%5.2f TB/s of weights)   mmsum_dec_gemm %6.1f us (%5.2f TB/s)"
           % (name, m, N, K, t_old, N * K * 2 / t_old / 1e6, t_new, N * K * 2 / t_new / 1e6), flush=True)
 
+# ---- the LM head: f32 rows (the un-rounded last LayerNorm) x bf16 weights [50265, 1024] -> f32 logits
+V_ = 50265
+reps = 4
+x32s = [torch.randn(M, 1024, device="cuda") for _ in range(reps)]
+wvs = [(torch.randn(V_, 1024, device="cuda") * 0.02).to(dt) for _ in range(reps)]
+lgs = [torch.empty(M, 50304, device="cuda") for _ in range(reps)]
+bz = torch.zeros(V_, device="cuda")
+wsv = kn.dec_gemm_workspace(96, V_, 1024, "cuda")
+
+
+def lm_old():
+    for x, w, y in zip(x32s, wvs, lgs):
+        for r0 in range(0, M, 64):
+            kn.gemm(x[r0:r0 + 64], w, y[r0:r0 + 64, :V_], bias=bz)
+
+
+def lm_new():
+    for x, w, y in zip(x32s, wvs, lgs):
+        kn.dec_gemm(x, w, y[:, :V_], wsv, bias=bz)
+
+
+lm_old(); r0_ = lgs[0].clone(); lm_new(); torch.cuda.synchronize()
+print("LM head outputs: max |old - new| = %.3e" % float((r0_[:, :V_] - lgs[0][:, :V_]).abs().max()))
+t_old, t_new = graph_time(lm_old, reps), graph_time(lm_new, reps)
+print("LM head M=%3d N=%5d K=1024 (f32 rows)   mmsum_gemm %6.1f us (%5.2f TB/s of weights)   mmsum_dec_gemm %6.1f us (%5.2f TB/s)"
+      % (M, V_, t_old, V_ * 1024 * 2 / t_old / 1e6, t_new, V_ * 1024 * 2 / t_new / 1e6), flush=True)
+
 # ---- cross-attention over the cached K / V: B businesses x qpb hypotheses, text 8 x 128 (trailing pads), table 1 x 47, images 4 x 196 (U{0..4} live)
 B, qpb, H, D = max(1, M // 4), 4, 16, 1024
 R = B * qpb
