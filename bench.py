@@ -970,20 +970,26 @@ def main():
         mem_rows = text_rows + ((47 + 196 * filled) if multimodal else 0)
         # images the branch runs per business: the filled slots + ONE representative per batch of its empty slots (engine.img_fwd's live-image window)
         windowed = multimodal and os.environ.get("MMSUM_IMAGE_DEDUPE") != "0"
-        img_run = min(float(I), filled + 1.0 / args.batch) if windowed else None
+        # (a batch runs ONE extra image -- the representative -- only when it has an empty slot at all)
+        img_run = (sum(im + (1 if im < args.batch * I else 0) for _, im in live_rows) / len(live_rows) / args.batch) if windowed else None
         fpb_exec = flops_per_business(*dims, multimodal=multimodal, enc_rows=text_rows, mem_rows=mem_rows, img_run=img_run)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         achieved = value / world * fpb / 1e12
-        step_roof = {"achieved": achieved, "frac": achieved / peak, "flops_per_business": fpb,
-                     "executed": {"achieved": value / world * fpb_exec / 1e12, "frac": value / world * fpb_exec / 1e12 / peak,
+        achieved_exec = value / world * fpb_exec / 1e12
+        # the step's PRIMARY figure counts the FLOPs that are executed; `canonical` is SURVEY.md 8d's padded count (every padded encoder row, every
+        # masked memory row and all I image slots per business, the skipped ones included), kept for comparison with earlier rounds
+        step_roof = {"achieved": achieved_exec, "frac": achieved_exec / peak, "flops_per_business": fpb_exec,
+                     "executed": {"achieved": achieved_exec, "frac": achieved_exec / peak,
                                   "flops_per_business": fpb_exec, "encoder_rows_per_business": text_rows, "memory_rows_per_business": mem_rows,
                                   "images_run_per_business": img_run,
                                   "note": "FLOPs of the rows the padding-free encoder layers / K-V projections really process and of the images the "
                                           "image branch really runs (filled slots + one representative of the empty ones); results identical"},
-                     "scope": "whole training step per GPU (canonical algorithmic FLOPs of SURVEY.md 8d, padded rows) / step time"}
+                     "canonical": {"achieved": achieved, "frac": achieved / peak, "flops_per_business": fpb,
+                                   "note": "SURVEY.md 8d's algorithmic count on padded rows and all image slots: includes work the step skips"},
+                     "scope": "whole training step per GPU: executed FLOPs / step time (canonical = the padded count of SURVEY.md 8d)"}
         if probe is None:
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-                    "scope": step_roof["scope"], "flops_per_business": fpb, "executed": step_roof["executed"]}
+            roof = {"bound": "mfma", "achieved": achieved_exec, "peak": peak, "unit": "TFLOP/s", "frac": achieved_exec / peak, "traffic": None,
+                    "scope": step_roof["scope"], "flops_per_business": fpb_exec, "executed": step_roof["executed"], "canonical": step_roof["canonical"]}
         else:
             traffic, src, pmc = pmc_traffic(probe["shape"])
             roof = {"bound": "mfma", "achieved": probe["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": probe["achieved"] / peak,

@@ -58,21 +58,37 @@ def clip_grad_norm_(parameters, max_norm, fused=False):
     does not own -- under quirk Q1 those are the no-decay gradients that keep accumulating (Q1b),
     so their stored values must carry the clip factor exactly like the reference's do.
     Returns the total norm as a 0-d device tensor (no host sync)."""
+    parameters = list(parameters)
     params = [p for p in parameters if p.grad is not None]
+    if not params:
+        return torch.zeros((), device=parameters[0].device if parameters else None)
     arena = _arena_of(params)
-    if arena is None:
-        if not params:
-            return torch.zeros(())
-        raise ValueError("multimodalsum_amd.clip_grad_norm_: parameters outside the package's arena (this path has no torch-op fallback)")
-    foreign = [p for p in params if getattr(p, "_mmsum_arena", None) is not arena]
-    if foreign:
-        raise ValueError("multimodalsum_amd.clip_grad_norm_: %d parameter(s) outside the arena (no torch-op fallback)" % len(foreign))
-    eng = params[0]._mmsum_engine
-    rs = _ranges(arena, params)
-    if not hasattr(eng, "norm_sq"):
-        eng.norm_sq = torch.zeros(1, device=arena.device)
+    # Parameters outside the arena (a head or an adapter a user added; a second model's parameters -- the reference clips arbitrary
+    # parameter lists with torch's clip_grad_norm_, multimodal_train.py:362, img_pretrain.py:192): their f32 gradients go through the
+    # same two library kernels as flat buffers -- the squared norm is added to the arena's, the clip factor scales them in place.
+    inside = [p for p in params if arena is not None and getattr(p, "_mmsum_arena", None) is arena]
+    foreign = [p for p in params if not (arena is not None and getattr(p, "_mmsum_arena", None) is arena)]
+    for p in foreign:
+        if not (p.grad.dtype == torch.float32 and p.grad.is_contiguous()):
+            raise ValueError("multimodalsum_amd.clip_grad_norm_: a parameter outside the arena needs a contiguous f32 gradient "
+                             "(this path has no torch-op fallback)")
+    if arena is not None:
+        eng = inside[0]._mmsum_engine
+        if not hasattr(eng, "norm_sq"):
+            eng.norm_sq = torch.zeros(1, device=arena.device)
+        norm_sq = eng.norm_sq
+        rs = _ranges(arena, inside)
+    else:
+        eng, rs = None, []
+        norm_sq = torch.zeros(1, device=foreign[0].grad.device)
     for i, (s, e) in enumerate(rs):
-        kn.l2norm_sq(arena.grad[s:e], eng.norm_sq, accumulate=i > 0)
+        kn.l2norm_sq(arena.grad[s:e], norm_sq, accumulate=i > 0)
+    for j, p in enumerate(foreign):
+        kn.l2norm_sq(p.grad.view(-1), norm_sq, accumulate=(j > 0 or bool(rs)))
+    for p in foreign:
+        kn.scale_by_clip(p.grad.view(-1), norm_sq, float(max_norm))
+    if eng is None:
+        return norm_sq.sqrt().reshape(())
     eng.pending_clip = float(max_norm)
     owned = getattr(eng, "optimizer_ranges", None) if fused else None
     for s, e in rs:

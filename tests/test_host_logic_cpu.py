@@ -929,3 +929,29 @@ def test_dropout_on_step_vs_oracle_on_the_same_masks(monkeypatch, kind):
         if ref is None or "img_encoder.resnet" in name:
             continue
         _close(q.grad, ref, 1e-3, 3e-5 if name.endswith("k_proj.bias") else 5e-6, name)
+
+
+def test_clip_grad_norm_with_parameters_outside_the_arena(monkeypatch):
+    """clip_grad_norm_ over an arbitrary parameter list (torch's, as the reference calls it: multimodal_train.py:362): parameters of the
+    arena, a head outside it and a second model's; all enter one norm and are scaled by one factor."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import TextSupervised
+    from multimodalsum_amd import optim
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40)
+    models = [TextSupervised(config=cfg, label_smoothing=0.1, device="cpu", dtype=torch.float32) for _ in range(2)]
+    extra = torch.nn.Linear(16, 8)
+    bc = syn.yelp_batch(2, 3, 16, 1, cfg.vocab_size, seed=5, img_hw=8)
+    for m in models:
+        m.train()
+        m(bc["reviews"], bc["reviews_mask"], bc["reviews_rating"])[0].backward()
+    extra(torch.randn(4, 16)).square().sum().backward()
+    params = list(models[0].parameters()) + list(extra.parameters()) + list(models[1].parameters())
+    live = [p for p in params if p.grad is not None]
+    before = [p.grad.detach().clone() for p in live]
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in before)))
+    norm = optim.clip_grad_norm_(params, 0.25 * total)
+    assert abs(float(norm) - total) <= 1e-5 * total
+    coef = 0.25 * total / (total + 1e-6)
+    for p, g0 in zip(live, before):
+        _close(p.grad, g0 * coef, 1e-5, 1e-9, "clipped gradient")
+    assert float(optim.clip_grad_norm_(list(extra.parameters()), 1e9)) > 0          # no arena parameter at all: still the library's kernels

@@ -805,3 +805,28 @@ def test_pretrain_wrappers_against_the_reference_classes(golden_dir):
                           ("tab_g_shared", "bart_model.model.shared.weight", lambda t: t[:64])):
         close(sl(n[name].grad), g[key], TOL_F32, 2e-6, "table " + name)
 
+
+
+def test_clip_grad_norm_takes_parameters_outside_the_arena():
+    """The reference clips arbitrary parameter lists (torch.nn.utils.clip_grad_norm_, multimodal_train.py:362, img_pretrain.py:192): a
+    head outside the arena and a second model's parameters enter the norm and are scaled, through the library's own two kernels."""
+    from multimodalsum_amd.modules import TextSupervised
+    from multimodalsum_amd import optim
+    cfg = tiny_cfg(vocab=60, d=256, ffn=64, layers=1, heads=4, maxpos=40)
+    models = [TextSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=torch.float32, deterministic=True) for _ in range(2)]
+    extra = torch.nn.Linear(16, 8).to(DEV)
+    b = to_dev(syn.yelp_batch(2, 3, 16, 1, cfg.vocab_size, seed=5, img_hw=8))
+    for m in models:
+        m.train()
+        m(b["reviews"], b["reviews_mask"], b["reviews_rating"])[0].backward()
+    extra(torch.randn(4, 16, device=DEV)).square().sum().backward()
+    params = list(models[0].parameters()) + list(extra.parameters()) + list(models[1].parameters())
+    before = [p.grad.detach().clone() for p in params if p.grad is not None]
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in before))
+    max_norm = 0.25 * float(total)
+    norm = optim.clip_grad_norm_(params, max_norm)
+    assert norm.is_cuda and abs(float(norm) - float(total)) <= 1e-4 * float(total)
+    coef = max_norm / (float(total) + 1e-6)
+    for p, g0 in zip([p for p in params if p.grad is not None], before):
+        close(p.grad, g0 * coef, 1e-5, 1e-8, "clipped gradient")
+    assert optim.clip_grad_norm_([torch.nn.Parameter(torch.zeros(3, device=DEV))], 1.0).is_cuda       # nothing carries a gradient: zero, on the device

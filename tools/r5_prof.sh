@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # usage: r5_prof.sh <tag> [noside]: rocprofv3 kernel trace of the step -> steady-state per-step table (tools/prof_steady.py) + idle gaps
-R="${GRAFT_REPO_ROOT:-.}"; cd "$R"; mkdir -p gpurun_out
+R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"; cd "$R"; mkdir -p gpurun_out
 tag="${1:-r05}"; [ "${2:-}" = "noside" ] && export MMSUM_SIDE_STREAM=0
 (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$R"/gpurun_out/${tag}_prof -o r --output-format csv -- python3 "$R"/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-probe --no-also > "$R"/gpurun_out/${tag}_prof.log 2>&1)
 t=$(find gpurun_out/${tag}_prof -name "*kernel_trace.csv" | head -1)
