@@ -27,7 +27,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define MMSUM_ABI_VERSION 6
+#define MMSUM_ABI_VERSION 7
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -382,6 +382,11 @@ int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* pr
  * [rows / num_beams, 2 * num_beams], best first, id = beam * V + token, ties by lower id.  The banned positions of `logits`
  * are overwritten with -inf.  workspace: mmsum_beam_topk_workspace() bytes (per-chunk statistics and candidates: the logits are
  * read once by rows x 8 chunk blocks).  num_beams <= 8, V <= 65,536.
+ * Repetition penalty (enforce_repetition_penalty_, generation_utils.py:47-55; ABI 7): `penalized` [rows, npen] int32 = a row's DISTINCT
+ * previous tokens (first -1 ends the list; NULL or penalty == 1: none); a listed score s becomes s * penalty when negative, s / penalty
+ * otherwise, BEFORE the bans (postprocess_next_token_scores' order) -- on the log-probabilities (penalty_on_logits = 0: beam search,
+ * :2874-2890; costs a second pass over the logits) or on the raw logits (penalty_on_logits = 1: _generate_no_beam_search post-processes
+ * the logits themselves, :2749-2783; with num_beams = 1 and beam_scores 0 the first candidate of a row is then the reference's argmax).
  * mmsum_decode_self_attn: single-query self-attention of every hypothesis over its K/V cache rows (:776-815), reached
  * through an ancestor table: key s (< len) of row r is row ancestors[r * Tmax + s] * Tmax + s of k_cache / v_cache
  * ([rows * Tmax, H*64]).  A beam reorder (_reorder_cache :3104-3115) is then a gather of the table, not of the caches.
@@ -390,7 +395,8 @@ int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* pr
  * cache append of the reference (:804-815). */
 long mmsum_beam_topk_workspace(int rows, int num_beams);
 int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const float* beam_scores, const int* banned, int nban, int force_token,
-                    int ban_token, int rows, int num_beams, void* workspace, float* out_scores, long long* out_ids, void* stream);
+                    int ban_token, int rows, int num_beams, void* workspace, float* out_scores, long long* out_ids,
+                    const int* penalized, int npen, float penalty, int penalty_on_logits, void* stream);
 int mmsum_decode_self_attn(int dtype, const void* q, long ldq, void* k_cache, void* v_cache, long ld_cache, const int* ancestors,
                            void* out, long ldo, int rows, int H, int len, int Tmax, float scale, const void* k_new, const void* v_new,
                            long ld_new, void* stream);

@@ -32,10 +32,17 @@ template <typename T> __device__ __forceinline__ float ldf(const T* p, long i) {
 constexpr int TK_CHUNKS = 8;
 constexpr int TK_NPT = 32;            // logits per thread: a chunk holds at most TK_THREADS * TK_NPT = 8,192 of them
 
+// Repetition penalty (enforce_repetition_penalty_, generation_utils.py:47-55; round 6): `pen` [rows, npen] lists a row's distinct previous
+// tokens (-1 ends a list); each listed score s becomes s * penalty when negative, s / penalty otherwise -- BEFORE the bans, as
+// postprocess_next_token_scores orders them.  pen_mode 1: on the raw logits (greedy decoding post-processes the logits themselves);
+// pen_mode 2: on the log-probabilities (beam search: after log_softmax), which needs the row's log-sum-exp first: the host launches this
+// kernel twice, `phase` 1 = statistics only, `phase` 2 = read them back (every chunk's pair: the row's log-sum-exp), penalise, ban, select;
+// a penalised candidate leaves as (lp' + lse) so that stage 2's subtraction of lse gives lp'.  phase 0: one launch, as before.
 template <typename T>
 __global__ __launch_bounds__(TK_THREADS) void beam_topk_chunk_kernel(T* __restrict__ logits, long ld, int V, int chunk_len, const int* __restrict__ banned,
                                                                      int nban, int ban_token, int K, float* __restrict__ part_ms,
-                                                                     float* __restrict__ part_v, int* __restrict__ part_t) {
+                                                                     float* __restrict__ part_v, int* __restrict__ part_t,
+                                                                     const int* __restrict__ pen, int npen, float penalty, int pen_mode, int phase) {
     __shared__ float red_m[TK_THREADS / 64], red_s[TK_THREADS / 64];
     __shared__ float win_v[TK_THREADS / 64];
     __shared__ int win_t[TK_THREADS / 64];
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(TK_THREADS) void beam_topk_chunk_kernel(T* __restri
     }
     if (lane == 0) { red_m[wave] = m; red_s[wave] = s; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid == 0 && phase != 2) {
         float mm = red_m[0], ss = red_s[0];
 #pragma unroll
         for (int w = 1; w < TK_THREADS / 64; ++w) {
@@ -71,6 +78,35 @@ __global__ __launch_bounds__(TK_THREADS) void beam_topk_chunk_kernel(T* __restri
         }
         part_ms[((long)row * TK_CHUNKS + ch) * 2] = mm;
         part_ms[((long)row * TK_CHUNKS + ch) * 2 + 1] = ss;
+    }
+    if (phase == 1) return;                                    // statistics only (the log-prob penalty's first launch)
+    // ---- repetition penalty, before the bans
+    if (pen != nullptr && pen_mode != 0) {
+        float lse = 0.f;
+        if (pen_mode == 2) {                                   // the row's log-sum-exp from the statistics launch (uniform loads)
+            float mm = -INFINITY, ss = 0.f;
+#pragma unroll
+            for (int c = 0; c < TK_CHUNKS; ++c) {
+                const float m2 = part_ms[((long)row * TK_CHUNKS + c) * 2], s2 = part_ms[((long)row * TK_CHUNKS + c) * 2 + 1];
+                const float mx = fmaxf(mm, m2);
+                ss = (mm == -INFINITY ? 0.f : ss * __expf(mm - mx)) + (m2 == -INFINITY ? 0.f : s2 * __expf(m2 - mx));
+                mm = mx;
+            }
+            lse = mm + __logf(ss);
+        }
+        for (int i = 0; i < npen; ++i) {
+            const int t = pen[(long)row * npen + i];
+            if (t < 0) break;
+            if (t >= c0 && t < c1 && ((t - c0) % TK_THREADS) == tid) {
+                const int kk = (t - c0) / TK_THREADS;
+#pragma unroll
+                for (int k = 0; k < TK_NPT; ++k)
+                    if (k == kk) {
+                        const float sc = val[k] - lse;         // mode 1: lse = 0, the raw logit
+                        val[k] = (sc < 0.f ? sc * penalty : sc / penalty) + lse;
+                    }
+            }
+        }
     }
     // ---- bans, after the statistics: the owner thread drops the value it holds and writes -inf into the logits (the contract)
     auto ban = [&](int t) {
@@ -290,9 +326,12 @@ extern "C" long mmsum_beam_topk_workspace(int rows, int num_beams) {
 }
 
 extern "C" int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const float* beam_scores, const int* banned, int nban, int force_token,
-                               int ban_token, int rows, int num_beams, void* workspace, float* out_scores, long long* out_ids, void* stream) {
+                               int ban_token, int rows, int num_beams, void* workspace, float* out_scores, long long* out_ids,
+                               const int* penalized, int npen, float penalty, int penalty_on_logits, void* stream) {
     const int K = 2 * num_beams;
     if (rows <= 0 || V <= 0 || ld < V || num_beams < 1 || num_beams > 8 || K > TK_MAX || rows % num_beams || V < K || nban < 0) return MMSUM_ERR_BAD_SHAPE;
+    if (npen < 0 || (penalized != nullptr && (npen == 0 || !(penalty > 0.f)))) return MMSUM_ERR_BAD_SHAPE;
+    const int pen_mode = (penalized == nullptr || penalty == 1.f) ? 0 : (penalty_on_logits ? 1 : 2);
     if (force_token >= V || ban_token >= V) return MMSUM_ERR_BAD_SHAPE;
     const int chunk_len = ((V + TK_CHUNKS - 1) / TK_CHUNKS + 7) & ~7;
     if (chunk_len > TK_THREADS * TK_NPT) return MMSUM_ERR_BAD_SHAPE;          // V <= 65,536
@@ -303,11 +342,16 @@ extern "C" int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const fl
     int* part_t = reinterpret_cast<int*>(part_v + (long)rows * TK_CHUNKS * K);
     if (force_token < 0) {
         const dim3 grid(rows, TK_CHUNKS);
-        if (dtype == MMSUM_BF16)
-            beam_topk_chunk_kernel<bf16_t><<<grid, dim3(TK_THREADS), 0, s>>>((bf16_t*)logits, ld, V, chunk_len, banned, nban, ban_token, K, part_ms, part_v, part_t);
-        else if (dtype == MMSUM_F32)
-            beam_topk_chunk_kernel<float><<<grid, dim3(TK_THREADS), 0, s>>>((float*)logits, ld, V, chunk_len, banned, nban, ban_token, K, part_ms, part_v, part_t);
-        else return MMSUM_ERR_BAD_DTYPE;
+        // (a penalty on the log-probabilities needs the row's log-sum-exp before it can rank: a statistics launch first)
+        for (int phase = (pen_mode == 2 ? 1 : 0); phase <= (pen_mode == 2 ? 2 : 0); ++phase) {
+            if (dtype == MMSUM_BF16)
+                beam_topk_chunk_kernel<bf16_t><<<grid, dim3(TK_THREADS), 0, s>>>((bf16_t*)logits, ld, V, chunk_len, banned, nban, ban_token, K, part_ms, part_v, part_t,
+                                                                                  penalized, npen, penalty, pen_mode, phase);
+            else if (dtype == MMSUM_F32)
+                beam_topk_chunk_kernel<float><<<grid, dim3(TK_THREADS), 0, s>>>((float*)logits, ld, V, chunk_len, banned, nban, ban_token, K, part_ms, part_v, part_t,
+                                                                                 penalized, npen, penalty, pen_mode, phase);
+            else return MMSUM_ERR_BAD_DTYPE;
+        }
     } else if (dtype != MMSUM_BF16 && dtype != MMSUM_F32) {
         return MMSUM_ERR_BAD_DTYPE;
     }

@@ -75,6 +75,37 @@ def _banned_ngram_table(tokens, n, cur_len, out):
     return out
 
 
+def _bad_word_bans(tokens, cur_len, bad_words, out, col0):
+    """calc_banned_bad_words_ids (generation_utils.py:871-904) for every hypothesis: the last token of a bad word is banned when the row
+    ends with the word's other tokens (a one-token word always).  The reference's length guard compares the word with the NUMBER OF
+    ROWS (`len(prev_input_ids)`), not with the row's length: kept.  Appends to the rows' ban lists of `out` starting at their first -1
+    at or after column col0 (lists are filled from the front)."""
+    rows = tokens.shape[0]
+    fill = (out[:, :] >= 0).sum(axis=1)
+    for seq in bad_words:
+        head = seq[:-1]
+        if len(head) == 0:
+            hit = np.ones(rows, dtype=bool)
+        elif len(head) > rows or len(head) > cur_len:
+            # (a word longer than the rows so far cannot match: the reference's list comparison of unequal lengths is False)
+            hit = np.zeros(rows, dtype=bool)
+        else:
+            hit = (tokens[:, cur_len - len(head):cur_len] == np.asarray(head, dtype=tokens.dtype)[None, :]).all(axis=1)
+        r = np.nonzero(hit)[0]
+        out[r, fill[r]] = seq[-1]
+        fill[r] += 1
+    return out
+
+
+def _distinct_tokens(tokens, cur_len, out):
+    """A row's distinct previous tokens, -1 padded (the set() of enforce_repetition_penalty_, generation_utils.py:47-55)."""
+    out.fill(-1)
+    for r in range(tokens.shape[0]):
+        u = np.unique(tokens[r, :cur_len])
+        out[r, :u.size] = u
+    return out
+
+
 class DecodeSession:
     """KV-cached single-token decoder over an engine's weights; rows = B * num_beams hypotheses.
 
@@ -89,7 +120,7 @@ class DecodeSession:
     bans and the top-k run in mmsum_beam_topk, and the beam reorder is a gather of the [rows, max_length] ancestor table
     (mmsum_decode_self_attn reads the caches through it) instead of a gather of every layer's K/V cache."""
 
-    def __init__(self, engine, layout, num_beams, max_length, has_rating, min_length=0, ngram=0):
+    def __init__(self, engine, layout, num_beams, max_length, has_rating, min_length=0, ngram=0, bad_words=None, penalty=1.0, greedy=False):
         e, cfg = engine, engine.cfg
         if max_length > 256:
             raise ValueError("max_length > 256 exceeds the decode self-attention kernel's cache walk (mmsum_decode_self_attn: Tmax <= 256)")
@@ -97,6 +128,8 @@ class DecodeSession:
             raise ValueError("num_beams > 8: the candidate kernel keeps 2*num_beams <= 16 entries per thread")
         self.e, self.L, self.qpb, self.Tmax = e, layout, num_beams, max_length
         self.min_length, self.ngram = min_length, ngram
+        self.bad_words = [list(map(int, w)) for w in bad_words] if bad_words else []
+        self.penalty, self.greedy = float(penalty), bool(greedy)
         D, R = cfg.d_model, layout.B * num_beams
         self.rows = R
         dev = e.device
@@ -115,12 +148,13 @@ class DecodeSession:
         self.arange = torch.arange(R, dtype=torch.int32, device=dev)
         self.mean, self.rstd = e.empty(R, dtype=torch.float32), e.empty(R, dtype=torch.float32)
         # host-filled inputs of a step: [tokens R | parent rows R | banned tokens R * nban] int32, beam scores f32
-        self.nban = max_length if ngram > 0 else 0
+        self.nban = (max_length if ngram > 0 else 0) + len(self.bad_words)
+        self.npen = max_length if self.penalty != 1.0 else 0       # the row's distinct previous tokens (repetition penalty)
         pin = dev.type == "cuda"
-        self.h_int = torch.zeros(R * (2 + self.nban), dtype=torch.int32, pin_memory=pin)
+        self.h_int = torch.zeros(R * (2 + self.nban + self.npen), dtype=torch.int32, pin_memory=pin)
         self.h_sc = torch.zeros(R, dtype=torch.float32, pin_memory=pin)
         self.h_int_np, self.h_sc_np = self.h_int.numpy(), self.h_sc.numpy()       # host views the bookkeeping writes with numpy
-        self.d_int = torch.zeros(R * (2 + self.nban), dtype=torch.int32, device=dev)
+        self.d_int = torch.zeros(R * (2 + self.nban + self.npen), dtype=torch.int32, device=dev)
         self.beam_scores = torch.zeros(R, dtype=torch.float32, device=dev)
         self.tokens = torch.zeros(R, 1, dtype=torch.long, device=dev)
         # the quantity that is ranked stays f32 in either compute mode: f32 logits [rows, Vpad] (6 MB), and in bf16 mode the last
@@ -181,7 +215,14 @@ class DecodeSession:
         hi[:R] = tokens
         hi[R:2 * R] = np.arange(R, dtype=np.int32) if parents is None else parents
         if nb:
-            _banned_ngram_table(history, self.ngram, t + 1, hi[2 * R:].reshape(R, nb))
+            table = hi[2 * R:2 * R + R * nb].reshape(R, nb)
+            table.fill(-1)
+            if self.ngram > 0:
+                _banned_ngram_table(history, self.ngram, t + 1, table)
+            if self.bad_words:
+                _bad_word_bans(history, t + 1, self.bad_words, table, 0)
+        if self.npen:
+            _distinct_tokens(history, t + 1, hi[2 * R + R * nb:].reshape(R, self.npen))
         self.h_sc_np[:] = scores
         self.d_int.copy_(self.h_int, non_blocking=True)
         self.beam_scores.copy_(self.h_sc, non_blocking=True)
@@ -322,8 +363,10 @@ class DecodeSession:
         eos = cfg.eos_token_id
         force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)
         ban = eos if (eos is not None and cur_len < self.min_length) else -1
-        banned = self.d_int[2 * R:].view(R, self.nban) if self.nban else None
-        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids)
+        banned = self.d_int[2 * R:2 * R + R * self.nban].view(R, self.nban) if self.nban else None
+        pen = self.d_int[2 * R + R * self.nban:].view(R, self.npen) if self.npen else None
+        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids, penalized=pen,
+                     penalty=self.penalty, penalty_on_logits=self.greedy)
 
     def _step(self, t):
         if self.fast:
@@ -403,23 +446,59 @@ class DecodeSession:
         eos = cfg.eos_token_id
         force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)      # :3084-3089
         ban = eos if (eos is not None and cur_len < self.min_length) else -1
-        banned = self.d_int[2 * R:].view(R, self.nban) if self.nban else None
-        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids)
+        banned = self.d_int[2 * R:2 * R + R * self.nban].view(R, self.nban) if self.nban else None
+        pen = self.d_int[2 * R + R * self.nban:].view(R, self.npen) if self.npen else None
+        kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids, penalized=pen,
+                     penalty=self.penalty, penalty_on_logits=self.greedy)
 
 
-def _session(engine, layout, num_beams, max_length, has_rating, min_length, ngram):
-    key = (tuple(layout.mods), layout.B, num_beams, max_length, has_rating, min_length, ngram)
+def _session(engine, layout, num_beams, max_length, has_rating, min_length, ngram, bad_words=None, penalty=1.0, greedy=False):
+    bw = tuple(tuple(int(t) for t in w) for w in bad_words) if bad_words else ()
+    key = (tuple(layout.mods), layout.B, num_beams, max_length, has_rating, min_length, ngram, bw, float(penalty), bool(greedy))
     cache = engine.__dict__.setdefault("_decode_sessions", {})
     if key not in cache:
         if len(cache) >= 4:                          # static buffers + graphs per shape: keep only a few
             cache.pop(next(iter(cache)))
-        cache[key] = DecodeSession(engine, layout, num_beams, max_length, has_rating, min_length, ngram)
+        cache[key] = DecodeSession(engine, layout, num_beams, max_length, has_rating, min_length, ngram, bw, penalty, greedy)
     return cache[key]
 
 
 @torch.no_grad()
+def greedy_search(engine, hiddens, layout, pads, rating_diff, max_length, min_length, no_repeat_ngram_size, decoder_start_token_id,
+                  bad_words_ids=None, repetition_penalty=1.0):
+    """Greedy decoding (_generate_no_beam_search with do_sample = False, modeling_multimodalsum.py:2767-2868 / :1767-1868) on the decode
+    session with ONE hypothesis per business: the step's tail (forced BOS / EOS, repetition penalty and bans on the LOGITS -- the
+    reference post-processes the tensor its argmax reads -- then the best candidate) is mmsum_beam_topk with num_beams = 1; a finished
+    row keeps being fed and is padded with pad_token_id; the loop ends when every row has produced EOS.  Returns LongTensor [B, L]."""
+    cfg = engine.cfg
+    pad, eos, V = cfg.pad_token_id, cfg.eos_token_id, cfg.vocab_size
+    B = layout.B
+    sess = _session(engine, layout, 1, max_length, rating_diff is not None, min_length if eos is not None else 0, no_repeat_ngram_size,
+                    bad_words_ids, repetition_penalty, greedy=True)
+    sess.begin(hiddens, pads, rating_diff)
+    hist = np.full((B, max_length), pad, dtype=np.int64)
+    hist[:, 0] = decoder_start_token_id
+    last = hist[:, 0].astype(np.int32)
+    unfinished = np.ones(B, dtype=bool)
+    zeros = np.zeros(B, dtype=np.float32)
+    cur_len = 1
+    while cur_len < max_length:
+        _, top_i = sess.step(last, None, zeros, hist, cur_len - 1)
+        tok = (top_i[:, 0] % V).astype(np.int64)
+        add = np.where(unfinished, tok, pad) if eos is not None else tok
+        hist[:, cur_len] = add
+        last = add.astype(np.int32)
+        cur_len += 1
+        if eos is not None:
+            unfinished &= add != eos
+        if not unfinished.any():
+            break
+    return torch.from_numpy(hist[:, :cur_len].copy()).to(engine.device)
+
+
+@torch.no_grad()
 def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size, early_stopping,
-                length_penalty, decoder_start_token_id, trace=None):
+                length_penalty, decoder_start_token_id, trace=None, bad_words_ids=None, repetition_penalty=1.0):
     """Greedy beam search (_generate_beam_search :2803-3067).  Returns LongTensor [B, L] on the engine's device.
     trace (a list, tests only): receives one dict per decode step -- the hypotheses the step scored, their beam scores, which
     businesses were still open and the 2 * num_beams candidates the device returned -- so that a CPU oracle can re-score the
@@ -429,7 +508,8 @@ def beam_search(engine, hiddens, layout, pads, rating_diff, num_beams, max_lengt
     dev = engine.device
     B = layout.B
     R = B * num_beams
-    sess = _session(engine, layout, num_beams, max_length, rating_diff is not None, min_length if eos is not None else 0, no_repeat_ngram_size)
+    sess = _session(engine, layout, num_beams, max_length, rating_diff is not None, min_length if eos is not None else 0, no_repeat_ngram_size,
+                    bad_words_ids, repetition_penalty)
     sess.begin(hiddens, pads, rating_diff)
     hist = np.full((R, max_length), pad, dtype=np.int64)                   # host copy of input_ids
     hist[:, 0] = decoder_start_token_id

@@ -487,30 +487,24 @@ def rows_gather(src, dst, row_map, live=None):
     return dst
 
 
-def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids):
+def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids, penalized=None, penalty=1.0,
+              penalty_on_logits=False):
     """Tail of one beam-search step (see mmsum_beam_topk): logits [rows, >=V] (banned entries are overwritten with -inf),
-    beam_scores [rows] f32, banned [rows, nban] int32 (filled from the front, the first -1 ends a row's list) or None -> out_scores f32 / out_ids int64 [B, 2*num_beams]."""
+    beam_scores [rows] f32, banned [rows, nban] int32 (filled from the front, the first -1 ends a row's list) or None -> out_scores f32 / out_ids int64 [B, 2*num_beams].
+    penalized [rows, npen] int32 (a row's distinct previous tokens, -1 terminated) + penalty: the repetition penalty, on the
+    log-probabilities (beam search) or on the raw logits (penalty_on_logits: greedy decoding)."""
     rows = logits.shape[0]
     assert beam_scores.dtype == torch.float32 and out_scores.dtype == torch.float32 and out_ids.dtype == torch.int64
     nban = 0 if banned is None else banned.shape[1]
     if banned is not None:
         assert banned.dtype == torch.int32 and banned.is_contiguous() and banned.shape[0] == rows
+    npen = 0 if penalized is None else penalized.shape[1]
+    if penalized is not None:
+        assert penalized.dtype == torch.int32 and penalized.is_contiguous() and penalized.shape[0] == rows
     ws = _workspace(lib.mmsum_beam_topk_workspace(rows, num_beams), logits.device, "topk")
     check(lib.mmsum_beam_topk(_dt(logits), _p(logits), _ld(logits), V, _p(beam_scores), _p(banned), nban, int(force_token), int(ban_token), rows,
-                              num_beams, _p(ws), _p(out_scores), _p(out_ids), _stream()), "mmsum_beam_topk")
-
-
-def decode_self_attn(q, k_cache, v_cache, ancestors, out, H, length, Tmax, scale, k_new=None, v_new=None):
-    """out[r] = softmax(q[r] . K_r^T) V_r per head, K_r / V_r = the first `length` cache positions of hypothesis r reached through
-    cache row ancestors[r, s] * Tmax + s (see mmsum_decode_self_attn).  k_new / v_new [rows, D]: this step's projections; the kernel
-    appends them to the caches at position length - 1 (ancestors[r, length - 1] must be r)."""
-    assert ancestors.dtype == torch.int32 and ancestors.is_contiguous() and ancestors.shape == (q.shape[0], Tmax)
-    assert k_cache.shape == v_cache.shape and (k_new is None) == (v_new is None)
-    if k_new is not None:
-        assert k_new.stride(0) == v_new.stride(0) and k_new.stride(1) == 1 and v_new.stride(1) == 1
-    check(lib.mmsum_decode_self_attn(_dt(q), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _ld(k_cache), _p(ancestors), _p(out), out.stride(0),
-                                     q.shape[0], H, int(length), Tmax, float(scale), _p(k_new), _p(v_new),
-                                     k_new.stride(0) if k_new is not None else 0, _stream()), "mmsum_decode_self_attn")
+                              num_beams, _p(ws), _p(out_scores), _p(out_ids), _p(penalized), npen, float(penalty), int(bool(penalty_on_logits)),
+                              _stream()), "mmsum_beam_topk")
 
 
 def decode_cross_attn_workspace(n_entities, H, qpb, B, nmod, device):

@@ -383,10 +383,10 @@ class _BartBase(nn.Module):
                   early_stopping=None, num_beams=None, temperature=None, top_k=None, top_p=None, repetition_penalty=None,
                   bad_words_ids=None, bos_token_id=None, pad_token_id=None, eos_token_id=None, length_penalty=None,
                   no_repeat_ngram_size=None, num_return_sequences=None, decoder_start_token_id=None, use_cache=None, trace=None, **unused):
-        """generate() of the reference (modeling_multimodalsum.py:2295-2693 / :1398-1700): greedy beam search as
-        test.py:156-158 calls it.  Sampling, repetition penalty, bad-word lists, prompts and num_beams == 1 are
-        not part of the scoped path and raise."""
-        from .generation import beam_search
+        """generate() of the reference (modeling_multimodalsum.py:2295-2693 / :1398-1700): beam search as test.py:156-158 calls it,
+        greedy decoding (num_beams == 1), bad_words_ids and repetition_penalty in either search (round 6).  Sampling (do_sample: torch's
+        random stream cannot be reproduced), prompts (input_ids) and more than one returned sequence are not built and raise."""
+        from .generation import beam_search, greedy_search
         cfg, e = self.config, self._engine
         pick = lambda v, d: d if v is None else v                                    # noqa: E731
         max_length, min_length = pick(max_length, cfg.max_length), pick(min_length, cfg.min_length)
@@ -395,11 +395,15 @@ class _BartBase(nn.Module):
         no_repeat_ngram_size = pick(no_repeat_ngram_size, cfg.no_repeat_ngram_size)
         start = pick(decoder_start_token_id, cfg.decoder_start_token_id)
         start = cfg.bos_token_id if start is None else start
-        if do_sample or (repetition_penalty not in (None, 1.0)) or bad_words_ids or input_ids is not None \
-                or (num_return_sequences not in (None, 1)) or num_beams < 2:
-            raise NotImplementedError("generate(): only greedy beam search (num_beams >= 2, one returned sequence, no prompt, "
-                                      "no sampling / repetition penalty / bad words) is built")
-        assert max_length > 1 and min_length >= 0 and length_penalty > 0 and no_repeat_ngram_size >= 0
+        repetition_penalty = pick(repetition_penalty, getattr(cfg, "repetition_penalty", 1.0))
+        do_sample = pick(do_sample, getattr(cfg, "do_sample", False))
+        if do_sample or input_ids is not None or (num_return_sequences not in (None, 1)) or num_beams < 1:
+            raise NotImplementedError("generate(): beam search and greedy decoding (one returned sequence, no prompt) are built; "
+                                      "sampling is not (torch's random stream cannot be reproduced)")
+        assert max_length > 1 and min_length >= 0 and length_penalty > 0 and no_repeat_ngram_size >= 0 and repetition_penalty > 0
+        if bad_words_ids is not None:
+            assert all(isinstance(w, (list, tuple)) and len(w) > 0 and all(int(t) >= 0 for t in w) for w in bad_words_ids), \
+                "`bad_words_ids` is a list of non-empty lists of non-negative token ids"
         was_training = e.training
         e.training = False
         try:
@@ -407,8 +411,12 @@ class _BartBase(nn.Module):
             B = hiddens[0].shape[0]
             layout = e.make_memory(B, [(h.shape[1], h.shape[2]) for h in hiddens])
             pads = [m.eq(0).to(torch.uint8).contiguous() for m in masks]
+            if num_beams == 1:
+                return greedy_search(e, hiddens, layout, pads, rating_diff, max_length, min_length, no_repeat_ngram_size, int(start),
+                                     bad_words_ids=bad_words_ids, repetition_penalty=float(repetition_penalty))
             return beam_search(e, hiddens, layout, pads, rating_diff, num_beams, max_length, min_length, no_repeat_ngram_size,
-                               bool(early_stopping), float(length_penalty), int(start), trace=trace)
+                               bool(early_stopping), float(length_penalty), int(start), trace=trace, bad_words_ids=bad_words_ids,
+                               repetition_penalty=float(repetition_penalty))
         finally:
             e.training = was_training
 

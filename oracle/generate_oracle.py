@@ -69,7 +69,102 @@ def next_token_logits(sd, cfg, input_ids, hiddens, masks, rating_diff, multimoda
     return F.linear(h[:, -1, :], sd[prefix + "model.shared.weight"])
 
 
-def step_scores(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, max_length, min_length=0, no_repeat_ngram_size=0, prefix=""):
+def banned_bad_words(rows, bad_words_ids):
+    """calc_banned_bad_words_ids (generation_utils.py:871-904), literally -- including its quirk: a bad word longer than the NUMBER OF
+    ROWS (`len(prev_input_ids)`, the batch dimension, not the sequence length) never matches."""
+    out = []
+    for toks in rows:
+        banned = []
+        for seq in bad_words_ids:
+            assert len(seq) > 0
+            head = list(seq[:-1])
+            if len(head) == 0:
+                ok = True
+            elif len(head) > len(rows):
+                ok = False
+            else:
+                ok = toks[-len(head):] == head
+            if ok:
+                banned.append(seq[-1])
+        out.append(banned)
+    return out
+
+
+def repetition_penalty_(scores, rows, penalty):
+    """enforce_repetition_penalty_ (generation_utils.py:47-55): every token already in the row: score < 0 -> * penalty, else / penalty."""
+    for i, toks in enumerate(rows):
+        for t in set(toks):
+            if scores[i, t] < 0:
+                scores[i, t] *= penalty
+            else:
+                scores[i, t] /= penalty
+
+
+def postprocess_(scores, input_ids, cfg, cur_len, min_length, no_repeat_ngram_size, bad_words_ids, repetition_penalty):
+    """postprocess_next_token_scores (generation_utils.py:57-98), in its order: repetition penalty, min-length EOS ban, n-gram bans, bad words."""
+    rows = input_ids.tolist()
+    eos = cfg.eos_token_id
+    if repetition_penalty != 1.0:
+        repetition_penalty_(scores, rows, repetition_penalty)
+    if eos is not None and cur_len < min_length:
+        scores[:, eos] = float("-inf")
+    if no_repeat_ngram_size > 0:
+        for i, banned in enumerate(banned_ngram_tokens(rows, no_repeat_ngram_size, cur_len)):
+            scores[i, banned] = float("-inf")
+    if bad_words_ids is not None:
+        for i, banned in enumerate(banned_bad_words(rows, bad_words_ids)):
+            scores[i, banned] = float("-inf")
+    return scores
+
+
+def _forced(logits, cfg, cur_len, max_length):
+    """adjust_logits_during_generation (:3084-3102): BOS forced at length 1, EOS at max_length - 1."""
+    bos, eos = cfg.bos_token_id, cfg.eos_token_id
+    if cur_len == 1:
+        keep = logits[:, bos].clone()
+        logits.fill_(float("-inf"))
+        logits[:, bos] = keep
+    if cur_len == max_length - 1 and eos is not None:
+        keep = logits[:, eos].clone()
+        logits.fill_(float("-inf"))
+        logits[:, eos] = keep
+    return logits
+
+
+def greedy_search(sd, cfg, hiddens, masks, rating_diff, multimodal, max_length, min_length=0, no_repeat_ngram_size=0, bad_words_ids=None,
+                  repetition_penalty=1.0, decoder_start_token_id=None, prefix=""):
+    """_generate_no_beam_search with do_sample = False (:2767-2868 / :1767-1868): argmax of the post-processed LOGITS (the post-processing
+    works in place on the tensor the argmax reads: penalty and bans apply to raw logits, there is no log_softmax), finished rows are
+    fed and padded with pad_token_id, the loop ends when every row has produced EOS.  Returns LongTensor [B, L]."""
+    pad, bos, eos = cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id
+    start = bos if decoder_start_token_id is None else decoder_start_token_id
+    first = hiddens[0] if multimodal else hiddens
+    B = first.shape[0]
+    input_ids = torch.full((B, 1), start, dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.long)
+    cur_len = 1
+    memo_store = {}
+    while cur_len < max_length:
+        prev, bo.KV_MEMO = bo.KV_MEMO, memo_store
+        try:
+            logits = next_token_logits(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, prefix)
+        finally:
+            bo.KV_MEMO = prev
+        logits = _forced(logits, cfg, cur_len, max_length)
+        postprocess_(logits, input_ids, cfg, cur_len, min_length, no_repeat_ngram_size, bad_words_ids, repetition_penalty)
+        nxt = torch.argmax(logits, dim=-1)
+        add = nxt * unfinished + pad * (1 - unfinished) if eos is not None else nxt
+        input_ids = torch.cat([input_ids, add[:, None]], dim=1)
+        cur_len += 1
+        if eos is not None:
+            unfinished = unfinished * (add != eos).long()
+        if unfinished.max() == 0:
+            break
+    return input_ids
+
+
+def step_scores(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, max_length, min_length=0, no_repeat_ngram_size=0, prefix="",
+                bad_words_ids=None, repetition_penalty=1.0):
     """Log-probabilities of the next token for every hypothesis row `input_ids` [rows, cur_len], with the reference's adjustments:
     BOS forced at length 1 and EOS at max_length - 1 on the logits (:3084-3102), log_softmax (:2874), EOS banned below min_length
     (:2877-2879) and the n-gram ban (:2890-2899) on the scores.  hiddens / masks / rating_diff: one entry per row."""
@@ -85,17 +180,12 @@ def step_scores(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, max
         logits.fill_(float("-inf"))
         logits[:, eos] = keep
     scores = F.log_softmax(logits, dim=-1)
-    if eos is not None and cur_len < min_length:
-        scores[:, eos] = float("-inf")
-    if no_repeat_ngram_size > 0:
-        for i, banned in enumerate(banned_ngram_tokens(input_ids.tolist(), no_repeat_ngram_size, cur_len)):
-            scores[i, banned] = float("-inf")
-    return scores
+    return postprocess_(scores, input_ids, cfg, cur_len, min_length, no_repeat_ngram_size, bad_words_ids, repetition_penalty)
 
 
 def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max_length, min_length=0,
                 no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.0, decoder_start_token_id=None, prefix="",
-                return_scores=False, margins=None, guide=None, return_all=False):
+                return_scores=False, margins=None, guide=None, return_all=False, bad_words_ids=None, repetition_penalty=1.0):
     """hiddens/masks: list of [B,N,S,D] / [B,N,S] (multimodal) or single tensors.  Returns LongTensor [B, L] (return_scores: and the
     best hypothesis' score per business, which the reference does not return; tests check sequence_score against it).
     margins (a list, tests only): receives per decode step the smallest gap between two consecutive candidates among the best
@@ -130,7 +220,8 @@ def beam_search(sd, cfg, hiddens, masks, rating_diff, multimodal, num_beams, max
         # cross-attention K / V of the (fixed) memory: projected once per generate() call like the reference's cache (:804-815)
         prev, bo.KV_MEMO = bo.KV_MEMO, memo_store
         try:
-            return step_scores(sd, cfg, ids, hid, msk, rd, multimodal, max_length, min_length, no_repeat_ngram_size, prefix)
+            return step_scores(sd, cfg, ids, hid, msk, rd, multimodal, max_length, min_length, no_repeat_ngram_size, prefix,
+                               bad_words_ids, repetition_penalty)
         finally:
             bo.KV_MEMO = prev
     memo_store = {}

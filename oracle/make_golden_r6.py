@@ -1,0 +1,65 @@
+"""TEST INFRASTRUCTURE, development container only (imports /root/reference): golden vectors of the generate() modes that round 6
+adds to the HIP path -- greedy decoding (num_beams = 1, _generate_no_beam_search), bad_words_ids and repetition_penalty (in greedy
+decoding and in beam search) -- produced by the REFERENCE's own generate() on the F2 model of oracle/make_golden.py (same formula
+weights, same inputs).  Writes tests/golden/g3_generate_modes.npz.  usage: python oracle/make_golden_r6.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import make_golden as mg                                   # noqa: E402
+from multimodalsum_amd import synthetic as syn                         # noqa: E402
+from multimodalsum_amd.formula_init import formula_tensor              # noqa: E402
+
+
+def main():
+    mt, tp, mm, BartConfig, te, ru, _A = mg.import_reference()
+    torch.manual_seed(0)
+    cfg = mg.tiny_cfg(BartConfig)
+    model = mm.BartForMultiEncConditionalGeneration(cfg)
+    mg.load_formula(model, prefix="f2.", std=0.08)
+    model.eval()
+    Bz, N, S = 3, 3, 8
+    ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
+    text_m = ids.ne(1).clone()
+    text_m[1, 2, :] = False
+    table_h = formula_tensor("f2.table_h", (Bz, 1, 6, cfg.d_model), std=1.0)
+    table_m = torch.ones(Bz, 1, 6, dtype=torch.bool)
+    table_m[2] = False
+    img_h = formula_tensor("f2.img_h", (Bz, 2, 4, cfg.d_model), std=1.0)
+    img_m = torch.ones(Bz, 2, 4, dtype=torch.bool)
+    img_m[0] = False
+    img_m[1, 1] = False
+    rating_diff = torch.tensor([[0.5], [-1.25], [2.0]])
+    out = {}
+    with torch.no_grad():
+        enc = model.model.encoder(input_ids=ids.view(-1, S), attention_mask=ids.view(-1, S).ne(1))[0].view(Bz, N, S, -1)
+        args = (enc, text_m, table_h, table_m, img_h, img_m)
+        g0 = model.generate(*args, rating_diff=rating_diff, num_beams=1, max_length=14, no_repeat_ngram_size=2)
+        # bad words from what the plain greedy run produced: one single-token word and one two-token word (its second token is banned
+        # only right after its first) -- so the bans really change the run
+        row0 = g0[0].tolist()
+        bad = [[int(row0[2])], [int(row0[3]), int(row0[4])], [int(g0[1, 2]), int(g0[1, 3])]]
+        out["bad_words"] = np.array([b + [-1] * (2 - len(b)) for b in bad], dtype=np.int64)
+        cases = {
+            "greedy": dict(num_beams=1, max_length=14, no_repeat_ngram_size=2),
+            "greedy_min": dict(num_beams=1, max_length=12, min_length=6, no_repeat_ngram_size=0),
+            "greedy_bad": dict(num_beams=1, max_length=14, no_repeat_ngram_size=2, bad_words_ids=bad),
+            "greedy_rep": dict(num_beams=1, max_length=14, no_repeat_ngram_size=0, repetition_penalty=1.7),
+            "beam_bad": dict(num_beams=4, max_length=14, no_repeat_ngram_size=3, early_stopping=True, length_penalty=1.0, bad_words_ids=bad),
+            "beam_rep": dict(num_beams=3, max_length=12, no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.5, repetition_penalty=1.3),
+        }
+        for name, kw in cases.items():
+            g = model.generate(*args, rating_diff=rating_diff, **kw)
+            out["gen_" + name] = g.numpy()
+            print(name, g.tolist())
+    assert not np.array_equal(out["gen_greedy"], out["gen_greedy_bad"]) and not np.array_equal(out["gen_greedy"], out["gen_greedy_rep"])
+    np.savez(os.path.join(ROOT, "tests", "golden", "g3_generate_modes.npz"), ids=ids.numpy(), text_m=text_m.numpy(), table_m=table_m.numpy(),
+             img_m=img_m.numpy(), rating_diff=rating_diff.numpy(), enc_eval=enc.numpy(), **out)
+
+
+if __name__ == "__main__":
+    main()

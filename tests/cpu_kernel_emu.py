@@ -646,15 +646,33 @@ def rows_gather(src, dst, row_map, live=None):
     return dst
 
 
-def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids):
-    """Contract of mmsum_beam_topk restated with torch ops in the reference's order (adjust_logits, log_softmax, bans, + beam
-    score, topk over [B, beams * V]); ties by lower flat index."""
+def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids, penalized=None, penalty=1.0,
+              penalty_on_logits=False):
+    """Contract of mmsum_beam_topk restated with torch ops in the reference's order (adjust_logits, log_softmax, repetition penalty,
+    bans, + beam score, topk over [B, beams * V]); ties by lower flat index.  penalty_on_logits: the penalty applies to the raw logits
+    (greedy decoding), and the candidates' scores are those penalised logits minus the ORIGINAL row's log-sum-exp (any per-row
+    constant: only the order within a row matters there)."""
     x = logits[:, :V].float().clone()
     if force_token >= 0:
         keep = x[:, force_token].clone()
         x.fill_(float("-inf"))
         x[:, force_token] = keep
-    sc = torch.log_softmax(x, dim=-1)
+
+    def penalise(t):
+        if penalized is None or penalty == 1.0 or force_token >= 0:
+            return
+        for r in range(penalized.shape[0]):
+            for tok in penalized[r].tolist():
+                if tok < 0:
+                    break
+                t[r, tok] = t[r, tok] * penalty if t[r, tok] < 0 else t[r, tok] / penalty
+    if penalty_on_logits:
+        lse = torch.logsumexp(x, dim=-1, keepdim=True)
+        penalise(x)
+        sc = x - lse
+    else:
+        sc = torch.log_softmax(x, dim=-1)
+        penalise(sc)
     if ban_token >= 0:
         sc[:, ban_token] = float("-inf")
     if banned is not None:

@@ -1063,6 +1063,50 @@ def test_dec_gemm(M, N, K, epi, k2, f32):
     assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(first, nan=7.0))
 
 
+@pytest.mark.parametrize("on_logits", [False, True], ids=["beam", "greedy"])
+@pytest.mark.parametrize("num_beams,V", [(1, 50265), (4, 50265), (3, 1000)])
+def test_beam_topk_repetition_penalty(num_beams, V, on_logits):
+    """mmsum_beam_topk with the repetition penalty (enforce_repetition_penalty_, generation_utils.py:47-55) in the reference's order --
+    log_softmax, penalty on the log-probabilities, bans (beam search, :2874-2900), or penalty and bans on the raw logits (greedy
+    decoding, :2749-2783: only the order within a row matters there) -- against the same torch ops: each row's best token is
+    penalised (the winner must change), one banned token is also listed (the ban wins), f32 logits."""
+    B = 3
+    R, K = B * num_beams, 2 * num_beams
+    ld = (V + 127) // 128 * 128
+    g = torch.Generator().manual_seed(17)
+    for penalty in (1.7, 0.6):
+        logits = (torch.randn(R, ld, generator=g) * 3).to(DEV)
+        beam_scores = torch.zeros(R, device=DEV) if on_logits else (torch.randn(R, generator=g) * 2).to(DEV)
+        order = logits[:, :V].argsort(-1, descending=True).cpu()
+        pen = torch.full((R, 9), -1, dtype=torch.int32)
+        banned = torch.full((R, 3), -1, dtype=torch.int32)
+        for r in range(R):
+            pen[r, 0], pen[r, 1], pen[r, 2], pen[r, 3] = int(order[r, 0]), int(order[r, 2]), int(order[r, 40]), (r * 13 + 5) % V
+            banned[r, 0] = int(order[r, 2])                      # listed AND banned: the ban comes after the penalty
+        ref = logits[:, :V].float().clone()
+        sc = ref if on_logits else torch.log_softmax(ref, dim=-1)
+        for r in range(R):
+            for t in pen[r].tolist():
+                if t >= 0:
+                    sc[r, t] = sc[r, t] * penalty if sc[r, t] < 0 else sc[r, t] / penalty
+        if on_logits:
+            sc = sc - torch.logsumexp(logits[:, :V].float(), dim=-1, keepdim=True)
+        for r in range(R):
+            sc[r, int(banned[r, 0])] = float("-inf")
+        cand = (sc + beam_scores[:, None]).view(B, num_beams * V)
+        want_s, want_i = torch.topk(cand, K, dim=1)
+        out_s = torch.zeros(B, K, device=DEV)
+        out_i = torch.zeros(B, K, dtype=torch.int64, device=DEV)
+        kn.beam_topk(logits, V, beam_scores, banned.to(DEV), -1, -1, num_beams, out_s, out_i, penalized=pen.to(DEV), penalty=penalty,
+                     penalty_on_logits=on_logits)
+        assert float((out_s - want_s).abs().max()) <= 2e-4, (penalty, float((out_s - want_s).abs().max()))
+        gaps = (want_s[:, :-1] - want_s[:, 1:]).min()
+        if float(gaps) > 1e-3:
+            assert torch.equal(out_i, want_i), (penalty, out_i, want_i)
+        for b in range(B):
+            assert float((cand[b][out_i[b]] - out_s[b]).abs().max()) <= 2e-4
+
+
 def test_handoff_stress():
     """The in-launch hand-offs: mmsum_dec_gemm's split-K slabs and mmsum_decode_cross_attn's entity mean (bf16 AND f32 kernels) meet in
     the LAST ARRIVER through write-through stores + a relaxed ticket, without release / acquire fences -- an ordering that rests on

@@ -830,3 +830,46 @@ def test_clip_grad_norm_takes_parameters_outside_the_arena():
     for p, g0 in zip([p for p in params if p.grad is not None], before):
         close(p.grad, g0 * coef, 1e-5, 1e-8, "clipped gradient")
     assert optim.clip_grad_norm_([torch.nn.Parameter(torch.zeros(3, device=DEV))], 1.0).is_cuda       # nothing carries a gradient: zero, on the device
+
+
+@pytest.mark.parametrize("name", ["greedy", "greedy_min", "greedy_bad", "greedy_rep", "beam_bad", "beam_rep"])
+def test_generate_modes_f32(name):
+    """generate() beside test.py's beam search -- greedy decoding (num_beams = 1), bad_words_ids, repetition_penalty in either search
+    (modeling_multimodalsum.py:2767-2868, generation_utils.py:47-98,871-904) -- on the HIP decode path, f32 mode: token ids equal to the
+    oracle's restatement, which tests/test_oracle_golden.py::test_g3_generate_modes holds to the REFERENCE's own generate() output."""
+    from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
+    from oracle import generate_oracle as go
+    from tests.test_oracle_golden import G3_CASES
+    cfg = tiny_cfg(vocab=100, d=256, ffn=128, layers=2, heads=4, maxpos=64)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
+    model = BartForMultiEncConditionalGeneration(cfg, device=DEV, dtype=torch.float32, deterministic=True)
+    model.load_state_dict(sd)
+    model.eval()
+    Bz, N, S = 3, 3, 8
+    ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=11, min_len=3).view(Bz, N, S)
+    text_m = ids.ne(1).clone()
+    text_m[1, 2, :] = False
+    table_h = formula_tensor("t.table_h", (Bz, 1, 6, cfg.d_model), std=1.0)
+    img_h = formula_tensor("t.img_h", (Bz, 2, 4, cfg.d_model), std=1.0)
+    table_m = torch.ones(Bz, 1, 6, dtype=torch.bool)
+    img_m = torch.ones(Bz, 2, 4, dtype=torch.bool)
+    img_m[2, 1] = False
+    rd = torch.tensor([[0.5], [-1.25], [2.0]])
+    kw = dict(G3_CASES[name])
+    with torch.no_grad():
+        enc = model.model.encoder(input_ids=ids.view(-1, S).to(DEV), attention_mask=ids.view(-1, S).ne(1).to(DEV))[0].view(Bz, N, S, -1)
+        oenc = bo.bart_encoder(sd, ocfg, ids.view(-1, S), ids.view(-1, S).ne(1)).view(Bz, N, S, -1)
+        hid, msk = [oenc, table_h, img_h], [text_m, table_m, img_m]
+        bw = None
+        if kw.pop("bad_words", False):
+            base = go.greedy_search(sd, ocfg, hid, msk, rd, True, max_length=14, no_repeat_ngram_size=2, decoder_start_token_id=cfg.bos_token_id)
+            bw = [[int(base[0, 2])], [int(base[0, 3]), int(base[0, 4])], [int(base[1, 2]), int(base[1, 3])]]
+        if "num_beams" in kw:
+            ref = go.beam_search(sd, ocfg, hid, msk, rd, True, decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)
+        else:
+            ref = go.greedy_search(sd, ocfg, hid, msk, rd, True, decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)
+            kw["num_beams"] = 1
+        out = model.generate(enc, text_m.to(DEV), table_h.to(DEV), table_m.to(DEV), img_h.to(DEV), img_m.to(DEV), rating_diff=rd.to(DEV),
+                             decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)
+    assert torch.equal(out.cpu(), ref), (name, out.cpu(), ref)

@@ -150,6 +150,45 @@ def test_g1_beam_search(golden_dir):
                 assert abs(got - scores[i]) <= 1e-4 * abs(scores[i]) + 1e-5, (i, got, scores[i])
 
 
+G3_CASES = {
+    "greedy": dict(max_length=14, no_repeat_ngram_size=2),
+    "greedy_min": dict(max_length=12, min_length=6, no_repeat_ngram_size=0),
+    "greedy_bad": dict(max_length=14, no_repeat_ngram_size=2, bad_words=True),
+    "greedy_rep": dict(max_length=14, no_repeat_ngram_size=0, repetition_penalty=1.7),
+    "beam_bad": dict(num_beams=4, max_length=14, no_repeat_ngram_size=3, early_stopping=True, length_penalty=1.0, bad_words=True),
+    "beam_rep": dict(num_beams=3, max_length=12, no_repeat_ngram_size=0, early_stopping=False, length_penalty=1.5, repetition_penalty=1.3),
+}
+
+
+def g3_bad_words(gg):
+    return [[int(t) for t in row if t >= 0] for row in gg["bad_words"].tolist()]
+
+
+def test_g3_generate_modes(golden_dir):
+    """The generate() modes beside test.py's beam search -- greedy decoding (num_beams = 1, _generate_no_beam_search), bad_words_ids and
+    repetition_penalty in both searches -- restated (oracle/generate_oracle.py) and held to the token ids the REFERENCE's own
+    generate() produced on the F2 model (tests/golden/g3_generate_modes.npz, oracle/make_golden_r6.py)."""
+    from oracle import generate_oracle as go
+    g = _load(golden_dir, "f2_decoder.npz")
+    gg = _load(golden_dir, "g3_generate_modes.npz")
+    cfg, sd, table_h, img_h = f2_setup(g)
+    ids = gg["ids"]
+    Bz, N, S = ids.shape
+    bad = g3_bad_words(gg)
+    with torch.no_grad():
+        enc = bo.bart_encoder(sd, cfg, ids.view(-1, S), ids.view(-1, S).ne(1), prefix="f2.").view(Bz, N, S, -1)
+        _close(enc, gg["enc_eval"], **TOL)
+        hid, msk = [enc, table_h, img_h], [gg["text_m"], gg["table_m"], gg["img_m"]]
+        for name, kw in G3_CASES.items():
+            kw = dict(kw)
+            bw = bad if kw.pop("bad_words", False) else None
+            if "num_beams" in kw:
+                out = go.beam_search(sd, cfg, hid, msk, gg["rating_diff"], True, prefix="f2.", bad_words_ids=bw, **kw)
+            else:
+                out = go.greedy_search(sd, cfg, hid, msk, gg["rating_diff"], True, prefix="f2.", bad_words_ids=bw, **kw)
+            assert torch.equal(out, gg["gen_" + name]), (name, out, gg["gen_" + name])
+
+
 def test_f2_text_only(golden_dir):
     g = _load(golden_dir, "f2_decoder.npz")
     gt = _load(golden_dir, "f2_textonly.npz")
