@@ -507,6 +507,19 @@ def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams,
                               _stream()), "mmsum_beam_topk")
 
 
+def decode_self_attn(q, k_cache, v_cache, ancestors, out, H, length, Tmax, scale, k_new=None, v_new=None):
+    """out[r] = softmax(q[r] . K_r^T) V_r per head, K_r / V_r = the first `length` cache positions of hypothesis r reached through
+    cache row ancestors[r, s] * Tmax + s (see mmsum_decode_self_attn).  k_new / v_new [rows, D]: this step's projections; the kernel
+    appends them to the caches at position length - 1 (ancestors[r, length - 1] must be r)."""
+    assert ancestors.dtype == torch.int32 and ancestors.is_contiguous() and ancestors.shape == (q.shape[0], Tmax)
+    assert k_cache.shape == v_cache.shape and (k_new is None) == (v_new is None)
+    if k_new is not None:
+        assert k_new.stride(0) == v_new.stride(0) and k_new.stride(1) == 1 and v_new.stride(1) == 1
+    check(lib.mmsum_decode_self_attn(_dt(q), _p(q), q.stride(0), _p(k_cache), _p(v_cache), _ld(k_cache), _p(ancestors), _p(out), out.stride(0),
+                                     q.shape[0], H, int(length), Tmax, float(scale), _p(k_new), _p(v_new),
+                                     k_new.stride(0) if k_new is not None else 0, _stream()), "mmsum_decode_self_attn")
+
+
 def decode_cross_attn_workspace(n_entities, H, qpb, B, nmod, device):
     return torch.zeros(max(16, lib.mmsum_decode_cross_attn_workspace(n_entities, H, qpb, B, nmod)), dtype=torch.uint8, device=device)
 

@@ -94,7 +94,7 @@ def _state(sd, dt):
             for k, v in sd.items()}
 
 
-def _compare(gh, g64, gemu, g32, dtype, skip=("img_encoder.resnet",), k_rows=None):
+def _compare(gh, g64, gemu, g32, dtype, skip=("img_encoder.resnet",), k_rows=None, k32=3):
     worst = []
     for n, ref in g64.items():
         if float(ref.abs().max()) <= 1e-9 or any(s in n for s in skip):
@@ -103,7 +103,7 @@ def _compare(gh, g64, gemu, g32, dtype, skip=("img_encoder.resnet",), k_rows=Non
         if dtype == torch.float32:
             e = float((gh[n].double() - ref).abs().max()) / float(ref.abs().max())
             e32 = float((g32[n].double() - ref).abs().max()) / float(ref.abs().max())
-            worst.append((e / max(1e-3, 3 * e32), n, e, e32))
+            worst.append((e / max(1e-3, k32 * e32), n, e, e32))
         else:
             nrm = float(ref.norm()) + 1e-30
             e, ee = float((gh[n].double() - ref).norm()) / nrm, float((gemu[n].double() - ref).norm()) / nrm
@@ -339,3 +339,61 @@ def test_amazon_fused_multimodal_step_vs_oracle(dtype):
         lemu, gemu = run(torch.float32, True)
         assert abs(lh - l64) <= 3 * abs(lemu - l64) + 1e-3 * abs(l64), (lh, lemu, l64)
         _compare(gh, g64, gemu, None, dtype, k_rows={"table_encoder.price_embedding.weight": 5, "table_encoder.rating_embedding.weight": 5})
+
+
+# ------------------------------------------------------------------------------------------------
+# (d) ResNet101 stages 1-3: per-tensor gradients on well-conditioned statistics
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_resnet_gradients_per_tensor_on_224px_images(dtype):
+    """Row I (Resnet.forward, src/img_encoder.py:21-41) with BatchNorm statistics over 4 x 196 positions -- four 224 x 224 images, the
+    size the model is fed -- instead of the handful of positions of the small images other tests use (where the fp32 stack is chaotic
+    and only error DISTRIBUTIONS can be held): ImgSupervised step (img_pretrain.py:85-141), EVERY image-encoder gradient tensor
+    against the oracle in fp64 -- f32 mode within max(1e-3, 4x the fp32 oracle's own error) of the tensor's largest entry, bf16 (the
+    timed path: implicit convolutions, statistics from the GEMM epilogues) within 3x the oracle's bf16 emulation + 1e-3 in relative
+    L2.  (The backbone definition itself stays unpinned: torchvision is in neither the reference tree nor the image.)"""
+    from multimodalsum_amd.modules import ImgSupervised
+    cfg = tiny_cfg(vocab=200, d=1024, ffn=64, layers=1, heads=16, maxpos=32)
+    ocfg = oracle_cfg(cfg)
+    labels = syn.token_batch(2, 12, cfg.vocab_size, seed=5, min_len=4)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, False, prefix="bart_model."), std=0.02)
+    sd.update(formula_state_dict(eo.resnet_param_shapes(1024), std=0.05))
+    g = torch.Generator().manual_seed(3)
+    imgs = torch.randn(2, 2, 3, 224, 224, generator=g)
+    imask = torch.tensor([[True, True], [True, True]])
+    im = ImgSupervised(config=cfg, label_smoothing=0.1, device=DEV, dtype=dtype, deterministic=(dtype == torch.float32))
+    im.load_state_dict({k: v.detach() for k, v in sd.items()})
+    im.train()
+    loss = im(imgs.to(DEV), imask.to(DEV), labels=labels.to(DEV))[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    gh = {n: q.grad.detach().float().cpu() for n, q in im.named_parameters() if q.grad is not None}
+
+    def run(dt, emulate=False):
+        bo.EMULATE_BF16 = emulate
+        try:
+            st = _state(sd, dt)
+            ih = eo.resnet101_features(st, imgs.reshape(-1, 3, 224, 224).to(dt), training=True).reshape(2, 2, -1, 1024)
+            lg = bo.enc_forward(st, ocfg, ih, torch.zeros(2, 1, dtype=dt), imask.unsqueeze(-1).repeat(1, 1, ih.shape[2]), labels,
+                                training=True, prefix="bart_model.")
+            ls = bo.label_smoothing_loss(lg.view(-1, cfg.vocab_size), labels.view(-1), cfg.vocab_size, 0.1)
+            ls.backward()
+            return float(ls.detach()), {k: v.grad for k, v in st.items() if getattr(v, "grad", None) is not None}
+        finally:
+            bo.EMULATE_BF16 = False
+
+    l64, g64 = run(torch.float64)
+    lh = float(loss.detach())
+    img = {n: r for n, r in g64.items() if n.startswith("img_encoder") and float(r.abs().max()) > 1e-12}
+    assert len(img) > 90                                     # layer3's 23 bottlenecks + the projection
+    if dtype == torch.float32:
+        l32, g32 = run(torch.float32)
+        assert abs(lh - l64) <= 1e-3 * abs(l64), (lh, l64)
+        # (even on these statistics the fp32 stack of 23 bottlenecks is 2 - 3 % from fp64 on single layer3 tensors -- the oracle's OWN fp32 run,
+        # measured -- and the HIP f32 path, a different summation order, lands within ~3x of that: held to 4x, per tensor)
+        worst = _compare(gh, img, None, g32, dtype, skip=(), k32=4)
+    else:
+        lemu, gemu = run(torch.float32, True)
+        assert abs(lh - l64) <= 3 * abs(lemu - l64) + 1e-3 * abs(l64), (lh, lemu, l64)
+        worst = _compare(gh, img, gemu, None, dtype, skip=())
+    print("resnet per-tensor gradients (%s): worst ratio to the bound %.3f on %s (error %.2e, yardstick %.2e)" % ((str(dtype),) + worst[0]))
