@@ -31,7 +31,8 @@ for tag in tags:
                 k = r["Kernel_Name"]
                 if any(s in k for s in SKIP) or r["Counter_Name"] != c:
                     continue
-                short = re.sub(r"\(.*", "", k)
+                short = re.sub(r"^void ", "", k).replace("(anonymous namespace)::", "")
+                short = re.sub(r"\(.*", "", short)                                   # drop the argument list, keep the template arguments
                 short = re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", short)[:44]
                 acc[short][c].append(float(r["Counter_Value"]))
                 if c == "FETCH_SIZE":
@@ -48,4 +49,4 @@ for tag in tags:
                                       "traffic_over_algorithmic": (rd + wr) / a if a else None, "gbps": (rd + wr) / ns}
         print("%-18s %-44s %8d %10.1f %10.1f %10s %8s %9.0f" % (tag, k, n, rd / 1e6, wr / 1e6, "%.1f" % (a / 1e6) if a else "-",
                                                                  "%.2f" % ((rd + wr) / a) if a else "-", (rd + wr) / ns))
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(d)), "r6_family_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(d)), (sys.argv[2] if len(sys.argv) > 2 else "r6_family_pmc") + ".json"), "w"), indent=1)

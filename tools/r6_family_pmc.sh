@@ -13,6 +13,8 @@ run() {   # tag, program args...
     timeout 600 rocprofv3 --output-format csv --kernel-trace --pmc $c -d "$R"/gpurun_out/fam/${tag}_$c -o p -- python3 "$@" > "$R"/gpurun_out/fam/${tag}_$c.log 2>&1
   done
 }
+ONLY="${FAMILY_ONLY:-all}"        # FAMILY_ONLY=attn: the attention programs only
+if [ "$ONLY" = all ]; then
 for f in ln_fwd ln_bwd gate_fwd gate_bwd loss adamw bn_apply bn_bwd slab_reduce; do run $f "$R"/tools/family_one.py $f 3; done
 run gemm_nt_1024 "$R"/tools/gemm_one.py 147456 1024 1024 nt 3
 run gemm_nt_gelu "$R"/tools/gemm_one.py 147456 4096 1024 gelu 3
@@ -20,11 +22,13 @@ run gemm_nt_k4096 "$R"/tools/gemm_one.py 147456 1024 4096 nt 3
 run gemm_nt_lmhead "$R"/tools/gemm_one.py 147456 50304 1024 nt 2
 run gemm_tn_1024 "$R"/tools/gemm_one.py 1024 1024 147456 tn 3
 run gemm_tn_4096 "$R"/tools/gemm_one.py 4096 1024 147456 tn 3
+fi
 export ATTN_BENCH_B=128 ATTN_BENCH_PADS=1 ATTN_BENCH_MAPS=1
 run attn_cross_text "$R"/tools/attn_bench.py cross_text
 run attn_cross_img4 "$R"/tools/attn_bench.py cross_img4
 run attn_self_causal "$R"/tools/attn_bench.py self_causal
 cd "$R"
-python tools/family_pmc_summary.py gpurun_out/fam > gpurun_out/r6_family_pmc.txt 2>&1
-cat gpurun_out/r6_family_pmc.txt
+out=r6_family_pmc; [ "$ONLY" = all ] || out=r6_family_pmc_$ONLY
+python tools/family_pmc_summary.py gpurun_out/fam $out > gpurun_out/$out.txt 2>&1
+cat gpurun_out/$out.txt
 rm -rf gpurun_out/fam/*_FETCH_SIZE gpurun_out/fam/*_WRITE_SIZE
