@@ -226,6 +226,9 @@ def parse(argv=None):
     ap.add_argument("--no-kernel-probe", action="store_true")
     ap.add_argument("--no-graphs", action="store_true", help="issue every kernel from Python instead of replaying captured HIP graphs")
     ap.add_argument("--fixed-batches", action="store_true", help="alternate two pre-generated batches instead of generating one per step")
+    ap.add_argument("--host-batches", action="store_true",
+                    help="PCIe-inclusive rate: the step's inputs start in pinned HOST memory and reach the HBM through yelp_data_prefetcher "
+                         "(side-stream copies under the previous step, multimodal_train.py:196-268); never the headline `value`")
     ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"], help="N > 1: dtype of the gradient buckets on the wire")
     ap.add_argument("--ddp-mode", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                     help="N > 1: one all-reduce per gradient bucket, or reduce-scatter + all-gather")
@@ -289,6 +292,24 @@ def batch_source(args, cfg, device, rank):
     if args.workload == "text_table":      # BASELINE config 3: the reference cannot run with I = 0 (multimodal_train.py:189), so one zero image, masked out
         gen = syn.DeviceBatches(args.batch, 9, 128, 1, cfg.vocab_size, device, seed=1234 + rank, img_hw=224, no_images=True)
         return gen.next
+    if getattr(args, "host_batches", False):
+        # two host batches (pinned), served in turn for ever through the reference's prefetcher protocol: every step's inputs cross PCIe
+        import itertools
+        from multimodalsum_amd import yelp_data_prefetcher
+        hosts = []
+        for i in range(2):
+            hb = syn.yelp_batch(args.batch, 9, 128, I, cfg.vocab_size, seed=1234 + 1000 * rank + i, img_hw=hw)
+            fv = hb["field_value"]
+            hosts.append(tuple(t.pin_memory() for t in (hb["reviews"], hb["reviews_mask"], hb["reviews_rating"], fv[0], fv[1], fv[2], fv[3], fv[4], fv[5],
+                                                         hb["img"], hb["img_mask"])))
+        field = hosts and syn.yelp_batch(1, 9, 128, I, cfg.vocab_size, seed=1234, img_hw=8)["field"].to(device)
+        pf = yelp_data_prefetcher(itertools.cycle(hosts), device)
+        args.host_bytes_per_step = sum(t.numel() * t.element_size() for t in hosts[0])
+
+        def nxt_host():
+            reviews, mask, rating, fvd, img, img_mask = pf.next()
+            return {"reviews": reviews, "reviews_mask": mask, "reviews_rating": rating, "field": field, "field_value": fvd, "img": img, "img_mask": img_mask}
+        return nxt_host
     if args.fixed_batches:
         fixed = [syn.batch_to(syn.yelp_batch(args.batch, 9, 128, I, cfg.vocab_size, seed=1234 + 1000 * rank + i, img_hw=hw), device)
                  for i in range(2)]
@@ -525,7 +546,11 @@ def step_pmc(workload, batch):
             if prof.get("workload") == workload and int(prof.get("per_gpu_batch", -1)) == int(batch):
                 return {"source": os.path.basename(path) + " (a separate rocprofv3 --pmc run of one eager step, kernels serialised; not collected by this run)",
                         "mfma_busy_frac": prof["mfma_busy_frac"], "by_family": {k: v.get("mfma_busy_frac") for k, v in prof.get("by_family", {}).items()},
-                        "mfma_flops_per_business": prof.get("mfma_flops_per_business"), "hbm_traffic": prof.get("hbm_traffic")}
+                        "mfma_flops_per_business": prof.get("mfma_flops_per_business"),
+                        # HBM-side bytes of the step from the TCC counters (round 6: assembled from isolated per-family passes -- the whole-step
+                        # FETCH_SIZE / WRITE_SIZE passes do not finish on this pool; the file has the method and the representatives)
+                        "hbm_traffic": ({k: v for k, v in prof["hbm_traffic"].items() if k not in ("gemm_representatives", "method")}
+                                        if isinstance(prof.get("hbm_traffic"), dict) else prof.get("hbm_traffic"))}
         except Exception:
             continue
     return None
@@ -1015,7 +1040,10 @@ def main():
                "value": value, "unit": "businesses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
                "data": "synthetic Yelp-shaped batches generated on the device inside every timed step (fresh review lengths and image counts "
-                       "per step), formula-initialised BART-large/ResNet101 weights" if not args.fixed_batches else
+                       "per step), formula-initialised BART-large/ResNet101 weights" if not (args.fixed_batches or getattr(args, "host_batches", False)) else
+                       ("two synthetic Yelp-shaped batches in pinned HOST memory, copied to the HBM every step by yelp_data_prefetcher (%.0f MB per step "
+                        "over PCIe, on a side stream under the previous step): the PCIe-INCLUSIVE rate, not the headline value" % (args.host_bytes_per_step / 1e6))
+                       if getattr(args, "host_batches", False) else
                        "two fixed synthetic Yelp-shaped batches (seeded), formula-initialised BART-large/ResNet101 weights",
                "config": {"workload": {"multimodal": "multimodal_train.py full text+img(4x224^2)+table step (fwd+bwd+clip+AdamW), 9 reviews x 128 tok",
                                        "text_table": "multimodal_train.py text+table step (one all-zero image slot per business, img_mask False), 9 reviews x 128 tok",

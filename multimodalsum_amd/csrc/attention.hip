@@ -22,7 +22,7 @@ namespace {
 constexpr int HD = 64;
 constexpr int ATT_THREADS = 256;
 #ifndef MMSUM_ATTN_W64
-#define MMSUM_ATTN_W64 0                  // 1 (make EXTRA=-DMMSUM_ATTN_W64=1): the round-6 one-wave-per-SIMD forward, measured 24 % SLOWER than the
+#define MMSUM_ATTN_W64 0                  // 1 (make EXTRA="-DMMSUM_ATTN_W64=1 -mllvm -amdgpu-mfma-vgpr-form"): the round-6 one-wave-per-SIMD forward, measured 24 % SLOWER than the
 #endif                                    // two-waves-per-SIMD kernel it was to replace (profiles/r06_attention_w64_fwd_pmc.txt, tools/r6_attn_ab.sh); kept for the record
 
 template <typename T> struct AttnTraits {
@@ -1404,8 +1404,9 @@ __device__ __forceinline__ bf16x8_t w64_pack(const f32x16_t& p, int s2, float no
 // O^T of the wave's two query groups lives in NAMED accumulation registers a[192:255] (block 2 g + db at a[192 + 16 (2 g + db)]):
 // the P V MFMAs are issued from inline asm on those names, so the register allocator never sees a 64-register value that is
 // live across the eight (key blocks, masked blocks) variants of the entity loop -- as compiler-managed values it copied them
-// around every variant (~200 v_accvgpr moves per entity).  The compiler allocates its own AGPRs from a0 upwards; the build checks that
-// no compiler-generated instruction of these kernels names a192 or above (csrc/check_resources.py).
+// around every variant (~200 v_accvgpr moves per entity).  The compiler allocates its own AGPRs from a0 upwards and does not know these
+// are taken: a build that dispatches this kernel must check that no compiler-generated instruction of it names a192 or above (done by
+// hand on the device assembly for the measured build -- none did; not a Makefile check, since the kernel is not dispatched).
 #define W64_AGPRS_0 "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207"
 #define W64_AGPRS_1 "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223"
 #define W64_AGPRS_2 "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239"

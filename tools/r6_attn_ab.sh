@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Attention A/B on one box: the attention tests, then tools/attn_bench.py (bench batch, trailing pads, compact K/V) with the tree's library
-# and with tools/build/base/libmmsum_hip.so, interleaved.  Round 6: 'new' was a build with EXTRA=-DMMSUM_ATTN_W64=1 (the
+# and with tools/build/base/libmmsum_hip.so, interleaved.  Round 6: 'new' was a build with EXTRA="-DMMSUM_ATTN_W64=1 -mllvm -amdgpu-mfma-vgpr-form" (the
 # one-wave-per-SIMD forward), 'base' the default build.  usage: r6_attn_ab.sh [cases...]
 R="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
 cd "$R"; mkdir -p gpurun_out
