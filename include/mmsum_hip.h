@@ -27,7 +27,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define MMSUM_ABI_VERSION 7
+#define MMSUM_ABI_VERSION 8
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -73,16 +73,23 @@ const char* mmsum_build_id(void);
  * deterministic, and cheaper than atomics).
  * live_rows: natural A (no A_T): live rows of A and C (M); weight-gradient layout (A_T | B_T): live reduction length K.
  * alpha_dev (device f32, may be NULL): alpha is multiplied by *alpha_dev when the kernel runs -- the upstream gradient of
- * the loss (loss.backward(g), loss / accumulation_steps) enters the LM-head backward products this way, with no host read. */
+ * the loss (loss.backward(g), loss / accumulation_steps) enters the LM-head backward products this way, with no host read.
+ * workspace (device, 16-byte aligned, may be NULL) / workspace_bytes: scratch the library may use to cut the reduction of a SMALL
+ * bf16 NT product (tile list <= half the CUs: the per-GPU batch 1 of multimodal_train.py:420 gives 1,152 decoder rows = 72 tiles)
+ * into slices on otherwise idle CUs, met inside the launch (MMSUM_GEMM_WORKSPACE_BYTES covers every such product).  It must be
+ * ZERO before its first use; the kernel leaves it reusable, so one workspace serves every product of a stream in turn -- but not
+ * two streams at once.  The result does not depend on the order the slices arrive in.  NULL: such products run unsplit. */
+#define MMSUM_GEMM_WORKSPACE_BYTES (4096L + 256L * 128 * 128 * 4)
 int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
-               const float* alpha_dev, int flags, int splitk, const int* live_rows, void* stream);
+               const float* alpha_dev, int flags, int splitk, const int* live_rows, void* workspace, long workspace_bytes, void* stream);
 
 /* What mmsum_gemm would launch for these arguments (pure: no device work, pointers are only checked for alignment / NULL --
  * live_rows and alpha_dev too: kernel selection depends on whether they are given, e.g. the weight-streaming kernel takes
  * neither):
  * plan[0] = kernel family, plan[1] x plan[2] = block tile, plan[3] = workgroups launched (fewer than tiles * splitk:
- * persistent workgroups walk the tile list).  Tests use it to assert that a shape reaches the kernel they mean to cover. */
+ * persistent workgroups walk the tile list; more than tiles * splitk: the reduction is cut over a lent workspace of
+ * workspace_bytes, see mmsum_gemm).  Tests use it to assert that a shape reaches the kernel they mean to cover. */
 enum { MMSUM_PLAN_GENERIC = 0,   /* gemm_kernel: register-staged 128x128, f32 or bf16, any layout */
        MMSUM_PLAN_NT_RING = 1,   /* LDS-DMA kernels for bf16 K-contiguous operands: gemm_nt_w4_kernel (256x256 tiles, four waves) or
                                     gemm_nt_ring_kernel (smaller tiles) */
@@ -90,7 +97,7 @@ enum { MMSUM_PLAN_GENERIC = 0,   /* gemm_kernel: register-staged 128x128, f32 or
        MMSUM_PLAN_SKINNY = 3 };  /* gemm_skinny_kernel: M <= 128 weight-streaming (decode steps) */
 int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                     const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
-                    int splitk, const int* live_rows, const float* alpha_dev, int* plan);
+                    int splitk, const int* live_rows, const float* alpha_dev, long workspace_bytes, int* plan);
 
 /* Two INDEPENDENT bf16 products of one shape in one launch (the decode step's alpha and beta projections, :738-739: each alone is 64
  * workgroups on a per-launch floor): C_i[M <= 64, N <= 4096] = A_i[M, ksplit] | A2_i[M, K - ksplit] . B_i[N, K]^T + bias_i, i = 0, 1.

@@ -204,10 +204,14 @@ static int gemm_check(int dtype, const void* A, long lda, const void* A2, long l
 
 extern "C" int mmsum_gemm(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                           void* C, long ldc, const float* bias, void* aux, long ldaux, int M, int N, int K, float alpha,
-                          const float* alpha_dev, int flags, int splitk, const int* live_rows, void* stream) {
+                          const float* alpha_dev, int flags, int splitk, const int* live_rows, void* workspace, long workspace_bytes,
+                          void* stream) {
     const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, C, ldc, aux, ldaux, M, N, K, flags, splitk, live_rows);
     if (rc != MMSUM_OK) return rc;
+    if (workspace != nullptr && ((((uintptr_t)workspace) & 15) || workspace_bytes < 0)) return MMSUM_ERR_WORKSPACE;
     GemmArgs a{A, A2, B, C, bias, aux, M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, alpha, flags, splitk, live_rows, alpha_dev};
+    a.split_ws = static_cast<float*>(workspace);
+    a.split_ws_bytes = workspace ? workspace_bytes : 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (gemm_skinny_eligible(dtype, a)) return launch_gemm_skinny(a, s);
     if (gemm_skinny_f32_eligible(dtype, a)) return launch_gemm_skinny_f32(a, s);
@@ -262,10 +266,12 @@ extern "C" int mmsum_conv3x3_wgrad(const void* dyp, const void* xp, float* out, 
 // means persistent workgroups walking the tile list).  Lets tests assert that a shape reaches the kernel they mean to cover.
 extern "C" int mmsum_gemm_plan(int dtype, const void* A, long lda, const void* A2, long lda2, int ksplit, const void* B, long ldb,
                                const void* C, long ldc, const float* bias, const void* aux, long ldaux, int M, int N, int K, int flags,
-                               int splitk, const int* live_rows, const float* alpha_dev, int* plan) {
+                               int splitk, const int* live_rows, const float* alpha_dev, long workspace_bytes, int* plan) {
     const int rc = gemm_check(dtype, A, lda, A2, lda2, ksplit, B, ldb, bias, C, ldc, aux, ldaux, M, N, K, flags, splitk, live_rows);
     if (rc != MMSUM_OK) return rc;
     GemmArgs a{A, A2, B, const_cast<void*>(C), bias, const_cast<void*>(aux), M, N, K, lda, lda2, ldb, ldc, ldaux, ksplit, 1.f, flags, splitk, live_rows, alpha_dev};
+    a.split_ws = workspace_bytes > 0 ? reinterpret_cast<float*>(16) : nullptr;         // never dereferenced here: "a workspace is lent"
+    a.split_ws_bytes = workspace_bytes > 0 ? workspace_bytes : 0;
     GemmPlan g;
     if (gemm_skinny_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 32, (a.N + 31) / 32};
     else if (gemm_skinny_f32_eligible(dtype, a)) g = GemmPlan{MMSUM_PLAN_SKINNY, a.M, 16, (a.N + 15) / 16};

@@ -13,7 +13,12 @@ struct GemmArgs {
     // with zero borders: the operand row of output pixel m for tap (ky, kx) is row conv_row(m) + ky * Wp + kx -- the im2col matrix is
     // never materialised: the LDS-DMA pieces of a 64-deep (32-deep) stage read C-contiguous runs of one tap.  C is a power of two >= 64.
     int conv_wp, conv_w, conv_hw, conv_hpwp, conv_cshift;
+    // Fused split of small NT products (gemm_nt_ring_kernel<..., FS>): the caller's workspace (split_ws_bytes; the launcher cuts it into the
+    // ticket words and the slabs), slices per tile.  NULL / 0: not lent.
+    float* split_ws; long split_ws_bytes; unsigned* split_tickets; int fsplit;
 };
+#define MMSUM_NT_FSPLIT_MAX 4
+#define MMSUM_NT_FSPLIT_TICKET_BYTES 4096
 
 // Padded-layout row of output pixel m = (n, y, x) for tap (0, 0): n * Hp * Wp + y * Wp + x.
 __device__ __forceinline__ int conv_row(const GemmArgs& p, int m) {

@@ -12,6 +12,7 @@
 // address and again on the fragment read (guide rule 21).  Rows past M/N are clamped (their results are never stored).
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -663,7 +664,13 @@ __device__ __forceinline__ void k64_piece(char* stage, const bf16_t* base, int v
 #endif
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
+// FS ("fused split"): the form for products whose tile list fills a fraction of the CUs (the small-batch step: 72 tiles of 1,152
+// decoder rows).  A CU takes in ~35 GB/s whatever the ring depth (tools/gemm_ksweep.py: one 128x128 tile costs 14 us per 1,024 of K, four
+// times its MFMA time), so the reduction of a tile is cut into p.fsplit slices on as many CUs; the slices meet like mmsum_dec_gemm's: every
+// slice stores its f32 accumulators write-through into its slab of p.split_ws, drains them, takes a ticket; the LAST arriver reads the
+// other slabs past the caches, adds the slices IN SLICE ORDER (its own accumulators in their place: the sum does not depend on who
+// arrived last) and runs the ordinary epilogue.  The ticket word is left zero for the stream's next product.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT, bool FS = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(GemmArgs p) {
     constexpr int NSTAGE = 4, AHEAD = NSTAGE - 1;   // three slabs of DMA in flight beyond the one being consumed
     using Cfg = RingCfg<BM, BN, WAVES_M, WAVES_N, NSTAGE>;
@@ -676,21 +683,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
     apply_live_rows(p, m_cap);                    // the tile list shrinks with the live row count
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
-    const int total = tiles * p.splitk;
+    const int nsp = FS ? p.fsplit : p.splitk;       // reduction slices per tile
+    const int total = tiles * nsp;
     void* const C0 = p.C;
     // persistent: a workgroup walks virtual ids blockIdx.x, +gridDim.x, ... (the grid is a multiple of 8, so every id
     // of a workgroup lands on its own XCD's chunk of the tile order)
     for (int vid = blockIdx.x; vid < total; vid += gridDim.x) {
     const int wg = xcd_remap(vid, total);
     const int ks = wg / tiles;
-    p.C = (p.flags & MMSUM_GEMM_SLABS) ? static_cast<void*>(static_cast<float*>(C0) + (long)ks * m_cap * p.ldc) : C0;
+    p.C = (!FS && (p.flags & MMSUM_GEMM_SLABS)) ? static_cast<void*>(static_cast<float*>(C0) + (long)ks * m_cap * p.ldc) : C0;
     const int t = wg % tiles;
     int tm, tn;
     tile_coords(t, tiles_m, tiles_n, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int nslab_total = p.K / 32;
-    const int per = ((nslab_total + p.splitk - 1) / p.splitk + 1) & ~1;       // even number of slabs per split
+    const int per = ((nslab_total + nsp - 1) / nsp + 1) & ~1;       // even number of slabs per split
     const int s_beg = ks * per, s_end = min(nslab_total, s_beg + per);
     const int ns = s_end - s_beg;
 
@@ -768,11 +776,60 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_nt_ring_kernel(Gem
             __builtin_amdgcn_s_setprio(0);
         }
     }
-    if constexpr (OUT == OUT_F32_ATOMIC) {
-        // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
-        gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT, LAY_16>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), ks, lane);
-    } else {
-        epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE, LAY_16>(p, acc, smem, m0, n0, ks, wm, wn, tid, lane);
+    bool finish = true;
+    if constexpr (FS) {
+        constexpr int WORDS = Cfg::TM * Cfg::TN * 16;                 // accumulator words per lane
+        float* const slabs = p.split_ws + (long)t * nsp * (BM * BN);
+        float* const mine = slabs + (long)ks * (BM * BN) + wave * (WORDS * 64) + lane;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    __hip_atomic_store(mine + ((i * Cfg::TN + j) * 16 + e) * 64, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wave's slab words are in memory ...
+        lds_barrier();                                                // ... and so are the other three waves' (and nobody reads the operand stages any more)
+        if (tid == 0) *reinterpret_cast<volatile unsigned*>(smem) = __hip_atomic_fetch_add(p.split_tickets + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_barrier();
+        const unsigned ticket = *reinterpret_cast<volatile unsigned*>(smem);
+        finish = ticket == (unsigned)(nsp - 1);
+        if (finish) {
+            if (tid == 0) __hip_atomic_store(p.split_tickets + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the stream's next product
+            const float* const theirs = slabs + wave * (WORDS * 64) + lane;
+#pragma unroll
+            for (int i = 0; i < Cfg::TM; ++i) {
+                float o[MMSUM_NT_FSPLIT_MAX][Cfg::TN][16];
+#pragma unroll
+                for (int sl = 0; sl < MMSUM_NT_FSPLIT_MAX; ++sl)
+                    if (sl < nsp && sl != ks) {
+#pragma unroll
+                        for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                            for (int e = 0; e < 16; ++e)
+                                o[sl][j][e] = __hip_atomic_load(theirs + (long)sl * (BM * BN) + ((i * Cfg::TN + j) * 16 + e) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                for (int j = 0; j < Cfg::TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float v = 0.f;
+#pragma unroll
+                        for (int sl = 0; sl < MMSUM_NT_FSPLIT_MAX; ++sl)
+                            if (sl < nsp) v += sl == ks ? acc[i][j][e] : o[sl][j][e];
+                        acc[i][j][e] = v;
+                    }
+            }
+        }
+    }
+    if (finish) {
+        const int eks = FS ? 0 : ks;
+        if constexpr (OUT == OUT_F32_ATOMIC) {
+            // f32 atomics want 128 contiguous bytes per half-wave instruction: that is the direct accumulator layout
+            gemm_epilogue<bf16_t, BM / WAVES_M / 32, BN / WAVES_N / 32, EPI, OUT, LAY_16>(p, acc, m0 + wm * (BM / WAVES_M), n0 + wn * (BN / WAVES_N), eks, lane);
+        } else {
+            epilogue_staged<BM, BN, WAVES_M, WAVES_N, EPI, OUT, Cfg::NSTAGE * Cfg::STAGE, LAY_16>(p, acc, smem, m0, n0, eks, wm, wn, tid, lane);
+        }
     }
     lds_barrier();            // the staging reads are done before the next tile's DMA lands in the same LDS (stores stay in flight)
     }
@@ -1395,10 +1452,43 @@ inline int ring_grid(const GemmArgs& a, int bm, int bn) {
     return tiles > cus ? cus : tiles;
 }
 
+inline bool nt_one_round(const GemmArgs& a) { return (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * a.splitk <= cu_count(); }
+
+// Reduction slices per tile of the fused-split form (1: not taken).  Taken when the caller lent a workspace, the 128x128 tile list
+// fills at most half the CUs and every slice keeps >= 768 of K (the slabs of a tile's slices go through memory: 64 KB each way per
+// slice; at K = 1,024 that costs more than the shorter loop saves: 16.5 against 13.7 us); the slab words of a tile's slices + the
+// ticket words must fit.
+inline int nt_fused_split(const GemmArgs& a) {
+    if (a.split_ws == nullptr || a.splitk != 1 || a.conv_wp != 0 || out_mode_of(a) == OUT_F32_ATOMIC) return 1;
+    const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    int s = (int)std::min<long>(MMSUM_NT_FSPLIT_MAX, cu_count() / std::max<long>(tiles, 1));
+    const int ns = a.K / 32;
+    for (; s >= 2; --s) {
+        const int per = ((ns + s - 1) / s + 1) & ~1;
+        if (per >= 24 && (s - 1) * per < ns && MMSUM_NT_FSPLIT_TICKET_BYTES + tiles * s * (128L * 128 * 4) <= a.split_ws_bytes) return s;
+    }
+    return 1;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
     using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
     const size_t lds = R::NSTAGE * R::STAGE;
+    if constexpr (BM == 128 && BN == 128 && OUT != OUT_F32_ATOMIC) {
+        const int fs = nt_fused_split(a);
+        if (fs > 1) {
+            static const hipError_t attr_fs = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, true>),
+                                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (attr_fs != hipSuccess) return MMSUM_ERR_HIP;
+            GemmArgs b = a;
+            b.fsplit = fs;
+            b.split_tickets = reinterpret_cast<unsigned*>(a.split_ws);
+            b.split_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(a.split_ws) + MMSUM_NT_FSPLIT_TICKET_BYTES);
+            const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+            gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, true><<<dim3(tiles * fs), dim3(R::THREADS), lds, stream>>>(b);
+            return hipGetLastError() == hipSuccess ? MMSUM_OK : MMSUM_ERR_HIP;
+        }
+    }
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return MMSUM_ERR_HIP;
@@ -1542,13 +1632,21 @@ int launch_gemm_glds(const GemmArgs& a, hipStream_t stream) {
     switch (choose_tile(a)) {
         case TILE_256x256: return launch_w4(a, stream);
         case TILE_256x128: return launch_cfg<256, 128, 4, 2>(a, stream);
-        default: return launch_cfg<128, 128, 2, 2>(a, stream);
+        default:
+            // a tile list of one round of the CUs or less: nobody shares the CU, so EIGHT waves (64x32 each) take the tile -- two per SIMD
+            // cover each other's DMA issue and LDS waits the way two co-resident four-wave workgroups do on the large products
+            // (tools/gemm_small_bench.py, 1,152 x 1,024 x 1,024: 17.8 -> 13.7 us)
+            if (nt_one_round(a)) return launch_cfg<128, 128, 4, 2>(a, stream);
+            return launch_cfg<128, 128, 2, 2>(a, stream);
     }
 }
 
 static const int kTileDims[3][2] = {{256, 256}, {256, 128}, {128, 128}};
 GemmPlan plan_gemm_glds(const GemmArgs& a) {
-    const int* d = kTileDims[choose_tile(a)];
+    const int tile = choose_tile(a);
+    const int* d = kTileDims[tile];
+    const int fs = tile == TILE_128x128 ? nt_fused_split(a) : 1;
+    if (fs > 1) return GemmPlan{MMSUM_PLAN_NT_RING, d[0], d[1], ((a.M + 127) / 128) * ((a.N + 127) / 128) * fs};
     return GemmPlan{MMSUM_PLAN_NT_RING, d[0], d[1], ring_grid(a, d[0], d[1])};
 }
 GemmPlan plan_gemm_tn(const GemmArgs& a) {

@@ -107,11 +107,19 @@ def resnet_specs(embedding_dim, prefix="img_encoder."):
     return live, frozen, bufs
 
 
-def splitk_rule(M, N, Kred, bf16=True, deterministic=False):
+def splitk_rule(M, N, Kred, bf16=True, deterministic=False, tile256=False):
     """Split count of the weight-gradient product dW[M, N] = dy[Kred, M]^T x[Kred, N] (Engine.wgrad; the bench-shape parity tests
-    call this same function, so they run the step's real slice counts)."""
+    call this same function, so they run the step's real slice counts).  tile256: the product runs on 256x256 tiles whatever its
+    size (mmsum_conv3x3_wgrad)."""
     if deterministic:
         return 1
+    if bf16 and not tile256 and Kred < 4096:
+        # few rows (the per-GPU batch 1 of multimodal_train.py:420: 1,152 decoder rows): the 128x128 tile list of a Linear's gradient
+        # already covers half the CUs or all of them, a slice would hold a handful of 32-deep slabs, and the slab pass is a launch
+        # of its own -- tools/gemm_small_bench.py at 1,152 rows: dW[4096,1024] 25.8 us unsplit against 40.3 at 4 slices,
+        # dW[3072,1024] 23.6 / 35.9, dW[1024,1024] 19.0 at 2 / 21.4 at 4; at 2,304 rows dW[1024,1024] 24.7 at 4 / 29.5 at 9
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        return max(1, min(256 // t128, (Kred // 32) // 16))
     ktiles = max(1, Kred // (64 if bf16 else 32))
     # one 256x256 tile per CU and launch: the TN kernel is not persistent, so tiles x slices should come as close to the 256
     # CUs as it can from below (tools/tn_sk_sweep.py at R = 64,512: dW[4096,1024] 521 us at 3 slices = 192 workgroups, 451 us
@@ -327,8 +335,8 @@ class Engine:
         self.arena.shadow_dirty = False
         self._conv_dirty = "layer3"
 
-    def splitk(self, M, N, Kred):
-        return splitk_rule(M, N, Kred, bf16=self.dtype == torch.bfloat16, deterministic=self.deterministic)
+    def splitk(self, M, N, Kred, tile256=False):
+        return splitk_rule(M, N, Kred, bf16=self.dtype == torch.bfloat16, deterministic=self.deterministic, tile256=tile256)
 
     def wgrad(self, dy, x, gname=None, gview=None, bias_g=None, live=None, alpha_dev=None):
         """dW[N_out, K_in] += dy[R, N_out]^T x[R, K_in] into the f32 gradient arena (live: device count of the rows R).
@@ -1108,7 +1116,7 @@ class Engine:
                     dc2p = padded[key] = self.zeros(n * (bc.H + 2) * (bc.W + 2), bc.pl)
                 self._bn_bwd(bc.bn2, do2, dx_padded=dc2p, dx_pad_hw=(bc.H, bc.W))
                 dwm = self.empty(wm.shape[0], 9 * bc.pl, dtype=torch.float32)
-                sk = self.splitk(bc.pl, 9 * bc.pl, dc2p.shape[0])
+                sk = self.splitk(bc.pl, 9 * bc.pl, dc2p.shape[0], tile256=True)
                 lvp = self._lv(dc2p.shape[0], -2 * (bc.W + 3))         # the reduction's length over the images that run
                 if sk > 1:
                     ws = self.empty(sk * wm.shape[0], 9 * bc.pl, dtype=torch.float32)

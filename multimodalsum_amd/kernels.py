@@ -101,10 +101,32 @@ def gemm_plan(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None
     dt, M, N, K, ksplit, flags, bias = _gemm_args(a, b, out.shape[0], out.shape[1], a_t, b_t, bias, epi, aux, accumulate, a2, splitk,
                                                    slabs, colsum, out.dtype == torch.float32)
     plan = (ctypes.c_int * 4)()
+    lend = _lends_split_workspace(dt, M, N, a_t, b_t, splitk)
     check(lib.mmsum_gemm_plan(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(out), _ld(out),
-                              _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, flags, splitk, _live(live), _p(alpha_dev), plan),
+                              _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, flags, splitk, _live(live), _p(alpha_dev),
+                              GEMM_WORKSPACE_BYTES if lend else 0, plan),
           "mmsum_gemm_plan")
     return tuple(plan)
+
+
+GEMM_WORKSPACE_BYTES = 4096 + 256 * 128 * 128 * 4          # MMSUM_GEMM_WORKSPACE_BYTES
+_split_ws_cache = {}
+
+
+def _lends_split_workspace(dt, M, N, a_t, b_t, splitk):
+    """Products that may take mmsum_gemm's fused split (bf16 NT, a 128x128 tile list of at most half the CUs): only they are lent the
+    workspace.  The library decides whether it uses it."""
+    return dt == BF16 and not a_t and not b_t and splitk == 1 and ((M + 127) // 128) * ((N + 127) // 128) <= 128
+
+
+def _split_workspace(device):
+    """The zeroed scratch of mmsum_gemm's fused split, one per stream (two streams' products may be in flight at once)."""
+    k = (str(device), _stream())
+    w = _split_ws_cache.get(k)
+    if w is None:
+        w = torch.zeros(GEMM_WORKSPACE_BYTES, dtype=torch.uint8, device=device)
+        _split_ws_cache[k] = w
+    return w
 
 
 def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, accumulate=False, alpha=1.0, a2=None,
@@ -117,9 +139,10 @@ def gemm(a, b, out, a_t=False, b_t=False, bias=None, epi=EPI_NONE, aux=None, acc
         assert _dt(out) == _dt(a)
     dt, M, N, K, ksplit, flags, bias = _gemm_args(a, b, out.shape[0], out.shape[1], a_t, b_t, bias, epi, aux, accumulate, a2, splitk,
                                                    slabs, colsum, out.dtype == torch.float32, colsum_sq)
+    ws = _split_workspace(out.device) if _lends_split_workspace(dt, M, N, a_t, b_t, splitk) else None
     check(lib.mmsum_gemm(dt, _p(a), _ld(a), _p(a2), _ld(a2) if a2 is not None else 0, ksplit, _p(b), _ld(b), _p(out), _ld(out),
                          _p(bias), _p(aux), _ld(aux) if aux is not None else 0, M, N, K, float(alpha), _p(alpha_dev), flags, splitk, _live(live),
-                         _stream()),
+                         _p(ws), GEMM_WORKSPACE_BYTES if ws is not None else 0, _stream()),
           "mmsum_gemm")
     return out
 

@@ -21,16 +21,16 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(_lib.lib, s), "libmmsum_hip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_argument_validation_without_gpu():
     from multimodalsum_amd import _lib
     lib = _lib.lib
     # bad dtype / shape are rejected before anything touches the device
-    assert lib.mmsum_gemm(7, None, 0, None, 0, 0, None, 0, None, 0, None, None, 0, 8, 8, 8, 1.0, None, 0, 1, None, None) == -2
-    assert lib.mmsum_gemm(_lib.BF16, None, 0, None, 0, 0, None, 0, None, 0, None, None, 0, 0, 8, 8, 1.0, None, 0, 1, None, None) == -1
-    assert lib.mmsum_gemm(_lib.BF16, None, 8, None, 0, 0, None, 8, None, 8, None, None, 0, 8, 8, 12, 1.0, None, 0, 1, None, None) == -1  # K % 8
+    assert lib.mmsum_gemm(7, None, 0, None, 0, 0, None, 0, None, 0, None, None, 0, 8, 8, 8, 1.0, None, 0, 1, None, None, 0, None) == -2
+    assert lib.mmsum_gemm(_lib.BF16, None, 0, None, 0, 0, None, 0, None, 0, None, None, 0, 0, 8, 8, 1.0, None, 0, 1, None, None, 0, None) == -1
+    assert lib.mmsum_gemm(_lib.BF16, None, 8, None, 0, 0, None, 8, None, 8, None, None, 0, 8, 8, 12, 1.0, None, 0, 1, None, None, 0, None) == -1  # K % 8
     d = _lib.AttnDesc()
     d.T, d.S, d.N, d.H, d.qpb, d.n_qblocks = 200, 10, 1, 1, 1, 1
     assert lib.mmsum_attn_fwd(_lib.BF16, ctypes.byref(d), None) == -1  # T > 128
