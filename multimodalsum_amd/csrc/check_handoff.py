@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build-time guard of the fence-free in-launch hand-offs (gemm_skinny.hip: dec_gemm_kernel's split-K slabs; decode.hip:
-decode_cross_attn_kernel / decode_cross_attn_f32_kernel's entity mean).
+decode_cross_attn_kernel / decode_cross_attn_f32_kernel's entity mean; gemm_fast.hip: the fused split of the small NT products).
 
 Those kernels pass partial results between workgroups of ONE launch through memory without release / acquire fences (an agent-scope
 release writes back an XCD's whole L2: 14 us per product when 256 - 512 workgroups each pay it, profiles/NOTES_r04.md): payload words
@@ -20,7 +20,10 @@ usage: check_handoff.py <device .s file> [...]
 import re
 import sys
 
-KERNELS = {"dec_gemm_kernel": 1, "decode_cross_attn_kernel": 0, "decode_cross_attn_f32_kernel": 0}      # name -> plain dword loads allowed after the ticket
+# kernel family (regular expression on the mangled name) -> plain dword loads allowed after the ticket (dec_gemm: the bias; the fused
+# split of the small NT products, gemm_nt_ring_kernel<..., FS = true>: whatever the ordinary epilogue behind the reduction reads --
+# bias, saved pre-activation, the C of an accumulating store)
+KERNELS = {"dec_gemm_kernel": 1, "decode_cross_attn_kernel": 0, "decode_cross_attn_f32_kernel": 0, r"gemm_nt_ring_kernel\w*Lb1EEEv8GemmArgs": 256}
 LABEL = re.compile(r"^(_Z\w+):")
 
 
@@ -71,7 +74,7 @@ def main(paths):
     seen, bad = {k: 0 for k in KERNELS}, 0
     for path in paths:
         for name, body in functions(path):
-            fam = next((k for k in sorted(KERNELS, key=len, reverse=True) if k in name), None)
+            fam = next((k for k in sorted(KERNELS, key=len, reverse=True) if re.search(k, name)), None)
             if fam is None or not any(t.startswith("s_endpgm") for t in body):
                 continue
             seen[fam] += 1

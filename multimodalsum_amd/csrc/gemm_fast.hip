@@ -1474,7 +1474,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int EPI, int OUT>
 int launch_one(const GemmArgs& a, hipStream_t stream) {
     using R = RingCfg<BM, BN, WAVES_M, WAVES_N>;
     const size_t lds = R::NSTAGE * R::STAGE;
-    if constexpr (BM == 128 && BN == 128 && OUT != OUT_F32_ATOMIC) {
+    if constexpr (BM == 128 && BN == 128 && WAVES_M == 4 && OUT != OUT_F32_ATOMIC) {       // the one-round form (eight waves): the only one a split tile list reaches
         const int fs = nt_fused_split(a);
         if (fs > 1) {
             static const hipError_t attr_fs = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_ring_kernel<BM, BN, WAVES_M, WAVES_N, EPI, OUT, true>),

@@ -49,11 +49,11 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
     plan = (ctypes.c_int * 4)()
     fake = 1 << 20                       # any 16-byte aligned non-NULL address: the plan never dereferences
 
-    def p(M, N, K, flags=0, splitk=1, lda=None, ldb=None, live=None, alpha_dev=None):
+    def p(M, N, K, flags=0, splitk=1, lda=None, ldb=None, live=None, alpha_dev=None, ws=0):
         at, bt = flags & _lib.GEMM_A_T, flags & _lib.GEMM_B_T
         lda = lda or (M if at else K)
         ldb = ldb or (N if bt else K)
-        rc = lib.mmsum_gemm_plan(_lib.BF16, fake, lda, None, 0, 0, fake, ldb, fake, N, None, None, 0, M, N, K, flags, splitk, live, alpha_dev, plan)
+        rc = lib.mmsum_gemm_plan(_lib.BF16, fake, lda, None, 0, 0, fake, ldb, fake, N, None, None, 0, M, N, K, flags, splitk, live, alpha_dev, ws, plan)
         assert rc == 0, rc
         return tuple(plan)
 
@@ -67,15 +67,21 @@ def test_gemm_plan_is_pure_and_reaches_the_benchmarked_kernels():
     tn = _lib.GEMM_A_T | _lib.GEMM_B_T | _lib.GEMM_OUT_F32 | _lib.GEMM_SLABS
     assert p(4096, 1024, 64512, tn, 8)[:3] == (_lib.PLAN_TN_RING, 256, 256)     # fc1 weight gradient, split-K slabs
     assert p(1000, 520, 128)[0] == _lib.PLAN_NT_RING and p(1000, 520, 128)[1:3] == (128, 128)
+    # the small-batch step (1,152 decoder rows at the per-GPU batch 1 of multimodal_train.py:420): one round of 128x128 tiles; with a lent
+    # workspace the K = 4,096 products are cut into three reduction slices per tile, the K = 1,024 ones are not (mmsum_gemm)
+    ws = 4096 + 256 * 128 * 128 * 4                                             # MMSUM_GEMM_WORKSPACE_BYTES
+    assert p(1152, 1024, 4096) == (_lib.PLAN_NT_RING, 128, 128, 72) and p(1152, 1024, 4096, ws=ws) == (_lib.PLAN_NT_RING, 128, 128, 216)
+    assert p(1152, 1024, 1024, ws=ws) == (_lib.PLAN_NT_RING, 128, 128, 72) and p(640, 1024, 4096, ws=ws)[3] == 160
+    assert p(1152, 1024, 4096, ws=4096 + 100 * 128 * 128 * 4)[3] == 72          # a workspace too small for the slabs: unsplit
     assert p(32, 4096, 1024)[0] == _lib.PLAN_SKINNY                              # decode-step rows
     # the decode LM head: f32 logits, and (bf16 mode) the final LayerNorm's f32 output as the A operand -- weight-streaming kernel only
     assert p(32, 50265, 1024, _lib.GEMM_OUT_F32, ldb=1024)[0] == _lib.PLAN_SKINNY
     assert p(32, 50265, 1024, _lib.GEMM_OUT_F32 | _lib.GEMM_A_F32, ldb=1024)[0] == _lib.PLAN_SKINNY
     assert lib.mmsum_gemm_plan(_lib.BF16, fake, 1024, None, 0, 0, fake, 1024, fake, 4096, None, None, 0, 4096, 4096, 1024,
-                               _lib.GEMM_OUT_F32 | _lib.GEMM_A_F32, 1, None, None, plan) == -2      # no tiled kernel reads an f32 A
+                               _lib.GEMM_OUT_F32 | _lib.GEMM_A_F32, 1, None, None, 0, plan) == -2      # no tiled kernel reads an f32 A
     # a live row count or a device-side scale takes the product off the weight-streaming kernel: the plan must say so
     assert p(32, 4096, 1024, live=fake)[0] == _lib.PLAN_NT_RING and p(32, 4096, 1024, alpha_dev=fake)[0] == _lib.PLAN_NT_RING
-    assert lib.mmsum_gemm_plan(_lib.F32, fake, 1024, None, 0, 0, fake, 1024, fake, 512, None, None, 0, 512, 512, 1024, 0, 1, None, None, plan) == 0
+    assert lib.mmsum_gemm_plan(_lib.F32, fake, 1024, None, 0, 0, fake, 1024, fake, 512, None, None, 0, 512, 512, 1024, 0, 1, None, None, 0, plan) == 0
     assert plan[0] == _lib.PLAN_GENERIC
 
 
