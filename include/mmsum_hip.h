@@ -27,7 +27,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define MMSUM_ABI_VERSION 8
+#define MMSUM_ABI_VERSION 9
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -192,7 +192,7 @@ int mmsum_add_ln_bwd(int dtype, const void* dy, const void* x, const void* res, 
  *   entity by entity, to entities n = 0..N-1 of b (rows mem_row0 + ((b*N+n)*S + s), S <= 224, N <= 32),
  *   skipping n == qb % qpb when `exclude_self` (leave-one-out) and entities with null[b*N+n] != 0;
  *   out = mean over the attended entities of softmax_s(scale * q.k + mask) v   (0 if none).
- *   pad [B*N*S] uint8 (1 = masked key) or NULL; causal: key s > query t masked (self-attention).
+ *   pad [B*N*S] uint8 (1 = masked key) or NULL; causal: key s > query t (+ causal_q0) masked (self-attention).
  * head_dim is 64; q/k/v/out are head-merged [rows, H*64] with leading dimensions ldq/ldk/ldv/ldo. */
 typedef struct {
     const void* q; const void* k; const void* v; void* out;
@@ -208,6 +208,10 @@ typedef struct {
      * A missing query row reads as zeros and is never written.  A missing key row must be a masked key (pad != 0); its dk / dv
      * rows do not exist.  Physical row * row pitch must stay below 2 GiB.  NULL = identity (the padded layout itself). */
     const int* q_rows; const int* kv_rows;
+    /* causal only: key position of the query block's first row (a multiple of 32, 0 = the usual self-attention): key s is masked
+     * for query row t when s > causal_q0 + t.  A causal sequence of 129 .. 224 positions runs as its first 128 queries (causal_q0 = 0
+     * over the first 128 keys) + the remaining ones as a second query block with causal_q0 = 128 over all keys. */
+    int causal_q0;
 } mmsum_attn_desc;
 int mmsum_entity_null(const uint8_t* pad, uint8_t* null_entity, int n_entities, int S, void* stream);
 int mmsum_attn_fwd(int dtype, const mmsum_attn_desc* d, void* stream);

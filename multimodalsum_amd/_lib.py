@@ -19,7 +19,7 @@ GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
 GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM, GEMM_COLSUM2, GEMM_A_F32 = 0x40, 0x80, 0x100, 0x200, 0x400, 0x800
 PLAN_GENERIC, PLAN_NT_RING, PLAN_TN_RING, PLAN_SKINNY = 0, 1, 2, 3
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def gemm_epi(e):
@@ -41,7 +41,7 @@ class AttnDesc(ctypes.Structure):
                 ("pad", c_void_p), ("null_entity", c_void_p),
                 ("n_qblocks", c_int), ("T", c_int), ("qpb", c_int), ("N", c_int), ("S", c_int), ("H", c_int),
                 ("exclude_self", c_int), ("causal", c_int), ("scale", c_float),
-                ("q_rows", c_void_p), ("kv_rows", c_void_p)]
+                ("q_rows", c_void_p), ("kv_rows", c_void_p), ("causal_q0", c_int)]
 
 
 # name -> (restype, argtypes); mirrors include/mmsum_hip.h one to one

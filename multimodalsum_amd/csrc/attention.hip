@@ -288,7 +288,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(mmsum_attn_desc d
         __syncthreads();
         f32x16_t sacc[NKB];
         float m, l;
-        scores_softmax<T, NKB>(sacc, tile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        scores_softmax<T, NKB>(sacc, tile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos + d.causal_q0, lane, m, l);
         const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
         __syncthreads();
         // V^T: tile row = d (64 rows), reduction = key
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dq_kernel(mmsum_attn_des
         __syncthreads();
         f32x16_t p[NKB];
         float m, l;
-        scores_softmax<T, NKB>(p, tile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos, lane, m, l);
+        scores_softmax<T, NKB>(p, tile, SPAD, qf, maskb, d.S, d.scale, d.causal, qpos + d.causal_q0, lane, m, l);
         const float invl = (l > 0.f) ? 1.f / l : 0.f;
         __syncthreads();
         stage_natural<T, SPAD, NS, ATT_THREADS>(tile, V + row0 * d.ldv + h * HD, d.ldv, 0, d.S, 0, HD, tid);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_dkv_kernel(mmsum_attn_de
                         for (int r = 0; r < 16; ++r) {
                             const int ql = qq * 32 + acc_row(r, lane);      // query within the staged chunk
                             const int qg = qc + ql;                         // query position in the block
-                            const bool masked = keymask[o] || qg >= d.T || (d.causal && key > qg);
+                            const bool masked = keymask[o] || qg >= d.T || (d.causal && key > qg + d.causal_q0);
                             const float pr = masked ? 0.f : __expf(s[r] * d.scale - st[ql * 2]);
                             dp[r] = pr * (dp[r] * inv_cnt - st[ql * 2 + 1]) * d.scale;   // dS
                             s[r] = pr * inv_cnt;                                        // P / count
@@ -597,6 +597,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
     T* O = static_cast<T*>(d.out);
 
     const int qpos = wave * 32 + (lane & 31);
+    const int cwave = wave + (d.causal_q0 >> 5);      // causal: the key block of this wave's diagonal (a query block may start past key 0)
     const bool qvalid = qpos < d.T;
     Frag qf[NS];
     {
@@ -630,11 +631,11 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
         if (rem) prefetch(__builtin_ctz(rem));
         f32x16_t sacc[NKB];
         float m, l;
-        scores_softmax2<T, NKB, CAUSAL>(sacc, ktile, SPAD, qf, biasf, slen, d.scale, qpos, wave, lane, fo, m, l);
+        scores_softmax2<T, NKB, CAUSAL>(sacc, ktile, SPAD, qf, biasf, slen, d.scale, qpos + d.causal_q0, cwave, lane, fo, m, l);
         const float norm = (l > 0.f) ? inv_cnt / l : 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < slen && (!CAUSAL || kb <= wave)) {
+            if (kb * 32 < slen && (!CAUSAL || kb <= cwave)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[kb][r] *= norm;
                 acc_to_image<T>(img, sacc[kb], lane);
@@ -679,6 +680,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
     const T* V = static_cast<const T*>(d.v);
 
     const int qpos = wave * 32 + (lane & 31);
+    const int cwave = wave + (d.causal_q0 >> 5);      // causal: the key block of this wave's diagonal (a query block may start past key 0)
     const bool qvalid = qpos < d.T;
     Frag qf[NS], dof[NS];
     {
@@ -722,7 +724,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
         if (rem) prefetch(__builtin_ctz(rem));
         f32x16_t p[NKB];
         float m, l;
-        scores_softmax2<T, NKB, CAUSAL>(p, ktile, SPAD, qf, biasf, slen, d.scale, qpos, wave, lane, fo, m, l);
+        scores_softmax2<T, NKB, CAUSAL>(p, ktile, SPAD, qf, biasf, slen, d.scale, qpos + d.causal_q0, cwave, lane, fo, m, l);
         const float invl = (l > 0.f) ? 1.f / l : 0.f;
         // dP^T = V dO^T.  With two resident workgroups per CU (NKB <= 2) the registers to keep it for all key blocks
         // are not there, so it is computed twice (delta pass, then dS pass); the text entities (NKB 3..4, one
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
         float delta = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < slen && (!CAUSAL || kb <= wave)) {
+            if (kb * 32 < slen && (!CAUSAL || kb <= cwave)) {
                 f32x16_t dpk = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 2 && sizeof(T) == 2) ? 2 : 1) 
         }
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            if (kb * 32 < slen && (!CAUSAL || kb <= wave)) {
+            if (kb * 32 < slen && (!CAUSAL || kb <= cwave)) {
                 f32x16_t dpk;
                 if constexpr (KEEP_DP) {
                     dpk = dpkeep[kb];
@@ -879,7 +881,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
 #pragma unroll
             for (int qq = 0; qq < TQ / 32; ++qq) {
                 if (qc + qq * 32 >= d.T) continue;
-                if (CAUSAL && kb * 32 > qc + qq * 32 + 31) continue;          // every key of the block lies above every query
+                if (CAUSAL && kb * 32 > d.causal_q0 + qc + qq * 32 + 31) continue;          // every key of the block lies above every query
                 f32x16_t s = zero_acc(), dp = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl) {
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(ATT_THREADS, (NKB <= 4 && sizeof(T) == 2) ? 2 : 1) 
                         const int r = 4 * g + j;
                         const int qg = qc + ql0 + j;
                         bool masked = keymask[o] || qg >= d.T;
-                        if (CAUSAL) masked = masked || key > qg;
+                        if (CAUSAL) masked = masked || key > qg + d.causal_q0;
                         const float pr = masked ? 0.f : __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[j]));
                         dp[r] = pr * (dp[r] * inv_cnt - del4[j]) * d.scale;
                         s[r] = pr * inv_cnt;
@@ -1296,11 +1298,11 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_fwd_ker
             prefetch(__builtin_ctz(rem));
             if constexpr (KVMAP) if (rem & (rem - 1)) lookup(__builtin_ctz(rem & (rem - 1)));     // one entity ahead of the loads that use it
         }
-        dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
+        dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave + (d.causal_q0 >> 5)), fmask >> 5, [&](auto nact, auto nfast) {
             constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
             f32x16_t sacc[NKB];
             float m, l;
-            scores_tr<NKB, NACT, NFAST, CAUSAL>(sacc, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
+            scores_tr<NKB, NACT, NFAST, CAUSAL>(sacc, st.k(), qf, st.bias(), c2, qpos + d.causal_q0, lane, fo, m, l);
             if (rem) commit(nx);
             const float norm = (l > 0.f) ? inv_cnt * __builtin_amdgcn_rcpf(l) : 0.f;
             f32x16_t tmp[2] = {zero_acc(), zero_acc()};
@@ -1912,11 +1914,11 @@ __global__ __launch_bounds__(ATT_THREADS, NKB <= 4 ? 2 : 1) void attn_tr_bwd_dq_
             prefetch(__builtin_ctz(rem));
             if constexpr (KVMAP) if (rem & (rem - 1)) lookup(__builtin_ctz(rem & (rem - 1)));
         }
-        dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave), fmask >> 5, [&](auto nact, auto nfast) {
+        dispatch_blocks<NKB>(active_blocks<CAUSAL>(slen, wave + (d.causal_q0 >> 5)), fmask >> 5, [&](auto nact, auto nfast) {
             constexpr int NACT = decltype(nact)::value, NFAST = decltype(nfast)::value;
             f32x16_t p[NKB];
             float m, l;
-            scores_tr<NKB, NACT, NFAST, CAUSAL>(p, st.k(), qf, st.bias(), c2, qpos, lane, fo, m, l);
+            scores_tr<NKB, NACT, NFAST, CAUSAL>(p, st.k(), qf, st.bias(), c2, qpos + d.causal_q0, lane, fo, m, l);
             if (rem) commit(nx);
             const float invl = (l > 0.f) ? __builtin_amdgcn_rcpf(l) : 0.f;
             typedef float pair_t __attribute__((ext_vector_type(2)));
@@ -2286,7 +2288,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
 #pragma unroll
             for (int qq = 0; qq < TQ / 32; ++qq) {
                 if (qc + qq * 32 >= d.T) continue;
-                if (CAUSAL && kb * 32 > qc + qq * 32 + 31) continue;          // every key of the block lies above every query
+                if (CAUSAL && kb * 32 > d.causal_q0 + qc + qq * 32 + 31) continue;          // every key of the block lies above every query
                 f32x16_t s = zero_acc(), dp = zero_acc();
 #pragma unroll
                 for (int sl = 0; sl < 2; ++sl) {
@@ -2304,7 +2306,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attn_tr_bwd_dkv_kernel(mmsum_a
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * g + j;
                         float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -lse4[j])) * icl;   // P / count
-                        if (CAUSAL && key > qc + ql0 + j) pr = 0.f;
+                        if (CAUSAL && key > d.causal_q0 + qc + ql0 + j) pr = 0.f;
                         s[r] = pr;
                         dp[r] = pr * fmaf(dp[r], d.scale, -del4[j]);                         // dS
                     }
@@ -2560,7 +2562,7 @@ template <typename T> size_t pipe_lds(int nkb, int ntiles) {
 
 // One entity per business shared by its qpb > 1 query blocks (table / image memory of the decoder's cross-attention).
 // Self-attention: one entity per sequence, attended by that sequence's one query block (the merged backward kernel)
-inline bool self_attention(const mmsum_attn_desc& d) { return d.N == 1 && d.qpb == 1 && !d.exclude_self && d.S <= 128 && d.T <= 128; }
+inline bool self_attention(const mmsum_attn_desc& d) { return d.N == 1 && d.qpb == 1 && !d.exclude_self && d.S <= 128 && d.T <= 128 && d.causal_q0 == 0; }
 inline size_t self_lds(int nkb) {
     const size_t stage = (size_t)2 * tr_tile_bytes(nkb * 32) + nkb * 32 * sizeof(float) + 32, tiles = 2 * (size_t)tr_tile_bytes(128);
     const size_t xoff = ((stage > tiles ? stage : tiles) + 15) & ~(size_t)15, x = (size_t)nkb * 32 * 264;
@@ -2701,6 +2703,7 @@ int check_desc(const mmsum_attn_desc* d, int dtype) {
         return MMSUM_ERR_BAD_SHAPE;
     if (dtype != MMSUM_F32 && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;
     if ((d->q_rows || d->kv_rows) && dtype != MMSUM_BF16) return MMSUM_ERR_BAD_DTYPE;      // row maps: the bf16 kernels only
+    if (d->causal_q0 != 0 && (!d->causal || d->causal_q0 < 0 || (d->causal_q0 & 31) || d->causal_q0 + d->T > d->S)) return MMSUM_ERR_BAD_SHAPE;
     const long es = dtype == MMSUM_BF16 ? 2 : 4;
     if (((uintptr_t)d->q | (uintptr_t)d->k | (uintptr_t)d->v) & 15) return MMSUM_ERR_BAD_ALIGN;
     if (((d->ldq | d->ldk | d->ldv) * es) & 15) return MMSUM_ERR_BAD_ALIGN;

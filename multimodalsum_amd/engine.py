@@ -505,17 +505,23 @@ class Engine:
         rmap = maps.p2c32 if c.mapped else None
         attn = self.empty(R if c.mapped else Bn * T, D)
         nq = 1
-        if T > 128:
-            # more than 128 tokens per sequence (the encoder at test.py's 158-token reviews; encoder_fwd made T a multiple of the
-            # split): `nq` query blocks of T / nq rows attend the sequence's T keys -- the descriptor of one entity shared by the
-            # query blocks of a "business" (the table / image memory's form), forward and backward
-            if causal:
-                raise ValueError("causal self-attention over %d > 128 positions is not built (the reference trains and generates at <= 128)" % T)
-            nq = self.seq_splits(T)
-            assert T % nq == 0
-        c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn, pad, None, Bn * nq, T // nq, nq, 1, T, H,
-                                   False, causal, 64 ** -0.5, q_rows=rmap, kv_rows=rmap)
-        kn.attn_fwd(c.desc, x)
+        c.long = None
+        if T > 128 and causal:
+            # a decoder sequence of 129 .. 224 positions (a training step on test.py's 158-token reviews): its first 128 queries as
+            # the usual causal self-attention over the first 128 keys + the remaining ones as a second query block whose first row
+            # sits at key 128 (mmsum_attn_desc.causal_q0) over all the keys
+            assert maps is None
+            attn = self._causal_long_fwd(c, pad, Bn, T)
+        else:
+            if T > 128:
+                # more than 128 tokens per sequence (the encoder at test.py's 158-token reviews; encoder_fwd made T a multiple of the
+                # split): `nq` query blocks of T / nq rows attend the sequence's T keys -- the descriptor of one entity shared by the
+                # query blocks of a "business" (the table / image memory's form), forward and backward
+                nq = self.seq_splits(T)
+                assert T % nq == 0
+            c.desc = kn.make_attn_desc(c.qkv[:, :D], c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn, pad, None, Bn * nq, T // nq, nq, 1, T, H,
+                                       False, causal, 64 ** -0.5, q_rows=rmap, kv_rows=rmap)
+            kn.attn_fwd(c.desc, x)
         c.attn = attn if (maps is None or c.mapped) else kn.rows_gather(attn, self.empty(R, D), maps.c2p, live=live)
         c.o = self.empty(R, D)
         kn.gemm(c.attn, a.w(lb + "self_attn.out_proj.weight"), c.o, bias=a.f32(lb + "self_attn.out_proj.bias"), live=live)
@@ -541,9 +547,12 @@ class Engine:
         Rp = c.Bn * c.T
         if c.maps is not None and not c.mapped:
             dattn = kn.rows_gather(dattn, self.empty(Rp, D), c.maps.p2c)
-        dqkv = self.empty(R if c.mapped else Rp, 3 * D)
-        stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
-        kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
+        if c.long is not None:
+            dqkv = self._causal_long_bwd(c, dattn)
+        else:
+            dqkv = self.empty(R if c.mapped else Rp, 3 * D)
+            stats = self.empty(kn.attn_bwd_workspace(c.desc) // 4, dtype=torch.float32)
+            kn.attn_bwd(c.desc, dattn, dqkv[:, :D], False, dqkv[:, D:2 * D], dqkv[:, 2 * D:], stats)
         if c.maps is not None and not c.mapped:
             dqkv = kn.rows_gather(dqkv, self.empty(R, 3 * D), c.maps.c2p, live=live)
         self.wgrad(dqkv, c.x, gview=a.gspan(q + ".weight", v + ".weight", (3 * D, D)), bias_g=a.gspan(q + ".bias", v + ".bias", (3 * D,)),
@@ -553,6 +562,67 @@ class Engine:
                    lb + "self_attn.out_proj.weight", lb + "self_attn.out_proj.bias", lb + "self_attn_layer_norm.weight",
                    lb + "self_attn_layer_norm.bias")
         return dx
+
+    LONG_HEAD = 128          # queries of a long decoder sequence that run as the ordinary (<= 128-row) query block
+
+    def _rows_of(self, x, Bn, T, lo, hi):
+        """Rows lo .. hi-1 of every sequence of x [Bn*T, D] as a matrix of their own [Bn*(hi-lo), D]."""
+        y = self.empty(Bn * (hi - lo), x.shape[1], dtype=x.dtype)
+        y.view(Bn, hi - lo, x.shape[1]).copy_(x.view(Bn, T, x.shape[1])[:, lo:hi])
+        return y
+
+    def _causal_long_fwd(self, c, pad, Bn, T):
+        """Causal self-attention over T in 129 .. 224 positions from c.qkv [Bn*T, 3D] -> [Bn*T, D] (see _self_block_fwd)."""
+        D, H, T0 = self.cfg.d_model, self.cfg.heads, self.LONG_HEAD
+        if T > 224:
+            raise ValueError("decoder sequences of %d > 224 positions are not built (the attention kernels stage at most 224 keys)" % T)
+        T1 = T - T0
+        qkv3 = c.qkv.view(Bn, T, 3 * D)
+        L = NS(T1=T1)
+        L.qkv0 = self.empty(Bn * T0, 3 * D)
+        L.qkv0.view(Bn, T0, 3 * D).copy_(qkv3[:, :T0])
+        L.q1 = self.empty(Bn * T1, D)
+        L.q1.view(Bn, T1, D).copy_(qkv3[:, T0:, :D])
+        L.pad0 = None
+        if pad is not None:
+            L.pad0 = self.empty(Bn * T0, dtype=torch.uint8)
+            L.pad0.view(Bn, T0).copy_(pad.reshape(Bn, T)[:, :T0])
+        attn0, attn1 = self.empty(Bn * T0, D), self.empty(Bn * T1, D)
+        L.d0 = kn.make_attn_desc(L.qkv0[:, :D], L.qkv0[:, D:2 * D], L.qkv0[:, 2 * D:], attn0, L.pad0, None, Bn, T0, 1, 1, T0, H, False, True,
+                                 64 ** -0.5)
+        L.d1 = kn.make_attn_desc(L.q1, c.qkv[:, D:2 * D], c.qkv[:, 2 * D:], attn1, pad, None, Bn, T1, 1, 1, T, H, False, True, 64 ** -0.5,
+                                 causal_q0=T0)
+        kn.attn_fwd(L.d0, c.qkv)
+        kn.attn_fwd(L.d1, c.qkv)
+        attn = self.empty(Bn * T, D)
+        a3 = attn.view(Bn, T, D)
+        a3[:, :T0].copy_(attn0.view(Bn, T0, D))
+        a3[:, T0:].copy_(attn1.view(Bn, T1, D))
+        c.long = L
+        return attn
+
+    def _causal_long_bwd(self, c, dattn):
+        """dattn [Bn*T, D] -> dqkv [Bn*T, 3D]: the two query blocks' gradients; the second block's dK / dV cover every key."""
+        D, T0 = self.cfg.d_model, self.LONG_HEAD
+        L, Bn, T = c.long, c.Bn, c.T
+        T1 = L.T1
+        da3 = dattn.view(Bn, T, D)
+        da0, da1 = self.empty(Bn * T0, D), self.empty(Bn * T1, D)
+        da0.view(Bn, T0, D).copy_(da3[:, :T0])
+        da1.view(Bn, T1, D).copy_(da3[:, T0:])
+        dqkv0 = self.empty(Bn * T0, 3 * D)
+        st0 = self.empty(kn.attn_bwd_workspace(L.d0) // 4, dtype=torch.float32)
+        kn.attn_bwd(L.d0, da0, dqkv0[:, :D], False, dqkv0[:, D:2 * D], dqkv0[:, 2 * D:], st0)
+        dq1, dkv1 = self.empty(Bn * T1, D), self.empty(Bn * T, 2 * D)
+        st1 = self.empty(kn.attn_bwd_workspace(L.d1) // 4, dtype=torch.float32)
+        kn.attn_bwd(L.d1, da1, dq1, False, dkv1[:, :D], dkv1[:, D:], st1)
+        dqkv = self.empty(Bn * T, 3 * D)
+        d3 = dqkv.view(Bn, T, 3 * D)
+        d3[:, :T0].copy_(dqkv0.view(Bn, T0, 3 * D))
+        d3[:, T0:, :D].copy_(dq1.view(Bn, T1, D))
+        d3[:, T0:, D:].zero_()
+        d3[:, :, D:].add_(dkv1.view(Bn, T, 2 * D))
+        return dqkv
 
     def _ffn_block_fwd(self, lb, x, out=None, maps=None):
         """x -> LN(x + drop(fc2(gelu(fc1(x)))))   (:299-308 / :479-489)."""
@@ -696,21 +766,37 @@ class Engine:
         c.kv = self.empty(dc.mem_c.shape[0], 2 * D)
         kn.gemm(dc.mem_c, a.wspan(k + ".weight", v + ".weight", (2 * D, D)), c.kv,
                 bias=a.span(a.data, k + ".bias", v + ".bias", (2 * D,)), live=mlive)                      # :788-789, hoisted
-        c.mapped = dc.mem_maps is not None and self.dtype == torch.bfloat16     # bf16: K / V stay compact, read through the row map
+        # bf16: K / V stay compact, read through the row map (not for the two query blocks of a long decoder sequence: their dK / dV are
+        # added per modality slice of the padded layout)
+        c.mapped = dc.mem_maps is not None and self.dtype == torch.bfloat16 and dc.T <= 128
         if dc.mem_maps is not None and not c.mapped:
             c.kv = kn.rows_gather(c.kv, self.empty(L.rows, 2 * D), dc.mem_maps.p2c)
         c.heads = self.empty(nm * Rq, D)
         c.descs = []
+        # query blocks hold at most 128 rows: a decoder sequence of 129 .. 224 positions runs as two query blocks per (business, pass)
+        # -- its first 128 rows and the rest, each gathered into a matrix of its own -- over the same memory
+        parts = [(0, dc.T)] if dc.T <= 128 else [(0, self.LONG_HEAD), (self.LONG_HEAD, dc.T)]
+        if dc.T > 224:
+            raise ValueError("decoder sequences of %d > 224 positions are not built" % dc.T)
+        c.parts = parts
+        c.qparts = [c.q] if len(parts) == 1 else [self._rows_of(c.q, dc.Bd, dc.T, lo, hi) for lo, hi in parts]
         for m, ((N, S), pad) in enumerate(zip(L.mods, dc.pads)):
             rows = slice(L.offs[m], L.offs[m] + L.B * N * S)
-            if c.mapped:      # physical rows are rows of the whole compact matrix; the map is the modality's slice of padded -> compact
-                d = kn.make_attn_desc(c.q, c.kv[:, :D], c.kv[:, D:], c.heads[m * Rq:(m + 1) * Rq], pad, dc.nulls[m], dc.Bd, dc.T, dc.qpb, N, S,
-                                      H, dc.exclude_self and m == 0, False, 64 ** -0.5, kv_rows=dc.mem_maps.p2c32[rows])
-            else:
-                d = kn.make_attn_desc(c.q, c.kv[rows, :D], c.kv[rows, D:], c.heads[m * Rq:(m + 1) * Rq], pad, dc.nulls[m],
-                                      dc.Bd, dc.T, dc.qpb, N, S, H, dc.exclude_self and m == 0, False, 64 ** -0.5)
-            kn.attn_fwd(d, x)                                                                              # :819-869
-            c.descs.append(d)
+            heads_m = c.heads[m * Rq:(m + 1) * Rq]
+            ds = []
+            for (lo, hi), qp in zip(parts, c.qparts):
+                out = heads_m if len(parts) == 1 else self.empty(dc.Bd * (hi - lo), D)
+                if c.mapped:  # physical rows are rows of the whole compact matrix; the map is the modality's slice of padded -> compact
+                    d = kn.make_attn_desc(qp, c.kv[:, :D], c.kv[:, D:], out, pad, dc.nulls[m], dc.Bd, hi - lo, dc.qpb, N, S,
+                                          H, dc.exclude_self and m == 0, False, 64 ** -0.5, kv_rows=dc.mem_maps.p2c32[rows])
+                else:
+                    d = kn.make_attn_desc(qp, c.kv[rows, :D], c.kv[rows, D:], out, pad, dc.nulls[m],
+                                          dc.Bd, hi - lo, dc.qpb, N, S, H, dc.exclude_self and m == 0, False, 64 ** -0.5)
+                kn.attn_fwd(d, x)                                                                          # :819-869
+                if len(parts) > 1:
+                    heads_m.view(dc.Bd, dc.T, D)[:, lo:hi].copy_(out.view(dc.Bd, hi - lo, D))
+                ds.append(d)
+            c.descs.append(ds)
         c.y = self.empty(nm * Rq, D)
         kn.gemm(c.heads, a.w(pre + "out_proj.weight"), c.y, bias=a.f32(pre + "out_proj.bias"))             # :728-730 / :885
         if self.multimodal:
@@ -765,10 +851,22 @@ class Engine:
         self.dgrad(dyy, pre + "out_proj.weight", a.w(pre + "out_proj.weight"), dheads)
         dq = self.empty(Rq, D)
         dkv = self.empty(dc.mem_maps.rows if c.mapped else L.rows, 2 * D)
+        long = len(c.parts) > 1
+        dqs = [dq] if not long else [self.empty(dc.Bd * (hi - lo), D) for lo, hi in c.parts]
         for m, (N, S) in enumerate(L.mods):
             rows = slice(None) if c.mapped else slice(L.offs[m], L.offs[m] + L.B * N * S)
-            stats = self.empty(kn.attn_bwd_workspace(c.descs[m]) // 4, dtype=torch.float32)
-            kn.attn_bwd(c.descs[m], dheads[m * Rq:(m + 1) * Rq], dq, m > 0, dkv[rows, :D], dkv[rows, D:], stats)
+            dh_m = dheads[m * Rq:(m + 1) * Rq]
+            for pi, ((lo, hi), d) in enumerate(zip(c.parts, c.descs[m])):
+                dh = dh_m if not long else self._rows_of(dh_m, dc.Bd, dc.T, lo, hi)
+                # every launch overwrites the dK / dV rows of its modality: the second query block's go to a buffer of their own and are added
+                dkv_p = dkv if pi == 0 else self.empty(dkv.shape[0], 2 * D)
+                stats = self.empty(kn.attn_bwd_workspace(d) // 4, dtype=torch.float32)
+                kn.attn_bwd(d, dh, dqs[pi], m > 0, dkv_p[rows, :D], dkv_p[rows, D:], stats)
+                if pi > 0:
+                    dkv[rows].add_(dkv_p[rows])
+        if long:
+            for (lo, hi), dqp in zip(c.parts, dqs):
+                dq.view(dc.Bd, dc.T, D)[:, lo:hi].copy_(dqp.view(dc.Bd, hi - lo, D))
         mlive = None
         if dc.mem_maps is not None:
             mlive = dc.mem_maps.count

@@ -229,9 +229,12 @@ def add_ln_bwd(dy, x, res, gamma, mean, rstd, dx, dres, accumulate_dres, dgamma,
                                _stream()), "mmsum_add_ln_bwd")
 
 
-def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale, q_rows=None, kv_rows=None):
-    """q_rows / kv_rows: optional int32 row maps (logical padded row -> physical row of the compact matrices, -1 = absent)."""
+def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale, q_rows=None, kv_rows=None,
+                   causal_q0=0):
+    """q_rows / kv_rows: optional int32 row maps (logical padded row -> physical row of the compact matrices, -1 = absent).
+    causal_q0 (causal only, a multiple of 32): key position of the query block's first row."""
     d = AttnDesc()
+    d.causal_q0 = int(causal_q0)
     d._keep = (q_rows, kv_rows)              # the maps must outlive the descriptor's launches
     d.q_rows, d.kv_rows = _p(q_rows), _p(kv_rows)
     d.q, d.k, d.v, d.out = _p(q), _p(k), _p(v), _p(out)

@@ -178,10 +178,10 @@ class _Desc:
     pass
 
 
-def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale, q_rows=None, kv_rows=None):
+def make_attn_desc(q, k, v, out, pad, null_entity, n_qblocks, T, qpb, N, S, H, exclude_self, causal, scale, q_rows=None, kv_rows=None, causal_q0=0):
     d = _Desc()
     d.__dict__.update(q=q, k=k, v=v, out=out, pad=pad, null=null_entity, nq=n_qblocks, T=T, qpb=qpb, N=N, S=S, H=H,
-                      excl=bool(exclude_self), causal=bool(causal), scale=scale, q_rows=q_rows, kv_rows=kv_rows)
+                      excl=bool(exclude_self), causal=bool(causal), scale=scale, q_rows=q_rows, kv_rows=kv_rows, q0=int(causal_q0))
     return d
 
 
@@ -230,7 +230,7 @@ def _attn_ref(d, q, k, v):
             if pad is not None:
                 s = s.masked_fill(pad[b, n][None, None, :], float("-inf"))
             if d.causal:
-                s = s + torch.triu(torch.full((d.T, d.S), float("-inf")), 1)
+                s = s + torch.triu(torch.full((d.T, d.S), float("-inf")), 1 + d.q0)          # key s masked when s > causal_q0 + t
             acc = acc + torch.einsum("hts,hsd->htd", torch.softmax(s, -1), vh[b, n])
             cnt += 1
         outs.append(acc / max(cnt, 1) + 0 * qh[qb])

@@ -917,6 +917,58 @@ def test_encoder_longer_than_128_tokens_schedule(monkeypatch, S, compact):
             _close(g, sd[n].grad, 5e-4, 3e-5 if n.endswith("k_proj.bias") else 5e-6, n)
 
 
+@pytest.mark.parametrize("T", [141, 158])
+def test_decoder_longer_than_128_positions_schedule(monkeypatch, T):
+    """The decoder's own sequence at 129 .. 224 positions (a training pass on test.py-length targets): causal self-attention as the
+    first 128 queries + a second query block with mmsum_attn_desc.causal_q0 = 128 over all keys, cross-attention as two query
+    blocks per sequence over the same memory with their dK / dV added -- host schedule through the kernel emulator against the
+    oracle's teacher-forced multi-encoder pass (logits, memory gradients, decoder parameter gradients).  GPU twin:
+    tests/test_long_sequences_gpu.py."""
+    emu.install(monkeypatch)
+    from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
+    cfg = tiny_cfg(vocab=100, d=256, ffn=64, layers=1, heads=4, maxpos=T + 8)
+    ocfg = oracle_cfg(cfg)
+    sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
+    model = BartForMultiEncConditionalGeneration(cfg, device="cpu", dtype=torch.float32)
+    model.load_state_dict(sd)
+    model.train()
+    Bz, N, S, D = 2, 2, 40, 256
+    text_m = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=3, min_len=10).view(Bz, N, S).ne(1)
+    text_h = formula_tensor("ld.text_h", (Bz, N, S, D), std=1.0)
+    table_h, table_m = formula_tensor("ld.table_h", (Bz, 1, 47, D), std=1.0), torch.ones(Bz, 1, 47, dtype=torch.bool)
+    img_h, img_m = formula_tensor("ld.img_h", (Bz, 1, 196, D), std=1.0), torch.ones(Bz, 1, 196, dtype=torch.bool)
+    labels = syn.token_batch(Bz, T, cfg.vocab_size, seed=12, min_len=T - 15)
+    labels[0] = torch.randint(3, cfg.vocab_size, (T,), generator=torch.Generator().manual_seed(5))
+    rd = torch.tensor([[0.5], [-1.25]])
+    seen = []
+    import multimodalsum_amd.engine as eng_mod
+    od = eng_mod.kn.make_attn_desc
+    monkeypatch.setattr(eng_mod.kn, "make_attn_desc", lambda *a, **k: seen.append((a[6:11], bool(a[13]), k.get("causal_q0", 0))) or od(*a, **k))
+    hd = [t.clone().requires_grad_(True) for t in (text_h, table_h, img_h)]
+    logits = model(hd[0], text_m, hd[1], table_m, hd[2], img_m, rating_diff=rd, labels=labels)[0]
+    wl = formula_tensor("ld.wl", tuple(logits.shape), std=1.0)
+    (logits * wl).sum().backward()
+    T1 = T - 128
+    # (query blocks, T, qpb, N, S), causal, causal_q0: the two self-attention blocks, then two query blocks per modality
+    assert seen[:2] == [((Bz, 128, 1, 1, 128), True, 0), ((Bz, T1, 1, 1, T), True, 128)], seen[:2]
+    assert [x[0][1] for x in seen[2:8]] == [128, T1] * 3 and all(not x[1] and x[2] == 0 for x in seen[2:8]), seen[2:8]
+    oh = [t.clone().requires_grad_(True) for t in (text_h, table_h, img_h)]
+    for v in sd.values():
+        v.requires_grad_(True)
+    ol = bo.multienc_forward(sd, ocfg, oh[0], text_m, oh[1], table_m, oh[2], img_m, rd, labels, training=True)
+    (ol * wl).sum().backward()
+    assert (logits - ol).abs().max() <= 5e-4 * ol.abs().max()
+    for a, b in zip(hd, oh):
+        _close(a.grad, b.grad, 5e-4, 5e-6, "memory gradient")
+    n = 0
+    for name, prm in model.named_parameters():
+        if prm.grad is None or sd[name].grad is None:
+            continue
+        _close(prm.grad, sd[name].grad, 5e-4, 3e-5 if name.endswith("k_proj.bias") else 5e-6, name)
+        n += 1
+    assert n >= 20
+
+
 @pytest.mark.parametrize("kind", ["multimodal", "text"])
 def test_dropout_on_step_vs_oracle_on_the_same_masks(monkeypatch, kind):
     """Dropout on (cfg/bart-large.json:23): the kernels' masks are a counter hash the host can restate (multimodalsum_amd/dropout.py;

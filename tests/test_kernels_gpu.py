@@ -313,7 +313,7 @@ def test_embed_ln(dtype):
 
 
 # ------------------------------------------------------------------------------------------------
-def attn_reference(q, k, v, pad, nq, T, qpb, N, S, H, exclude, causal, scale, mm=None):
+def attn_reference(q, k, v, pad, nq, T, qpb, N, S, H, exclude, causal, scale, mm=None, q0=0):
     """q [nq*T, H*64]; k/v [B*N*S, H*64]; pad [B,N,S] bool.  Returns out [nq*T, H*64] (autograd, in the dtype of q).
     mm: the two attention products (default torch.matmul; the bf16 yardstick passes the oracle's bf16-operand product)."""
     mm = mm or torch.matmul
@@ -334,7 +334,7 @@ def attn_reference(q, k, v, pad, nq, T, qpb, N, S, H, exclude, causal, scale, mm
             if pad is not None:
                 s = s.masked_fill(pad[b, n][None, None, :], float("-inf"))
             if causal:
-                s = s + torch.triu(torch.full((T, S), float("-inf"), device=s.device, dtype=s.dtype), 1)
+                s = s + torch.triu(torch.full((T, S), float("-inf"), device=s.device, dtype=s.dtype), 1 + q0)     # key s masked when s > q0 + t
             acc = acc + mm(torch.softmax(s, -1), vh[b, n])
             cnt += 1
         if cnt == 0:
@@ -434,6 +434,45 @@ def test_attention(dtype, case):
     dq_o.copy_(base)
     kn.attn_bwd(desc_o, dout, dq_o, True, dk_o, dv_o, stats)
     assert torch.equal(dq_o, dq2) and torch.equal(dk_o, dk) and torch.equal(dv_o, dv)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("S,T,q0", [(158, 30, 128), (224, 96, 128), (129, 1, 128), (141, 13, 128), (96, 32, 64), (200, 128, 64)])
+def test_attention_causal_query_offset(dtype, S, T, q0):
+    """mmsum_attn_desc.causal_q0: a causal query block whose first row sits at key q0 (the second query block of a decoder sequence of
+    129 .. 224 positions, engine._causal_long_fwd): key s is masked for query row t when s > q0 + t.  Forward, dQ and dK / dV (every key
+    row, the ones no query sees included: zeros) against the fp32 reference, with trailing key padding; bad offsets are refused."""
+    B, H = 3, 2
+    D = H * 64
+    pad = torch.zeros(B, 1, S, dtype=torch.bool)
+    pad[1, 0, S - 7:] = True
+    pad[2, 0, q0 + max(1, T // 2):] = True          # the padding starts inside the diagonal region
+    pad = pad.to(DEV)
+    q = rnd(B * T, D, dtype=dtype, seed=1)
+    kv = rnd(B * S, 2 * D, dtype=dtype, seed=2)
+    k, v = kv[:, :D], kv[:, D:]
+    dout = rnd(B * T, D, dtype=dtype, seed=3)
+    qf, kf, vf = (t.float().contiguous().requires_grad_(True) for t in (q, k, v))
+    ref = attn_reference(qf, kf, vf, pad, B, T, 1, 1, S, H, False, True, 0.125, q0=q0)
+    ref.backward(dout.float())
+    pad_u8 = pad.to(torch.uint8).contiguous()
+    out = torch.full((B * T, D), float("nan"), device=DEV, dtype=dtype)
+    desc = kn.make_attn_desc(q, k, v, out, pad_u8, None, B, T, 1, 1, S, H, False, True, 0.125, causal_q0=q0)
+    kn.attn_fwd(desc, q)
+    close(out, ref, dtype, what="fwd")
+    dq = torch.full((B * T, D), float("nan"), device=DEV, dtype=dtype)
+    dk = torch.full((B * S, D), float("nan"), device=DEV, dtype=dtype)
+    dv = torch.full((B * S, D), float("nan"), device=DEV, dtype=dtype)
+    stats = torch.empty(kn.attn_bwd_workspace(desc) // 4, device=DEV)
+    kn.attn_bwd(desc, dout, dq, False, dk, dv, stats)
+    close(dq, qf.grad, dtype, what="dq")
+    close(dk, kf.grad, dtype, what="dk")
+    close(dv, vf.grad, dtype, what="dv")
+    for bad in (kn.make_attn_desc(q, k, v, out, pad_u8, None, B, T, 1, 1, S, H, False, True, 0.125, causal_q0=q0 + 8),       # not a multiple of 32
+                kn.make_attn_desc(q, k, v, out, pad_u8, None, B, T, 1, 1, S, H, False, False, 0.125, causal_q0=q0),          # not causal
+                kn.make_attn_desc(q, k, v, out, pad_u8, None, B, T, 1, 1, S, H, False, True, 0.125, causal_q0=S)):           # past the keys
+        with pytest.raises(RuntimeError):
+            kn.attn_fwd(bad, q)
 
 
 @pytest.mark.parametrize("std", [1.0, 0.25], ids=["peaked", "flat"])

@@ -8,8 +8,9 @@ of at most 128 rows, so engine.encoder_fwd cuts a longer sequence into two query
   * the padding-free (compact row) encoder of the fused steps at S = 158 against the padded one;
   * the decoder's cross-attention over 158-token text entities (teacher-forced pass, T = 24) against the oracle;
   * beam search on [B, 8, 158] text + table + images: tests/test_generation_gpu.py::test_generation_f32_on_158_token_reviews.
-The decoder's own (causal) sequence stays <= 128 positions: the reference trains on 128-token targets
-(src/multimodal_train.py:30) and test.py generates max_length <= 128; engine._self_block_fwd raises above that.
+  * the decoder's own (causal) sequence at 129 .. 224 positions (the reference trains on 128-token targets, src/multimodal_train.py:30,
+    and test.py generates max_length <= 128: this is the training pass on test.py-length targets): logits, memory gradients and every
+    decoder parameter's gradient against the oracle; the fused leave-one-out step at S = 158: tests/test_parity_gaps_gpu.py.
 """
 import pytest
 import torch
@@ -143,14 +144,41 @@ def test_padding_free_encoder_equals_padded_at_158_tokens(S):
 def test_decoder_cross_attention_over_158_token_entities(dtype):
     """Teacher-forced multi-encoder pass (modeling_multimodalsum.py:819-869) whose text entities are 158 keys long -- the memory
     test.py's inputs produce -- with a table and images: logits and the gradients of the memory against the oracle."""
+    _multienc_case(dtype, 24, False)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T", [158, 141, 129, 224])
+def test_decoder_sequences_longer_than_128_positions(dtype, T):
+    """The DECODER's own sequence at 129 .. 224 positions (a training pass on 158-token targets): causal self-attention as the first
+    128 queries + a second query block whose first row sits at key 128 (mmsum_attn_desc.causal_q0), cross-attention as two query
+    blocks per sequence over the same memory (dK / dV of the two added).  Logits, the gradients of the memory and the gradient of
+    every decoder parameter against the oracle."""
+    _multienc_case(dtype, T, True)
+
+
+def test_decoder_over_224_positions_is_refused():
     from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
-    cfg = tiny_cfg(vocab=300, d=256, ffn=512, layers=2, heads=4, maxpos=200)
+    cfg = tiny_cfg(vocab=300, d=256, ffn=256, layers=1, heads=4, maxpos=260)
+    model = BartForMultiEncConditionalGeneration(cfg, device=DEV, dtype=torch.float32, deterministic=True)
+    h = torch.zeros(1, 1, 8, 256, device=DEV)
+    m = torch.ones(1, 1, 8, dtype=torch.bool, device=DEV)
+    th, tm = torch.zeros(1, 1, 47, 256, device=DEV), torch.ones(1, 1, 47, dtype=torch.bool, device=DEV)
+    ih, im = torch.zeros(1, 1, 196, 256, device=DEV), torch.ones(1, 1, 196, dtype=torch.bool, device=DEV)
+    labels = torch.full((1, 230), 5, device=DEV)
+    with pytest.raises(ValueError):
+        model(h, m, th, tm, ih, im, labels=labels)
+
+
+def _multienc_case(dtype, T, check_params):
+    from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
+    cfg = tiny_cfg(vocab=300, d=256, ffn=512, layers=2, heads=4, maxpos=240)
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
     model = BartForMultiEncConditionalGeneration(cfg, device=DEV, dtype=dtype, deterministic=True)
     model.load_state_dict(sd)
     model.train()
-    Bz, N, S, T, D = 2, 3, 158, 24, 256
+    Bz, N, S, D = 2, 3, 158, 256
     ids = syn.token_batch(Bz * N, S, cfg.vocab_size, seed=3, mean_len=120.0, std_len=30.0, min_len=40).view(Bz, N, S)
     text_m = ids.ne(1).clone()
     text_m[1, 2, :] = False
@@ -160,7 +188,8 @@ def test_decoder_cross_attention_over_158_token_entities(dtype):
     table_m = torch.ones(Bz, 1, 47, dtype=torch.bool)
     img_m = torch.ones(Bz, 2, 196, dtype=torch.bool)
     img_m[0, 1] = False
-    labels = syn.token_batch(Bz, T, cfg.vocab_size, seed=12, min_len=8)
+    labels = syn.token_batch(Bz, T, cfg.vocab_size, seed=12, min_len=max(8, T - 20))
+    labels[0] = torch.randint(3, cfg.vocab_size, (T,), generator=torch.Generator().manual_seed(5))      # one full-length target
     rd = torch.tensor([[0.5], [-1.25]])
     cast = lambda t: t.to(DEV).to(dtype)
     hd = [cast(text_h).requires_grad_(True), cast(table_h).requires_grad_(True), cast(img_h).requires_grad_(True)]
@@ -169,25 +198,109 @@ def test_decoder_cross_attention_over_158_token_entities(dtype):
     wl = formula_tensor("l.wl", tuple(logits.shape), std=1.0)
     (logits.float() * wl.to(DEV)).sum().backward()
     oh = [t.clone().requires_grad_(True) for t in (text_h, table_h, img_h)]
+    dec_names = [k for k in sd if k.startswith("model.decoder.") or k == "model.shared.weight"] if check_params else []
+    mine = {k: pr.grad.detach().float().cpu().clone() for k, pr in model.named_parameters() if k in dec_names and pr.grad is not None}
 
     def run(quant):
         bo.EMULATE_BF16 = quant
         try:
             for t in oh:
                 t.grad = None
+            for k in dec_names:
+                sd[k].grad = None
+                sd[k].requires_grad_(True)
             ol = bo.multienc_forward(sd, ocfg, oh[0], text_m, oh[1], table_m, oh[2], img_m, rd, labels, training=True)
             (ol * wl).sum().backward()
         finally:
             bo.EMULATE_BF16 = False
-        return ol.detach(), [t.grad.clone() for t in oh]
+        return ol.detach(), [t.grad.clone() for t in oh], {k: sd[k].grad.clone() for k in dec_names if sd[k].grad is not None}
 
-    ol, og = run(False)
+    ol, og, op = run(False)
+    assert not check_params or (len(mine) >= 30 and set(mine) == set(op)), (len(mine), len(op))
+    op = {k: g for k, g in op.items() if not k.endswith("k_proj.bias")}       # exactly zero analytically (a softmax ignores a shift of its scores): rounding noise on both sides
     if dtype == torch.float32:
         assert _err(logits.cpu(), ol) <= 1e-3 * ol.abs().max().item()
         for t, g in zip(hd, og):
             assert _err(t.grad.cpu(), g) <= 1e-3 * g.abs().max().item() + 1e-6
+        for k, g in op.items():
+            assert _err(mine[k], g) <= 1e-3 * g.abs().max().item() + 1e-5, k
     else:
-        oq, gq = run(True)
+        oq, gq, pq = run(True)
         assert _err(logits.cpu(), ol) <= 3 * _err(oq, ol) + 1e-3 * ol.abs().max().item()
         for t, g, q in zip(hd, og, gq):
             assert _err(t.grad.cpu(), g) <= 3 * _err(q, g) + 1e-3 * g.abs().max().item() + 1e-6
+        for k, g in op.items():
+            assert _err(mine[k], g) <= 3 * _err(pq[k], g) + 2e-3 * g.abs().max().item() + 1e-5, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("S", [158, 141])
+def test_fused_multimodal_training_step_at_158_tokens(dtype, S):
+    """The fused leave-one-out training step of multimodal_train.py on test.py-length reviews ([B, NR, 158]: encoder sequences AND the
+    decoder's NR teacher-forced passes are 158 positions long) against the oracle: loss and every gradient -- f32 within 1e-3, bf16 as
+    tests/test_modules_gpu.py::test_multimodal_step_f3 holds the 128-token step.  Eager and under graph replay (bf16)."""
+    from multimodalsum_amd.modules import MultimodalSum
+    from oracle import step_oracle as so
+    from tests.test_host_logic_cpu import f3_state
+    from tests.test_modules_gpu import close, cosine, to_dev, TOL_F32
+    cfg = tiny_cfg(maxpos=S + 8)
+    ocfg = oracle_cfg(cfg)
+    sd = f3_state(ocfg)
+    model = MultimodalSum(config=cfg, label_smoothing=0.1, device=DEV, dtype=dtype, deterministic=True)
+    model.load_state_dict(sd)
+    model.train()
+    bc = syn.yelp_batch(2, 3, S, 1, cfg.vocab_size, seed=158, img_hw=64, mean_len=0.85 * S, std_len=0.1 * S, min_len=S // 2)
+    bc["reviews"][0, 0] = torch.randint(3, cfg.vocab_size, (S,), generator=torch.Generator().manual_seed(9))        # one full-length review
+    bc["reviews_mask"] = bc["reviews"].ne(1).long()
+    bc["img"] = torch.zeros_like(bc["img"])                     # images off through img_mask: a ResNet BatchNorm stack over a few 64x64 images is
+    bc["img_mask"] = torch.zeros_like(bc["img_mask"])           # too ill-conditioned in fp32 to compare at 1e-3 (test_multimodal_step_ragged_shapes_f32)
+    assert int(bc["reviews_mask"].sum(-1).max()) == S           # at least one full-length review
+    b = to_dev(bc)
+    loss = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+    loss.backward()
+    torch.cuda.synchronize()
+    for k, v in sd.items():
+        if v.is_floating_point() and v.dim() > 0 and "running" not in k:
+            v.requires_grad_(True)
+    ol = so.multimodal_step_loss(sd, ocfg, bc["reviews"], bc["reviews_mask"], bc["reviews_rating"], bc["field"], bc["field_value"],
+                                 bc["img"], bc["img_mask"], 0.1, training=True)
+    ol.backward()
+    named = dict(model.named_parameters())
+    if dtype == torch.float32:
+        close(loss, ol, TOL_F32, 1e-5, "loss")
+        n = 0
+        for name, p in named.items():
+            ref = sd[name].grad
+            if ref is None:
+                assert p.grad is None, name
+                continue
+            if "img_encoder.resnet" in name:
+                assert torch.isfinite(p.grad).all(), name
+                continue
+            close(p.grad, ref, TOL_F32, 5e-6, name)
+            n += 1
+        assert n >= 50
+    else:
+        assert abs(loss.item() - ol.item()) < 2e-2 * abs(ol.item())
+        worst = 1.0
+        for name, p in named.items():
+            ref = sd[name].grad
+            if ref is None or "img_encoder.resnet" in name:
+                continue
+            assert torch.isfinite(p.grad).all(), name
+            if ref.abs().max() > 1e-6 and ref.numel() >= 1024:
+                worst = min(worst, cosine(p.grad, ref))
+        assert worst > 0.97, worst
+        # the same step under graph replay: priming (eager + capture), then a replay on the same batch gives the same loss and gradients
+        eager_loss = loss.detach().clone()
+        eager = {k: p.grad.detach().clone() for k, p in named.items() if p.grad is not None}
+        model.enable_step_graphs()
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            l2 = model(b["reviews"], b["reviews_mask"], b["reviews_rating"], b["field"], b["field_value"], b["img"], b["img_mask"])[0]
+            l2.backward()
+        torch.cuda.synchronize()
+        assert abs(l2.item() - eager_loss.item()) <= 1e-3 * abs(eager_loss.item())
+        for k, g in eager.items():
+            if g.numel() >= 1024 and g.abs().max() > 1e-6 and "img_encoder.resnet" not in k:
+                assert cosine(named[k].grad, g) > 0.999, k
