@@ -394,7 +394,10 @@ def test_wide_step_f32_and_bf16_vs_oracle():
     cfg = _bart_large()
     cfg.encoder_layers = cfg.decoder_layers = 2
     sd, ocfg = _full_state(cfg, "cpu")
-    bc = syn.yelp_batch(2, 9, 128, 2, cfg.vocab_size, seed=77, img_hw=64)
+    # 224 px images (196 positions each): BatchNorm statistics over the handful of positions of small images make the ResNet stack chaotic --
+    # the bf16 mode's f32 atomics (statistics from the GEMM epilogues, summed in arrival order) then move the TRAIN-mode loss by +-1 % from run
+    # to run (measured at 64 px: 9.67 .. 9.84 around 9.72; the eval-mode loss, on running statistics, is bit-stable)
+    bc = syn.yelp_batch(2, 9, 128, 2, cfg.vocab_size, seed=77, img_hw=224)
     bc["img_mask"][0, 0] = True
     b = syn.batch_to(bc, DEV)
 
@@ -448,6 +451,8 @@ def test_wide_step_f32_and_bf16_vs_oracle():
     ro = torch.tensor([rel(g32[n], g64[n]) for n in live if "img_encoder.resnet" in n])
     assert rh.median() <= 3 * ro.median() + 1e-4 and rh.max() <= max(10 * float(ro.max()), 1e-3), (rh.median(), ro.median(), rh.max(), ro.max())
     lb, gb, evb = hip(torch.bfloat16)
+    print("wide step losses: fp64 %.6f  fp32 oracle %.6f  bf16 emulation %.6f  HIP f32 %.6f  HIP bf16 %.6f (eval: fp64 %.6f, HIP f32 %.6f, HIP bf16 %.6f)"
+          % (l64, l32, lemu, lf, lb, leval, evf, evb))
     assert abs(lb - l64) <= 3 * abs(lemu - l64) + 1e-3 * abs(l64), (lb, l64, lemu)
     assert abs(evb - leval) <= 3 * abs(lemu - l64) + 2e-3 * abs(leval), ("eval-mode loss bf16", evb, leval)
     worst = []
