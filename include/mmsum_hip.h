@@ -27,7 +27,7 @@ extern "C" {
 /* The library is built with -fvisibility=hidden: only the entry points declared here are exported. */
 #pragma GCC visibility push(default)
 
-#define MMSUM_ABI_VERSION 9
+#define MMSUM_ABI_VERSION 10
 
 enum { MMSUM_F32 = 0, MMSUM_BF16 = 1 };
 enum { MMSUM_OK = 0, MMSUM_ERR_BAD_SHAPE = -1, MMSUM_ERR_BAD_DTYPE = -2, MMSUM_ERR_BAD_ALIGN = -3,
@@ -398,16 +398,19 @@ int mmsum_amazon_table_gather_bwd(int dtype, const void* dall, const int64_t* pr
  * otherwise, BEFORE the bans (postprocess_next_token_scores' order) -- on the log-probabilities (penalty_on_logits = 0: beam search,
  * :2874-2890; costs a second pass over the logits) or on the raw logits (penalty_on_logits = 1: _generate_no_beam_search post-processes
  * the logits themselves, :2749-2783; with num_beams = 1 and beam_scores 0 the first candidate of a row is then the reference's argmax).
+ * ncand (ABI 10; 0 = 2 * num_beams): candidates returned per business, <= 64 -- sampling (_generate_no_beam_search with do_sample, :1831-1839)
+ * asks for the top_k best of a row (num_beams = 1, force_token -1: the reference skips the forced tokens when it samples) and draws among
+ * them on the host; out_scores / out_ids are then [rows / num_beams, ncand].
  * mmsum_decode_self_attn: single-query self-attention of every hypothesis over its K/V cache rows (:776-815), reached
  * through an ancestor table: key s (< len) of row r is row ancestors[r * Tmax + s] * Tmax + s of k_cache / v_cache
  * ([rows * Tmax, H*64]).  A beam reorder (_reorder_cache :3104-3115) is then a gather of the table, not of the caches.
  * k_new / v_new [rows, H*64] (optional, both or neither): this step's key / value projections (position len - 1, where
  * ancestors[r, len - 1] must be r): the kernel stores them into the caches and uses them for that position, which replaces the
  * cache append of the reference (:804-815). */
-long mmsum_beam_topk_workspace(int rows, int num_beams);
+long mmsum_beam_topk_workspace(int rows, int num_beams, int ncand);
 int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const float* beam_scores, const int* banned, int nban, int force_token,
                     int ban_token, int rows, int num_beams, void* workspace, float* out_scores, long long* out_ids,
-                    const int* penalized, int npen, float penalty, int penalty_on_logits, void* stream);
+                    const int* penalized, int npen, float penalty, int penalty_on_logits, int ncand, void* stream);
 int mmsum_decode_self_attn(int dtype, const void* q, long ldq, void* k_cache, void* v_cache, long ld_cache, const int* ancestors,
                            void* out, long ldo, int rows, int H, int len, int Tmax, float scale, const void* k_new, const void* v_new,
                            long ld_new, void* stream);

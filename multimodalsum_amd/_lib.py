@@ -19,7 +19,7 @@ GEMM_A_T, GEMM_B_T, GEMM_BIAS = 0x1, 0x2, 0x4
 EPI_NONE, EPI_GELU, EPI_GELU_BWD, EPI_RELU, EPI_RELU_BWD = 0, 1, 2, 3, 4
 GEMM_ACCUM, GEMM_OUT_F32, GEMM_SLABS, GEMM_COLSUM, GEMM_COLSUM2, GEMM_A_F32 = 0x40, 0x80, 0x100, 0x200, 0x400, 0x800
 PLAN_GENERIC, PLAN_NT_RING, PLAN_TN_RING, PLAN_SKINNY = 0, 1, 2, 3
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def gemm_epi(e):
@@ -117,9 +117,9 @@ SIGNATURES = {
     "mmsum_table_gather_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmsum_amazon_table_gather": (c_int, [c_int] + [c_void_p] * 12 + [c_int, c_int, c_int, c_void_p]),
     "mmsum_amazon_table_gather_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "mmsum_beam_topk_workspace": (c_long, [c_int, c_int]),
+    "mmsum_beam_topk_workspace": (c_long, [c_int, c_int, c_int]),
     "mmsum_beam_topk": (c_int, [c_int, c_void_p, c_long, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                c_void_p, c_void_p, c_int, c_float, c_int, c_void_p]),
+                                c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_void_p]),
     "mmsum_decode_self_attn": (c_int, [c_int, c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
                                        c_int, c_float, c_void_p, c_void_p, c_long, c_void_p]),
 }

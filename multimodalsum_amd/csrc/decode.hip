@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int TK_MAX = 16;            // 2 * num_beams, num_beams <= 8
+constexpr int TK_MAX_CAND = 64;       // an explicit candidate count (sampling: the top_k best of a row)
 constexpr int TK_THREADS = 256;
 
 struct Cand { float v; int tok; };
@@ -320,16 +321,18 @@ __global__ __launch_bounds__(64) void decode_self_attn_kernel(const T* __restric
 
 }  // namespace
 
-extern "C" long mmsum_beam_topk_workspace(int rows, int num_beams) {
-    const long K = 2L * num_beams;
+extern "C" long mmsum_beam_topk_workspace(int rows, int num_beams, int ncand) {
+    const long K = ncand > 0 ? ncand : 2L * num_beams;
     return (long)rows * TK_CHUNKS * (2 * sizeof(float) + K * (sizeof(float) + sizeof(int)));
 }
 
 extern "C" int mmsum_beam_topk(int dtype, void* logits, long ld, int V, const float* beam_scores, const int* banned, int nban, int force_token,
                                int ban_token, int rows, int num_beams, void* workspace, float* out_scores, long long* out_ids,
-                               const int* penalized, int npen, float penalty, int penalty_on_logits, void* stream) {
-    const int K = 2 * num_beams;
-    if (rows <= 0 || V <= 0 || ld < V || num_beams < 1 || num_beams > 8 || K > TK_MAX || rows % num_beams || V < K || nban < 0) return MMSUM_ERR_BAD_SHAPE;
+                               const int* penalized, int npen, float penalty, int penalty_on_logits, int ncand, void* stream) {
+    const int K = ncand > 0 ? ncand : 2 * num_beams;
+    // (candidates per lane of the merge wave: num_beams * TK_CHUNKS * K / 64 <= TK_MAXC -- 2 * num_beams of <= 8 beams, or up to 64 of one row)
+    if (rows <= 0 || V <= 0 || ld < V || num_beams < 1 || num_beams > 8 || ncand < 0 || K > (ncand > 0 ? TK_MAX_CAND : TK_MAX) ||
+        num_beams * TK_CHUNKS * K > TK_MAXC * 64 || rows % num_beams || V < K || nban < 0) return MMSUM_ERR_BAD_SHAPE;
     if (npen < 0 || (penalized != nullptr && (npen == 0 || !(penalty > 0.f)))) return MMSUM_ERR_BAD_SHAPE;
     const int pen_mode = (penalized == nullptr || penalty == 1.f) ? 0 : (penalty_on_logits ? 1 : 2);
     if (force_token >= V || ban_token >= V) return MMSUM_ERR_BAD_SHAPE;

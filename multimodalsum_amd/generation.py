@@ -120,7 +120,7 @@ class DecodeSession:
     bans and the top-k run in mmsum_beam_topk, and the beam reorder is a gather of the [rows, max_length] ancestor table
     (mmsum_decode_self_attn reads the caches through it) instead of a gather of every layer's K/V cache."""
 
-    def __init__(self, engine, layout, num_beams, max_length, has_rating, min_length=0, ngram=0, bad_words=None, penalty=1.0, greedy=False):
+    def __init__(self, engine, layout, num_beams, max_length, has_rating, min_length=0, ngram=0, bad_words=None, penalty=1.0, greedy=False, ncand=0):
         e, cfg = engine, engine.cfg
         if max_length > 256:
             raise ValueError("max_length > 256 exceeds the decode self-attention kernel's cache walk (mmsum_decode_self_attn: Tmax <= 256)")
@@ -130,6 +130,11 @@ class DecodeSession:
         self.min_length, self.ngram = min_length, ngram
         self.bad_words = [list(map(int, w)) for w in bad_words] if bad_words else []
         self.penalty, self.greedy = float(penalty), bool(greedy)
+        # ncand > 0 (sampling): the step returns that many candidates of every row (its top_k best) and forces no token -- the reference
+        # skips adjust_logits_during_generation when it samples (:1811)
+        self.ncand = int(ncand)
+        if self.ncand and (num_beams != 1 or not greedy or self.ncand > 64):
+            raise ValueError("candidate lists (sampling) are built for one hypothesis per business and at most 64 candidates")
         D, R = cfg.d_model, layout.B * num_beams
         self.rows = R
         dev = e.device
@@ -162,7 +167,7 @@ class DecodeSession:
         # f32 activations multiplied as bf16 hi + lo parts, f32 accumulation and f32 store)
         self.logits = e.empty(R, e.Vpad, dtype=torch.float32)
         self.x32 = e.empty(R, D, dtype=torch.float32) if (e.dtype == torch.bfloat16 and D % 128 == 0) else None
-        K = 2 * num_beams
+        K = self.ncand or 2 * num_beams
         self.out_scores = torch.zeros(layout.B, K, dtype=torch.float32, device=dev)
         self.out_ids = torch.zeros(layout.B, K, dtype=torch.int64, device=dev)
         self.h_out_scores = torch.zeros(layout.B, K, dtype=torch.float32, pin_memory=pin)
@@ -362,11 +367,13 @@ class DecodeSession:
         cur_len = t + 1
         eos = cfg.eos_token_id
         force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)
+        if self.ncand:
+            force = -1
         ban = eos if (eos is not None and cur_len < self.min_length) else -1
         banned = self.d_int[2 * R:2 * R + R * self.nban].view(R, self.nban) if self.nban else None
         pen = self.d_int[2 * R + R * self.nban:].view(R, self.npen) if self.npen else None
         kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids, penalized=pen,
-                     penalty=self.penalty, penalty_on_logits=self.greedy)
+                     penalty=self.penalty, penalty_on_logits=self.greedy, ncand=self.ncand)
 
     def _step(self, t):
         if self.fast:
@@ -445,21 +452,23 @@ class DecodeSession:
         cur_len = t + 1
         eos = cfg.eos_token_id
         force = cfg.bos_token_id if cur_len == 1 else (eos if (cur_len == Tm - 1 and eos is not None) else -1)      # :3084-3089
+        if self.ncand:
+            force = -1
         ban = eos if (eos is not None and cur_len < self.min_length) else -1
         banned = self.d_int[2 * R:2 * R + R * self.nban].view(R, self.nban) if self.nban else None
         pen = self.d_int[2 * R + R * self.nban:].view(R, self.npen) if self.npen else None
         kn.beam_topk(self.logits, V, self.beam_scores, banned, force, ban, self.qpb, self.out_scores, self.out_ids, penalized=pen,
-                     penalty=self.penalty, penalty_on_logits=self.greedy)
+                     penalty=self.penalty, penalty_on_logits=self.greedy, ncand=self.ncand)
 
 
-def _session(engine, layout, num_beams, max_length, has_rating, min_length, ngram, bad_words=None, penalty=1.0, greedy=False):
+def _session(engine, layout, num_beams, max_length, has_rating, min_length, ngram, bad_words=None, penalty=1.0, greedy=False, ncand=0):
     bw = tuple(tuple(int(t) for t in w) for w in bad_words) if bad_words else ()
-    key = (tuple(layout.mods), layout.B, num_beams, max_length, has_rating, min_length, ngram, bw, float(penalty), bool(greedy))
+    key = (tuple(layout.mods), layout.B, num_beams, max_length, has_rating, min_length, ngram, bw, float(penalty), bool(greedy), int(ncand))
     cache = engine.__dict__.setdefault("_decode_sessions", {})
     if key not in cache:
         if len(cache) >= 4:                          # static buffers + graphs per shape: keep only a few
             cache.pop(next(iter(cache)))
-        cache[key] = DecodeSession(engine, layout, num_beams, max_length, has_rating, min_length, ngram, bw, penalty, greedy)
+        cache[key] = DecodeSession(engine, layout, num_beams, max_length, has_rating, min_length, ngram, bw, penalty, greedy, ncand)
     return cache[key]
 
 
@@ -485,6 +494,79 @@ def greedy_search(engine, hiddens, layout, pads, rating_diff, max_length, min_le
     while cur_len < max_length:
         _, top_i = sess.step(last, None, zeros, hist, cur_len - 1)
         tok = (top_i[:, 0] % V).astype(np.int64)
+        add = np.where(unfinished, tok, pad) if eos is not None else tok
+        hist[:, cur_len] = add
+        last = add.astype(np.int32)
+        cur_len += 1
+        if eos is not None:
+            unfinished &= add != eos
+        if not unfinished.any():
+            break
+    return torch.from_numpy(hist[:, :cur_len].copy()).to(engine.device)
+
+
+def sample_from_candidates(scores, tokens, u, temperature=1.0, top_k=50, top_p=1.0):
+    """One draw per row from the step's candidate lists (host; a few dozen numbers per row).  scores [B, K] = the K best post-processed
+    log-probabilities of a row, best first, tokens [B, K] their ids; K = top_k + 1: the extra candidate tells whether the top_k-th value
+    is tied (the reference keeps every token whose logit is not BELOW the top_k-th largest, generation_utils.py:923-927).
+    / temperature, the top-p cut on the sorted probabilities (:929-944: everything up to and including the first token whose
+    cumulative probability exceeds top_p), softmax over what is left, then the pinned sampling rule of the oracle and the fixtures
+    (oracle/generate_oracle.inverse_cdf_draw: the first token, in vocabulary order, whose cumulative probability exceeds u * total)."""
+    B, K = scores.shape
+    out = np.zeros(B, dtype=np.int64)
+    for b in range(B):
+        s = scores[b].astype(np.float64)
+        keep = np.isfinite(s)
+        keep[top_k:] &= s[top_k:] == s[top_k - 1]                # beyond the top_k only exact ties with the top_k-th value stay
+        if keep[top_k:].all() and K > top_k and np.isfinite(s[K - 1]) and s[K - 1] == s[top_k - 1]:
+            raise RuntimeError("sampling: more ties at the top_k-th logit than the candidate list holds")
+        s, t = s[keep] / temperature, tokens[b][keep]
+        if top_p < 1.0:
+            p = np.exp(s - s.max())
+            p /= p.sum()
+            remove = np.cumsum(p) > top_p
+            remove[1:] = remove[:-1].copy()
+            remove[0] = False
+            s, t = s[~remove], t[~remove]
+        p = np.exp(s - s.max())
+        order = np.argsort(t, kind="stable")                      # vocabulary order
+        cdf = np.cumsum(p[order])
+        out[b] = t[order][int(np.argmax(cdf > float(u[b]) * cdf[-1]))]
+    return out
+
+
+@torch.no_grad()
+def sample_search(engine, hiddens, layout, pads, rating_diff, max_length, min_length, no_repeat_ngram_size, decoder_start_token_id,
+                  bad_words_ids=None, repetition_penalty=1.0, temperature=1.0, top_k=50, top_p=1.0, draws=None):
+    """Sampling (_generate_no_beam_search with do_sample = True, modeling_multimodalsum.py:1767-1868): the greedy session with
+    candidate lists -- no forced BOS / EOS (the reference skips them when it samples), repetition penalty and bans on the logits, the
+    top_k + 1 best of every row from mmsum_beam_topk -- and one draw per row on the host (sample_from_candidates).
+    draws: callable(step, B) -> B uniforms in [0, 1) (tests and fixtures pass recorded ones); default torch.rand on the host, i.e.
+    torch.manual_seed reproduces a run of THIS implementation; torch.multinomial's stream of the reference is not reproducible across
+    implementations.  top_k must be 1 .. 63 (the reference's default is 50).  Returns LongTensor [B, L]."""
+    cfg = engine.cfg
+    pad, eos, V = cfg.pad_token_id, cfg.eos_token_id, cfg.vocab_size
+    if not (1 <= int(top_k) <= 63):
+        raise NotImplementedError("sampling is built for 1 <= top_k <= 63 (the candidate kernel returns at most 64 of a row); top_k = 0 "
+                                  "(the whole vocabulary) is not")
+    if not (temperature > 0.0):
+        raise ValueError("temperature must be positive")
+    top_k = min(int(top_k), V - 1)
+    B = layout.B
+    sess = _session(engine, layout, 1, max_length, rating_diff is not None, min_length if eos is not None else 0, no_repeat_ngram_size,
+                    bad_words_ids, repetition_penalty, greedy=True, ncand=top_k + 1)
+    sess.begin(hiddens, pads, rating_diff)
+    hist = np.full((B, max_length), pad, dtype=np.int64)
+    hist[:, 0] = decoder_start_token_id
+    last = hist[:, 0].astype(np.int32)
+    unfinished = np.ones(B, dtype=bool)
+    zeros = np.zeros(B, dtype=np.float32)
+    cur_len, step = 1, 0
+    while cur_len < max_length:
+        top_s, top_i = sess.step(last, None, zeros, hist, cur_len - 1)
+        u = draws(step, B) if draws is not None else torch.rand(B, dtype=torch.float64).numpy()
+        tok = sample_from_candidates(top_s, top_i % V, np.asarray(u, dtype=np.float64), temperature, top_k, top_p)
+        step += 1
         add = np.where(unfinished, tok, pad) if eos is not None else tok
         hist[:, cur_len] = add
         last = add.astype(np.int32)

@@ -514,11 +514,12 @@ def rows_gather(src, dst, row_map, live=None):
 
 
 def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids, penalized=None, penalty=1.0,
-              penalty_on_logits=False):
+              penalty_on_logits=False, ncand=0):
     """Tail of one beam-search step (see mmsum_beam_topk): logits [rows, >=V] (banned entries are overwritten with -inf),
     beam_scores [rows] f32, banned [rows, nban] int32 (filled from the front, the first -1 ends a row's list) or None -> out_scores f32 / out_ids int64 [B, 2*num_beams].
     penalized [rows, npen] int32 (a row's distinct previous tokens, -1 terminated) + penalty: the repetition penalty, on the
-    log-probabilities (beam search) or on the raw logits (penalty_on_logits: greedy decoding)."""
+    log-probabilities (beam search) or on the raw logits (penalty_on_logits: greedy decoding).
+    ncand > 0: that many candidates per business instead of 2 * num_beams (sampling: the top_k best of a row; out_* [B, ncand])."""
     rows = logits.shape[0]
     assert beam_scores.dtype == torch.float32 and out_scores.dtype == torch.float32 and out_ids.dtype == torch.int64
     nban = 0 if banned is None else banned.shape[1]
@@ -527,10 +528,11 @@ def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams,
     npen = 0 if penalized is None else penalized.shape[1]
     if penalized is not None:
         assert penalized.dtype == torch.int32 and penalized.is_contiguous() and penalized.shape[0] == rows
-    ws = _workspace(lib.mmsum_beam_topk_workspace(rows, num_beams), logits.device, "topk")
+    assert out_scores.shape[1] == (ncand or 2 * num_beams) and out_ids.shape == out_scores.shape
+    ws = _workspace(lib.mmsum_beam_topk_workspace(rows, num_beams, int(ncand)), logits.device, "topk")
     check(lib.mmsum_beam_topk(_dt(logits), _p(logits), _ld(logits), V, _p(beam_scores), _p(banned), nban, int(force_token), int(ban_token), rows,
                               num_beams, _p(ws), _p(out_scores), _p(out_ids), _p(penalized), npen, float(penalty), int(bool(penalty_on_logits)),
-                              _stream()), "mmsum_beam_topk")
+                              int(ncand), _stream()), "mmsum_beam_topk")
 
 
 def decode_self_attn(q, k_cache, v_cache, ancestors, out, H, length, Tmax, scale, k_new=None, v_new=None):

@@ -382,11 +382,15 @@ class _BartBase(nn.Module):
     def _generate(self, hiddens, masks, rating_diff, input_ids=None, max_length=None, min_length=None, do_sample=None,
                   early_stopping=None, num_beams=None, temperature=None, top_k=None, top_p=None, repetition_penalty=None,
                   bad_words_ids=None, bos_token_id=None, pad_token_id=None, eos_token_id=None, length_penalty=None,
-                  no_repeat_ngram_size=None, num_return_sequences=None, decoder_start_token_id=None, use_cache=None, trace=None, **unused):
+                  no_repeat_ngram_size=None, num_return_sequences=None, decoder_start_token_id=None, use_cache=None, trace=None,
+                  sample_draws=None, **unused):
         """generate() of the reference (modeling_multimodalsum.py:2295-2693 / :1398-1700): beam search as test.py:156-158 calls it,
-        greedy decoding (num_beams == 1), bad_words_ids and repetition_penalty in either search (round 6).  Sampling (do_sample: torch's
-        random stream cannot be reproduced), prompts (input_ids) and more than one returned sequence are not built and raise."""
-        from .generation import beam_search, greedy_search
+        greedy decoding (num_beams == 1), bad_words_ids and repetition_penalty in either search, and (round 6) sampling with
+        num_beams == 1: temperature, top_k in 1 .. 63 (the reference's default is 50) and top_p, one draw per row and step from
+        torch.rand on the host -- torch.multinomial's own stream is not reproducible across implementations; `sample_draws`
+        (callable(step, B) -> B uniforms; not a reference argument) lets tests and fixtures pin the draws.  Beam sampling, top_k = 0,
+        prompts (input_ids) and more than one returned sequence are not built and raise."""
+        from .generation import beam_search, greedy_search, sample_search
         cfg, e = self.config, self._engine
         pick = lambda v, d: d if v is None else v                                    # noqa: E731
         max_length, min_length = pick(max_length, cfg.max_length), pick(min_length, cfg.min_length)
@@ -397,9 +401,11 @@ class _BartBase(nn.Module):
         start = cfg.bos_token_id if start is None else start
         repetition_penalty = pick(repetition_penalty, getattr(cfg, "repetition_penalty", 1.0))
         do_sample = pick(do_sample, getattr(cfg, "do_sample", False))
-        if do_sample or input_ids is not None or (num_return_sequences not in (None, 1)) or num_beams < 1:
-            raise NotImplementedError("generate(): beam search and greedy decoding (one returned sequence, no prompt) are built; "
-                                      "sampling is not (torch's random stream cannot be reproduced)")
+        temperature = pick(temperature, getattr(cfg, "temperature", 1.0))
+        top_k, top_p = pick(top_k, getattr(cfg, "top_k", 50)), pick(top_p, getattr(cfg, "top_p", 1.0))
+        if (do_sample and num_beams != 1) or input_ids is not None or (num_return_sequences not in (None, 1)) or num_beams < 1:
+            raise NotImplementedError("generate(): beam search, greedy decoding and sampling with num_beams = 1 (one returned sequence, no "
+                                      "prompt) are built; beam sampling is not")
         assert max_length > 1 and min_length >= 0 and length_penalty > 0 and no_repeat_ngram_size >= 0 and repetition_penalty > 0
         if bad_words_ids is not None:
             assert all(isinstance(w, (list, tuple)) and len(w) > 0 and all(int(t) >= 0 for t in w) for w in bad_words_ids), \
@@ -411,6 +417,10 @@ class _BartBase(nn.Module):
             B = hiddens[0].shape[0]
             layout = e.make_memory(B, [(h.shape[1], h.shape[2]) for h in hiddens])
             pads = [m.eq(0).to(torch.uint8).contiguous() for m in masks]
+            if do_sample:
+                return sample_search(e, hiddens, layout, pads, rating_diff, max_length, min_length, no_repeat_ngram_size, int(start),
+                                     bad_words_ids=bad_words_ids, repetition_penalty=float(repetition_penalty), temperature=float(temperature),
+                                     top_k=int(top_k), top_p=float(top_p), draws=sample_draws)
             if num_beams == 1:
                 return greedy_search(e, hiddens, layout, pads, rating_diff, max_length, min_length, no_repeat_ngram_size, int(start),
                                      bad_words_ids=bad_words_ids, repetition_penalty=float(repetition_penalty))

@@ -163,6 +163,66 @@ def greedy_search(sd, cfg, hiddens, masks, rating_diff, multimodal, max_length, 
     return input_ids
 
 
+def top_k_top_p_filtering_(logits, top_k=0, top_p=1.0, min_tokens_to_keep=1):
+    """generation_utils.py:907-945, in place on logits [rows, V]: keep the tokens whose logit is not below the top_k-th largest (ties
+    with it stay), then, of the sorted probabilities, everything up to and including the first token whose cumulative probability
+    exceeds top_p."""
+    if top_k > 0:
+        top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
+        logits[logits < torch.topk(logits, top_k)[0][..., -1, None]] = float("-inf")
+    if top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        remove = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1) > top_p
+        if min_tokens_to_keep > 1:
+            remove[..., :min_tokens_to_keep] = False
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = False
+        logits[remove.scatter(1, sorted_indices, remove)] = float("-inf")
+    return logits
+
+
+def inverse_cdf_draw(probs, u):
+    """The sampling rule the fixtures and tests pin torch.multinomial to (its own random stream differs between devices and versions):
+    token = the first index, in VOCABULARY order, whose cumulative probability (float64) exceeds u * total.  probs [rows, V], u [rows]."""
+    cdf = torch.cumsum(probs.double(), dim=-1)
+    return (cdf > (u.double() * cdf[:, -1])[:, None]).float().argmax(-1)
+
+
+def sample_search(sd, cfg, hiddens, masks, rating_diff, multimodal, max_length, draws, min_length=0, no_repeat_ngram_size=0, bad_words_ids=None,
+                  repetition_penalty=1.0, temperature=1.0, top_k=50, top_p=1.0, decoder_start_token_id=None, prefix=""):
+    """_generate_no_beam_search with do_sample = True (:1767-1868): NO forced BOS / EOS (adjust_logits_during_generation is skipped when
+    sampling, :1811), post-processing on the logits, / temperature, top_k_top_p_filtering, softmax, one draw per row -- draws [steps, B]
+    uniforms through inverse_cdf_draw in the place of torch.multinomial.  Returns LongTensor [B, L]."""
+    pad, bos, eos = cfg.pad_token_id, cfg.bos_token_id, cfg.eos_token_id
+    start = bos if decoder_start_token_id is None else decoder_start_token_id
+    first = hiddens[0] if multimodal else hiddens
+    B = first.shape[0]
+    input_ids = torch.full((B, 1), start, dtype=torch.long)
+    unfinished = torch.ones(B, dtype=torch.long)
+    cur_len, step = 1, 0
+    memo_store = {}
+    while cur_len < max_length:
+        prev, bo.KV_MEMO = bo.KV_MEMO, memo_store
+        try:
+            logits = next_token_logits(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, prefix)
+        finally:
+            bo.KV_MEMO = prev
+        postprocess_(logits, input_ids, cfg, cur_len, min_length, no_repeat_ngram_size, bad_words_ids, repetition_penalty)
+        if temperature != 1.0:
+            logits = logits / temperature
+        top_k_top_p_filtering_(logits, top_k=top_k, top_p=top_p)
+        nxt = inverse_cdf_draw(F.softmax(logits, dim=-1), draws[step])
+        step += 1
+        add = nxt * unfinished + pad * (1 - unfinished) if eos is not None else nxt
+        input_ids = torch.cat([input_ids, add[:, None]], dim=1)
+        cur_len += 1
+        if eos is not None:
+            unfinished = unfinished * (add != eos).long()
+        if unfinished.max() == 0:
+            break
+    return input_ids
+
+
 def step_scores(sd, cfg, input_ids, hiddens, masks, rating_diff, multimodal, max_length, min_length=0, no_repeat_ngram_size=0, prefix="",
                 bad_words_ids=None, repetition_penalty=1.0):
     """Log-probabilities of the next token for every hypothesis row `input_ids` [rows, cur_len], with the reference's adjustments:

@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE, development container only (imports /root/reference): golden vectors of the generate() modes that round 6
 adds to the HIP path -- greedy decoding (num_beams = 1, _generate_no_beam_search), bad_words_ids and repetition_penalty (in greedy
-decoding and in beam search) -- produced by the REFERENCE's own generate() on the F2 model of oracle/make_golden.py (same formula
+decoding and in beam search), sampling (do_sample, torch.multinomial pinned to an inverse-CDF rule on recorded uniforms) -- produced by the REFERENCE's own generate() on the F2 model of oracle/make_golden.py (same formula
 weights, same inputs).  Writes tests/golden/g3_generate_modes.npz.  usage: python oracle/make_golden_r6.py"""
 import os
 import sys
@@ -56,7 +56,34 @@ def main():
             g = model.generate(*args, rating_diff=rating_diff, **kw)
             out["gen_" + name] = g.numpy()
             print(name, g.tolist())
+        # sampling (do_sample = True): the reference's own loop with torch.multinomial pinned to the inverse-CDF rule of
+        # oracle/generate_oracle.inverse_cdf_draw on recorded uniforms (its random stream is not reproducible across implementations)
+        from oracle.generate_oracle import inverse_cdf_draw
+        sample_cases = {
+            "sample_k": dict(num_beams=1, do_sample=True, max_length=14, no_repeat_ngram_size=2, top_k=20, temperature=0.8),
+            "sample_kp": dict(num_beams=1, do_sample=True, max_length=16, min_length=5, no_repeat_ngram_size=0, top_k=40, top_p=0.85, temperature=1.3,
+                              repetition_penalty=1.2),
+        }
+        real_multinomial = torch.multinomial
+        for si, (name, kw) in enumerate(sample_cases.items()):
+            u = torch.rand(kw["max_length"], Bz, generator=torch.Generator().manual_seed(600 + si), dtype=torch.float64)
+            state = {"i": 0}
+
+            def pinned(probs, num_samples=1, **_):
+                assert num_samples == 1
+                r = inverse_cdf_draw(probs, u[state["i"]])
+                state["i"] += 1
+                return r[:, None]
+            torch.multinomial = pinned
+            try:
+                g = model.generate(*args, rating_diff=rating_diff, **kw)
+            finally:
+                torch.multinomial = real_multinomial
+            out["gen_" + name] = g.numpy()
+            out["draws_" + name] = u.numpy()
+            print(name, g.tolist(), "draws used", state["i"])
     assert not np.array_equal(out["gen_greedy"], out["gen_greedy_bad"]) and not np.array_equal(out["gen_greedy"], out["gen_greedy_rep"])
+    assert not np.array_equal(out["gen_sample_k"][:, :12], out["gen_greedy"][:, :12])
     np.savez(os.path.join(ROOT, "tests", "golden", "g3_generate_modes.npz"), ids=ids.numpy(), text_m=text_m.numpy(), table_m=table_m.numpy(),
              img_m=img_m.numpy(), rating_diff=rating_diff.numpy(), enc_eval=enc.numpy(), **out)
 

@@ -647,7 +647,7 @@ def rows_gather(src, dst, row_map, live=None):
 
 
 def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams, out_scores, out_ids, penalized=None, penalty=1.0,
-              penalty_on_logits=False):
+              penalty_on_logits=False, ncand=0):
     """Contract of mmsum_beam_topk restated with torch ops in the reference's order (adjust_logits, log_softmax, repetition penalty,
     bans, + beam score, topk over [B, beams * V]); ties by lower flat index.  penalty_on_logits: the penalty applies to the raw logits
     (greedy decoding), and the candidates' scores are those penalised logits minus the ORIGINAL row's log-sum-exp (any per-row
@@ -683,7 +683,7 @@ def beam_topk(logits, V, beam_scores, banned, force_token, ban_token, num_beams,
                 sc[r, t] = float("-inf")
     B = logits.shape[0] // num_beams
     cand = (sc + beam_scores[:, None]).view(B, num_beams * V)
-    K = 2 * num_beams
+    K = ncand or 2 * num_beams
     order = torch.sort(cand, dim=1, descending=True, stable=True)
     out_scores.copy_(order.values[:, :K])
     out_ids.copy_(order.indices[:, :K])

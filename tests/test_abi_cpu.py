@@ -21,7 +21,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(_lib.lib, s), "libmmsum_hip.so does not export %s" % s
         assert s in _lib.SIGNATURES, "no ctypes signature for %s" % s
     assert sorted(_lib.SIGNATURES) == syms
-    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 9
+    assert _lib.lib.mmsum_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_argument_validation_without_gpu():

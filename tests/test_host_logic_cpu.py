@@ -496,19 +496,20 @@ def test_beam_search_host_logic(monkeypatch, case):
             out = model.generate(enc, text_m, rating_diff=rd, decoder_start_token_id=cfg.bos_token_id, **kw)
             ref = go.beam_search(sd, ocfg, oenc, text_m, rd, False, decoder_start_token_id=cfg.bos_token_id, **kw)
     assert torch.equal(out, ref), (out, ref)
-    with pytest.raises(NotImplementedError):          # sampling: torch's random stream cannot be reproduced
-        model.generate(*([enc, text_m, table_h, table_m, img_h, img_m] if multimodal else [enc, text_m]), do_sample=True, max_length=5)
+    with pytest.raises(NotImplementedError):          # beam sampling is not built (sampling with num_beams = 1 is: test_generate_modes_host_logic)
+        model.generate(*([enc, text_m, table_h, table_m, img_h, img_m] if multimodal else [enc, text_m]), do_sample=True, num_beams=2, max_length=5)
 
 
-@pytest.mark.parametrize("name", ["greedy", "greedy_min", "greedy_bad", "greedy_rep", "beam_bad", "beam_rep"])
+@pytest.mark.parametrize("name", ["greedy", "greedy_min", "greedy_bad", "greedy_rep", "beam_bad", "beam_rep", "sample_k", "sample_kp"])
 def test_generate_modes_host_logic(monkeypatch, name):
     """generate() beside test.py's call: greedy decoding (num_beams = 1: _generate_no_beam_search), bad_words_ids and repetition_penalty
-    in either search -- multimodalsum_amd/generation.py through the kernel emulator against the oracle's restatement (which
+    in either search, sampling with num_beams = 1 (recorded uniforms on both sides) -- multimodalsum_amd/generation.py through the
+    kernel emulator against the oracle's restatement (which
     tests/test_oracle_golden.py::test_g3_generate_modes holds to the reference's own generate())."""
     emu.install(monkeypatch)
     from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
     from oracle import generate_oracle as go
-    from tests.test_oracle_golden import G3_CASES
+    from tests.test_oracle_golden import G3_CASES, G3_SAMPLE_CASES
     cfg = tiny_cfg(vocab=100, d=256, ffn=128, layers=2, heads=4, maxpos=64)
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
@@ -525,7 +526,8 @@ def test_generate_modes_host_logic(monkeypatch, name):
     img_m = torch.ones(Bz, 2, 4, dtype=torch.bool)
     img_m[2, 1] = False
     rd = torch.tensor([[0.5], [-1.25], [2.0]])
-    kw = dict(G3_CASES[name])
+    sampling = name in G3_SAMPLE_CASES
+    kw = dict(G3_SAMPLE_CASES[name] if sampling else G3_CASES[name])
     with torch.no_grad():
         enc = model.model.encoder(input_ids=ids.view(-1, S), attention_mask=ids.view(-1, S).ne(1))[0].view(Bz, N, S, -1)
         oenc = bo.bart_encoder(sd, ocfg, ids.view(-1, S), ids.view(-1, S).ne(1)).view(Bz, N, S, -1)
@@ -534,7 +536,11 @@ def test_generate_modes_host_logic(monkeypatch, name):
         if kw.pop("bad_words", False):       # bad words taken from the unconstrained run, so that the bans change it
             base = go.greedy_search(sd, ocfg, hid, msk, rd, True, max_length=14, no_repeat_ngram_size=2, decoder_start_token_id=cfg.bos_token_id)
             bw = [[int(base[0, 2])], [int(base[0, 3]), int(base[0, 4])], [int(base[1, 2]), int(base[1, 3])]]
-        if "num_beams" in kw:
+        if sampling:        # recorded uniforms in the place of torch.multinomial, on both sides (generate_oracle.inverse_cdf_draw)
+            u = torch.rand(kw["max_length"], Bz, generator=torch.Generator().manual_seed(77), dtype=torch.float64)
+            ref = go.sample_search(sd, ocfg, hid, msk, rd, True, draws=u, decoder_start_token_id=cfg.bos_token_id, **kw)
+            kw.update(num_beams=1, do_sample=True, sample_draws=lambda step, B: u[step].numpy())
+        elif "num_beams" in kw:
             ref = go.beam_search(sd, ocfg, hid, msk, rd, True, decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)
         else:
             ref = go.greedy_search(sd, ocfg, hid, msk, rd, True, decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)

@@ -1146,6 +1146,51 @@ def test_beam_topk_repetition_penalty(num_beams, V, on_logits):
             assert float((cand[b][out_i[b]] - out_s[b]).abs().max()) <= 2e-4
 
 
+@pytest.mark.parametrize("ncand,V", [(21, 50265), (64, 50265), (41, 1000), (3, 100)])
+def test_beam_topk_candidate_lists(ncand, V):
+    """mmsum_beam_topk with an explicit candidate count (ABI 10; sampling asks for the top_k + 1 best of every row, num_beams = 1, no
+    forced token): the ncand best post-processed logits of a row, best first, ties by lower token -- with a repetition penalty, an EOS
+    ban and banned tokens -- against torch.topk on the same processed scores; more than 64 candidates, or candidate lists with several
+    beams past the merge wave's capacity, are refused."""
+    B = 4
+    ld = (V + 127) // 128 * 128
+    g = torch.Generator().manual_seed(23)
+    logits = (torch.randn(B, ld, generator=g) * 3).to(DEV)
+    zeros = torch.zeros(B, device=DEV)
+    order = logits[:, :V].argsort(-1, descending=True).cpu()
+    pen = torch.full((B, 5), -1, dtype=torch.int32)
+    banned = torch.full((B, 3), -1, dtype=torch.int32)
+    for r in range(B):
+        pen[r, 0], pen[r, 1] = int(order[r, 0]), int(order[r, 3])
+        banned[r, 0] = int(order[r, 1])
+    sc = logits[:, :V].float().clone()
+    for r in range(B):
+        for t in pen[r].tolist():
+            if t >= 0:
+                sc[r, t] = sc[r, t] * 1.4 if sc[r, t] < 0 else sc[r, t] / 1.4
+    sc = sc - torch.logsumexp(logits[:, :V].float(), dim=-1, keepdim=True)
+    sc[:, 2] = float("-inf")                                  # the EOS ban (cur_len < min_length)
+    for r in range(B):
+        sc[r, int(banned[r, 0])] = float("-inf")
+    want_s, want_i = torch.topk(sc, ncand, dim=1)
+    out_s = torch.zeros(B, ncand, device=DEV)
+    out_i = torch.zeros(B, ncand, dtype=torch.int64, device=DEV)
+    kn.beam_topk(logits, V, zeros, banned.to(DEV), -1, 2, 1, out_s, out_i, penalized=pen.to(DEV), penalty=1.4, penalty_on_logits=True, ncand=ncand)
+    assert float((out_s - want_s).abs().max()) <= 2e-4
+    if float((want_s[:, :-1] - want_s[:, 1:]).min()) > 1e-4:
+        assert torch.equal(out_i, want_i)
+    for b in range(B):
+        assert float((sc[b][out_i[b]] - out_s[b]).abs().max()) <= 2e-4
+        assert bool((out_s[b][:-1] >= out_s[b][1:]).all())
+    big_s, big_i = torch.zeros(B, 65, device=DEV), torch.zeros(B, 65, dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError):
+        kn.beam_topk(logits, V, zeros, None, -1, -1, 1, big_s, big_i, ncand=65)
+    if V > 1000:
+        s4, i4 = torch.zeros(1, 40, device=DEV), torch.zeros(1, 40, dtype=torch.int64, device=DEV)
+        with pytest.raises(RuntimeError):                     # 4 beams x 8 chunks x 40 candidates > the merge wave's 1,024 slots
+            kn.beam_topk(logits, V, zeros, None, -1, -1, 4, s4, i4, ncand=40)
+
+
 def test_handoff_stress():
     """The in-launch hand-offs: mmsum_dec_gemm's split-K slabs and mmsum_decode_cross_attn's entity mean (bf16 AND f32 kernels) meet in
     the LAST ARRIVER through write-through stores + a relaxed ticket, without release / acquire fences -- an ordering that rests on

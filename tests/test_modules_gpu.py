@@ -832,14 +832,14 @@ def test_clip_grad_norm_takes_parameters_outside_the_arena():
     assert optim.clip_grad_norm_([torch.nn.Parameter(torch.zeros(3, device=DEV))], 1.0).is_cuda       # nothing carries a gradient: zero, on the device
 
 
-@pytest.mark.parametrize("name", ["greedy", "greedy_min", "greedy_bad", "greedy_rep", "beam_bad", "beam_rep"])
+@pytest.mark.parametrize("name", ["greedy", "greedy_min", "greedy_bad", "greedy_rep", "beam_bad", "beam_rep", "sample_k", "sample_kp"])
 def test_generate_modes_f32(name):
-    """generate() beside test.py's beam search -- greedy decoding (num_beams = 1), bad_words_ids, repetition_penalty in either search
+    """generate() beside test.py's beam search -- greedy decoding (num_beams = 1), sampling (do_sample with top_k / top_p / temperature), bad_words_ids, repetition_penalty in either search
     (modeling_multimodalsum.py:2767-2868, generation_utils.py:47-98,871-904) -- on the HIP decode path, f32 mode: token ids equal to the
     oracle's restatement, which tests/test_oracle_golden.py::test_g3_generate_modes holds to the REFERENCE's own generate() output."""
     from multimodalsum_amd.modules import BartForMultiEncConditionalGeneration
     from oracle import generate_oracle as go
-    from tests.test_oracle_golden import G3_CASES
+    from tests.test_oracle_golden import G3_CASES, G3_SAMPLE_CASES
     cfg = tiny_cfg(vocab=100, d=256, ffn=128, layers=2, heads=4, maxpos=64)
     ocfg = oracle_cfg(cfg)
     sd = formula_state_dict(bo.bart_param_shapes(ocfg, True, prefix=""), std=0.08)
@@ -856,7 +856,8 @@ def test_generate_modes_f32(name):
     img_m = torch.ones(Bz, 2, 4, dtype=torch.bool)
     img_m[2, 1] = False
     rd = torch.tensor([[0.5], [-1.25], [2.0]])
-    kw = dict(G3_CASES[name])
+    sampling = name in G3_SAMPLE_CASES
+    kw = dict(G3_SAMPLE_CASES[name] if sampling else G3_CASES[name])
     with torch.no_grad():
         enc = model.model.encoder(input_ids=ids.view(-1, S).to(DEV), attention_mask=ids.view(-1, S).ne(1).to(DEV))[0].view(Bz, N, S, -1)
         oenc = bo.bart_encoder(sd, ocfg, ids.view(-1, S), ids.view(-1, S).ne(1)).view(Bz, N, S, -1)
@@ -865,7 +866,12 @@ def test_generate_modes_f32(name):
         if kw.pop("bad_words", False):
             base = go.greedy_search(sd, ocfg, hid, msk, rd, True, max_length=14, no_repeat_ngram_size=2, decoder_start_token_id=cfg.bos_token_id)
             bw = [[int(base[0, 2])], [int(base[0, 3]), int(base[0, 4])], [int(base[1, 2]), int(base[1, 3])]]
-        if "num_beams" in kw:
+        if sampling:        # do_sample: recorded uniforms take torch.multinomial's place on both sides (generate_oracle.inverse_cdf_draw);
+            # the oracle's sample_search is held to the reference's own generate() by test_g3_generate_modes
+            u = torch.rand(kw["max_length"], Bz, generator=torch.Generator().manual_seed(77), dtype=torch.float64)
+            ref = go.sample_search(sd, ocfg, hid, msk, rd, True, draws=u, decoder_start_token_id=cfg.bos_token_id, **kw)
+            kw.update(num_beams=1, do_sample=True, sample_draws=lambda step, B: u[step].numpy())
+        elif "num_beams" in kw:
             ref = go.beam_search(sd, ocfg, hid, msk, rd, True, decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)
         else:
             ref = go.greedy_search(sd, ocfg, hid, msk, rd, True, decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)
@@ -873,3 +879,12 @@ def test_generate_modes_f32(name):
         out = model.generate(enc, text_m.to(DEV), table_h.to(DEV), table_m.to(DEV), img_h.to(DEV), img_m.to(DEV), rating_diff=rd.to(DEV),
                              decoder_start_token_id=cfg.bos_token_id, bad_words_ids=bw, **kw)
     assert torch.equal(out.cpu(), ref), (name, out.cpu(), ref)
+    if sampling:            # without pinned draws: torch.rand on the host -- reproducible under torch.manual_seed, and not the pinned run
+        kw.pop("sample_draws")
+        runs = []
+        for seed in (5, 5, 6):
+            torch.manual_seed(seed)
+            with torch.no_grad():
+                runs.append(model.generate(enc, text_m.to(DEV), table_h.to(DEV), table_m.to(DEV), img_h.to(DEV), img_m.to(DEV), rating_diff=rd.to(DEV),
+                                           decoder_start_token_id=cfg.bos_token_id, **kw).cpu())
+        assert torch.equal(runs[0], runs[1]) and runs[0].shape[1] <= kw["max_length"] and int(runs[0].min()) >= 0

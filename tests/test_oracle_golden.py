@@ -150,6 +150,11 @@ def test_g1_beam_search(golden_dir):
                 assert abs(got - scores[i]) <= 1e-4 * abs(scores[i]) + 1e-5, (i, got, scores[i])
 
 
+G3_SAMPLE_CASES = {      # do_sample = True: the recorded uniforms of the fixture take torch.multinomial's place (generate_oracle.inverse_cdf_draw)
+    "sample_k": dict(max_length=14, no_repeat_ngram_size=2, top_k=20, temperature=0.8),
+    "sample_kp": dict(max_length=16, min_length=5, no_repeat_ngram_size=0, top_k=40, top_p=0.85, temperature=1.3, repetition_penalty=1.2),
+}
+
 G3_CASES = {
     "greedy": dict(max_length=14, no_repeat_ngram_size=2),
     "greedy_min": dict(max_length=12, min_length=6, no_repeat_ngram_size=0),
@@ -166,7 +171,7 @@ def g3_bad_words(gg):
 
 def test_g3_generate_modes(golden_dir):
     """The generate() modes beside test.py's beam search -- greedy decoding (num_beams = 1, _generate_no_beam_search), bad_words_ids and
-    repetition_penalty in both searches -- restated (oracle/generate_oracle.py) and held to the token ids the REFERENCE's own
+    repetition_penalty in both searches, sampling (top-k / top-p / temperature, torch.multinomial pinned to recorded uniforms) -- restated (oracle/generate_oracle.py) and held to the token ids the REFERENCE's own
     generate() produced on the F2 model (tests/golden/g3_generate_modes.npz, oracle/make_golden_r6.py)."""
     from oracle import generate_oracle as go
     g = _load(golden_dir, "f2_decoder.npz")
@@ -186,6 +191,9 @@ def test_g3_generate_modes(golden_dir):
                 out = go.beam_search(sd, cfg, hid, msk, gg["rating_diff"], True, prefix="f2.", bad_words_ids=bw, **kw)
             else:
                 out = go.greedy_search(sd, cfg, hid, msk, gg["rating_diff"], True, prefix="f2.", bad_words_ids=bw, **kw)
+            assert torch.equal(out, gg["gen_" + name]), (name, out, gg["gen_" + name])
+        for name, kw in G3_SAMPLE_CASES.items():
+            out = go.sample_search(sd, cfg, hid, msk, gg["rating_diff"], True, draws=gg["draws_" + name], prefix="f2.", **kw)
             assert torch.equal(out, gg["gen_" + name]), (name, out, gg["gen_" + name])
 
 
