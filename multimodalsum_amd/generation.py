@@ -507,8 +507,9 @@ def greedy_search(engine, hiddens, layout, pads, rating_diff, max_length, min_le
 
 def sample_from_candidates(scores, tokens, u, temperature=1.0, top_k=50, top_p=1.0):
     """One draw per row from the step's candidate lists (host; a few dozen numbers per row).  scores [B, K] = the K best post-processed
-    log-probabilities of a row, best first, tokens [B, K] their ids; K = top_k + 1: the extra candidate tells whether the top_k-th value
-    is tied (the reference keeps every token whose logit is not BELOW the top_k-th largest, generation_utils.py:923-927).
+    log-probabilities of a row, best first, tokens [B, K] their ids; K > top_k: the extra candidates tell whether the top_k-th value
+    is tied (the reference keeps every token whose logit is not BELOW the top_k-th largest, generation_utils.py:923-927); a tie that
+    runs to the end of the list cannot be resolved and raises.
     / temperature, the top-p cut on the sorted probabilities (:929-944: everything up to and including the first token whose
     cumulative probability exceeds top_p), softmax over what is left, then the pinned sampling rule of the oracle and the fixtures
     (oracle/generate_oracle.inverse_cdf_draw: the first token, in vocabulary order, whose cumulative probability exceeds u * total)."""
@@ -540,7 +541,7 @@ def sample_search(engine, hiddens, layout, pads, rating_diff, max_length, min_le
                   bad_words_ids=None, repetition_penalty=1.0, temperature=1.0, top_k=50, top_p=1.0, draws=None):
     """Sampling (_generate_no_beam_search with do_sample = True, modeling_multimodalsum.py:1767-1868): the greedy session with
     candidate lists -- no forced BOS / EOS (the reference skips them when it samples), repetition penalty and bans on the logits, the
-    top_k + 1 best of every row from mmsum_beam_topk -- and one draw per row on the host (sample_from_candidates).
+    top_k + 4 (at most 64) best of every row from mmsum_beam_topk -- and one draw per row on the host (sample_from_candidates).
     draws: callable(step, B) -> B uniforms in [0, 1) (tests and fixtures pass recorded ones); default torch.rand on the host, i.e.
     torch.manual_seed reproduces a run of THIS implementation; torch.multinomial's stream of the reference is not reproducible across
     implementations.  top_k must be 1 .. 63 (the reference's default is 50).  Returns LongTensor [B, L]."""
@@ -554,7 +555,7 @@ def sample_search(engine, hiddens, layout, pads, rating_diff, max_length, min_le
     top_k = min(int(top_k), V - 1)
     B = layout.B
     sess = _session(engine, layout, 1, max_length, rating_diff is not None, min_length if eos is not None else 0, no_repeat_ngram_size,
-                    bad_words_ids, repetition_penalty, greedy=True, ncand=top_k + 1)
+                    bad_words_ids, repetition_penalty, greedy=True, ncand=min(64, top_k + 4))      # up to three ties with the top_k-th value are followed
     sess.begin(hiddens, pads, rating_diff)
     hist = np.full((B, max_length), pad, dtype=np.int64)
     hist[:, 0] = decoder_start_token_id

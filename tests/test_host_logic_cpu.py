@@ -550,6 +550,42 @@ def test_generate_modes_host_logic(monkeypatch, name):
     assert torch.equal(out, ref), (name, out, ref)
 
 
+@pytest.mark.parametrize("top_k,top_p,temperature", [(20, 1.0, 1.0), (5, 0.7, 1.3), (40, 0.5, 0.7), (1, 1.0, 1.0), (60, 0.9, 2.0)])
+def test_sample_from_candidates_equals_the_reference_filters(top_k, top_p, temperature):
+    """generation.sample_from_candidates (the host half of sampling: a row's best post-processed scores -> temperature, top-k with
+    the reference's tie rule, top-p, the pinned draw) against the oracle's statement of the reference's steps on the WHOLE vocabulary
+    (generate_oracle.top_k_top_p_filtering_ = generation_utils.py:907-945, softmax, inverse_cdf_draw), on rows with exact ties at the
+    top_k-th value, banned (-inf) tokens, and a per-row constant added to the candidates' scores (the kernel returns logit - lse)."""
+    from multimodalsum_amd.generation import sample_from_candidates
+    from oracle import generate_oracle as go
+    g = torch.Generator().manual_seed(top_k)
+    B, V = 6, 300
+    logits = (torch.randn(B, V, generator=g) * 2).float()
+    order = logits.argsort(-1, descending=True)
+    if top_k >= 2:
+        logits[0, order[0, top_k]] = logits[0, order[0, top_k - 1]]            # one tie with the top_k-th value: the extra token stays
+        logits[1, order[1, top_k + 1]] = logits[1, order[1, top_k]] = logits[1, order[1, top_k - 1]]   # two
+    logits[2, order[2, :3]] = float("-inf")                                   # banned tokens
+    K = min(64, top_k + 4)
+    cand_s, cand_i = [], []
+    for b in range(B):                       # the kernel's order: value descending, lower token first among equals
+        idx = sorted(range(V), key=lambda t: (-float(logits[b, t]), t))[:K]
+        cand_i.append(idx)
+        cand_s.append([float(logits[b, t]) - 3.25 * (b + 1) for t in idx])
+    u = torch.rand(50, B, generator=g, dtype=torch.float64)
+    for step in range(50):
+        ref = logits.clone() / temperature if temperature != 1.0 else logits.clone()
+        go.top_k_top_p_filtering_(ref, top_k=top_k, top_p=top_p)
+        want = go.inverse_cdf_draw(torch.softmax(ref, dim=-1), u[step])
+        got = sample_from_candidates(np.array(cand_s, dtype=np.float32), np.array(cand_i, dtype=np.int64), u[step].numpy(), temperature, top_k, top_p)
+        assert got.tolist() == want.tolist(), (step, got, want)
+    if top_k + 4 <= 64 and top_k >= 2:       # a tie that runs to the end of the candidate list cannot be resolved
+        tied = np.array(cand_s, dtype=np.float32)
+        tied[3, top_k - 1:] = tied[3, top_k - 1]
+        with pytest.raises(RuntimeError):
+            sample_from_candidates(tied, np.array(cand_i, dtype=np.int64), u[0].numpy(), temperature, top_k, top_p)
+
+
 def test_beam_search_long_run_guided_check(monkeypatch):
     """A 255-step search (max_length 256: the decode self-attention kernel's limit, four cache positions per lane; bans over 250-token
     prefixes; the ancestor table's last columns) through the kernel emulator, held to the oracle by tests/gen_check.py's guided
